@@ -1,0 +1,140 @@
+/*
+  vsx.h -- C-ABI of libvsx: MI355X-native (gfx950) replacement for the global
+  pairwise alignment hot path of vsearch (search16 / align_simd).
+
+  The reference has no FFI layer; its seam for this path is the translation
+  unit src/core/align_simd.cpp, whose whole external surface is four C++
+  functions (src/core/align_simd.hpp:76-108).  Every entry point below cites
+  the reference interface it replaces.  Plain pointers and sizes only; all
+  memory handed out is malloc-compatible (the reference frees CIGARs with
+  xfree == free, src/os/posix/system.cc:123).
+
+  Error convention: functions return VSX_OK (0) or a negative VSX_E* code and
+  leave a message retrievable with vsx_last_error().  A *pair* that the 16-bit
+  aligner cannot represent is NOT an error: it is reported exactly as the
+  reference does, score == VSX_SCORE_SENTINEL (SHRT_MAX), statistics 0, CIGAR ""
+  (src/core/align_simd.cpp:1463-1479, :1867-1882, :1774-1786), and the caller
+  falls back to its linear-memory aligner (src/core/searchcore.cpp:806-832).
+  There is no CPU fallback inside libvsx: without a usable gfx950 device every
+  compute entry point fails with VSX_ENODEVICE.
+*/
+#ifndef VSX_H
+#define VSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSX_API_VERSION 1000          /* MAJOR*1000000 + MINOR*1000 + PATCH */
+#define VSX_SCORE_SENTINEL 32767      /* SHRT_MAX: "use the scalar fallback" */
+
+#define VSX_OK         0
+#define VSX_EINVAL    -1
+#define VSX_ENODEVICE -2
+#define VSX_ENOMEM    -3
+#define VSX_EHIP      -4
+
+typedef struct vsx_ctx vsx_ctx;         /* replaces s16info_s (align_simd.cpp:411-443); opaque */
+typedef struct vsx_seqset vsx_seqset;   /* device mirror of Database (core/db.hpp:100-107)     */
+typedef struct vsx_plan vsx_plan;       /* a batch of (query, target) pairs bound to buffers   */
+
+/* The 14 post-fixup scores/penalties + flag that search16_init receives
+   (align_simd.hpp:76-90; call site core/search.cpp:147-161).  Same order. */
+typedef struct vsx_scoring {
+  int64_t match;
+  int64_t mismatch;
+  int64_t gap_open_query_left;
+  int64_t gap_open_target_left;
+  int64_t gap_open_query_interior;
+  int64_t gap_open_target_interior;
+  int64_t gap_open_query_right;
+  int64_t gap_open_target_right;
+  int64_t gap_ext_query_left;
+  int64_t gap_ext_target_left;
+  int64_t gap_ext_query_interior;
+  int64_t gap_ext_target_interior;
+  int64_t gap_ext_query_right;
+  int64_t gap_ext_target_right;
+  int32_t n_mismatch;                   /* opt_n_mismatch */
+} vsx_scoring;
+
+/* Per-pair results, exactly the five output arrays + CIGAR of search16
+   (align_simd.hpp:99-108).  cigar_blob holds the NUL-terminated run-length
+   strings back to back; cigar_off[k] is the start of pair k's string. */
+typedef struct vsx_results {
+  uint64_t   n_pairs;
+  int16_t  * score;        /* pscores[]      (CELL)            */
+  uint16_t * aligned;      /* paligned[]     alignment columns */
+  uint16_t * matches;      /* pmatches[]                       */
+  uint16_t * mismatches;   /* pmismatches[]                    */
+  uint16_t * gaps;         /* pgaps[]        gap runs          */
+  uint64_t * cigar_off;
+  char     * cigar_blob;
+  uint64_t   cigar_bytes;
+} vsx_results;
+
+/* Timing of the last vsx_plan_run, measured with hipEvents on the plan's stream. */
+typedef struct vsx_timing {
+  float    forward_ms;      /* DP (score + direction) kernel(s)        */
+  float    traceback_ms;    /* traceback / statistics / CIGAR kernel    */
+  float    total_ms;        /* first launch -> last kernel done         */
+  uint32_t forward_launches;
+  uint32_t traceback_launches;
+  uint64_t cells;           /* sum over pairs of qlen*tlen (DP cells)   */
+  uint64_t dir_bytes;       /* direction bytes written by the DP kernel */
+} vsx_timing;
+
+const char * vsx_version_string(void);
+int vsx_device_count(void);                       /* usable gfx950 devices, 0 if none */
+const char * vsx_last_error(void);                /* thread-local message of the last failure */
+
+/* search16_init (align_simd.cpp:1282-1376): build aligner state on `device`. */
+int vsx_create(vsx_ctx ** out, const vsx_scoring * scoring, int device);
+/* search16_exit (align_simd.cpp:1379-1403). */
+void vsx_destroy(vsx_ctx * ctx);
+
+/* Database::add / getsequence / getsequencelen (core/db.hpp:146-152,172,198):
+   n ASCII sequences (any case, IUPAC; blob + offsets + lengths) are encoded to
+   4-bit codes (utils/maps.cpp:75-117) ON THE DEVICE and kept resident in HBM.
+   The same call serves the query side (search16_qprep, align_simd.cpp:1406-1428). */
+int vsx_seqset_create(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n,
+                      const char * blob, uint64_t blob_bytes,
+                      const uint64_t * offsets, const uint32_t * lengths);
+/* Same, but `d_blob` is ASCII already resident in device memory (bench path). */
+int vsx_seqset_create_from_device(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n,
+                                  const void * d_blob, uint64_t blob_bytes,
+                                  const uint64_t * offsets, const uint32_t * lengths);
+void vsx_seqset_destroy(vsx_seqset * s);
+uint64_t vsx_seqset_count(const vsx_seqset * s);
+
+/* search16 (align_simd.cpp:1447-2060), generalised from "one query, n targets"
+   to an arbitrary pair list: pair k aligns queries[qidx[k]] with targets[tidx[k]].
+   A pair's result is a pure function of (query, target, scoring) in the reference
+   (lanes are independent), so batching across queries changes nothing.
+   vsx_plan_create groups pairs by query into wavefront tasks (<= 8 targets each),
+   uploads the task list and sizes the device buffers; vsx_plan_run launches the
+   DP + traceback kernels (asynchronously, in chunks that fit `dir_budget_bytes`
+   of direction storage; 0 = default); vsx_plan_fetch waits, copies the results
+   back and formats the CIGAR strings. */
+int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out,
+                    const vsx_seqset * queries, const vsx_seqset * targets,
+                    uint64_t n_pairs, const uint32_t * qidx, const uint32_t * tidx,
+                    uint64_t dir_budget_bytes);
+int vsx_plan_run(vsx_plan * plan);
+int vsx_plan_sync(vsx_plan * plan, vsx_timing * timing /* may be NULL */);
+int vsx_plan_fetch(vsx_plan * plan, vsx_results * out);
+void vsx_plan_destroy(vsx_plan * plan);
+
+/* Convenience: create + run + fetch + destroy. */
+int vsx_align_pairs(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets,
+                    uint64_t n_pairs, const uint32_t * qidx, const uint32_t * tidx,
+                    vsx_results * out);
+void vsx_results_free(vsx_results * r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSX_H */

@@ -1,0 +1,240 @@
+"""Host-side mirror of the reference's aligner interface (src/core/align_simd.hpp:76-108) on top of
+the libvsx C-ABI.  Names and argument meaning follow the reference:
+
+    search16_init(...)   -> Aligner(...)            14 post-fixup penalties + n_mismatch
+    search16_qprep(q)    -> Aligner.qprep(q)
+    search16(seqnos, db) -> Aligner.search16(seqnos, db)  -> per-target (score, aligned, matches,
+                                                             mismatches, gaps, cigar)
+    Database             -> SequenceSet                    device-resident, 4-bit coded
+    (new) multi-query batch: Aligner.align_pairs(queries, targets, qidx, tidx)
+
+Unalignable pairs come back exactly as the reference reports them: score 32767, stats 0, cigar "".
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib
+from ._lib import Scoring, Results, Timing, check
+
+# post-fixup defaults: src/vsearch.h:450-461 after vsearch_apply_defaults_fixups (src/vsearch.cc:250-259)
+DEFAULT_SCORING = dict(match=2, mismatch=-4,
+                       gap_open_query_left=1, gap_open_target_left=1,
+                       gap_open_query_interior=18, gap_open_target_interior=18,
+                       gap_open_query_right=1, gap_open_target_right=1,
+                       gap_ext_query_left=1, gap_ext_target_left=1,
+                       gap_ext_query_interior=2, gap_ext_target_interior=2,
+                       gap_ext_query_right=1, gap_ext_target_right=1)
+P_ORDER = [n for n, _ in Scoring._fields_[:14]]
+
+
+def scoring_from_tuple(P, n_mismatch=False):
+    """P in search16_init argument order (match, mismatch, go_q_l, go_t_l, go_q_i, go_t_i, go_q_r,
+    go_t_r, ge_q_l, ge_t_l, ge_q_i, ge_t_i, ge_q_r, ge_t_r)."""
+    s = Scoring()
+    for n, v in zip(P_ORDER, P):
+        setattr(s, n, int(v))
+    s.n_mismatch = 1 if n_mismatch else 0
+    return s
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class AlignmentResults:
+    """numpy view of vsx_results (copied out, then freed)."""
+
+    def __init__(self, res):
+        n = int(res.n_pairs)
+        cp = lambda p, dt: np.ctypeslib.as_array(p, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+        self.score = cp(res.score, np.int16)
+        self.aligned = cp(res.aligned, np.uint16)
+        self.matches = cp(res.matches, np.uint16)
+        self.mismatches = cp(res.mismatches, np.uint16)
+        self.gaps = cp(res.gaps, np.uint16)
+        off = cp(res.cigar_off, np.uint64)
+        blob = C.string_at(res.cigar_blob, int(res.cigar_bytes)) if res.cigar_bytes else b""
+        self.cigar = [blob[int(o):blob.index(b"\0", int(o))].decode() for o in off]
+
+    def __len__(self):
+        return len(self.score)
+
+    def row(self, k):
+        return (int(self.score[k]), int(self.aligned[k]), int(self.matches[k]), int(self.mismatches[k]),
+                int(self.gaps[k]), self.cigar[k])
+
+
+class SequenceSet:
+    """Device-resident sequences (mirror of Database: core/db.hpp getsequence/getsequencelen)."""
+
+    def __init__(self, aligner, seqs=None, blob=None, offsets=None, lengths=None, device_ptr=None):
+        self.aligner = aligner
+        aligner._children.add(self)
+        lib = _lib.load()
+        if seqs is not None:
+            bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+            lengths = np.array([len(b) for b in bs], np.uint32)
+            offsets = np.zeros(len(bs), np.uint64)
+            if len(bs):
+                offsets[1:] = np.cumsum(lengths[:-1], dtype=np.uint64)
+            blob = b"".join(bs)
+        self.offsets = np.ascontiguousarray(offsets, np.uint64)
+        self.lengths = np.ascontiguousarray(lengths, np.uint32)
+        self.n = len(self.lengths)
+        self.h = C.c_void_p()
+        if device_ptr is not None:
+            nbytes = int(blob)          # blob carries the byte count when the data is already in HBM
+            check(lib.vsx_seqset_create_from_device(aligner.h, C.byref(self.h), self.n, C.c_void_p(device_ptr),
+                                                    nbytes, _ptr(self.offsets), _ptr(self.lengths)),
+                  "vsx_seqset_create_from_device")
+        else:
+            if isinstance(blob, np.ndarray):
+                self._keep = np.ascontiguousarray(blob, np.uint8)
+                p, nbytes = _ptr(self._keep), self._keep.size
+            else:
+                self._keep = bytes(blob)
+                p, nbytes = C.cast(C.c_char_p(self._keep), C.c_void_p), len(self._keep)
+            check(lib.vsx_seqset_create(aligner.h, C.byref(self.h), self.n, p, nbytes,
+                                        _ptr(self.offsets), _ptr(self.lengths)), "vsx_seqset_create")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            _lib.load().vsx_seqset_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.n
+
+
+class Plan:
+    """A batch of (query, target) pairs bound to device buffers (vsx_plan)."""
+
+    def __init__(self, aligner, queries, targets, qidx, tidx, dir_budget_bytes=0):
+        self.aligner, self.queries, self.targets = aligner, queries, targets
+        aligner._children.add(self)
+        self.qidx = np.ascontiguousarray(qidx, np.uint32)
+        self.tidx = np.ascontiguousarray(tidx, np.uint32)
+        if self.qidx.shape != self.tidx.shape:
+            raise ValueError("qidx and tidx must have the same length")
+        self.h = C.c_void_p()
+        check(_lib.load().vsx_plan_create(aligner.h, C.byref(self.h), queries.h, targets.h, self.qidx.size,
+                                          _ptr(self.qidx), _ptr(self.tidx), int(dir_budget_bytes)),
+              "vsx_plan_create")
+
+    def run(self):
+        check(_lib.load().vsx_plan_run(self.h), "vsx_plan_run")
+
+    def sync(self):
+        t = Timing()
+        check(_lib.load().vsx_plan_sync(self.h, C.byref(t)), "vsx_plan_sync")
+        return t
+
+    def fetch(self):
+        res = Results()
+        lib = _lib.load()
+        check(lib.vsx_plan_fetch(self.h, C.byref(res)), "vsx_plan_fetch")
+        try:
+            return AlignmentResults(res)
+        finally:
+            lib.vsx_results_free(C.byref(res))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            _lib.load().vsx_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Aligner:
+    """search16_init .. search16_exit.  One per (device, scoring); not thread-safe, like s16info_s."""
+
+    def __init__(self, scoring=None, n_mismatch=False, device=0, **kw):
+        lib = _lib.load()
+        if scoring is None:
+            d = dict(DEFAULT_SCORING)
+            d.update(kw)
+            s = Scoring()
+            for k, v in d.items():
+                setattr(s, k, int(v))
+            s.n_mismatch = 1 if n_mismatch else 0
+        elif isinstance(scoring, Scoring):
+            s = scoring
+        else:
+            s = scoring_from_tuple(scoring, n_mismatch)
+        self.scoring = s
+        self._children = weakref.WeakSet()      # plans / sequence sets must die before the context
+        self.h = C.c_void_p()
+        check(lib.vsx_create(C.byref(self.h), C.byref(s), int(device)), "vsx_create")
+        self._q = None
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            kids = list(self._children)
+            for k in [k for k in kids if isinstance(k, Plan)] + [k for k in kids if not isinstance(k, Plan)]:
+                k.close()
+            self._q = None
+            _lib.load().vsx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- the reference's per-query interface -------------------------------------------------
+    def sequences(self, seqs):
+        return SequenceSet(self, seqs=seqs)
+
+    def qprep(self, qseq):
+        """search16_qprep (align_simd.cpp:1406-1428): bind the query of the following search16 calls."""
+        if self._q is not None:
+            self._q.close()
+        self._q = SequenceSet(self, seqs=[qseq])
+
+    def search16(self, seqnos, db):
+        """search16 (align_simd.cpp:1447-2060): align the bound query against db[seqnos]."""
+        if self._q is None:
+            raise RuntimeError("search16 called before qprep")
+        seqnos = np.ascontiguousarray(seqnos, np.uint32)
+        return self.align_pairs(self._q, db, np.zeros(seqnos.size, np.uint32), seqnos)
+
+    # -- the batched entry ---------------------------------------------------------------------
+    def plan(self, queries, targets, qidx, tidx, dir_budget_bytes=0):
+        return Plan(self, queries, targets, qidx, tidx, dir_budget_bytes)
+
+    def align_pairs(self, queries, targets, qidx, tidx):
+        p = self.plan(queries, targets, qidx, tidx)
+        try:
+            p.run()
+            return p.fetch()
+        finally:
+            p.close()
+
+    def align(self, q, t):
+        """one pair -> (score, aligned, matches, mismatches, gaps, cigar)"""
+        qs, ts = SequenceSet(self, seqs=[q]), SequenceSet(self, seqs=[t])
+        try:
+            return self.align_pairs(qs, ts, [0], [0]).row(0)
+        finally:
+            qs.close()
+            ts.close()

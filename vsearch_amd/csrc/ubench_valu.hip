@@ -1,0 +1,122 @@
+// Micro-benchmark: VALU issue rates on gfx950 for the instruction classes the DP kernel can use
+// (this is where the roofline `peak` for the integer DP comes from).
+// Build: hipcc --offload-arch=gfx950 -O3 ubench_valu.hip -o ubench_valu
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e)); exit(1); } } while (0)
+
+// 16 independent destination registers per unrolled body, 8 bodies per loop trip.
+#define BODY16(INS) \
+  asm volatile(INS(%0) INS(%1) INS(%2) INS(%3) INS(%4) INS(%5) INS(%6) INS(%7) \
+               INS(%8) INS(%9) INS(%10) INS(%11) INS(%12) INS(%13) INS(%14) INS(%15) \
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), \
+                 "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) \
+               : "v"(b), "v"(c) : "vcc")
+
+#define I_PK_ADD(x)   "v_pk_add_i16 " #x ", " #x ", %16 clamp\n"
+#define I_PK_SUB(x)   "v_pk_sub_i16 " #x ", " #x ", %16 clamp\n"
+#define I_PK_MAX(x)   "v_pk_max_i16 " #x ", " #x ", %16\n"
+#define I_PK_MIN(x)   "v_pk_min_u16 " #x ", " #x ", %16\n"
+#define I_PK_LSHR(x)  "v_pk_lshrrev_b16 " #x ", 1, " #x "\n"
+#define I_PK_ASHR(x)  "v_pk_ashrrev_i16 " #x ", 15, " #x "\n"
+#define I_PK_MAD(x)   "v_pk_mad_u16 " #x ", " #x ", %16, %17\n"
+#define I_PK_MUL(x)   "v_pk_mul_lo_u16 " #x ", " #x ", %16\n"
+#define I_XOR(x)      "v_xor_b32 " #x ", " #x ", %16\n"
+#define I_ANDOR(x)    "v_and_or_b32 " #x ", " #x ", %16, %17\n"
+#define I_LSHR(x)     "v_lshrrev_b32 " #x ", 1, " #x "\n"
+#define I_BFI(x)      "v_bfi_b32 " #x ", %16, " #x ", %17\n"
+#define I_LSHLOR(x)   "v_lshl_or_b32 " #x ", " #x ", 1, %16\n"
+#define I_ADD32(x)    "v_add_u32 " #x ", " #x ", %16\n"
+#define I_ADD3(x)     "v_add3_u32 " #x ", " #x ", %16, %17\n"
+#define I_MAX32(x)    "v_max_i32 " #x ", " #x ", %16\n"
+#define I_MAX3_32(x)  "v_max3_i32 " #x ", " #x ", %16, %17\n"
+#define I_ADD16(x)    "v_add_i16 " #x ", " #x ", %16 clamp\n"
+#define I_MAX16(x)    "v_max_i16 " #x ", " #x ", %16\n"
+#define I_MAX3_16(x)  "v_max3_i16 " #x ", " #x ", %16, %17\n"
+#define I_DPP(x)      "v_mov_b32_dpp " #x ", %16 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define I_PERM(x)     "v_perm_b32 " #x ", " #x ", %16, %17\n"
+#define I_CNDMASK(x)  "v_cndmask_b32 " #x ", " #x ", %16, vcc\n"
+#define I_CMP16(x)    "v_cmp_gt_i16 vcc, " #x ", %16\n"
+#define I_MOV(x)      "v_mov_b32 " #x ", %16\n"
+#define I_ALIGNBIT(x) "v_alignbit_b32 " #x ", " #x ", %16, 1\n"
+#define I_DOT2(x)     "v_dot2_u32_u16 " #x ", " #x ", %16, %17\n"
+#define I_SAD16(x)    "v_sad_u16 " #x ", " #x ", %16, %17\n"
+#define I_MAD_I32_I16(x) "v_mad_i32_i16 " #x ", " #x ", %16, %17\n"
+
+#define DEFK(NAME, INS) \
+  __global__ void __launch_bounds__(256) NAME(int iters, int * out, int seed) { \
+    int r[16]; int b = seed + threadIdx.x, c = seed * 7 + 3; \
+    for (int i = 0; i < 16; ++i) r[i] = i * 1315423911 + threadIdx.x; \
+    for (int it = 0; it < iters; ++it) { \
+      BODY16(INS); BODY16(INS); BODY16(INS); BODY16(INS); BODY16(INS); BODY16(INS); BODY16(INS); BODY16(INS); } \
+    int acc = 0; for (int i = 0; i < 16; ++i) acc ^= r[i]; \
+    if (acc == 0x12345678) out[0] = acc; }
+
+DEFK(k_pk_add, I_PK_ADD)
+DEFK(k_pk_sub, I_PK_SUB)
+DEFK(k_pk_max, I_PK_MAX)
+DEFK(k_pk_min, I_PK_MIN)
+DEFK(k_pk_lshr, I_PK_LSHR)
+DEFK(k_pk_ashr, I_PK_ASHR)
+DEFK(k_pk_mad, I_PK_MAD)
+DEFK(k_pk_mul, I_PK_MUL)
+DEFK(k_xor, I_XOR)
+DEFK(k_andor, I_ANDOR)
+DEFK(k_lshr, I_LSHR)
+DEFK(k_bfi, I_BFI)
+DEFK(k_lshlor, I_LSHLOR)
+DEFK(k_add32, I_ADD32)
+DEFK(k_add3, I_ADD3)
+DEFK(k_max32, I_MAX32)
+DEFK(k_max3_32, I_MAX3_32)
+DEFK(k_add16, I_ADD16)
+DEFK(k_max16, I_MAX16)
+DEFK(k_max3_16, I_MAX3_16)
+DEFK(k_dpp, I_DPP)
+DEFK(k_perm, I_PERM)
+DEFK(k_cndmask, I_CNDMASK)
+DEFK(k_cmp16, I_CMP16)
+DEFK(k_mov, I_MOV)
+DEFK(k_alignbit, I_ALIGNBIT)
+DEFK(k_dot2, I_DOT2)
+DEFK(k_sad16, I_SAD16)
+DEFK(k_mad_i32_i16, I_MAD_I32_I16)
+
+typedef void (*kfn)(int, int *, int);
+
+static void run(const char * name, kfn k, int waves_per_simd)
+{
+  int * out; CK(hipMalloc(&out, 4));
+  const int iters = 1000;
+  const int blocks = 256 * waves_per_simd;    // 256-thread blocks = 1 wave per SIMD each
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, 10, out, 1);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, iters, out, 1);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  double instr = (double) iters * 8 * 16 * blocks * 256;   // lane-instructions
+  double rate = instr / (ms * 1e-3) / 1e12;
+  // lanes per clock per SIMD assuming 2.4 GHz, 1024 SIMDs
+  printf("%-22s w/simd=%d %8.3f ms  %7.2f T lane-instr/s  (%.1f lanes/clk/SIMD @2.4GHz)\n", name, waves_per_simd, ms, rate,
+         rate * 1e12 / (1024 * 2.4e9));
+  CK(hipFree(out));
+}
+
+int main()
+{
+  hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+  printf("device %s  CUs %d  clock %d kHz  arch %s\n", p.name, p.multiProcessorCount, p.clockRate, p.gcnArchName);
+#define R(NAME) run(#NAME, NAME, 4);
+  R(k_pk_add) R(k_pk_sub) R(k_pk_max) R(k_pk_min) R(k_pk_lshr) R(k_pk_ashr) R(k_pk_mad) R(k_pk_mul)
+  R(k_xor) R(k_andor) R(k_lshr) R(k_bfi) R(k_lshlor) R(k_add32) R(k_add3) R(k_max32) R(k_max3_32)
+  R(k_add16) R(k_max16) R(k_max3_16) R(k_dpp) R(k_perm) R(k_cndmask) R(k_cmp16) R(k_mov) R(k_alignbit)
+  R(k_dot2) R(k_sad16) R(k_mad_i32_i16)
+  run("k_pk_add", k_pk_add, 1); run("k_pk_add", k_pk_add, 2); run("k_pk_add", k_pk_add, 8);
+  run("k_xor", k_xor, 1); run("k_xor", k_xor, 2); run("k_xor", k_xor, 8);
+  return 0;
+}

@@ -1,0 +1,541 @@
+// vsx_device.hip -- hand-written gfx950 (CDNA4) kernels for the vsearch global-alignment hot path.
+//
+// Replaces, bit for bit, the arithmetic of the reference's 8-lane SSE2 aligner
+// (src/core/align_simd.cpp: onestep :752-781, aligncolumns_first/rest :783-1010, the search16
+// driver :1447-2060 and backtrack16 :1052-1245) with a wavefront design:
+//
+//   * one wavefront (64 lanes) = one TASK = one query x up to 8 targets;
+//   * a 16-lane group (one DPP row) sweeps TWO targets at once: target 2g lives in the low
+//     int16 half of every VGPR, target 2g+1 in the high half (v_pk_*_i16, saturating = `clamp`);
+//   * lane l of a group owns R consecutive query rows; at step t it processes target column
+//     j = t - l (systolic skew), so H/F cross lanes through one v_mov_b32_dpp row_shr:1 per step
+//     and E / the left-neighbour H never leave VGPRs;
+//   * the column descriptor (target symbol pair, column penalties, score delta) travels down the
+//     same DPP pipeline; lane 0 is fed from a 16-column block that rotates with row_ror:15;
+//   * the 4 direction bits per cell are the SIGN bits of four saturating subtractions
+//     (a > b  <=>  ssub(b, a) < 0, exact under saturation), funnelled into 16-bit fields with
+//     v_lshrrev_b32 + v_bfi_b32; each lane stores R/4 dwords per step, coalesced by [step][lane];
+//   * no MFMA: this is a max-plus recurrence on int16, bound by VALU issue.
+//
+// A second kernel walks the stored direction bits (one lane per pair) and emits the alignment
+// statistics and run-length CIGAR exactly as backtrack16 does.
+#include <hip/hip_runtime.h>
+#include "vsx_internal.h"
+
+typedef unsigned int u32;
+typedef short s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+#define DEV __device__ __forceinline__
+
+#define SIGN2 0x80008000u
+
+DEV s2 S2(u32 x) { return __builtin_bit_cast(s2, x); }
+DEV us2 U2(u32 x) { return __builtin_bit_cast(us2, x); }
+DEV u32 UI(s2 x) { return __builtin_bit_cast(u32, x); }
+DEV u32 UI(us2 x) { return __builtin_bit_cast(u32, x); }
+
+DEV u32 sadd(u32 a, u32 b) { return UI(__builtin_elementwise_add_sat(S2(a), S2(b))); }   // v_pk_add_i16 clamp
+DEV u32 ssub(u32 a, u32 b) { return UI(__builtin_elementwise_sub_sat(S2(a), S2(b))); }   // v_pk_sub_i16 clamp
+DEV u32 pmax(u32 a, u32 b) { return UI(__builtin_elementwise_max(S2(a), S2(b))); }       // v_pk_max_i16
+DEV u32 pmin(u32 a, u32 b) { return UI(__builtin_elementwise_min(S2(a), S2(b))); }       // v_pk_min_i16
+DEV u32 pminu(u32 a, u32 b) { return UI(__builtin_elementwise_min(U2(a), U2(b))); }      // v_pk_min_u16
+DEV u32 pmad(u32 a, u32 b, u32 c) { return UI((us2) (U2(a) * U2(b) + U2(c))); }          // v_pk_mad_u16
+DEV u32 pashr15(u32 a) { return UI((s2) (S2(a) >> (s2){15, 15})); }                      // v_pk_ashrrev_i16
+DEV u32 bfi(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }                 // v_bfi_b32
+// Pinned encodings: hipcc otherwise rewrites these idioms into v_cmp/v_cndmask/v_perm sequences.
+DEV u32 a_pk_minu(u32 a, u32 b) { u32 r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b)); return r; }
+DEV u32 a_pk_mad(u32 a, u32 b, u32 c) { u32 r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c)); return r; }
+DEV u32 a_bfi(u32 mask, u32 a, u32 b) { u32 r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b)); return r; }
+DEV u32 a_bfi_v(u32 mask, u32 a, u32 b) { u32 r; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b)); return r; }
+DEV u32 a_lshr1(u32 a) { u32 r; asm("v_lshrrev_b32 %0, 1, %1" : "=v"(r) : "v"(a)); return r; }
+DEV u32 a_pk_ashr15(u32 a) { u32 r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
+// direction funnel: shift the accumulator right by one, drop the sign bits of d into bits 15 / 31
+DEV u32 funnel(u32 acc, u32 d) { return a_bfi(SIGN2, d, a_lshr1(acc)); }
+DEV u32 pack16(int v) { const u32 x = (u32) v & 0xffffu; return x | (x << 16); }
+
+// lane l <- lane l-1 within each 16-lane row; lane 0 of a row keeps `feed`
+DEV u32 dpp_shr1(u32 feed, u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) feed, (int) src, 0x111, 0xF, 0xF, false); }
+// rotate left by one within each 16-lane row (row_ror:15): lane l <- lane (l+1) mod 16
+DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, (int) src, 0x12F, 0xF, 0xF, false); }
+
+
+// ---------------------------------------------------------------------------------------------
+// DP kernel: scores + direction bits.  R = query rows per lane.  GENERIC = score lookup through a
+// 16 KB LDS table (any IUPAC / unknown symbol in the QUERY); the fast variant requires a pure
+// A/C/G/T(U) query and derives the score from an XOR of the 4-bit codes (targets may contain
+// anything: an ambiguous target symbol scores a per-column constant against unambiguous rows).
+// ---------------------------------------------------------------------------------------------
+template <int R, bool GENERIC>
+__global__ void __launch_bounds__(64)
+vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
+                   const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
+                   u32 * __restrict__ dir, uint2 * strip, VsxSlotOut * __restrict__ slot_out)
+{
+  constexpr int ND = (R + 3) / 4;                  // direction dwords per lane per step
+  __shared__ u32 W[GENERIC ? 4096 : 1];            // W[a][bA][bB] = {S[bA][a], S[bB][a]}
+
+  const VsxTask & T = tasks[blockIdx.x];
+  const int lane = (int) threadIdx.x;
+  const int g = lane >> 4;
+  const int l = lane & 15;
+
+  const int Q = (int) T.qlen;
+  const int total_lanes = (Q + R - 1) / R;         // pipeline positions holding query rows
+  const int rcnt0 = Q - (total_lanes - 1) * R;     // rows in position 0 (1..R); all others hold R
+  const int nstrips = (total_lanes + 15) >> 4;
+  const int steps = (int) T.steps;
+
+  const int DA = (int) T.tlen[2 * g];
+  const int DB = (int) T.tlen[2 * g + 1];
+  const int DpA = (DA + 3) & ~3;                   // the reference pads the last 4-column block
+  const int DpB = (DB + 3) & ~3;
+  const int Dpg = DpA > DpB ? DpA : DpB;
+  const uint8_t * __restrict__ tA = tc + T.toff[2 * g];
+  const uint8_t * __restrict__ tB = tc + T.toff[2 * g + 1];
+  const uint8_t * __restrict__ qq = qc + T.qoff;
+
+  if (GENERIC)
+    {
+      for (int idx = lane; idx < 4096; idx += 64)
+        {
+          const int a = idx >> 8, bA = (idx >> 4) & 15, bB = idx & 15;
+          W[idx] = ((u32) (uint16_t) P.matrix[bA * 16 + a]) | ((u32) (uint16_t) P.matrix[bB * 16 + a] << 16);
+        }
+      __syncthreads();
+    }
+
+  u32 hmin = 0, hmax = 0;      // running min(0, H...) / max(0, H...) of align_simd.cpp:810-811,772-773
+  u32 score = 0;
+
+  for (int s = 0; s < nstrips; ++s)
+    {
+      const int L = 16 * s + l;                    // global pipeline position
+      const bool lane_on = (L < total_lanes) && (Dpg > 0);
+      const bool first = (L == 0);
+      const int i0 = first ? 0 : rcnt0 + (L - 1) * R;
+
+      // ---- per-lane row state: left border (aligncolumns_first :844-859, :881-887) ----
+      u32 hprev[R];      // H(i, j-1): left neighbour, next column's diagonal for row i+1
+      u32 E[R];          // E(i, j)
+      u32 ac[R];         // query symbol of the row (fast: code in both halves; generic: code << 8)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        {
+          int i = i0 + r;
+          if (i > Q - 1) i = Q - 1;                // dummy rows (skipped or idle lanes): any valid address
+          const u32 a = qq[i];
+          ac[r] = GENERIC ? (a << 8) : (a | (a << 16));
+          const u32 hl = pack16(P.hleft[i]);
+          hprev[r] = hl;
+          E[r] = ssub(hl, (i < Q - 1) ? P.qrq_i_pk : P.qrq_r_pk);
+        }
+      u32 diag = first ? 0u : pack16(P.hleft[i0 - 1]);    // H(i0-1, -1); Htop(-1) = 0 (:1895)
+      // query-gap penalties of row R-1: only the globally last row uses the right-end pair (:836-897)
+      const bool lastpos = (L == total_lanes - 1);
+      const u32 qrq_last = lastpos ? P.qrq_r_pk : P.qrq_i_pk;
+      const u32 rq_last = lastpos ? P.rq_r_pk : P.rq_i_pk;
+
+      // ---- column pipeline ----
+      u32 sym = 0, nd = 0, qrt = 0, rt = 0;        // this lane's current column descriptor
+      u32 outH = 0, outF = 0;                      // H(bottom row, j), F(bottom row + 1, j)
+      u32 f_sym = 0, f_nd = 0, f_qrt = 0, f_rt = 0, f_H = 0, f_F = 0;   // 16-column feed block
+      u32 rawA = 0, rawB = 0;
+      int rawH = 0;
+      uint2 rawS = make_uint2(0, 0);
+      const uint2 * strip_in = strip + T.strip_off + (size_t) (((s + 1) & 1) * 4 + g) * (size_t) steps;
+      uint2 * strip_outp = strip + T.strip_off + (size_t) ((s & 1) * 4 + g) * (size_t) steps;
+
+      auto prefetch = [&](int blk) {
+        const int c = 16 * blk + l;
+        rawA = (c < DA) ? (u32) tA[c] : 0u;
+        rawB = (c < DB) ? (u32) tB[c] : 0u;
+        if (s == 0) rawH = P.htop[c];
+        else if (c < Dpg) rawS = strip_in[c];
+      };
+      prefetch(0);
+
+      for (int t = 0; t < steps; ++t)
+        {
+          if ((t & 15) == 0)
+            {
+              // build the feed block for columns 16k..16k+15 (lane l describes column 16k+l)
+              const int c = t + l;
+              auto mne = [&](u32 code) -> int {     // score of an unambiguous query row vs `code` when codes differ
+                const bool unamb = (code != 0) && ((code & (code - 1)) == 0);
+                return unamb ? P.mismatch : ((P.n_mismatch && code == 15) ? P.mismatch : 0);
+              };
+              const u32 ndA = (u32) (mne(rawA) - P.match) & 0xffffu;
+              const u32 ndB = (u32) (mne(rawB) - P.match) & 0xffffu;
+              const u32 qA = (u32) ((c < DA - 1) ? P.qrt_i : P.qrt_r) & 0xffffu;   // :1719-1753
+              const u32 qB = (u32) ((c < DB - 1) ? P.qrt_i : P.qrt_r) & 0xffffu;
+              const u32 rA = (u32) ((c < DA - 1) ? P.rt_i : P.rt_r) & 0xffffu;
+              const u32 rB = (u32) ((c < DB - 1) ? P.rt_i : P.rt_r) & 0xffffu;
+              const u32 sA = rawA | ((c == DA - 1) ? 0x100u : 0u) | ((c < DpA) ? 0x200u : 0u);
+              const u32 sB = rawB | ((c == DB - 1) ? 0x100u : 0u) | ((c < DpB) ? 0x200u : 0u);
+              f_sym = sA | (sB << 16);
+              f_nd = ndA | (ndB << 16);
+              f_qrt = qA | (qB << 16);
+              f_rt = rA | (rB << 16);
+              if (s == 0)
+                {
+                  f_H = pack16(rawH);                  // H(-1, j) = Htop(j)
+                  f_F = ssub(f_H, f_qrt);              // f = v_sub(f, QR_t) at block entry (:830-833)
+                }
+              else
+                {
+                  f_H = rawS.x;                        // handed over by the previous strip's last lane
+                  f_F = rawS.y;
+                }
+              prefetch((t >> 4) + 1);
+            }
+
+          // ---- systolic shift (all lanes, full EXEC) ----
+          sym = dpp_shr1(f_sym, sym);   f_sym = dpp_rol1(f_sym);
+          nd  = dpp_shr1(f_nd, nd);     f_nd  = dpp_rol1(f_nd);
+          qrt = dpp_shr1(f_qrt, qrt);   f_qrt = dpp_rol1(f_qrt);
+          rt  = dpp_shr1(f_rt, rt);     f_rt  = dpp_rol1(f_rt);
+          const u32 inH = dpp_shr1(f_H, outH);   f_H = dpp_rol1(f_H);
+          const u32 inF = dpp_shr1(f_F, outF);   f_F = dpp_rol1(f_F);
+
+          const int j = t - l;
+          if (lane_on && j >= 0 && j < Dpg)
+            {
+              const u32 code = sym & 0x000F000Fu;
+              const u32 bcol = GENERIC ? (((code & 0xFu) << 4) | (code >> 16)) : 0u;
+              u32 Hd = diag;
+              u32 F = inF;
+              u32 smn = 0x7FFF7FFFu, smx = 0x80008000u;
+              u32 acc = 0, h2 = 0;
+              u32 capH = 0, capF = 0, capmn = 0, capmx = 0;    // position 0: state after its last real row
+              u32 dw[ND];
+#pragma unroll
+              for (int r = 0; r < R; ++r)
+                {
+                  u32 V;
+                  if (GENERIC) V = W[ac[r] | bcol];
+                  else V = a_pk_mad(a_pk_minu(ac[r] ^ code, 0x00010001u), nd, P.match_pk);
+                  // onestep (:765-780)
+                  const u32 h0 = sadd(Hd, V);
+                  const u32 dU = ssub(h0, F);              // sign <=> F > H      (up)
+                  const u32 h1 = pmax(h0, F);
+                  const u32 dL = ssub(h1, E[r]);           // sign <=> E > H      (left)
+                  h2 = pmax(h1, E[r]);
+                  smn = pmin(smn, h2);
+                  smx = pmax(smx, h2);
+                  Hd = hprev[r];
+                  hprev[r] = h2;
+                  const u32 qrq = (r == R - 1) ? qrq_last : P.qrq_i_pk;
+                  const u32 rq = (r == R - 1) ? rq_last : P.rq_i_pk;
+                  const u32 hf = ssub(h2, qrt);
+                  const u32 f = ssub(F, rt);
+                  const u32 dEU = ssub(hf, f);             // sign <=> F-R > H-QR (extend up)
+                  F = pmax(f, hf);
+                  const u32 he = ssub(h2, qrq);
+                  const u32 e = ssub(E[r], rq);
+                  const u32 dEL = ssub(he, e);             // sign <=> E-R > H-QR (extend left)
+                  E[r] = pmax(e, he);
+                  acc = funnel(funnel(funnel(funnel(acc, dU), dL), dEU), dEL);
+                  if ((r & 3) == 3 || r == R - 1) dw[r >> 2] = acc;
+                  // position 0 holds only rcnt0 rows: its later rows compute junk that never leaves the lane
+                  if (__builtin_expect(r + 1 == rcnt0, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
+                }
+              const u32 hl = first ? capH : h2;
+              F = first ? capF : F;
+              smn = first ? capmn : smn;
+              smx = first ? capmx : smx;
+              outH = hl;
+              outF = F;
+              diag = inH;
+
+              // per-block h_min/h_max tracking incl. padded columns (:772-773, :1774-1786), gated per half
+              const u32 vm = a_pk_ashr15(sym << 6);     // bit 9 (column < padded length) -> 0xFFFF
+              hmin = pmin(hmin, a_bfi_v(vm, smn, 0x7FFF7FFFu));
+              hmax = pmax(hmax, a_bfi_v(vm, smx, 0x80008000u));
+              const u32 lm = a_pk_ashr15(sym << 7);     // bit 8 (column == D-1)
+              score = a_bfi_v(lm, hl, score);            // S[(D+3)%4] of the last row (:1835-1836)
+
+              u32 * dp = dir + T.dir_off + ((size_t) ((size_t) s * steps + t) * 64 + lane) * ND;
+              if (ND == 4) *reinterpret_cast<uint4 *>(dp) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+              else if (ND == 2) *reinterpret_cast<uint2 *>(dp) = make_uint2(dw[0], dw[1]);
+              else
+                {
+#pragma unroll
+                  for (int w = 0; w < ND; ++w) dp[w] = dw[w];
+                }
+              if (l == 15 && s + 1 < nstrips) strip_outp[j] = make_uint2(outH, outF);
+            }
+        }
+
+      if (s + 1 < nstrips)
+        {
+          // hand-over rows were written with global stores by this wave: make them visible to its own loads
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+
+  // ---- epilogue: reduce min/max over the group, fetch the score from the last pipeline position ----
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1)
+    {
+      hmin = pmin(hmin, (u32) __shfl_xor((int) hmin, m, 16));
+      hmax = pmax(hmax, (u32) __shfl_xor((int) hmax, m, 16));
+    }
+  const int l_last = (total_lanes - 1) & 15;
+  score = (u32) __shfl((int) score, l_last, 16);
+  if (l == 0)
+    {
+      const int mnA = (int16_t) (hmin & 0xffff), mnB = (int16_t) (hmin >> 16);
+      const int mxA = (int16_t) (hmax & 0xffff), mxB = (int16_t) (hmax >> 16);
+      VsxSlotOut oA, oB;
+      oA.score = (int16_t) (score & 0xffff);
+      oB.score = (int16_t) (score >> 16);
+      oA.overflow = (mnA <= P.smin || mxA >= 32767) ? 1 : 0;     // :1774-1786
+      oB.overflow = (mnB <= P.smin || mxB >= 32767) ? 1 : 0;
+      slot_out[(size_t) blockIdx.x * VSX_TASK_SLOTS + 2 * g] = oA;
+      slot_out[(size_t) blockIdx.x * VSX_TASK_SLOTS + 2 * g + 1] = oB;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Traceback: one lane per pair; follows backtrack16 (align_simd.cpp:1137-1235) over the direction
+// bits written above.  Emits statistics and the run-length op list (reverse order: last column first).
+// run word = (length << 2) | op,  op: 0 = M, 1 = I (gap in query, consumes target), 2 = D.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+vsx_traceback_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
+                     const u32 * __restrict__ pair_slot, const u32 * __restrict__ pair_ids, u32 npairs,
+                     const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
+                     const u32 * __restrict__ dir, const VsxSlotOut * __restrict__ slot,
+                     u32 * __restrict__ slab, const uint64_t * __restrict__ slab_off,
+                     u32 * __restrict__ runs, uint64_t runs_capacity, unsigned long long * cursor,
+                     VsxPairOut * __restrict__ out)
+{
+  const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= npairs) return;
+  const u32 ts = pair_slot[k];
+  const u32 task = ts >> 3, sl = ts & 7;
+  const VsxTask & T = tasks[task];
+  const VsxSlotOut so = slot[ts];
+
+  VsxPairOut o;
+  o.pad = 0;
+  o.nruns = 0;
+  o.run_off = 0;
+  if (so.overflow)
+    {
+      o.score = 32767; o.aligned = 0; o.matches = 0; o.mismatches = 0; o.gaps = 0;
+      out[pair_ids[k]] = o;
+      return;
+    }
+
+  const int R = (int) T.rows;
+  const int ND = (R + 3) >> 2;
+  const int Q = (int) T.qlen;
+  const int D = (int) T.tlen[sl];
+  const int total_lanes = (Q + R - 1) / R;
+  const int rcnt0 = Q - (total_lanes - 1) * R;
+  const size_t steps = T.steps;
+  const int g = (int) (sl >> 1);
+  const bool hi = (sl & 1) != 0;
+  const uint8_t * __restrict__ q = qc + T.qoff;
+  const uint8_t * __restrict__ d = tc + T.toff[sl];
+  u32 * __restrict__ my = slab + slab_off[k];
+
+  int i = Q - 1, j = D - 1;
+  int L = total_lanes - 1;                 // pipeline position of row i
+  int r = (L == 0 ? rcnt0 : R) - 1;        // row inside that position
+  int op = -1;                             // -1 none, 0 M, 1 I, 2 D
+  u32 runlen = 0, nruns = 0;
+  u32 al = 0, ma = 0, mi = 0, ga = 0;
+
+  auto push = [&](int newop) {             // pushop (:1013-1030), run-length
+    if (newop == op) { ++runlen; return; }
+    if (op >= 0) my[nruns++] = (runlen << 2) | (u32) op;
+    op = newop;
+    runlen = 1;
+  };
+  auto row_up = [&]() {
+    --i;
+    if (--r < 0) { --L; r = (L == 0 ? rcnt0 : R) - 1; }
+  };
+
+  while (i >= 0 && j >= 0)
+    {
+      const int s = L >> 4, l = L & 15;
+      const size_t t = (size_t) j + (size_t) l;
+      const u32 w = dir[T.dir_off + ((size_t) s * steps + t) * 64 * ND + (size_t) (g * 16 + l) * ND + (size_t) (r >> 2)];
+      const u32 hw = hi ? (w >> 16) : (w & 0xffffu);
+      int rid = R - 4 * (r >> 2);                          // every position funnels all R rows (dummy rows incl.)
+      if (rid > 4) rid = 4;                                // rows sharing this dword
+      const int pos = 16 - 4 * rid + 4 * (r & 3);
+      const u32 b = (hw >> pos) & 15u;                     // bit0 up, bit1 left, bit2 ext-up, bit3 ext-left
+      ++al;
+      if (op == 1 && (b & 8u)) { --j; push(1); }
+      else if (op == 2 && (b & 4u)) { row_up(); push(2); }
+      else if (b & 2u) { if (op != 1) ++ga; --j; push(1); }
+      else if (b & 1u) { if (op != 2) ++ga; row_up(); push(2); }
+      else
+        {
+          const u32 a = q[i], c = d[j];
+          if ((a & c) != 0 && !(P.n_mismatch && (a == 15 || c == 15))) ++ma; else ++mi;
+          row_up(); --j; push(0);
+        }
+    }
+  while (i >= 0) { ++al; if (op != 2) ++ga; --i; push(2); }
+  while (j >= 0) { ++al; if (op != 1) ++ga; --j; push(1); }
+  if (op >= 0) my[nruns++] = (runlen << 2) | (u32) op;     // finishop (:1033-1049)
+
+  // dense (unordered) allocation of the run list
+  const unsigned long long base = atomicAdd(cursor, (unsigned long long) nruns);
+  if (base + nruns <= runs_capacity)
+    for (u32 x = 0; x < nruns; ++x) runs[base + x] = my[x];
+
+  o.score = so.score;
+  o.aligned = (uint16_t) al; o.matches = (uint16_t) ma; o.mismatches = (uint16_t) mi; o.gaps = (uint16_t) ga;
+  o.nruns = nruns;
+  o.run_off = base;
+  out[pair_ids[k]] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ASCII -> 4-bit IUPAC set code (utils/maps.cpp:75-117), 16 bytes per lane; HBM-bound.
+// ---------------------------------------------------------------------------------------------
+DEV u32 map4(u32 ch)
+{
+  const u32 c = ch | 0x20u;                 // fold case; non-letters never match a letter below
+  if (((ch | 0x20u) < 'a') || ((ch | 0x20u) > 'z') || ((ch & 0xC0u) != 0x40u)) return 0;
+  switch (c)
+    {
+    case 'a': return 1;  case 'b': return 14; case 'c': return 2;  case 'd': return 13;
+    case 'g': return 4;  case 'h': return 11; case 'k': return 12; case 'm': return 3;
+    case 'n': return 15; case 'r': return 5;  case 's': return 6;  case 't': return 8;
+    case 'u': return 8;  case 'v': return 7;  case 'w': return 9;  case 'y': return 10;
+    default: return 0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+vsx_encode_kernel(const uint8_t * __restrict__ ascii, uint8_t * __restrict__ codes, uint64_t nbytes)
+{
+  __shared__ uint8_t lut[256];
+  lut[threadIdx.x] = (uint8_t) map4(threadIdx.x);
+  __syncthreads();
+  const uint64_t nvec = nbytes >> 4;
+  const uint64_t stride = (uint64_t) gridDim.x * blockDim.x;
+  for (uint64_t v = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride)
+    {
+      const uint4 in = reinterpret_cast<const uint4 *>(ascii)[v];
+      u32 w[4] = {in.x, in.y, in.z, in.w};
+      u32 o[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        o[x] = (u32) lut[w[x] & 0xff] | ((u32) lut[(w[x] >> 8) & 0xff] << 8) |
+               ((u32) lut[(w[x] >> 16) & 0xff] << 16) | ((u32) lut[w[x] >> 24] << 24);
+      reinterpret_cast<uint4 *>(codes)[v] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  // tail (< 16 bytes)
+  if (blockIdx.x == 0 && threadIdx.x < (nbytes & 15))
+    {
+      const uint64_t p = (nvec << 4) + threadIdx.x;
+      codes[p] = lut[ascii[p]];
+    }
+}
+
+// one wavefront per sequence: impure[s] = 1 if any symbol is not an unambiguous A/C/G/T(U) code
+__global__ void __launch_bounds__(256)
+vsx_purity_kernel(const uint8_t * __restrict__ codes, const uint64_t * __restrict__ off,
+                  const uint32_t * __restrict__ len, uint64_t nseq, uint8_t * __restrict__ impure)
+{
+  const uint64_t s = (uint64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= nseq) return;
+  const int lane = threadIdx.x & 63;
+  const uint8_t * p = codes + off[s];
+  const uint32_t n = len[s];
+  int bad = 0;
+  for (uint32_t x = lane; x < n; x += 64)
+    {
+      const u32 c = p[x];
+      bad |= !((c != 0) && ((c & (c - 1)) == 0));
+    }
+  const unsigned long long any = __ballot(bad);
+  if (lane == 0) impure[s] = any ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static const int kRows[] = {1, 4, 8, 12, 16, 20, 24, 28, 32};
+
+extern "C" const int * vsx_supported_rows(int * count)
+{
+  *count = (int) (sizeof(kRows) / sizeof(kRows[0]));
+  return kRows;
+}
+
+extern "C" hipError_t vsx_launch_encode(const uint8_t * d_ascii, uint8_t * d_codes, uint64_t nbytes, hipStream_t st)
+{
+  if (nbytes == 0) return hipSuccess;
+  uint64_t blocks = ((nbytes >> 4) + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(vsx_encode_kernel, dim3((unsigned) blocks), dim3(256), 0, st, d_ascii, d_codes, nbytes);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t vsx_launch_purity(const uint8_t * d_codes, const uint64_t * d_off, const uint32_t * d_len,
+                                        uint64_t nseq, uint8_t * d_impure, hipStream_t st)
+{
+  if (nseq == 0) return hipSuccess;
+  hipLaunchKernelGGL(vsx_purity_kernel, dim3((unsigned) ((nseq + 3) / 4)), dim3(256), 0, st,
+                     d_codes, d_off, d_len, nseq, d_impure);
+  return hipGetLastError();
+}
+
+template <int R>
+static hipError_t launch_fwd(int generic, const VsxDevParams & P, const VsxTask * d_tasks, uint32_t ntasks,
+                             const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
+                             VsxSlotOut * slot, hipStream_t st)
+{
+  if (generic)
+    hipLaunchKernelGGL((vsx_forward_kernel<R, true>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+  else
+    hipLaunchKernelGGL((vsx_forward_kernel<R, false>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t vsx_launch_forward(int rows, int generic, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
+                                         const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
+                                         VsxSlotOut * slot, hipStream_t st)
+{
+  if (ntasks == 0) return hipSuccess;
+  switch (rows)
+    {
+    case 1:  return launch_fwd<1>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 4:  return launch_fwd<4>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 8:  return launch_fwd<8>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 12: return launch_fwd<12>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 16: return launch_fwd<16>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 20: return launch_fwd<20>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 24: return launch_fwd<24>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 28: return launch_fwd<28>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 32: return launch_fwd<32>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+extern "C" hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
+                                           const uint32_t * d_pair_ids, uint32_t npairs,
+                                           const uint8_t * q, const uint8_t * t,
+                                           const uint32_t * dir, const VsxSlotOut * slot,
+                                           uint32_t * slab, const uint64_t * slab_off,
+                                           uint32_t * runs, uint64_t runs_capacity, unsigned long long * cursor,
+                                           VsxPairOut * out, hipStream_t st)
+{
+  if (npairs == 0) return hipSuccess;
+  hipLaunchKernelGGL(vsx_traceback_kernel, dim3((npairs + 255) / 256), dim3(256), 0, st,
+                     P, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, dir, slot, slab, slab_off,
+                     runs, runs_capacity, cursor, out);
+  return hipGetLastError();
+}

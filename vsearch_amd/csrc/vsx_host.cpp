@@ -1,0 +1,702 @@
+// vsx_host.cpp -- host side of libvsx: the C-ABI of include/vsx.h, batch planning (pairs -> wavefront
+// tasks -> direction-buffer chunks), device memory, result marshalling.
+//
+// Reference seams replaced here (see include/vsx.h for per-function citations):
+//   search16_init/exit/qprep/search16            src/core/align_simd.cpp:1282-2060
+//   the "<= 8 targets per call" batch shape      src/core/searchcore.cpp:757-778
+// Everything that touches sequence data runs on the GPU; the host only groups indices, evaluates the
+// reference's closed-form special cases (empty query / empty target / size guard / forced fallback)
+// and turns run lists into CIGAR text.
+#include "../../include/vsx.h"
+#include "vsx_internal.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cinttypes>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char * fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(call)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(e_ == hipErrorOutOfMemory ? VSX_ENOMEM : VSX_EHIP, "%s failed: %s (%s:%d)", \
+                  #call, hipGetErrorString(e_), __FILE__, __LINE__);                        \
+  } while (0)
+
+inline int sat16(int x) { return x > 32767 ? 32767 : (x < -32768 ? -32768 : x); }
+
+inline bool fits(int64_t q, int64_t d)      // search16_fits, core/align_simd.cpp:130-134
+{
+  return (q + d <= VSX_MAX_SEQLEN_SUM) && (q * d <= VSX_MAX_SEQLEN_PRODUCT);
+}
+
+template <typename T>
+struct DevBuf {
+  T * p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void) hipFree(p); p = nullptr; n = 0; } }
+  hipError_t alloc(size_t count)
+  {
+    release();
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  hipError_t ensure(size_t count) { return (count <= n && p) ? hipSuccess : alloc(count); }
+};
+
+}  // namespace
+
+struct vsx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  vsx_scoring sc {};
+  bool force_fallback = false;      // a score/penalty left the 16-bit range: every pair -> sentinel
+  int pen[12] {};                   // clamped CELL penalties: go_q_l, go_t_l, go_q_i, go_t_i, go_q_r, go_t_r, ge_*
+  VsxDevParams P {};
+  DevBuf<int16_t> d_htop, d_hleft, d_matrix;
+};
+
+struct vsx_seqset {
+  vsx_ctx * ctx = nullptr;
+  int device = 0;
+  uint64_t n = 0;
+  uint64_t bytes = 0;
+  std::vector<uint64_t> off;
+  std::vector<uint32_t> len;
+  DevBuf<uint8_t> d_codes;
+  DevBuf<uint64_t> d_off;
+  DevBuf<uint32_t> d_len;
+  std::vector<uint8_t> impure;      // lazily computed on the device (vsx_purity_kernel)
+  bool have_impure = false;
+};
+
+namespace {
+
+struct Launch { int rows; int generic; uint32_t first, count; };
+
+struct Chunk {
+  uint32_t task_first = 0, task_count = 0;
+  uint32_t pair_first = 0, pair_count = 0;      // into the gpu-pair arrays
+  std::vector<Launch> launches;
+  uint64_t dir_dwords = 0, strip_elems = 0, slab_words = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+};
+
+}  // namespace
+
+struct vsx_plan {
+  vsx_ctx * ctx = nullptr;
+  const vsx_seqset * Q = nullptr;
+  const vsx_seqset * T = nullptr;
+  uint64_t n_pairs = 0;
+  std::vector<VsxPairOut> host_out;      // closed-form / sentinel pairs pre-filled; GPU pairs overwritten on fetch
+  std::vector<uint8_t> is_gpu;
+  std::vector<std::string> host_cigar;   // only for the Q == 0 closed form
+  std::vector<uint32_t> host_cigar_pair;
+
+  std::vector<VsxTask> tasks;
+  std::vector<uint32_t> pair_slot, pair_ids;
+  std::vector<uint64_t> slab_off;
+  std::vector<Chunk> chunks;
+  uint64_t cells = 0, dir_bytes_total = 0;
+
+  DevBuf<VsxTask> d_tasks;
+  DevBuf<uint32_t> d_pair_slot, d_pair_ids, d_dir, d_slab, d_runs;
+  DevBuf<uint64_t> d_slab_off;
+  DevBuf<uint2> d_strip;
+  DevBuf<VsxSlotOut> d_slot;
+  DevBuf<VsxPairOut> d_out;
+  DevBuf<unsigned long long> d_cursor;
+  uint64_t runs_capacity = 0;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  bool ran = false;
+
+  ~vsx_plan()
+  {
+    for (auto & c : chunks)
+      {
+        if (c.e0) (void) hipEventDestroy(c.e0);
+        if (c.e1) (void) hipEventDestroy(c.e1);
+        if (c.e2) (void) hipEventDestroy(c.e2);
+      }
+    if (ev_begin) (void) hipEventDestroy(ev_begin);
+    if (ev_end) (void) hipEventDestroy(ev_end);
+  }
+};
+
+extern "C" {
+
+const char * vsx_version_string(void) { return "libvsx 0.1.0 (gfx950)"; }
+
+const char * vsx_last_error(void) { return g_err.c_str(); }
+
+int vsx_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); return 0; }
+  int usable = 0;
+  for (int d = 0; d < n; ++d)
+    {
+      hipDeviceProp_t p;
+      if (hipGetDeviceProperties(&p, d) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++usable;
+    }
+  return usable;
+}
+
+int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
+{
+  if (!out || !s) return fail(VSX_EINVAL, "vsx_create: null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    {
+      (void) hipGetLastError();
+      return fail(VSX_ENODEVICE, "vsx_create: no HIP device visible (libvsx has no CPU fallback)");
+    }
+  if (device < 0 || device >= ndev) return fail(VSX_EINVAL, "vsx_create: device %d out of range (0..%d)", device, ndev - 1);
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(VSX_ENODEVICE, "vsx_create: device %d is %s, libvsx is built for gfx950 only", device, prop.gcnArchName);
+  HIPCHK(hipSetDevice(device));
+
+  auto * c = new vsx_ctx;
+  c->device = device;
+  c->sc = *s;
+
+  // search16_init, align_simd.cpp:1282-1376: scores must fit a CELL, each penalty SHRT_MAX/(1+CDEPTH)
+  auto clamp = [&](int64_t v, int64_t lim) -> int {
+    if (v > lim) { c->force_fallback = true; return (int) lim; }
+    if (v < -lim) { c->force_fallback = true; return (int) -lim; }
+    return (int) v;
+  };
+  const int match = clamp(s->match, 32767);
+  const int mism = clamp(s->mismatch, 32767);
+  const int64_t raw[12] = {s->gap_open_query_left, s->gap_open_target_left, s->gap_open_query_interior,
+                           s->gap_open_target_interior, s->gap_open_query_right, s->gap_open_target_right,
+                           s->gap_ext_query_left, s->gap_ext_target_left, s->gap_ext_query_interior,
+                           s->gap_ext_target_interior, s->gap_ext_query_right, s->gap_ext_target_right};
+  for (int k = 0; k < 12; ++k) c->pen[k] = clamp(raw[k], 6553);
+  const int goql = c->pen[0], gotl = c->pen[1], goqi = c->pen[2], goti = c->pen[3], goqr = c->pen[4], gotr = c->pen[5];
+  const int geql = c->pen[6], getl = c->pen[7], geqi = c->pen[8], geti = c->pen[9], geqr = c->pen[10], getr = c->pen[11];
+
+  auto pk = [](int v) -> uint32_t { uint32_t x = (uint32_t) v & 0xffffu; return x | (x << 16); };
+  VsxDevParams & P = c->P;
+  P.match_pk = pk(match);
+  P.qrq_i_pk = pk(goqi + geqi); P.rq_i_pk = pk(geqi);
+  P.qrq_r_pk = pk(goqr + geqr); P.rq_r_pk = pk(geqr);
+  P.qrt_i = goti + geti; P.rt_i = geti;
+  P.qrt_r = gotr + getr; P.rt_r = getr;
+  P.match = match; P.mismatch = mism;
+  P.n_mismatch = s->n_mismatch ? 1 : 0;
+  int pmax = 0;
+  for (int v : {goql + geql, goqi + geqi, goqr + geqr, gotl + getl, goti + geti, gotr + getr}) pmax = std::max(pmax, v);
+  P.smin = -32768 + pmax;                                       // compute_score_min :1432-1444
+
+  // border chains, evaluated with the reference's saturating steps
+  std::vector<int16_t> htop(VSX_TABLE_LEN), hleft(VSX_TABLE_LEN), matrix(256);
+  {
+    int h = -goql - geql;                                       // :1895-1910 (plain casts, in range by the 6553 limit)
+    for (int j = 0; j < VSX_TABLE_LEN; ++j) { htop[j] = (int16_t) h; h = sat16(h - geql); }   // :2043-2051
+    int m = gotl + getl;                                        // M_QR_target_left
+    for (int i = 0; i < VSX_TABLE_LEN; ++i) { hleft[i] = (int16_t) sat16(0 - m); m = sat16(m + getl); }  // :844-859
+  }
+  auto amb = [](unsigned x) { return !(x == 1 || x == 2 || x == 4 || x == 8); };
+  for (unsigned x = 0; x < 16; ++x)                              // :1319-1342
+    for (unsigned y = 0; y < 16; ++y)
+      {
+        int v;
+        if (P.n_mismatch && (x == 15 || y == 15)) v = mism;
+        else if (amb(x) || amb(y)) v = 0;
+        else v = (x == y) ? match : mism;
+        matrix[x * 16 + y] = (int16_t) v;
+      }
+
+  auto cleanup = [&]() { if (c->stream) (void) hipStreamDestroy(c->stream); delete c; };
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = c->d_htop.alloc(VSX_TABLE_LEN)) != hipSuccess || (e = c->d_hleft.alloc(VSX_TABLE_LEN)) != hipSuccess ||
+      (e = c->d_matrix.alloc(256)) != hipSuccess ||
+      (e = hipMemcpy(c->d_htop.p, htop.data(), VSX_TABLE_LEN * 2, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(c->d_hleft.p, hleft.data(), VSX_TABLE_LEN * 2, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(c->d_matrix.p, matrix.data(), 512, hipMemcpyHostToDevice)) != hipSuccess)
+    {
+      cleanup();
+      return fail(VSX_EHIP, "vsx_create: %s", hipGetErrorString(e));
+    }
+  P.htop = c->d_htop.p;
+  P.hleft = c->d_hleft.p;
+  P.matrix = c->d_matrix.p;
+  *out = c;
+  return VSX_OK;
+}
+
+void vsx_destroy(vsx_ctx * c)
+{
+  if (!c) return;
+  (void) hipSetDevice(c->device);
+  if (c->stream) { (void) hipStreamSynchronize(c->stream); (void) hipStreamDestroy(c->stream); }
+  delete c;
+}
+
+static int seqset_common(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const void * blob, bool blob_on_device,
+                         uint64_t blob_bytes, const uint64_t * offsets, const uint32_t * lengths)
+{
+  if (!ctx || !out || (n && (!offsets || !lengths)) || (blob_bytes && !blob))
+    return fail(VSX_EINVAL, "vsx_seqset_create: null argument");
+  *out = nullptr;
+  for (uint64_t i = 0; i < n; ++i)
+    if (offsets[i] + lengths[i] > blob_bytes)
+      return fail(VSX_EINVAL, "vsx_seqset_create: sequence %" PRIu64 " exceeds the blob", i);
+  HIPCHK(hipSetDevice(ctx->device));
+  auto * s = new vsx_seqset;
+  s->ctx = ctx;
+  s->device = ctx->device;
+  s->n = n;
+  s->bytes = blob_bytes;
+  s->off.assign(offsets, offsets + n);
+  s->len.assign(lengths, lengths + n);
+  hipError_t e = hipSuccess;
+  DevBuf<uint8_t> staging;
+  const uint8_t * d_ascii = static_cast<const uint8_t *>(blob);
+  do {
+    if ((e = s->d_codes.alloc(blob_bytes + 16)) != hipSuccess) break;
+    if ((e = s->d_off.alloc(n)) != hipSuccess) break;
+    if ((e = s->d_len.alloc(n)) != hipSuccess) break;
+    if (n)
+      {
+        if ((e = hipMemcpyAsync(s->d_off.p, offsets, n * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(s->d_len.p, lengths, n * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+      }
+    if (!blob_on_device && blob_bytes)
+      {
+        if ((e = staging.alloc(blob_bytes + 16)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(staging.p, blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        d_ascii = staging.p;
+      }
+    if ((e = vsx_launch_encode(d_ascii, s->d_codes.p, blob_bytes, ctx->stream)) != hipSuccess) break;
+    e = hipStreamSynchronize(ctx->stream);
+  } while (false);
+  if (e != hipSuccess)
+    {
+      delete s;
+      return fail(e == hipErrorOutOfMemory ? VSX_ENOMEM : VSX_EHIP, "vsx_seqset_create: %s", hipGetErrorString(e));
+    }
+  *out = s;
+  return VSX_OK;
+}
+
+int vsx_seqset_create(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const char * blob, uint64_t blob_bytes,
+                      const uint64_t * offsets, const uint32_t * lengths)
+{
+  return seqset_common(ctx, out, n, blob, false, blob_bytes, offsets, lengths);
+}
+
+int vsx_seqset_create_from_device(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const void * d_blob,
+                                  uint64_t blob_bytes, const uint64_t * offsets, const uint32_t * lengths)
+{
+  return seqset_common(ctx, out, n, d_blob, true, blob_bytes, offsets, lengths);
+}
+
+void vsx_seqset_destroy(vsx_seqset * s)
+{
+  if (!s) return;
+  (void) hipSetDevice(s->device);       // the owning context may already be gone
+  delete s;
+}
+
+uint64_t vsx_seqset_count(const vsx_seqset * s) { return s ? s->n : 0; }
+
+static int ensure_impure(vsx_seqset * s)
+{
+  if (s->have_impure) return VSX_OK;
+  vsx_ctx * ctx = s->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf<uint8_t> d_flags;
+  HIPCHK(d_flags.alloc(s->n));
+  HIPCHK(vsx_launch_purity(s->d_codes.p, s->d_off.p, s->d_len.p, s->n, d_flags.p, ctx->stream));
+  s->impure.assign(s->n, 0);
+  if (s->n) HIPCHK(hipMemcpyAsync(s->impure.data(), d_flags.p, s->n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  s->have_impure = true;
+  return VSX_OK;
+}
+
+static int pick_rows(int Q)
+{
+  int cnt = 0;
+  const int * rows = vsx_supported_rows(&cnt);
+  int idx = cnt - 1;
+  for (int k = 0; k < cnt; ++k)
+    if (16 * rows[k] >= Q) { idx = k; break; }
+  // a single, partially filled pipeline position would put the last query row at r != R-1
+  while (idx > 0 && Q < rows[idx]) --idx;
+  return rows[idx];
+}
+
+int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, const vsx_seqset * targets,
+                    uint64_t n_pairs, const uint32_t * qidx, const uint32_t * tidx, uint64_t dir_budget_bytes)
+{
+  if (!ctx || !out || !queries || !targets || (n_pairs && (!qidx || !tidx)))
+    return fail(VSX_EINVAL, "vsx_plan_create: null argument");
+  *out = nullptr;
+  if (queries->ctx != ctx || targets->ctx != ctx) return fail(VSX_EINVAL, "vsx_plan_create: seqset belongs to another context");
+  if (n_pairs > 0xffffffffull / 8) return fail(VSX_EINVAL, "vsx_plan_create: too many pairs for one plan");
+  for (uint64_t k = 0; k < n_pairs; ++k)
+    if (qidx[k] >= queries->n || tidx[k] >= targets->n)
+      return fail(VSX_EINVAL, "vsx_plan_create: pair %" PRIu64 " references a sequence out of range", k);
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = ensure_impure(const_cast<vsx_seqset *>(queries));
+  if (rc != VSX_OK) return rc;
+
+  std::unique_ptr<vsx_plan> pl(new vsx_plan);
+  pl->ctx = ctx; pl->Q = queries; pl->T = targets; pl->n_pairs = n_pairs;
+  pl->host_out.assign(n_pairs, VsxPairOut {});
+  pl->is_gpu.assign(n_pairs, 0);
+
+  // ---- the reference's closed-form / sentinel cases (no DP) ----
+  std::vector<uint32_t> gpu_pairs;
+  gpu_pairs.reserve(n_pairs);
+  for (uint64_t k = 0; k < n_pairs; ++k)
+    {
+      const int64_t Q = queries->len[qidx[k]], D = targets->len[tidx[k]];
+      VsxPairOut & o = pl->host_out[k];
+      auto sentinel = [&]() { o = VsxPairOut {}; o.score = 32767; };
+      if (ctx->force_fallback) { sentinel(); continue; }              // align_simd.cpp:1463-1479
+      if (Q == 0)                                                      // :1481-1539
+        {
+          if (!fits(0, D)) { sentinel(); continue; }
+          o = VsxPairOut {};
+          o.aligned = (uint16_t) D; o.gaps = (uint16_t) D;
+          if (D > 0)
+            {
+              const int64_t a = -(int64_t) ctx->pen[1] - D * (int64_t) ctx->pen[7];
+              const int64_t b = -(int64_t) ctx->pen[5] - D * (int64_t) ctx->pen[11];
+              o.score = (int16_t) (uint16_t) (std::max(a, b) & 0xffff);   // plain narrowing cast :1515
+              pl->host_cigar.push_back(std::to_string(D) + "I");
+              pl->host_cigar_pair.push_back((uint32_t) k);
+            }
+          continue;
+        }
+      if (D == 0 || !fits(Q, D)) { sentinel(); continue; }            // :1867-1882
+      pl->is_gpu[k] = 1;
+      gpu_pairs.push_back((uint32_t) k);
+      pl->cells += (uint64_t) Q * (uint64_t) D;
+    }
+
+  // ---- group by query -> tasks of <= 8 targets, similar lengths together ----
+  std::stable_sort(gpu_pairs.begin(), gpu_pairs.end(), [&](uint32_t a, uint32_t b) { return qidx[a] < qidx[b]; });
+  struct ProtoTask { uint32_t q; int rows; int generic; uint32_t n; uint32_t pair[8]; };
+  std::vector<ProtoTask> protos;
+  for (size_t b = 0; b < gpu_pairs.size();)
+    {
+      size_t e = b;
+      const uint32_t q = qidx[gpu_pairs[b]];
+      while (e < gpu_pairs.size() && qidx[gpu_pairs[e]] == q) ++e;
+      std::stable_sort(gpu_pairs.begin() + b, gpu_pairs.begin() + e,
+                       [&](uint32_t x, uint32_t y) { return targets->len[tidx[x]] > targets->len[tidx[y]]; });
+      const int rows = pick_rows((int) queries->len[q]);
+      const int generic = queries->impure[q] ? 1 : 0;
+      for (size_t x = b; x < e; x += VSX_TASK_SLOTS)
+        {
+          ProtoTask pt {};
+          pt.q = q; pt.rows = rows; pt.generic = generic;
+          pt.n = (uint32_t) std::min<size_t>(VSX_TASK_SLOTS, e - x);
+          for (uint32_t s = 0; s < pt.n; ++s) pt.pair[s] = gpu_pairs[x + s];
+          protos.push_back(pt);
+        }
+      b = e;
+    }
+  // kernel classes together (one launch per class and chunk)
+  std::stable_sort(protos.begin(), protos.end(), [](const ProtoTask & a, const ProtoTask & b) {
+    return a.rows != b.rows ? a.rows < b.rows : a.generic < b.generic;
+  });
+
+  // ---- direction-buffer budget ----
+  if (dir_budget_bytes == 0)
+    {
+      size_t free_b = 0, total_b = 0;
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      dir_budget_bytes = std::min<uint64_t>((uint64_t) (free_b * 0.5), 64ull << 30);
+    }
+  const uint64_t budget_dwords = std::max<uint64_t>(dir_budget_bytes / 4, 1);
+
+  pl->tasks.reserve(protos.size());
+  Chunk cur;
+  auto close_chunk = [&]() {
+    if (cur.task_count) pl->chunks.push_back(cur);
+    Chunk nc;
+    nc.task_first = cur.task_first + cur.task_count;
+    nc.pair_first = cur.pair_first + cur.pair_count;
+    cur = nc;
+  };
+  for (const ProtoTask & pt : protos)
+    {
+      VsxTask t {};
+      t.qoff = queries->off[pt.q];
+      t.qlen = queries->len[pt.q];
+      t.rows = (uint32_t) pt.rows;
+      uint32_t dmax = 0;
+      for (uint32_t s = 0; s < pt.n; ++s)
+        {
+          const uint32_t ti = tidx[pt.pair[s]];
+          t.toff[s] = targets->off[ti];
+          t.tlen[s] = targets->len[ti];
+          dmax = std::max(dmax, (targets->len[ti] + 3u) & ~3u);
+        }
+      t.steps = dmax + 15;
+      const uint64_t total_lanes = (t.qlen + pt.rows - 1) / pt.rows;
+      const uint64_t nstrips = (total_lanes + 15) / 16;
+      const uint64_t nd = (uint64_t) (pt.rows + 3) / 4;
+      const uint64_t dwords = nstrips * t.steps * 64 * nd;
+      const uint64_t strip = nstrips > 1 ? 2ull * 4 * t.steps : 0;
+      if (cur.task_count && cur.dir_dwords + dwords > budget_dwords) close_chunk();
+      t.dir_off = cur.dir_dwords;
+      t.strip_off = cur.strip_elems;
+      cur.dir_dwords += dwords;
+      cur.strip_elems += strip;
+      pl->dir_bytes_total += dwords * 4;
+      const uint32_t task_index = (uint32_t) pl->tasks.size();
+      if (cur.launches.empty() || cur.launches.back().rows != pt.rows || cur.launches.back().generic != pt.generic)
+        cur.launches.push_back(Launch {pt.rows, pt.generic, task_index, 0});
+      cur.launches.back().count++;
+      for (uint32_t s = 0; s < pt.n; ++s)
+        {
+          pl->pair_slot.push_back(task_index * VSX_TASK_SLOTS + s);
+          pl->pair_ids.push_back(pt.pair[s]);
+          pl->slab_off.push_back(cur.slab_words);
+          cur.slab_words += (uint64_t) t.qlen + t.tlen[s] + 1;
+          cur.pair_count++;
+        }
+      cur.task_count++;
+      pl->tasks.push_back(t);
+    }
+  close_chunk();
+
+  // ---- device buffers ----
+  uint64_t max_dir = 1, max_strip = 1, max_slab = 1, worst_runs = 0;
+  for (const Chunk & c : pl->chunks)
+    {
+      max_dir = std::max(max_dir, c.dir_dwords);
+      max_strip = std::max(max_strip, c.strip_elems);
+      max_slab = std::max(max_slab, c.slab_words);
+      worst_runs += c.slab_words;
+    }
+  const size_t ngp = pl->pair_ids.size();
+  pl->runs_capacity = std::min<uint64_t>(worst_runs, std::max<uint64_t>(16ull << 20, 48ull * ngp)) + 1;
+  HIPCHK(pl->d_tasks.alloc(pl->tasks.size()));
+  HIPCHK(pl->d_pair_slot.alloc(ngp));
+  HIPCHK(pl->d_pair_ids.alloc(ngp));
+  HIPCHK(pl->d_slab_off.alloc(ngp));
+  HIPCHK(pl->d_slot.alloc(pl->tasks.size() * VSX_TASK_SLOTS));
+  HIPCHK(pl->d_out.alloc(n_pairs));
+  HIPCHK(pl->d_cursor.alloc(1));
+  HIPCHK(pl->d_dir.alloc(max_dir));
+  HIPCHK(pl->d_strip.alloc(max_strip));
+  HIPCHK(pl->d_slab.alloc(max_slab));
+  HIPCHK(pl->d_runs.alloc(pl->runs_capacity));
+  if (!pl->tasks.empty())
+    HIPCHK(hipMemcpyAsync(pl->d_tasks.p, pl->tasks.data(), pl->tasks.size() * sizeof(VsxTask), hipMemcpyHostToDevice, ctx->stream));
+  if (ngp)
+    {
+      HIPCHK(hipMemcpyAsync(pl->d_pair_slot.p, pl->pair_slot.data(), ngp * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(pl->d_pair_ids.p, pl->pair_ids.data(), ngp * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(pl->d_slab_off.p, pl->slab_off.data(), ngp * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+  HIPCHK(hipEventCreate(&pl->ev_begin));
+  HIPCHK(hipEventCreate(&pl->ev_end));
+  for (Chunk & c : pl->chunks)
+    {
+      HIPCHK(hipEventCreate(&c.e0));
+      HIPCHK(hipEventCreate(&c.e1));
+      HIPCHK(hipEventCreate(&c.e2));
+    }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *out = pl.release();
+  return VSX_OK;
+}
+
+int vsx_plan_run(vsx_plan * pl)
+{
+  if (!pl) return fail(VSX_EINVAL, "vsx_plan_run: null plan");
+  vsx_ctx * ctx = pl->ctx;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemsetAsync(pl->d_cursor.p, 0, sizeof(unsigned long long), st));
+  HIPCHK(hipEventRecord(pl->ev_begin, st));
+  for (Chunk & c : pl->chunks)
+    {
+      HIPCHK(hipEventRecord(c.e0, st));
+      for (const Launch & L : c.launches)
+        HIPCHK(vsx_launch_forward(L.rows, L.generic, ctx->P, pl->d_tasks.p + L.first, L.count,
+                                  pl->Q->d_codes.p, pl->T->d_codes.p, pl->d_dir.p, pl->d_strip.p,
+                                  pl->d_slot.p + (size_t) L.first * VSX_TASK_SLOTS, st));
+      HIPCHK(hipEventRecord(c.e1, st));
+      HIPCHK(vsx_launch_traceback(ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + c.pair_first, pl->d_pair_ids.p + c.pair_first,
+                                  c.pair_count, pl->Q->d_codes.p, pl->T->d_codes.p, pl->d_dir.p, pl->d_slot.p,
+                                  pl->d_slab.p, pl->d_slab_off.p + c.pair_first, pl->d_runs.p, pl->runs_capacity,
+                                  pl->d_cursor.p, pl->d_out.p, st));
+      HIPCHK(hipEventRecord(c.e2, st));
+    }
+  HIPCHK(hipEventRecord(pl->ev_end, st));
+  pl->ran = true;
+  return VSX_OK;
+}
+
+int vsx_plan_sync(vsx_plan * pl, vsx_timing * tm)
+{
+  if (!pl) return fail(VSX_EINVAL, "vsx_plan_sync: null plan");
+  if (!pl->ran) return fail(VSX_EINVAL, "vsx_plan_sync: plan has not been run");
+  HIPCHK(hipSetDevice(pl->ctx->device));
+  HIPCHK(hipEventSynchronize(pl->ev_end));
+  if (tm)
+    {
+      *tm = vsx_timing {};
+      for (Chunk & c : pl->chunks)
+        {
+          float a = 0, b = 0;
+          HIPCHK(hipEventElapsedTime(&a, c.e0, c.e1));
+          HIPCHK(hipEventElapsedTime(&b, c.e1, c.e2));
+          tm->forward_ms += a;
+          tm->traceback_ms += b;
+          tm->forward_launches += (uint32_t) c.launches.size();
+          tm->traceback_launches += 1;
+        }
+      HIPCHK(hipEventElapsedTime(&tm->total_ms, pl->ev_begin, pl->ev_end));
+      tm->cells = pl->cells;
+      tm->dir_bytes = pl->dir_bytes_total;
+    }
+  return VSX_OK;
+}
+
+static void append_cigar(std::string & s, const uint32_t * runs, uint32_t n)
+{
+  // runs are in traceback order (last column first); the text runs left to right,
+  // count omitted when 1 (pushop/finishop, align_simd.cpp:1013-1049)
+  static const char ops[4] = {'M', 'I', 'D', '?'};
+  char buf[16];
+  for (uint32_t k = n; k-- > 0;)
+    {
+      const uint32_t len = runs[k] >> 2;
+      if (len > 1) { int w = snprintf(buf, sizeof buf, "%u", len); s.append(buf, (size_t) w); }
+      s.push_back(ops[runs[k] & 3]);
+    }
+}
+
+int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
+{
+  if (!pl || !out) return fail(VSX_EINVAL, "vsx_plan_fetch: null argument");
+  std::memset(out, 0, sizeof *out);
+  vsx_ctx * ctx = pl->ctx;
+  if (!pl->ran) { int rc = vsx_plan_run(pl); if (rc != VSX_OK) return rc; }
+  int rc = vsx_plan_sync(pl, nullptr);
+  if (rc != VSX_OK) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+
+  unsigned long long used = 0;
+  HIPCHK(hipMemcpy(&used, pl->d_cursor.p, sizeof used, hipMemcpyDeviceToHost));
+  if (used > pl->runs_capacity)
+    {
+      // the dense run buffer was sized for typical alignments; size it exactly and run again
+      pl->runs_capacity = used + 1;
+      HIPCHK(pl->d_runs.alloc(pl->runs_capacity));
+      if ((rc = vsx_plan_run(pl)) != VSX_OK) return rc;
+      if ((rc = vsx_plan_sync(pl, nullptr)) != VSX_OK) return rc;
+      HIPCHK(hipMemcpy(&used, pl->d_cursor.p, sizeof used, hipMemcpyDeviceToHost));
+      if (used > pl->runs_capacity) return fail(VSX_EHIP, "vsx_plan_fetch: run buffer overflow after resize");
+    }
+
+  const uint64_t n = pl->n_pairs;
+  std::vector<VsxPairOut> dev(n);
+  std::vector<uint32_t> runs(used);
+  if (n) HIPCHK(hipMemcpy(dev.data(), pl->d_out.p, n * sizeof(VsxPairOut), hipMemcpyDeviceToHost));
+  if (used) HIPCHK(hipMemcpy(runs.data(), pl->d_runs.p, used * 4, hipMemcpyDeviceToHost));
+
+  out->n_pairs = n;
+  out->score = (int16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
+  out->aligned = (uint16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
+  out->matches = (uint16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
+  out->mismatches = (uint16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
+  out->gaps = (uint16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
+  out->cigar_off = (uint64_t *) std::malloc(std::max<uint64_t>(n, 1) * 8);
+  if (!out->score || !out->aligned || !out->matches || !out->mismatches || !out->gaps || !out->cigar_off)
+    { vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: host allocation failed"); }
+
+  std::string blob;
+  blob.reserve(used * 3 + n + 16);
+  size_t hc = 0;
+  for (uint64_t k = 0; k < n; ++k)
+    {
+      const VsxPairOut & o = pl->is_gpu[k] ? dev[k] : pl->host_out[k];
+      out->score[k] = o.score;
+      out->aligned[k] = o.aligned;
+      out->matches[k] = o.matches;
+      out->mismatches[k] = o.mismatches;
+      out->gaps[k] = o.gaps;
+      out->cigar_off[k] = blob.size();
+      if (pl->is_gpu[k]) { if (o.nruns) append_cigar(blob, runs.data() + o.run_off, o.nruns); }
+      else if (hc < pl->host_cigar_pair.size() && pl->host_cigar_pair[hc] == k) blob += pl->host_cigar[hc++];
+      blob.push_back('\0');
+    }
+  out->cigar_bytes = blob.size();
+  out->cigar_blob = (char *) std::malloc(std::max<size_t>(blob.size(), 1));
+  if (!out->cigar_blob) { vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: host allocation failed"); }
+  std::memcpy(out->cigar_blob, blob.data(), blob.size());
+  return VSX_OK;
+}
+
+void vsx_plan_destroy(vsx_plan * pl)
+{
+  if (!pl) return;
+  (void) hipSetDevice(pl->ctx->device);
+  (void) hipStreamSynchronize(pl->ctx->stream);
+  delete pl;
+}
+
+int vsx_align_pairs(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
+                    const uint32_t * qidx, const uint32_t * tidx, vsx_results * out)
+{
+  vsx_plan * pl = nullptr;
+  int rc = vsx_plan_create(ctx, &pl, queries, targets, n_pairs, qidx, tidx, 0);
+  if (rc != VSX_OK) return rc;
+  rc = vsx_plan_run(pl);
+  if (rc == VSX_OK) rc = vsx_plan_fetch(pl, out);
+  vsx_plan_destroy(pl);
+  return rc;
+}
+
+void vsx_results_free(vsx_results * r)
+{
+  if (!r) return;
+  std::free(r->score); std::free(r->aligned); std::free(r->matches); std::free(r->mismatches);
+  std::free(r->gaps); std::free(r->cigar_off); std::free(r->cigar_blob);
+  std::memset(r, 0, sizeof *r);
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// vsx_internal.h -- shared between the HIP kernels (vsx_device.hip) and the host layer (vsx_host.cpp).
+#ifndef VSX_INTERNAL_H
+#define VSX_INTERNAL_H
+
+#include <stdint.h>
+#include <hip/hip_runtime_api.h>
+
+#define VSX_TASK_SLOTS 8          // targets per wavefront task: 4 lane groups x 2 packed int16 halves
+#define VSX_GROUP_LANES 16        // lanes per group == DPP row
+#define VSX_MAX_SEQLEN_SUM 65535LL        // reference core/align_simd.cpp:89
+#define VSX_MAX_SEQLEN_PRODUCT 25000000LL // reference core/align_simd.cpp:88
+#define VSX_TABLE_LEN (65536 + 64)
+
+// Device-side constants derived from the 14 post-fixup penalties (reference search16_init,
+// core/align_simd.cpp:1282-1376 and the QR/R vectors at :1629-1649).  "pk" = the int16 value
+// replicated in both halves of a dword.
+struct VsxDevParams {
+  uint32_t match_pk;
+  uint32_t qrq_i_pk, rq_i_pk;     // gap in target ("E"/left moves): query-row penalties, interior rows
+  uint32_t qrq_r_pk, rq_r_pk;     //                                  last query row
+  int32_t  qrt_i, rt_i;           // gap in query  ("F"/up moves):  target-column penalties, interior columns
+  int32_t  qrt_r, rt_r;           //                                  last target column and padding
+  int32_t  match, mismatch;
+  int32_t  smin;                  // overflow threshold, compute_score_min (:1432-1444)
+  int32_t  n_mismatch;
+  const int16_t * htop;           // H(-1, j), j >= 0: top border chain (:1895-1910, :2043-2051)
+  const int16_t * hleft;          // H(i, -1), i >= 0: left border chain (:844-859, :881-887)
+  const int16_t * matrix;         // 16x16 score matrix S[target code][query code] (:1319-1342)
+};
+
+// One wavefront task: one query against up to 8 targets (the reference's own batch shape,
+// core/searchcore.cpp:757-778).  Lane group g (16 lanes) aligns targets 2g (low int16 halves)
+// and 2g+1 (high halves).
+struct VsxTask {
+  uint64_t qoff;                      // query codes offset
+  uint64_t toff[VSX_TASK_SLOTS];      // target codes offsets
+  uint64_t dir_off;                   // first dword of this task's direction block (chunk-relative)
+  uint64_t strip_off;                 // first uint2 of this task's strip hand-over scratch (multi-strip only)
+  uint32_t tlen[VSX_TASK_SLOTS];      // 0 = empty slot
+  uint32_t qlen;
+  uint32_t steps;                     // per strip: max padded target length + 15
+  uint32_t rows;                      // R: query rows per lane for this task's kernel variant
+  uint32_t pad;
+};
+
+// Per (task, slot) output of the DP kernel.
+struct VsxSlotOut {
+  int16_t  score;
+  uint16_t overflow;      // 1 = the reference's 16-bit overflow rule fired -> sentinel
+};
+
+// Per pair output of the traceback kernel.
+struct VsxPairOut {
+  int16_t  score;
+  uint16_t aligned, matches, mismatches, gaps;
+  uint16_t pad;
+  uint32_t nruns;
+  uint64_t run_off;       // offset into the dense run buffer (unordered allocation)
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// launchers implemented in vsx_device.hip (host code compiled by hipcc)
+hipError_t vsx_launch_encode(const uint8_t * d_ascii, uint8_t * d_codes, uint64_t nbytes, hipStream_t st);
+hipError_t vsx_launch_purity(const uint8_t * d_codes, const uint64_t * d_off, const uint32_t * d_len,
+                             uint64_t nseq, uint8_t * d_impure, hipStream_t st);
+// rows must be one of vsx_supported_rows(); generic != 0 selects the LDS score-table variant
+hipError_t vsx_launch_forward(int rows, int generic, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
+                              const uint8_t * d_qcodes, const uint8_t * d_tcodes,
+                              uint32_t * d_dir, uint2 * d_strip, VsxSlotOut * d_slot, hipStream_t st);
+hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
+                                const uint32_t * d_pair_ids, uint32_t npairs,
+                                const uint8_t * d_qcodes, const uint8_t * d_tcodes,
+                                const uint32_t * d_dir, const VsxSlotOut * d_slot,
+                                uint32_t * d_slab, const uint64_t * d_slab_off,
+                                uint32_t * d_runs, uint64_t runs_capacity, unsigned long long * d_cursor,
+                                VsxPairOut * d_out, hipStream_t st);
+const int * vsx_supported_rows(int * count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
