@@ -126,6 +126,13 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out,
 int vsx_plan_run(vsx_plan * plan);
 int vsx_plan_sync(vsx_plan * plan, vsx_timing * timing /* may be NULL */);
 int vsx_plan_fetch(vsx_plan * plan, vsx_results * out);
+/* Device-side hit records of the last run, for a multi-GPU gather without a host round trip:
+   copies n_pairs records of VSX_HIT_RECORD_BYTES each {int16 score; uint16 aligned, matches,
+   mismatches, gaps, pad; uint32 n_cigar_runs; uint64 cigar_run_offset} into device memory `d_dst`
+   (asynchronously on the plan's stream, then waits).  Records of pairs resolved on the host
+   (sentinels / empty query) are filled from the host copy. */
+#define VSX_HIT_RECORD_BYTES 24
+int vsx_plan_export_hits(vsx_plan * plan, void * d_dst, uint64_t dst_bytes);
 void vsx_plan_destroy(vsx_plan * plan);
 
 /* Convenience: create + run + fetch + destroy. */

@@ -196,6 +196,7 @@ void vsref_lma(void * ctx, const char * q, int qlen, const char * t, int tlen,
   CPU baseline: time the reference SSE2 aligner (search16 incl. its scalar
   backtrack) on a pair list grouped by query, `threads` std::threads, each with
   its own s16info_s (the reference's threading contract, core/search.cpp:128).
+  Thread creation, search16_init and one warm-up group per thread are outside the timed region.
 
   Sequences are given as one ASCII blob + offsets/lengths.  Groups: query g has
   targets tidx[goff[g] .. goff[g+1]).  Returns wall seconds; *cells receives
@@ -222,8 +223,30 @@ double vsref_time_groups(const int64_t * P, int n_mismatch,
   std::atomic<uint32_t> next {0};
   std::atomic<uint64_t> tot_cells {0};
   std::atomic<int64_t> tot_sum {0};
+  std::atomic<int> ready {0};
+  std::atomic<bool> go {false};
   bool const nmm = (n_mismatch != 0);
   Database const & cdb = db;
+
+  auto run_group = [&](s16info_s * s, uint32_t gi, std::vector<char> & qbuf, std::vector<int16_t> & sc,
+                       std::vector<uint16_t> & a, std::vector<uint16_t> & m, std::vector<uint16_t> & mm,
+                       std::vector<uint16_t> & g, std::vector<char *> & cg, uint64_t & my_cells, int64_t & my_sum) {
+    uint32_t const qi = gq[gi];
+    uint64_t const b = goff[gi];
+    uint64_t const e = goff[gi + 1];
+    auto const n = static_cast<unsigned int>(e - b);
+    qbuf.assign(qblob + qoff[qi], qblob + qoff[qi] + qlen[qi]);
+    qbuf.push_back('\0');
+    sc.resize(n); a.resize(n); m.resize(n); mm.resize(n); g.resize(n); cg.resize(n);
+    search16_qprep(s, qbuf.data(), static_cast<int>(qlen[qi]));
+    search16(s, n, tidx + b, sc.data(), a.data(), m.data(), mm.data(), g.data(), cg.data(), cdb);
+    for (unsigned int k = 0; k < n; ++k)
+      {
+        my_cells += static_cast<uint64_t>(qlen[qi]) * tlen[tidx[b + k]];
+        my_sum += sc[k] + a[k] + m[k];
+        std::free(cg[k]);
+      }
+  };
 
   auto worker = [&]() {
     s16info_s * s = make_s16(P, nmm);
@@ -233,35 +256,30 @@ double vsref_time_groups(const int64_t * P, int n_mismatch,
     std::vector<char *> cg;
     uint64_t my_cells = 0;
     int64_t my_sum = 0;
+    if (n_groups > 0)
+      {
+        /* untimed warm-up: sizes this thread's direction/cigar buffers (first-touch page faults) */
+        uint64_t wc = 0; int64_t ws = 0;
+        run_group(s, 0, qbuf, sc, a, m, mm, g, cg, wc, ws);
+      }
+    ready.fetch_add(1);
+    while (!go.load(std::memory_order_acquire)) { std::this_thread::yield(); }
     while (true)
       {
         uint32_t const gi = next.fetch_add(1);
         if (gi >= n_groups) { break; }
-        uint32_t const qi = gq[gi];
-        uint64_t const b = goff[gi];
-        uint64_t const e = goff[gi + 1];
-        auto const n = static_cast<unsigned int>(e - b);
-        qbuf.assign(qblob + qoff[qi], qblob + qoff[qi] + qlen[qi]);
-        qbuf.push_back('\0');
-        sc.resize(n); a.resize(n); m.resize(n); mm.resize(n); g.resize(n); cg.resize(n);
-        search16_qprep(s, qbuf.data(), static_cast<int>(qlen[qi]));
-        search16(s, n, tidx + b, sc.data(), a.data(), m.data(), mm.data(), g.data(),
-                 cg.data(), cdb);
-        for (unsigned int k = 0; k < n; ++k)
-          {
-            my_cells += static_cast<uint64_t>(qlen[qi]) * tlen[tidx[b + k]];
-            my_sum += sc[k] + a[k] + m[k];
-            std::free(cg[k]);
-          }
+        run_group(s, gi, qbuf, sc, a, m, mm, g, cg, my_cells, my_sum);
       }
     search16_exit(s);
     tot_cells += my_cells;
     tot_sum += my_sum;
   };
 
-  auto const t0 = std::chrono::steady_clock::now();
   std::vector<std::thread> pool;
   for (int t = 0; t < threads; ++t) { pool.emplace_back(worker); }
+  while (ready.load() < threads) { std::this_thread::yield(); }
+  auto const t0 = std::chrono::steady_clock::now();
+  go.store(true, std::memory_order_release);
   for (auto & th : pool) { th.join(); }
   auto const t1 = std::chrono::steady_clock::now();
   *cells = tot_cells.load();

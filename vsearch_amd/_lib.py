@@ -17,7 +17,7 @@ SENTINEL = 32767
 SYMBOLS = [
     "vsx_version_string", "vsx_device_count", "vsx_last_error", "vsx_create", "vsx_destroy",
     "vsx_seqset_create", "vsx_seqset_create_from_device", "vsx_seqset_destroy", "vsx_seqset_count",
-    "vsx_plan_create", "vsx_plan_run", "vsx_plan_sync", "vsx_plan_fetch", "vsx_plan_destroy",
+    "vsx_plan_create", "vsx_plan_run", "vsx_plan_sync", "vsx_plan_fetch", "vsx_plan_export_hits", "vsx_plan_destroy",
     "vsx_align_pairs", "vsx_results_free",
 ]
 
@@ -74,6 +74,7 @@ def load():
     lib.vsx_plan_run.argtypes = [vp]
     lib.vsx_plan_sync.argtypes = [vp, C.POINTER(Timing)]
     lib.vsx_plan_fetch.argtypes = [vp, C.POINTER(Results)]
+    lib.vsx_plan_export_hits.argtypes = [vp, vp, C.c_uint64]
     lib.vsx_plan_destroy.argtypes = [vp]
     lib.vsx_plan_destroy.restype = None
     lib.vsx_align_pairs.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.POINTER(Results)]

@@ -146,6 +146,10 @@ class Plan:
         finally:
             lib.vsx_results_free(C.byref(res))
 
+    def export_hits(self, device_ptr, nbytes):
+        """copy the 24-byte hit records of the last run into device memory (e.g. a torch tensor)"""
+        check(_lib.load().vsx_plan_export_hits(self.h, C.c_void_p(device_ptr), int(nbytes)), "vsx_plan_export_hits")
+
     def close(self):
         if getattr(self, "h", None) and self.h.value:
             _lib.load().vsx_plan_destroy(self.h)

@@ -136,6 +136,7 @@ struct vsx_plan {
   uint64_t runs_capacity = 0;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   bool ran = false;
+  bool host_patched = false;
 
   ~vsx_plan()
   {
@@ -668,6 +669,27 @@ int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
   out->cigar_blob = (char *) std::malloc(std::max<size_t>(blob.size(), 1));
   if (!out->cigar_blob) { vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: host allocation failed"); }
   std::memcpy(out->cigar_blob, blob.data(), blob.size());
+  return VSX_OK;
+}
+
+int vsx_plan_export_hits(vsx_plan * pl, void * d_dst, uint64_t dst_bytes)
+{
+  static_assert(sizeof(VsxPairOut) == VSX_HIT_RECORD_BYTES, "hit record layout");
+  if (!pl || !d_dst) return fail(VSX_EINVAL, "vsx_plan_export_hits: null argument");
+  if (!pl->ran) return fail(VSX_EINVAL, "vsx_plan_export_hits: plan has not been run");
+  if (dst_bytes < pl->n_pairs * sizeof(VsxPairOut)) return fail(VSX_EINVAL, "vsx_plan_export_hits: destination too small");
+  HIPCHK(hipSetDevice(pl->ctx->device));
+  hipStream_t st = pl->ctx->stream;
+  if (!pl->host_patched)
+    {
+      // pairs answered without DP live on the host: patch them into the device array once
+      for (uint64_t k = 0; k < pl->n_pairs; ++k)
+        if (!pl->is_gpu[k])
+          HIPCHK(hipMemcpyAsync(pl->d_out.p + k, &pl->host_out[k], sizeof(VsxPairOut), hipMemcpyHostToDevice, st));
+      pl->host_patched = true;
+    }
+  HIPCHK(hipMemcpyAsync(d_dst, pl->d_out.p, pl->n_pairs * sizeof(VsxPairOut), hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
   return VSX_OK;
 }
 
