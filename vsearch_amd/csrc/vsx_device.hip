@@ -66,7 +66,9 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // A/C/G/T(U) query and derives the score from an XOR of the 4-bit codes (targets may contain
 // anything: an ambiguous target symbol scores a per-column constant against unambiguous rows).
 // ---------------------------------------------------------------------------------------------
-template <int R, bool GENERIC>
+// TRACK = false drops the running H min/max (the overflow rule): the planner selects it only for tasks
+// whose score range provably stays inside (SHRT_MIN + max(go+ge), SHRT_MAX) -- see vsx_host.cpp no_overflow_possible().
+template <int R, bool GENERIC, bool TRACK>
 __global__ void __launch_bounds__(64)
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
@@ -221,8 +223,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   const u32 h1 = pmax(h0, F);
                   const u32 dL = ssub(h1, E[r]);           // sign <=> E > H      (left)
                   h2 = pmax(h1, E[r]);
-                  smn = pmin(smn, h2);
-                  smx = pmax(smx, h2);
+                  if (TRACK) { smn = pmin(smn, h2); smx = pmax(smx, h2); }
                   Hd = hprev[r];
                   hprev[r] = h2;
                   const u32 qrq = (r == R - 1) ? qrq_last : P.qrq_i_pk;
@@ -249,9 +250,12 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               diag = inH;
 
               // per-block h_min/h_max tracking incl. padded columns (:772-773, :1774-1786), gated per half
-              const u32 vm = a_pk_ashr15(sym << 6);     // bit 9 (column < padded length) -> 0xFFFF
-              hmin = pmin(hmin, a_bfi_v(vm, smn, 0x7FFF7FFFu));
-              hmax = pmax(hmax, a_bfi_v(vm, smx, 0x80008000u));
+              if (TRACK)
+                {
+                  const u32 vm = a_pk_ashr15(sym << 6);     // bit 9 (column < padded length) -> 0xFFFF
+                  hmin = pmin(hmin, a_bfi_v(vm, smn, 0x7FFF7FFFu));
+                  hmax = pmax(hmax, a_bfi_v(vm, smx, 0x80008000u));
+                }
               const u32 lm = a_pk_ashr15(sym << 7);     // bit 8 (column == D-1)
               score = a_bfi_v(lm, hl, score);            // S[(D+3)%4] of the last row (:1835-1836)
 
@@ -494,33 +498,37 @@ extern "C" hipError_t vsx_launch_purity(const uint8_t * d_codes, const uint64_t 
 }
 
 template <int R>
-static hipError_t launch_fwd(int generic, const VsxDevParams & P, const VsxTask * d_tasks, uint32_t ntasks,
+static hipError_t launch_fwd(int generic, int track, const VsxDevParams & P, const VsxTask * d_tasks, uint32_t ntasks,
                              const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
                              VsxSlotOut * slot, hipStream_t st)
 {
-  if (generic)
-    hipLaunchKernelGGL((vsx_forward_kernel<R, true>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+  if (generic && track)
+    hipLaunchKernelGGL((vsx_forward_kernel<R, true, true>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+  else if (generic)
+    hipLaunchKernelGGL((vsx_forward_kernel<R, true, false>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+  else if (track)
+    hipLaunchKernelGGL((vsx_forward_kernel<R, false, true>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
   else
-    hipLaunchKernelGGL((vsx_forward_kernel<R, false>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+    hipLaunchKernelGGL((vsx_forward_kernel<R, false, false>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
   return hipGetLastError();
 }
 
-extern "C" hipError_t vsx_launch_forward(int rows, int generic, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
+extern "C" hipError_t vsx_launch_forward(int rows, int generic, int track, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
                                          const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
                                          VsxSlotOut * slot, hipStream_t st)
 {
   if (ntasks == 0) return hipSuccess;
   switch (rows)
     {
-    case 1:  return launch_fwd<1>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 4:  return launch_fwd<4>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 8:  return launch_fwd<8>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 12: return launch_fwd<12>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 16: return launch_fwd<16>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 20: return launch_fwd<20>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 24: return launch_fwd<24>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 28: return launch_fwd<28>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 32: return launch_fwd<32>(generic, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 1:  return launch_fwd<1>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 4:  return launch_fwd<4>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 8:  return launch_fwd<8>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 12: return launch_fwd<12>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 16: return launch_fwd<16>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 20: return launch_fwd<20>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 24: return launch_fwd<24>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 28: return launch_fwd<28>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 32: return launch_fwd<32>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -98,7 +98,7 @@ struct vsx_seqset {
 
 namespace {
 
-struct Launch { int rows; int generic; uint32_t first, count; };
+struct Launch { int rows; int generic; int track; uint32_t first, count; };
 
 struct Chunk {
   uint32_t task_first = 0, task_count = 0;
@@ -349,6 +349,26 @@ static int ensure_impure(vsx_seqset * s)
   return VSX_OK;
 }
 
+// Can any H/E/F value of a (Q x D) alignment reach the 16-bit limits?  With all 12 penalties >= 0,
+//   B = max(|match|, |mismatch|, every gap extension), G = max(every gap open):
+//   every H, E, F, border and intermediate of onestep lies in [-(3G + (Q+Dp+4)B) - (G+B), min(Q,Dp)*B]
+//   (lower bound: the pure-extension chains E(i,j) >= E(i,0) - jB, F(i,j) >= F(0,j) - iB from the borders
+//   -(go + k*ge); upper bound: <= one match per diagonal step).  If that interval is inside
+//   (SHRT_MIN + max(go+ge), SHRT_MAX), no saturation occurs and the reference's overflow rule
+//   (align_simd.cpp:1432-1444, :1774-1786) can never fire, so the kernel may skip the min/max tracking.
+static bool no_overflow_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
+{
+  int64_t B = std::max<int64_t>(std::llabs(ctx->P.match), std::llabs(ctx->P.mismatch));
+  int64_t G = 0;
+  for (int k = 0; k < 12; ++k)
+    {
+      if (ctx->pen[k] < 0) return false;
+      if (k < 6) G = std::max<int64_t>(G, ctx->pen[k]); else B = std::max<int64_t>(B, ctx->pen[k]);
+    }
+  const int64_t Dp = (D + 3) & ~3ll;
+  return 4 * G + (Q + Dp + 16) * B < 32000;
+}
+
 static int pick_rows(int Q)
 {
   int cnt = 0;
@@ -413,7 +433,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
 
   // ---- group by query -> tasks of <= 8 targets, similar lengths together ----
   std::stable_sort(gpu_pairs.begin(), gpu_pairs.end(), [&](uint32_t a, uint32_t b) { return qidx[a] < qidx[b]; });
-  struct ProtoTask { uint32_t q; int rows; int generic; uint32_t n; uint32_t pair[8]; };
+  struct ProtoTask { uint32_t q; int rows; int generic; int track; uint32_t n; uint32_t pair[8]; };
   std::vector<ProtoTask> protos;
   for (size_t b = 0; b < gpu_pairs.size();)
     {
@@ -429,14 +449,22 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
           ProtoTask pt {};
           pt.q = q; pt.rows = rows; pt.generic = generic;
           pt.n = (uint32_t) std::min<size_t>(VSX_TASK_SLOTS, e - x);
-          for (uint32_t s = 0; s < pt.n; ++s) pt.pair[s] = gpu_pairs[x + s];
+          uint32_t dmax = 0;
+          for (uint32_t s = 0; s < pt.n; ++s)
+            {
+              pt.pair[s] = gpu_pairs[x + s];
+              dmax = std::max(dmax, targets->len[tidx[pt.pair[s]]]);
+            }
+          pt.track = no_overflow_possible(ctx, queries->len[q], dmax) ? 0 : 1;
           protos.push_back(pt);
         }
       b = e;
     }
   // kernel classes together (one launch per class and chunk)
   std::stable_sort(protos.begin(), protos.end(), [](const ProtoTask & a, const ProtoTask & b) {
-    return a.rows != b.rows ? a.rows < b.rows : a.generic < b.generic;
+    if (a.rows != b.rows) return a.rows < b.rows;
+    if (a.generic != b.generic) return a.generic < b.generic;
+    return a.track < b.track;
   });
 
   // ---- direction-buffer budget ----
@@ -484,8 +512,9 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       cur.strip_elems += strip;
       pl->dir_bytes_total += dwords * 4;
       const uint32_t task_index = (uint32_t) pl->tasks.size();
-      if (cur.launches.empty() || cur.launches.back().rows != pt.rows || cur.launches.back().generic != pt.generic)
-        cur.launches.push_back(Launch {pt.rows, pt.generic, task_index, 0});
+      if (cur.launches.empty() || cur.launches.back().rows != pt.rows || cur.launches.back().generic != pt.generic ||
+          cur.launches.back().track != pt.track)
+        cur.launches.push_back(Launch {pt.rows, pt.generic, pt.track, task_index, 0});
       cur.launches.back().count++;
       for (uint32_t s = 0; s < pt.n; ++s)
         {
@@ -555,7 +584,7 @@ int vsx_plan_run(vsx_plan * pl)
     {
       HIPCHK(hipEventRecord(c.e0, st));
       for (const Launch & L : c.launches)
-        HIPCHK(vsx_launch_forward(L.rows, L.generic, ctx->P, pl->d_tasks.p + L.first, L.count,
+        HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->P, pl->d_tasks.p + L.first, L.count,
                                   pl->Q->d_codes.p, pl->T->d_codes.p, pl->d_dir.p, pl->d_strip.p,
                                   pl->d_slot.p + (size_t) L.first * VSX_TASK_SLOTS, st));
       HIPCHK(hipEventRecord(c.e1, st));

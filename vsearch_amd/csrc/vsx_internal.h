@@ -66,8 +66,9 @@ extern "C" {
 hipError_t vsx_launch_encode(const uint8_t * d_ascii, uint8_t * d_codes, uint64_t nbytes, hipStream_t st);
 hipError_t vsx_launch_purity(const uint8_t * d_codes, const uint64_t * d_off, const uint32_t * d_len,
                              uint64_t nseq, uint8_t * d_impure, hipStream_t st);
-// rows must be one of vsx_supported_rows(); generic != 0 selects the LDS score-table variant
-hipError_t vsx_launch_forward(int rows, int generic, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
+// rows must be one of vsx_supported_rows(); generic != 0 selects the LDS score-table variant;
+// track == 0 selects the variant without overflow (H min/max) tracking
+hipError_t vsx_launch_forward(int rows, int generic, int track, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
                               const uint8_t * d_qcodes, const uint8_t * d_tcodes,
                               uint32_t * d_dir, uint2 * d_strip, VsxSlotOut * d_slot, hipStream_t st);
 hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
