@@ -14,7 +14,7 @@
 //     same DPP pipeline; lane 0 is fed from a 16-column block that rotates with row_ror:15;
 //   * the 4 direction bits per cell are the SIGN bits of four saturating subtractions
 //     (a > b  <=>  ssub(b, a) < 0, exact under saturation), funnelled into 16-bit fields with
-//     v_lshrrev_b32 + v_bfi_b32; each lane stores R/4 dwords per step, coalesced by [step][lane];
+//     v_lshrrev_b32 + v_bfi_b32; each lane stores R/4 dwords per step, laid out [4-step block][lane][step];
 //   * no MFMA: this is a max-plus recurrence on int16, bound by VALU issue.
 //
 // A second kernel walks the stored direction bits (one lane per pair) and emits the alignment
@@ -259,7 +259,10 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               const u32 lm = a_pk_ashr15(sym << 7);     // bit 8 (column == D-1)
               score = a_bfi_v(lm, hl, score);            // S[(D+3)%4] of the last row (:1835-1836)
 
-              u32 * dp = dir + T.dir_off + ((size_t) ((size_t) s * steps + t) * 64 + lane) * ND;
+              // [4-step block][lane][step in block][ND]: a lane's 4 consecutive steps share one 64 B line
+              // (4x fewer lines for the traceback walk) while a wave-step still lands in one 4 KB window
+              const size_t gt = (size_t) s * steps + t;
+              u32 * dp = dir + T.dir_off + (((gt >> 2) * 64 + lane) * 4 + (gt & 3)) * ND;
               if (ND == 4) *reinterpret_cast<uint4 *>(dp) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
               else if (ND == 2) *reinterpret_cast<uint2 *>(dp) = make_uint2(dw[0], dw[1]);
               else
@@ -369,7 +372,8 @@ vsx_traceback_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
     {
       const int s = L >> 4, l = L & 15;
       const size_t t = (size_t) j + (size_t) l;
-      const u32 w = dir[T.dir_off + ((size_t) s * steps + t) * 64 * ND + (size_t) (g * 16 + l) * ND + (size_t) (r >> 2)];
+      const size_t gt = (size_t) s * steps + t;
+      const u32 w = dir[T.dir_off + (((gt >> 2) * 64 + (size_t) (g * 16 + l)) * 4 + (gt & 3)) * ND + (size_t) (r >> 2)];
       const u32 hw = hi ? (w >> 16) : (w & 0xffffu);
       int rid = R - 4 * (r >> 2);                          // every position funnels all R rows (dummy rows incl.)
       if (rid > 4) rid = 4;                                // rows sharing this dword

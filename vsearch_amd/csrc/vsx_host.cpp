@@ -74,7 +74,8 @@ struct DevBuf {
 
 struct vsx_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // DP kernels, copies
+  hipStream_t stream2 = nullptr;     // traceback kernels (overlap with the next chunk's DP)
   vsx_scoring sc {};
   bool force_fallback = false;      // a score/penalty left the 16-bit range: every pair -> sentinel
   int pen[12] {};                   // clamped CELL penalties: go_q_l, go_t_l, go_q_i, go_t_i, go_q_r, go_t_r, ge_*
@@ -105,7 +106,7 @@ struct Chunk {
   uint32_t pair_first = 0, pair_count = 0;      // into the gpu-pair arrays
   std::vector<Launch> launches;
   uint64_t dir_dwords = 0, strip_elems = 0, slab_words = 0;
-  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e1b = nullptr, e2 = nullptr;   // DP begin/end (stream), traceback begin/end (stream2)
 };
 
 }  // namespace
@@ -127,7 +128,7 @@ struct vsx_plan {
   uint64_t cells = 0, dir_bytes_total = 0;
 
   DevBuf<VsxTask> d_tasks;
-  DevBuf<uint32_t> d_pair_slot, d_pair_ids, d_dir, d_slab, d_runs;
+  DevBuf<uint32_t> d_pair_slot, d_pair_ids, d_dir[2], d_slab, d_runs;   // two direction buffers: chunk k uses k & 1
   DevBuf<uint64_t> d_slab_off;
   DevBuf<uint2> d_strip;
   DevBuf<VsxSlotOut> d_slot;
@@ -144,6 +145,7 @@ struct vsx_plan {
       {
         if (c.e0) (void) hipEventDestroy(c.e0);
         if (c.e1) (void) hipEventDestroy(c.e1);
+        if (c.e1b) (void) hipEventDestroy(c.e1b);
         if (c.e2) (void) hipEventDestroy(c.e2);
       }
     if (ev_begin) (void) hipEventDestroy(ev_begin);
@@ -239,9 +241,14 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
         matrix[x * 16 + y] = (int16_t) v;
       }
 
-  auto cleanup = [&]() { if (c->stream) (void) hipStreamDestroy(c->stream); delete c; };
+  auto cleanup = [&]() {
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    if (c->stream2) (void) hipStreamDestroy(c->stream2);
+    delete c;
+  };
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
       (e = c->d_htop.alloc(VSX_TABLE_LEN)) != hipSuccess || (e = c->d_hleft.alloc(VSX_TABLE_LEN)) != hipSuccess ||
       (e = c->d_matrix.alloc(256)) != hipSuccess ||
       (e = hipMemcpy(c->d_htop.p, htop.data(), VSX_TABLE_LEN * 2, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -263,6 +270,7 @@ void vsx_destroy(vsx_ctx * c)
   if (!c) return;
   (void) hipSetDevice(c->device);
   if (c->stream) { (void) hipStreamSynchronize(c->stream); (void) hipStreamDestroy(c->stream); }
+  if (c->stream2) { (void) hipStreamSynchronize(c->stream2); (void) hipStreamDestroy(c->stream2); }
   delete c;
 }
 
@@ -472,7 +480,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
     {
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
-      dir_budget_bytes = std::min<uint64_t>((uint64_t) (free_b * 0.5), 64ull << 30);
+      // per buffer; two buffers are kept so the traceback of chunk k overlaps the DP of chunk k+1
+      dir_budget_bytes = std::min<uint64_t>((uint64_t) (free_b * 0.2), 24ull << 30);
     }
   const uint64_t budget_dwords = std::max<uint64_t>(dir_budget_bytes / 4, 1);
 
@@ -503,7 +512,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       const uint64_t total_lanes = (t.qlen + pt.rows - 1) / pt.rows;
       const uint64_t nstrips = (total_lanes + 15) / 16;
       const uint64_t nd = (uint64_t) (pt.rows + 3) / 4;
-      const uint64_t dwords = nstrips * t.steps * 64 * nd;
+      const uint64_t dwords = ((nstrips * t.steps + 3) & ~3ull) * 64 * nd;     // [4-step block][lane][4][nd]
       const uint64_t strip = nstrips > 1 ? 2ull * 4 * t.steps : 0;
       if (cur.task_count && cur.dir_dwords + dwords > budget_dwords) close_chunk();
       t.dir_off = cur.dir_dwords;
@@ -547,7 +556,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   HIPCHK(pl->d_slot.alloc(pl->tasks.size() * VSX_TASK_SLOTS));
   HIPCHK(pl->d_out.alloc(n_pairs));
   HIPCHK(pl->d_cursor.alloc(1));
-  HIPCHK(pl->d_dir.alloc(max_dir));
+  HIPCHK(pl->d_dir[0].alloc(max_dir));
+  if (pl->chunks.size() > 1) HIPCHK(pl->d_dir[1].alloc(max_dir));
   HIPCHK(pl->d_strip.alloc(max_strip));
   HIPCHK(pl->d_slab.alloc(max_slab));
   HIPCHK(pl->d_runs.alloc(pl->runs_capacity));
@@ -565,6 +575,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
     {
       HIPCHK(hipEventCreate(&c.e0));
       HIPCHK(hipEventCreate(&c.e1));
+      HIPCHK(hipEventCreate(&c.e1b));
       HIPCHK(hipEventCreate(&c.e2));
     }
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -577,23 +588,31 @@ int vsx_plan_run(vsx_plan * pl)
   if (!pl) return fail(VSX_EINVAL, "vsx_plan_run: null plan");
   vsx_ctx * ctx = pl->ctx;
   HIPCHK(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->stream, st2 = ctx->stream2;
   HIPCHK(hipMemsetAsync(pl->d_cursor.p, 0, sizeof(unsigned long long), st));
   HIPCHK(hipEventRecord(pl->ev_begin, st));
-  for (Chunk & c : pl->chunks)
+  // DP kernels run back to back on `st`; each chunk's traceback runs on `st2` as soon as its DP is done and
+  // overlaps the next chunk's DP (VALU-bound vs HBM-latency-bound).  Chunk k owns direction buffer k & 1.
+  for (size_t k = 0; k < pl->chunks.size(); ++k)
     {
+      Chunk & c = pl->chunks[k];
+      uint32_t * dir = pl->d_dir[k & 1].p;
+      if (k >= 2) HIPCHK(hipStreamWaitEvent(st, pl->chunks[k - 2].e2, 0));      // buffer reuse
       HIPCHK(hipEventRecord(c.e0, st));
       for (const Launch & L : c.launches)
         HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->P, pl->d_tasks.p + L.first, L.count,
-                                  pl->Q->d_codes.p, pl->T->d_codes.p, pl->d_dir.p, pl->d_strip.p,
+                                  pl->Q->d_codes.p, pl->T->d_codes.p, dir, pl->d_strip.p,
                                   pl->d_slot.p + (size_t) L.first * VSX_TASK_SLOTS, st));
       HIPCHK(hipEventRecord(c.e1, st));
+      HIPCHK(hipStreamWaitEvent(st2, c.e1, 0));
+      HIPCHK(hipEventRecord(c.e1b, st2));
       HIPCHK(vsx_launch_traceback(ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + c.pair_first, pl->d_pair_ids.p + c.pair_first,
-                                  c.pair_count, pl->Q->d_codes.p, pl->T->d_codes.p, pl->d_dir.p, pl->d_slot.p,
+                                  c.pair_count, pl->Q->d_codes.p, pl->T->d_codes.p, dir, pl->d_slot.p,
                                   pl->d_slab.p, pl->d_slab_off.p + c.pair_first, pl->d_runs.p, pl->runs_capacity,
-                                  pl->d_cursor.p, pl->d_out.p, st));
-      HIPCHK(hipEventRecord(c.e2, st));
+                                  pl->d_cursor.p, pl->d_out.p, st2));
+      HIPCHK(hipEventRecord(c.e2, st2));
     }
+  if (!pl->chunks.empty()) HIPCHK(hipStreamWaitEvent(st, pl->chunks.back().e2, 0));   // st2 is in order
   HIPCHK(hipEventRecord(pl->ev_end, st));
   pl->ran = true;
   return VSX_OK;
@@ -612,7 +631,7 @@ int vsx_plan_sync(vsx_plan * pl, vsx_timing * tm)
         {
           float a = 0, b = 0;
           HIPCHK(hipEventElapsedTime(&a, c.e0, c.e1));
-          HIPCHK(hipEventElapsedTime(&b, c.e1, c.e2));
+          HIPCHK(hipEventElapsedTime(&b, c.e1b, c.e2));
           tm->forward_ms += a;
           tm->traceback_ms += b;
           tm->forward_launches += (uint32_t) c.launches.size();
@@ -727,6 +746,7 @@ void vsx_plan_destroy(vsx_plan * pl)
   if (!pl) return;
   (void) hipSetDevice(pl->ctx->device);
   (void) hipStreamSynchronize(pl->ctx->stream);
+  (void) hipStreamSynchronize(pl->ctx->stream2);
   delete pl;
 }
 
