@@ -1,0 +1,104 @@
+/*
+  vsx_search.h -- C-ABI of the candidate-batch dispatch layer of libvsx: the part of vsearch's search core
+  that decides WHICH (query, target) pairs reach the aligner and what happens to the results.
+
+  Replaces (all citations relative to the reference's src/):
+    search_onequery        core/searchcore.cpp:884-957   candidate loop, batches of MAXDELAYED = 8
+    align_delayed          core/searchcore.cpp:740-881   batch alignment + sequential accept/reject bookkeeping
+    search_acceptable_unaligned / _aligned   :541-609 / :664-737
+    align_trim             core/searchcore.cpp:343-464   terminal-gap trimming, id0..id4
+    search_joinhits / hit_compare_byid       :1028-1052 / :133-179
+    search_topscores + unique_count + Dbindex + minheap order   (host side in this phase)
+                           core/searchcore.cpp:260-340, core/unique.cpp:155-352, core/dbindex.cpp:163-255,
+                           core/minheap.cpp:82-146
+  and mirrors the reference's library entry points search_session_* / search_batch
+  (core/search.hpp:88-145): one searcher per (database, options), batches of queries in, hit lists out.
+
+  Control flow: instead of one search16 call of <= 8 targets per query, a WINDOW of queries advances in
+  lock step -- every open query contributes its next delayed batch (exactly the targets the reference's
+  align_delayed would pass to search16), all batches of the window go to the GPU as one vsx_plan, and the
+  accept/reject counters are then replayed per query in the reference's order.  The set of aligned pairs
+  and every hit field are identical to the reference's.
+*/
+#ifndef VSX_SEARCH_H
+#define VSX_SEARCH_H
+
+#include "vsx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vsx_searcher vsx_searcher;
+
+/* The Parameters fields this path reads (src/vsearch.h:224-540), with the reference's defaults after
+   vsearch_apply_defaults_fixups (src/vsearch.cc:186-278).  Fill with vsx_search_opts_default() first. */
+typedef struct vsx_search_opts {
+  double  id;               /* --id (fraction, e.g. 0.9); required                               */
+  double  weak_id;          /* --weak_id; default 10.0, clamped to id                             */
+  int64_t maxaccepts;       /* 1;  0 = all                                                        */
+  int64_t maxrejects;       /* 32; 0 = all                                                        */
+  int64_t wordlength;       /* 8   (3..15)                                                        */
+  int64_t minwordmatches;   /* -1 = table minwordmatches_defaults (core/searchcore.hpp:75-76)     */
+  int32_t iddef;            /* 2                                                                  */
+  int32_t soft_mask;        /* 0: --qmask/--dbmask none (lower case searchable); 1: soft (lower case excluded from k-mers) */
+  int64_t maxsubs, maxgaps, mincols, maxdiffs;
+  double  query_cov, target_cov, maxid, mid;
+  int32_t leftjust, rightjust;
+  double  minqt, maxqt, minsl, maxsl;
+  int64_t idprefix, idsuffix;
+  int32_t selfid;
+  int32_t threads;          /* host threads for the k-mer heuristic; 0 = all usable CPUs          */
+  int64_t window;           /* queries advanced together; 0 = default (65536)                     */
+} vsx_search_opts;
+
+void vsx_search_opts_default(vsx_search_opts * o);
+
+/* One reported hit: the fields of `struct hit` (core/searchcore.hpp:78-126) that survive search_joinhits. */
+typedef struct vsx_hit {
+  uint32_t query;           /* index into the batch                                               */
+  uint32_t target;          /* database sequence number                                           */
+  uint32_t count;           /* shared unique k-mers (candidate rank key)                          */
+  uint8_t  accepted, weak, used_fallback, pad;
+  int32_t  nwscore, nwdiff, nwgaps, nwindels, nwalignmentlength;
+  int32_t  matches, mismatches;
+  int32_t  internal_alignmentlength, internal_gaps, internal_indels;
+  int32_t  trim_q_left, trim_q_right, trim_t_left, trim_t_right;
+  int32_t  shortest, longest;
+  double   nwid, id, id0, id1, id2, id3, id4;
+  uint64_t cigar_off;       /* into vsx_hits.cigar_blob (NUL-terminated)                          */
+} vsx_hit;
+
+typedef struct vsx_hits {
+  uint64_t   n_queries;
+  uint64_t   n_hits;
+  uint64_t * first;         /* n_queries + 1: hits of query q are hit[first[q] .. first[q+1]), best first */
+  vsx_hit  * hit;
+  char     * cigar_blob;
+  uint64_t   cigar_bytes;
+  /* accounting ("exactly the pairs the reference passes to search16") */
+  uint64_t   pairs_aligned, cells_aligned, stages, sentinel_pairs;
+  double     seconds_kmer, seconds_align, seconds_total;
+} vsx_hits;
+
+/* Database + k-mer index (Database::add + Dbindex::prepare/add_all_sequences): n ASCII sequences.
+   The sequences are also mirrored in HBM (vsx_seqset) for the aligner. */
+int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opts * opts,
+                        uint64_t n, const char * blob, uint64_t blob_bytes,
+                        const uint64_t * offsets, const uint32_t * lengths);
+void vsx_searcher_destroy(vsx_searcher * s);
+
+/* search_batch (core/search.hpp:131-145), plus strand only. */
+int vsx_search_batch(vsx_searcher * s, uint64_t n_queries, const char * qblob, uint64_t qblob_bytes,
+                     const uint64_t * qoffsets, const uint32_t * qlengths, vsx_hits * out);
+void vsx_hits_free(vsx_hits * h);
+
+/* Candidate list of ONE query exactly as search_topscores + minheap_sort produce it (best first):
+   fills up to `cap` (target, count) pairs, returns the number of candidates. For tests / tooling. */
+int64_t vsx_search_candidates(vsx_searcher * s, const char * q, uint32_t qlen,
+                              uint32_t * targets, uint32_t * counts, uint64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

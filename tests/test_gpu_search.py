@@ -1,0 +1,94 @@
+"""-m gpu: the candidate-batch dispatch layer (include/vsx_search.h) against the reference CLI itself
+(oracle/_ref/vsearch_ref: every translation unit of the reference compiled in place by oracle/Makefile,
+SURVEY.md 8c level 2).  --usearch_global ... --userout is compared line for line: same hits, same order,
+same %id, alignment length, mismatches, gap opens, raw score and CIGAR."""
+import os
+import random
+import subprocess
+
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "vsearch_ref")
+FIELDS = ["query", "target", "id", "alnlen", "mism", "opens", "exts", "raw", "caln", "id0", "id1", "id2", "id3", "id4"]
+
+
+def run_reference(tmp, db, qs, extra):
+    dbf, qf, uf = os.path.join(tmp, "db.fa"), os.path.join(tmp, "q.fa"), os.path.join(tmp, "u.tsv")
+    with open(dbf, "w") as f:
+        f.write("".join(f">t{i}\n{s}\n" for i, s in enumerate(db)))
+    with open(qf, "w") as f:
+        f.write("".join(f">q{i}\n{s}\n" for i, s in enumerate(qs)))
+    cmd = [REF_BIN, "--usearch_global", qf, "--db", dbf, "--qmask", "none", "--dbmask", "none", "--threads", "1",
+           "--userout", uf, "--userfields", "+".join(FIELDS), "--quiet"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    return open(uf).read().splitlines()
+
+
+CASES = [
+    ("default_id90", dict(id=0.9), ["--id", "0.9"]),
+    ("id97_maxaccepts4", dict(id=0.97, maxaccepts=4), ["--id", "0.97", "--maxaccepts", "4"]),
+    ("id70_ma3_mr16", dict(id=0.7, maxaccepts=3, maxrejects=16), ["--id", "0.7", "--maxaccepts", "3", "--maxrejects", "16"]),
+    ("id80_all", dict(id=0.8, maxaccepts=0, maxrejects=0), ["--id", "0.8", "--maxaccepts", "0", "--maxrejects", "0"]),
+    ("iddef1_weak", dict(id=0.95, weak_id=0.8, iddef=1, maxaccepts=2), ["--id", "0.95", "--weak_id", "0.8", "--iddef", "1", "--maxaccepts", "2"]),
+    ("filters", dict(id=0.85, maxaccepts=5, maxgaps=2, maxsubs=20, mincols=100, query_cov=0.5, maxrejects=64),
+     ["--id", "0.85", "--maxaccepts", "5", "--maxgaps", "2", "--maxsubs", "20", "--mincols", "100", "--query_cov", "0.5", "--maxrejects", "64"]),
+    ("word7", dict(id=0.9, wordlength=7, maxaccepts=2), ["--id", "0.9", "--wordlength", "7", "--maxaccepts", "2"]),
+]
+
+
+@pytest.mark.parametrize("name,opts,extra", CASES, ids=[c[0] for c in CASES])
+def test_usearch_global_matches_reference_cli(gpu_required, tmp_path, name, opts, extra):
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing: run `make -C oracle ref_full` in the build container "
+                    "(it travels to the GPU box with the repo)")
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(hash(name) & 0xffff)
+    db, fam = common.family_db(rng, 25, 12, 420, div=0.06)
+    db += [common.rnd_seq(rng, rng.randint(200, 500)) for _ in range(40)]            # unrelated decoys
+    db += [common.mutate(rng, db[3], 0.02, "ACGTN") for _ in range(4)]               # N-containing relatives
+    qs, _ = common.queries_from_db(rng, db, 120, 160)
+    qs += [common.mutate(rng, db[rng.randrange(len(db))], 0.05) for _ in range(30)]  # full-length queries
+    qs += [common.rnd_seq(rng, 120), "ACGT" * 30, common.mutate(rng, db[7], 0.04, "ACGTRYN")]
+    exp = run_reference(str(tmp_path), db, qs, extra)
+    with Aligner() as al:
+        ss = SearchSession(al, db, **opts)
+        got = ss.userout(qs, fields=FIELDS)
+        stats = dict(ss.stats)
+    assert len(exp) > 50
+    assert got == exp, _first_diff(got, exp)
+    assert stats["pairs_aligned"] > 0 and stats["sentinel_pairs"] == 0
+
+
+def _first_diff(got, exp):
+    for i, (a, b) in enumerate(zip(got, exp)):
+        if a != b:
+            return f"line {i}:\n got {a}\n exp {b}"
+    return f"length {len(got)} vs {len(exp)}"
+
+
+def test_candidate_order_matches_reference_hits(gpu_required, tmp_path):
+    """with --maxaccepts 0 --maxrejects 0 --id 0 every candidate is aligned and reported: the reference's
+    reported target SET per query must equal our candidate list (search_topscores + minheap order)."""
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing")
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(11)
+    db, fam = common.family_db(rng, 8, 6, 300, div=0.1)
+    qs, _ = common.queries_from_db(rng, db, 12, 120)
+    exp = run_reference(str(tmp_path), db, qs, ["--id", "0.0", "--maxaccepts", "0", "--maxrejects", "0"])
+    per_q = {}
+    for line in exp:
+        c = line.split("\t")
+        per_q.setdefault(c[0], set()).add(c[1])
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.0, maxaccepts=0, maxrejects=0)
+        for i, q in enumerate(qs):
+            cands = ss.candidates(q)
+            assert {f"t{t}" for t, _ in cands} == per_q.get(f"q{i}", set()), i
+            assert all(cands[k][1] >= cands[k + 1][1] for k in range(len(cands) - 1))

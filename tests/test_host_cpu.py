@@ -20,7 +20,10 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "vsx.h")).read()
     declared = set(re.findall(r"\b(vsx_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-    for s in declared:
+    hdr2 = open(os.path.join(ROOT, "include", "vsx_search.h")).read()
+    declared2 = set(re.findall(r"\b(vsx_[a-z0-9_]+)\s*\(", hdr2))
+    assert declared2 == set(_lib.SEARCH_SYMBOLS), declared2 ^ set(_lib.SEARCH_SYMBOLS)
+    for s in declared | declared2:
         assert hasattr(lib, s), s
     assert b"gfx950" in lib.vsx_version_string()
 

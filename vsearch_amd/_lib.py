@@ -20,6 +20,41 @@ SYMBOLS = [
     "vsx_plan_create", "vsx_plan_run", "vsx_plan_sync", "vsx_plan_fetch", "vsx_plan_export_hits", "vsx_plan_destroy",
     "vsx_align_pairs", "vsx_results_free",
 ]
+# include/vsx_search.h
+SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
+                  "vsx_hits_free", "vsx_search_candidates"]
+
+
+class SearchOpts(C.Structure):
+    """vsx_search_opts (include/vsx_search.h): the Parameters fields the search path reads"""
+    _fields_ = [("id", C.c_double), ("weak_id", C.c_double), ("maxaccepts", C.c_int64), ("maxrejects", C.c_int64),
+                ("wordlength", C.c_int64), ("minwordmatches", C.c_int64), ("iddef", C.c_int32), ("soft_mask", C.c_int32),
+                ("maxsubs", C.c_int64), ("maxgaps", C.c_int64), ("mincols", C.c_int64), ("maxdiffs", C.c_int64),
+                ("query_cov", C.c_double), ("target_cov", C.c_double), ("maxid", C.c_double), ("mid", C.c_double),
+                ("leftjust", C.c_int32), ("rightjust", C.c_int32),
+                ("minqt", C.c_double), ("maxqt", C.c_double), ("minsl", C.c_double), ("maxsl", C.c_double),
+                ("idprefix", C.c_int64), ("idsuffix", C.c_int64), ("selfid", C.c_int32), ("threads", C.c_int32),
+                ("window", C.c_int64)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("query", C.c_uint32), ("target", C.c_uint32), ("count", C.c_uint32),
+                ("accepted", C.c_uint8), ("weak", C.c_uint8), ("used_fallback", C.c_uint8), ("pad", C.c_uint8),
+                ("nwscore", C.c_int32), ("nwdiff", C.c_int32), ("nwgaps", C.c_int32), ("nwindels", C.c_int32),
+                ("nwalignmentlength", C.c_int32), ("matches", C.c_int32), ("mismatches", C.c_int32),
+                ("internal_alignmentlength", C.c_int32), ("internal_gaps", C.c_int32), ("internal_indels", C.c_int32),
+                ("trim_q_left", C.c_int32), ("trim_q_right", C.c_int32), ("trim_t_left", C.c_int32), ("trim_t_right", C.c_int32),
+                ("shortest", C.c_int32), ("longest", C.c_int32),
+                ("nwid", C.c_double), ("id", C.c_double), ("id0", C.c_double), ("id1", C.c_double), ("id2", C.c_double),
+                ("id3", C.c_double), ("id4", C.c_double), ("cigar_off", C.c_uint64)]
+
+
+class Hits(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("n_hits", C.c_uint64), ("first", C.POINTER(C.c_uint64)),
+                ("hit", C.POINTER(Hit)), ("cigar_blob", C.POINTER(C.c_char)), ("cigar_bytes", C.c_uint64),
+                ("pairs_aligned", C.c_uint64), ("cells_aligned", C.c_uint64), ("stages", C.c_uint64),
+                ("sentinel_pairs", C.c_uint64), ("seconds_kmer", C.c_double), ("seconds_align", C.c_double),
+                ("seconds_total", C.c_double)]
 
 
 class Scoring(C.Structure):
@@ -80,6 +115,16 @@ def load():
     lib.vsx_align_pairs.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.POINTER(Results)]
     lib.vsx_results_free.argtypes = [C.POINTER(Results)]
     lib.vsx_results_free.restype = None
+    lib.vsx_search_opts_default.argtypes = [C.POINTER(SearchOpts)]
+    lib.vsx_search_opts_default.restype = None
+    lib.vsx_searcher_create.argtypes = [vp, C.POINTER(vp), C.POINTER(SearchOpts), C.c_uint64, vp, C.c_uint64, vp, vp]
+    lib.vsx_searcher_destroy.argtypes = [vp]
+    lib.vsx_searcher_destroy.restype = None
+    lib.vsx_search_batch.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, vp, C.POINTER(Hits)]
+    lib.vsx_hits_free.argtypes = [C.POINTER(Hits)]
+    lib.vsx_hits_free.restype = None
+    lib.vsx_search_candidates.argtypes = [vp, C.c_char_p, C.c_uint32, vp, vp, C.c_uint64]
+    lib.vsx_search_candidates.restype = C.c_int64
     _lib = lib
     return lib
 

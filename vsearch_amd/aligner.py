@@ -187,6 +187,7 @@ class Aligner:
     def close(self):
         if getattr(self, "h", None) and self.h.value:
             kids = list(self._children)
+            # plans first, then searchers / sequence sets
             for k in [k for k in kids if isinstance(k, Plan)] + [k for k in kids if not isinstance(k, Plan)]:
                 k.close()
             self._q = None

@@ -155,6 +155,9 @@ struct vsx_plan {
 
 extern "C" {
 
+// shared with vsx_search.cpp: one thread-local error slot for the whole library
+void vsx_internal_set_error(const char * msg) { g_err = msg ? msg : ""; }
+
 const char * vsx_version_string(void) { return "libvsx 0.1.0 (gfx950)"; }
 
 const char * vsx_last_error(void) { return g_err.c_str(); }

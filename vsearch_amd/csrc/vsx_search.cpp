@@ -1,0 +1,611 @@
+// vsx_search.cpp -- candidate-batch dispatch (include/vsx_search.h): the reference's per-query search loop
+// re-expressed as "a window of queries advances in lock step, every stage is one GPU plan".
+//
+// Restated from the reference (src/, v2.31.0) -- each function cites what it follows:
+//   unique k-mers            core/unique.cpp:155-352   (set of valid words; masked/ambiguous symbols poison w words)
+//   index                    core/dbindex.cpp:125-255  (k-mer -> targets containing it; list/bitmap split is an
+//                                                       implementation detail there, a CSR posting list here)
+//   candidate ranking        core/searchcore.cpp:260-340 + core/minheap.cpp:82-146 (count desc, length asc, seqno asc)
+//   search loop              core/searchcore.cpp:884-957 ; align_delayed :740-881 ; filters :541-609, :664-737
+//   align_trim               core/searchcore.cpp:343-464 ; hit order :133-179, :1028-1052
+#include "../../include/vsx_search.h"
+#include "vsx_internal.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cinttypes>
+#include <climits>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <sched.h>
+
+extern "C" void vsx_internal_set_error(const char * msg);
+
+namespace {
+
+int sfail(int code, const std::string & msg) { vsx_internal_set_error(msg.c_str()); return code; }
+
+double now_s()
+{
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int usable_cpus()
+{
+  cpu_set_t set;
+  int n = (sched_getaffinity(0, sizeof set, &set) == 0) ? CPU_COUNT(&set) : (int) std::thread::hardware_concurrency();
+  if (FILE * f = std::fopen("/sys/fs/cgroup/cpu.max", "r"))
+    {
+      char q[64]; long long period = 0;
+      if (std::fscanf(f, "%63s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0)
+        n = std::max(1, std::min<int>(n, (int) (std::atoll(q) / period)));
+      std::fclose(f);
+    }
+  return std::max(1, n);
+}
+
+// utils/maps.cpp: chrmap_2bit (:156-186), chrmap_mask_ambig (:208-236), chrmap_mask_lower (:239-267), chrmap_4bit
+inline unsigned map2(unsigned char c)
+{
+  switch (c) { case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': case 'U': case 'u': return 3; default: return 0; }
+}
+inline unsigned mask_ambig(unsigned char c)
+{
+  switch (c) { case 'A': case 'C': case 'G': case 'T': case 'U': case 'a': case 'c': case 'g': case 't': case 'u': return 0; default: return 1; }
+}
+inline unsigned mask_lower(unsigned char c)
+{
+  switch (c) { case 'A': case 'C': case 'G': case 'T': case 'U': return 0; default: return 1; }
+}
+inline unsigned map4(unsigned char c)
+{
+  switch (c)
+    {
+    case 'A': case 'a': return 1;  case 'B': case 'b': return 14; case 'C': case 'c': return 2;  case 'D': case 'd': return 13;
+    case 'G': case 'g': return 4;  case 'H': case 'h': return 11; case 'K': case 'k': return 12; case 'M': case 'm': return 3;
+    case 'N': case 'n': return 15; case 'R': case 'r': return 5;  case 'S': case 's': return 6;
+    case 'T': case 't': case 'U': case 'u': return 8;
+    case 'V': case 'v': return 7;  case 'W': case 'w': return 9;  case 'Y': case 'y': return 10;
+    default: return 0;
+    }
+}
+
+// seqcmp, utils/seqcmp.cpp:70-92 (4-bit codes, stops at NUL)
+int seqcmp(const char * a, const char * b, int64_t n)
+{
+  for (int64_t i = 0; i < n; ++i)
+    {
+      if (a[i] == 0 || b[i] == 0) break;
+      const unsigned x = map4((unsigned char) a[i]), y = map4((unsigned char) b[i]);
+      if (x < y) return -1;
+      if (x > y) return 1;
+    }
+  return 0;
+}
+
+// unique_count, core/unique.cpp:155-352: every distinct word of length w that overlaps no masked symbol.
+// `seen` is a 4^w-bit scratch bitmap (w < 10) that is left all-zero on return.
+void unique_kmers(const char * seq, int64_t len, int w, bool soft, std::vector<uint32_t> & out, std::vector<uint64_t> & seen)
+{
+  out.clear();
+  const uint64_t mask = (1ull << (2 * w)) - 1;
+  uint64_t bad = 0, kmer = 0;
+  int64_t s = 0;
+  const int64_t e1 = std::min<int64_t>(len, w - 1);
+  for (; s < e1; ++s)
+    {
+      const unsigned char c = (unsigned char) seq[s];
+      bad = (bad << 2) | (soft ? mask_lower(c) : mask_ambig(c));
+      kmer = (kmer << 2) | map2(c);
+    }
+  for (; s < len; ++s)
+    {
+      const unsigned char c = (unsigned char) seq[s];
+      bad = ((bad << 2) | (soft ? mask_lower(c) : mask_ambig(c))) & mask;
+      kmer = ((kmer << 2) | map2(c)) & mask;
+      if (bad == 0)
+        {
+          if (w < 10)
+            {
+              uint64_t & word = seen[kmer >> 6];
+              const uint64_t bit = 1ull << (kmer & 63);
+              if (!(word & bit)) { word |= bit; out.push_back((uint32_t) kmer); }
+            }
+          else out.push_back((uint32_t) kmer);
+        }
+    }
+  if (w < 10) { for (uint32_t k : out) seen[k >> 6] = 0; }
+  else { std::sort(out.begin(), out.end()); out.erase(std::unique(out.begin(), out.end()), out.end()); }
+}
+
+struct Cand { uint32_t target, count, length; };
+
+// minheap order (core/minheap.cpp:111-146), best first: count desc, length asc, seqno asc
+inline bool cand_better(const Cand & a, const Cand & b)
+{
+  if (a.count != b.count) return a.count > b.count;
+  if (a.length != b.length) return a.length < b.length;
+  return a.target < b.target;
+}
+
+struct Hit {
+  uint32_t target = 0, count = 0;
+  bool accepted = false, rejected = false, aligned = false, weak = false, fallback = false;
+  int nwscore = 0, nwdiff = 0, nwgaps = 0, nwindels = 0, nwalignmentlength = 0, matches = 0, mismatches = 0;
+  int internal_alignmentlength = 0, internal_gaps = 0, internal_indels = 0;
+  int trim_q_left = 0, trim_q_right = 0, trim_t_left = 0, trim_t_right = 0, trim_aln_left = 0, trim_aln_right = 0;
+  int shortest = 0, longest = 0;
+  double nwid = 0, id = 0, id0 = 0, id1 = 0, id2 = 0, id3 = 0, id4 = 0;
+  std::string cigar;
+};
+
+// align_trim, core/searchcore.cpp:343-464
+void align_trim(Hit & h, int iddef)
+{
+  h.trim_aln_left = h.trim_q_left = h.trim_t_left = 0;
+  h.trim_aln_right = h.trim_q_right = h.trim_t_right = 0;
+  const char * const a = h.cigar.c_str();
+  const char * p = a;
+  if (*p != 0)
+    {
+      long long run = 1; int scan = 0;
+      std::sscanf(p, "%lld%n", &run, &scan);
+      const char op = p[scan];
+      if (op != 'M')
+        {
+          h.trim_aln_left = 1 + scan;
+          if (op == 'D') h.trim_q_left = (int) run; else h.trim_t_left = (int) run;
+        }
+    }
+  const char * e = a + h.cigar.size();
+  if (e > a)
+    {
+      p = e - 1;
+      const char op = *p;
+      if (op != 'M')
+        {
+          while (p > a && *(p - 1) <= '9') --p;
+          long long run = 1;
+          std::sscanf(p, "%lld", &run);
+          h.trim_aln_right = (int) (e - p);
+          if (op == 'D') h.trim_q_right = (int) run; else h.trim_t_right = (int) run;
+        }
+    }
+  if (h.trim_q_left >= h.nwalignmentlength) h.trim_q_right = 0;
+  if (h.trim_t_left >= h.nwalignmentlength) h.trim_t_right = 0;
+  h.internal_alignmentlength = h.nwalignmentlength - h.trim_q_left - h.trim_t_left - h.trim_q_right - h.trim_t_right;
+  h.internal_indels = h.nwindels - h.trim_q_left - h.trim_t_left - h.trim_q_right - h.trim_t_right;
+  h.internal_gaps = h.nwgaps - ((h.trim_q_left + h.trim_t_left) > 0 ? 1 : 0) - ((h.trim_q_right + h.trim_t_right) > 0 ? 1 : 0);
+  h.id0 = h.shortest > 0 ? 100.0 * h.matches / h.shortest : 0.0;
+  h.id1 = h.nwalignmentlength > 0 ? 100.0 * h.matches / h.nwalignmentlength : 0.0;
+  h.id2 = h.internal_alignmentlength > 0 ? 100.0 * h.matches / h.internal_alignmentlength : 0.0;
+  h.id3 = std::max(0.0, 100.0 * (1.0 - (1.0 * (h.mismatches + h.nwgaps) / h.longest)));
+  h.id4 = h.nwalignmentlength > 0 ? 100.0 * h.matches / h.nwalignmentlength : 0.0;
+  switch (iddef)
+    {
+    case 0: h.id = h.id0; break;
+    case 1: h.id = h.id1; break;
+    case 2: h.id = h.id2; break;
+    case 3: h.id = h.id3; break;
+    case 4: h.id = h.id4; break;
+    default: break;
+    }
+}
+
+// hit_compare_byid_typed, core/searchcore.cpp:133-179 (negative = lhs first)
+int hit_compare_byid(const Hit & l, const Hit & r)
+{
+  if (l.rejected < r.rejected) return -1;
+  if (l.rejected > r.rejected) return +1;
+  if (l.aligned > r.aligned) return -1;
+  if (l.aligned < r.aligned) return +1;
+  if (!l.aligned) return 0;
+  if (l.id > r.id) return -1;
+  if (l.id < r.id) return +1;
+  if (l.target < r.target) return -1;
+  if (l.target > r.target) return +1;
+  return 0;
+}
+
+struct QState {
+  std::vector<Cand> cands;      // best first
+  size_t next = 0;
+  std::vector<Hit> hits;        // si->hits[0 .. hit_count)
+  int64_t accepts = 0, rejects = 0, finalized = 0;
+  int delayed = 0;
+  bool done = false;
+  uint64_t req_first = 0;       // first pair of this query's pending batch in the stage plan
+  uint32_t req_count = 0;
+};
+
+}  // namespace
+
+struct vsx_searcher {
+  vsx_ctx * ctx = nullptr;
+  vsx_search_opts o {};
+  std::vector<char> blob;
+  std::vector<uint64_t> off;
+  std::vector<uint32_t> len;
+  vsx_seqset * dbset = nullptr;
+  int w = 8;
+  std::vector<uint64_t> kstart;      // 4^w + 1
+  std::vector<uint32_t> postings;    // targets containing the k-mer, ascending
+  int64_t ma = 1, mr = 32, tophits = 0, minwordmatches = 12;
+  int threads = 1;
+};
+
+namespace {
+
+// search_topscores (core/searchcore.cpp:260-340) for one query; counts = zeroed per-thread scratch of size seqcount
+void candidates_for(const vsx_searcher & S, const char * q, int64_t qlen, std::vector<uint16_t> & counts,
+                    std::vector<uint32_t> & touched, std::vector<uint32_t> & kmers, std::vector<uint64_t> & seen,
+                    std::vector<Cand> & out)
+{
+  out.clear();
+  unique_kmers(q, qlen, S.w, S.o.soft_mask != 0, kmers, seen);
+  touched.clear();
+  for (uint32_t k : kmers)
+    for (uint64_t p = S.kstart[k]; p < S.kstart[k + 1]; ++p)
+      {
+        uint16_t & c = counts[S.postings[p]];
+        if (c == 0) touched.push_back(S.postings[p]);
+        if (c < 32767) ++c;                                     // saturates at INT16_MAX (:306-315)
+      }
+  const uint32_t minmatches = (uint32_t) std::min<int64_t>(S.minwordmatches, (int64_t) kmers.size());   // :320
+  if (minmatches == 0)
+    {
+      for (uint32_t t = 0; t < S.len.size(); ++t) out.push_back(Cand {t, counts[t], S.len[t]});
+    }
+  else
+    {
+      for (uint32_t t : touched)
+        if (counts[t] >= minmatches) out.push_back(Cand {t, counts[t], S.len[t]});
+    }
+  for (uint32_t t : touched) counts[t] = 0;
+  const size_t keep = std::min<size_t>(out.size(), (size_t) S.tophits);       // heap of `tophits` best
+  std::partial_sort(out.begin(), out.begin() + keep, out.end(), cand_better);
+  out.resize(keep);
+}
+
+// search_acceptable_unaligned, core/searchcore.cpp:541-609 (abundance filters need sizes: all 1 here)
+bool acceptable_unaligned(const vsx_searcher & S, const char * q, int64_t qlen, uint32_t target)
+{
+  const vsx_search_opts & o = S.o;
+  const char * d = S.blob.data() + S.off[target];
+  const int64_t dlen = S.len[target];
+  const double dl = (double) dlen;
+  return (qlen >= o.minqt * dl) && (qlen <= o.maxqt * dl) &&
+         (qlen < dlen ? qlen >= o.minsl * dl : dl >= o.minsl * qlen) &&
+         (qlen < dlen ? qlen <= o.maxsl * dl : dl <= o.maxsl * qlen) &&
+         ((qlen >= o.idprefix) && (dlen >= o.idprefix) && (seqcmp(q, d, o.idprefix) == 0)) &&
+         ((qlen >= o.idsuffix) && (dlen >= o.idsuffix) &&
+          (seqcmp(q + qlen - o.idsuffix, d + dlen - o.idsuffix, o.idsuffix) == 0)) &&
+         ((o.selfid == 0) || (qlen != dlen) || (seqcmp(q, d, qlen) != 0));
+}
+
+// search_acceptable_aligned, core/searchcore.cpp:664-737 (finite penalties, no unoise)
+bool acceptable_aligned(const vsx_searcher & S, int64_t qlen, Hit & h)
+{
+  const vsx_search_opts & o = S.o;
+  if ((h.id >= 100.0 * o.weak_id) && (h.mismatches <= o.maxsubs) && (h.internal_gaps <= o.maxgaps) &&
+      (h.internal_alignmentlength >= o.mincols) &&
+      ((o.leftjust == 0) || (h.trim_q_left + h.trim_t_left == 0)) &&
+      ((o.rightjust == 0) || (h.trim_q_right + h.trim_t_right == 0)) &&
+      (h.matches + h.mismatches >= o.query_cov * qlen) &&
+      (h.matches + h.mismatches >= o.target_cov * (double) S.len[h.target]) &&
+      (h.id <= 100.0 * o.maxid) &&
+      (100.0 * h.matches / (h.matches + h.mismatches) >= o.mid) &&
+      (h.mismatches + h.internal_indels <= o.maxdiffs))
+    {
+      if (h.id >= 100.0 * o.id) { h.accepted = true; h.weak = false; return true; }
+      h.rejected = true; h.weak = true; return false;
+    }
+  h.rejected = true; h.weak = false;
+  return false;
+}
+
+// The while loop of search_onequery (:915-950) up to the point where align_delayed would be called.
+// Returns true if a batch of targets must be aligned now (appended to tq/tt), false if the query is finished.
+bool advance(const vsx_searcher & S, QState & st, const char * q, int64_t qlen, uint32_t qlocal,
+             std::vector<uint32_t> & pq, std::vector<uint32_t> & pt)
+{
+  while ((st.finalized + st.delayed < S.ma + S.mr - 1) && (st.rejects < S.mr) && (st.accepts < S.ma) &&
+         (st.next < st.cands.size()))
+    {
+      const Cand & c = st.cands[st.next++];            // minheap_poplast: best remaining
+      Hit h;
+      h.target = c.target; h.count = c.count;
+      if (acceptable_unaligned(S, q, qlen, c.target)) ++st.delayed; else h.rejected = true;
+      st.hits.push_back(std::move(h));
+      if (st.delayed == 8) break;                      // MAXDELAYED
+    }
+  if (st.delayed == 0) { st.done = true; return false; }
+  st.req_first = pq.size();
+  st.req_count = 0;
+  for (size_t x = (size_t) st.finalized; x < st.hits.size(); ++x)
+    if (!st.hits[x].rejected) { pq.push_back(qlocal); pt.push_back(st.hits[x].target); ++st.req_count; }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vsx_search_opts_default(vsx_search_opts * o)
+{
+  std::memset(o, 0, sizeof *o);
+  o->id = -1.0; o->weak_id = 10.0; o->maxaccepts = 1; o->maxrejects = 32; o->wordlength = 8; o->minwordmatches = -1;
+  o->iddef = 2; o->soft_mask = 0;
+  o->maxsubs = INT_MAX; o->maxgaps = INT_MAX; o->mincols = 0; o->maxdiffs = INT_MAX;
+  o->query_cov = 0; o->target_cov = 0; o->maxid = 1.0; o->mid = 0;
+  o->minqt = 0; o->maxqt = DBL_MAX; o->minsl = 0; o->maxsl = DBL_MAX;
+  o->threads = 0; o->window = 0;
+}
+
+int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opts * opts, uint64_t n,
+                        const char * blob, uint64_t blob_bytes, const uint64_t * offsets, const uint32_t * lengths)
+{
+  if (!ctx || !out || !opts || (n && (!blob || !offsets || !lengths))) return sfail(VSX_EINVAL, "vsx_searcher_create: null argument");
+  *out = nullptr;
+  if (opts->id < 0.0 || opts->id > 1.0) return sfail(VSX_EINVAL, "vsx_searcher_create: --id must be in [0, 1]");
+  if (opts->wordlength < 3 || opts->wordlength > 15) return sfail(VSX_EINVAL, "vsx_searcher_create: wordlength must be 3..15");
+  if (opts->maxaccepts < 0 || opts->maxrejects < 0) return sfail(VSX_EINVAL, "vsx_searcher_create: negative maxaccepts/maxrejects");
+  std::unique_ptr<vsx_searcher> S(new vsx_searcher);
+  S->ctx = ctx;
+  S->o = *opts;
+  if (S->o.weak_id > S->o.id) S->o.weak_id = S->o.id;                       // vsearch.cc:206-209
+  S->w = (int) opts->wordlength;
+  static const int defaults[16] = {-1, -1, -1, 18, 17, 16, 15, 14, 12, 11, 10, 9, 8, 7, 5, 3};   // searchcore.hpp:75-76
+  S->minwordmatches = opts->minwordmatches < 0 ? defaults[S->w] : opts->minwordmatches;
+  S->blob.assign(blob, blob + blob_bytes);
+  S->blob.push_back(0);
+  S->off.assign(offsets, offsets + n);
+  S->len.assign(lengths, lengths + n);
+  for (uint64_t i = 0; i < n; ++i)
+    if (offsets[i] + lengths[i] > blob_bytes) return sfail(VSX_EINVAL, "vsx_searcher_create: sequence exceeds the blob");
+  // clamp to the database size; 0 means "all" (usearch_global.cpp:598-611)
+  const int64_t sc = (int64_t) n;
+  S->mr = (opts->maxrejects == 0 || opts->maxrejects > sc) ? sc : opts->maxrejects;
+  S->ma = (opts->maxaccepts == 0 || opts->maxaccepts > sc) ? sc : opts->maxaccepts;
+  S->tophits = std::min<int64_t>(S->mr + S->ma + 8, sc);
+  S->threads = opts->threads > 0 ? opts->threads : usable_cpus();
+
+  // Dbindex::prepare + add_all_sequences (core/dbindex.cpp:163-255): count, prefix-sum, fill
+  const uint64_t nk = 1ull << (2 * S->w);
+  S->kstart.assign(nk + 1, 0);
+  std::vector<uint64_t> seen(S->w < 10 ? (nk + 63) / 64 : 1, 0);
+  std::vector<uint32_t> km;
+  for (uint64_t i = 0; i < n; ++i)
+    {
+      unique_kmers(S->blob.data() + S->off[i], S->len[i], S->w, S->o.soft_mask != 0, km, seen);
+      for (uint32_t k : km) ++S->kstart[k + 1];
+    }
+  for (uint64_t k = 0; k < nk; ++k) S->kstart[k + 1] += S->kstart[k];
+  S->postings.resize(S->kstart[nk]);
+  std::vector<uint64_t> fill(S->kstart.begin(), S->kstart.end() - 1);
+  for (uint64_t i = 0; i < n; ++i)
+    {
+      unique_kmers(S->blob.data() + S->off[i], S->len[i], S->w, S->o.soft_mask != 0, km, seen);
+      for (uint32_t k : km) S->postings[fill[k]++] = (uint32_t) i;
+    }
+
+  int rc = vsx_seqset_create(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths);
+  if (rc != VSX_OK) return rc;
+  *out = S.release();
+  return VSX_OK;
+}
+
+void vsx_searcher_destroy(vsx_searcher * s)
+{
+  if (!s) return;
+  vsx_seqset_destroy(s->dbset);
+  delete s;
+}
+
+int64_t vsx_search_candidates(vsx_searcher * S, const char * q, uint32_t qlen, uint32_t * targets, uint32_t * counts, uint64_t cap)
+{
+  if (!S || (qlen && !q)) return -1;
+  std::vector<uint16_t> cnt(S->len.size(), 0);
+  std::vector<uint32_t> touched, km;
+  std::vector<uint64_t> seen(S->w < 10 ? ((1ull << (2 * S->w)) + 63) / 64 : 1, 0);
+  std::vector<Cand> c;
+  candidates_for(*S, q, qlen, cnt, touched, km, seen, c);
+  for (size_t i = 0; i < c.size() && i < cap; ++i) { targets[i] = c[i].target; counts[i] = c[i].count; }
+  return (int64_t) c.size();
+}
+
+int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t qbytes, const uint64_t * qoff,
+                     const uint32_t * qlen, vsx_hits * out)
+{
+  if (!S || !out || (nq && (!qblob || !qoff || !qlen))) return sfail(VSX_EINVAL, "vsx_search_batch: null argument");
+  std::memset(out, 0, sizeof *out);
+  for (uint64_t i = 0; i < nq; ++i)
+    if (qoff[i] + qlen[i] > qbytes) return sfail(VSX_EINVAL, "vsx_search_batch: query exceeds the blob");
+  const double t_begin = now_s();
+  const uint64_t window = S->o.window > 0 ? (uint64_t) S->o.window : 65536;
+  std::vector<std::vector<Hit>> kept(nq);
+  double t_kmer = 0, t_align = 0;
+  uint64_t pairs = 0, cells = 0, stages = 0, sentinels = 0;
+
+  // per-thread k-mer scratch
+  const int nth = std::max(1, S->threads);
+  struct Scratch { std::vector<uint16_t> counts; std::vector<uint32_t> touched, km; std::vector<uint64_t> seen; };
+  std::vector<Scratch> scratch((size_t) nth);
+  for (auto & sc : scratch)
+    {
+      sc.counts.assign(S->len.size(), 0);
+      sc.seen.assign(S->w < 10 ? ((1ull << (2 * S->w)) + 63) / 64 : 1, 0);
+    }
+
+  for (uint64_t w0 = 0; w0 < nq; w0 += window)
+    {
+      const uint64_t wn = std::min<uint64_t>(window, nq - w0);
+      std::vector<QState> st(wn);
+
+      // ---- k-mer heuristic for the whole window (host threads; SURVEY 8f "next #1" moves this to the GPU) ----
+      double t0 = now_s();
+      {
+        std::atomic<uint64_t> next {0};
+        auto work = [&](int tid) {
+          Scratch & sc = scratch[(size_t) tid];
+          for (;;)
+            {
+              const uint64_t k = next.fetch_add(1);
+              if (k >= wn) break;
+              candidates_for(*S, qblob + qoff[w0 + k], qlen[w0 + k], sc.counts, sc.touched, sc.km, sc.seen, st[k].cands);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto & th : pool) th.join();
+      }
+      t_kmer += now_s() - t0;
+
+      // ---- the window's queries as a device sequence set ----
+      vsx_seqset * qset = nullptr;
+      {
+        std::vector<uint64_t> lo(wn);
+        const uint64_t base = qoff[w0];
+        uint64_t hi = base;
+        for (uint64_t k = 0; k < wn; ++k) { lo[k] = qoff[w0 + k]; hi = std::max(hi, qoff[w0 + k] + qlen[w0 + k]); }
+        uint64_t mn = base;
+        for (uint64_t k = 0; k < wn; ++k) mn = std::min(mn, lo[k]);
+        for (uint64_t k = 0; k < wn; ++k) lo[k] -= mn;
+        int rc = vsx_seqset_create(S->ctx, &qset, wn, qblob + mn, hi - mn, lo.data(), qlen + w0);
+        if (rc != VSX_OK) return rc;
+      }
+
+      // ---- stages: every open query contributes its next align_delayed batch ----
+      std::vector<uint32_t> open(wn);
+      for (uint64_t k = 0; k < wn; ++k) open[k] = (uint32_t) k;
+      std::vector<uint32_t> pq, pt;
+      while (!open.empty())
+        {
+          pq.clear(); pt.clear();
+          std::vector<uint32_t> waiting;
+          for (uint32_t k : open)
+            if (advance(*S, st[k], qblob + qoff[w0 + k], qlen[w0 + k], k, pq, pt)) waiting.push_back(k);
+          if (waiting.empty()) break;
+          ++stages;
+          t0 = now_s();
+          vsx_results res;
+          int rc = vsx_align_pairs(S->ctx, qset, S->dbset, pq.size(), pq.data(), pt.data(), &res);
+          t_align += now_s() - t0;
+          if (rc != VSX_OK) { vsx_seqset_destroy(qset); return rc; }
+          pairs += pq.size();
+
+          // ---- align_delayed bookkeeping (:782-878), sequential per query, reference order ----
+          for (uint32_t k : waiting)
+            {
+              QState & q = st[k];
+              const int64_t ql = qlen[w0 + k];
+              uint64_t i = q.req_first;
+              for (size_t x = (size_t) q.finalized; x < q.hits.size(); ++x)
+                {
+                  Hit & h = q.hits[x];
+                  const bool live = (q.rejects < S->mr) && (q.accepts < S->ma);
+                  if (h.rejected) { if (live) ++q.rejects; continue; }
+                  const uint64_t r = i++;
+                  cells += (uint64_t) ql * S->len[h.target];
+                  if (!live) continue;                                   // ignored hit: stays unaligned (:785, :875-878)
+                  if (res.score[r] == VSX_SCORE_SENTINEL)
+                    {
+                      ++sentinels;
+                      vsx_results_free(&res);
+                      vsx_seqset_destroy(qset);
+                      return sfail(VSX_EINVAL, "vsx_search_batch: a pair needs the linear-memory fallback "
+                                               "(LinearMemoryAligner, searchcore.cpp:806-832), which this build does not provide yet");
+                    }
+                  const int64_t alnlen = res.aligned[r], nm = res.matches[r], nmm = res.mismatches[r];
+                  const int64_t dl = S->len[h.target];
+                  h.aligned = true;
+                  h.shortest = (int) std::min<int64_t>(ql, dl);
+                  h.longest = (int) std::max<int64_t>(ql, dl);
+                  h.cigar = res.cigar_blob + res.cigar_off[r];
+                  h.nwscore = res.score[r];
+                  h.nwdiff = (int) (alnlen - nm);
+                  h.nwgaps = res.gaps[r];
+                  h.nwindels = (int) (alnlen - nm - nmm);
+                  h.nwalignmentlength = (int) alnlen;
+                  h.nwid = 100.0 * (double) (alnlen - h.nwdiff) / (double) alnlen;
+                  h.matches = (int) (alnlen - h.nwdiff);
+                  h.mismatches = h.nwdiff - h.nwindels;
+                  align_trim(h, S->o.iddef);
+                  if (acceptable_aligned(*S, ql, h)) ++q.accepts; else ++q.rejects;
+                }
+              q.finalized = (int64_t) q.hits.size();
+              q.delayed = 0;
+            }
+          vsx_results_free(&res);
+          open.swap(waiting);
+        }
+      vsx_seqset_destroy(qset);
+
+      // ---- search_joinhits (:1028-1052): accepted | weak, ordered by hit_compare_byid ----
+      for (uint64_t k = 0; k < wn; ++k)
+        {
+          std::vector<Hit> & dst = kept[w0 + k];
+          for (Hit & h : st[k].hits) if (h.accepted || h.weak) dst.push_back(std::move(h));
+          std::sort(dst.begin(), dst.end(), [](const Hit & a, const Hit & b) { return hit_compare_byid(a, b) < 0; });
+        }
+    }
+
+  // ---- marshal ----
+  uint64_t total = 0;
+  for (auto & v : kept) total += v.size();
+  out->n_queries = nq;
+  out->n_hits = total;
+  out->first = (uint64_t *) std::malloc((nq + 1) * sizeof(uint64_t));
+  out->hit = (vsx_hit *) std::malloc(std::max<uint64_t>(total, 1) * sizeof(vsx_hit));
+  std::string blob;
+  if (!out->first || !out->hit) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "vsx_search_batch: host allocation failed"); }
+  uint64_t pos = 0;
+  for (uint64_t q = 0; q < nq; ++q)
+    {
+      out->first[q] = pos;
+      for (const Hit & h : kept[q])
+        {
+          vsx_hit & o = out->hit[pos++];
+          std::memset(&o, 0, sizeof o);
+          o.query = (uint32_t) q; o.target = h.target; o.count = h.count;
+          o.accepted = h.accepted; o.weak = h.weak; o.used_fallback = h.fallback;
+          o.nwscore = h.nwscore; o.nwdiff = h.nwdiff; o.nwgaps = h.nwgaps; o.nwindels = h.nwindels;
+          o.nwalignmentlength = h.nwalignmentlength; o.matches = h.matches; o.mismatches = h.mismatches;
+          o.internal_alignmentlength = h.internal_alignmentlength; o.internal_gaps = h.internal_gaps;
+          o.internal_indels = h.internal_indels;
+          o.trim_q_left = h.trim_q_left; o.trim_q_right = h.trim_q_right; o.trim_t_left = h.trim_t_left; o.trim_t_right = h.trim_t_right;
+          o.shortest = h.shortest; o.longest = h.longest;
+          o.nwid = h.nwid; o.id = h.id; o.id0 = h.id0; o.id1 = h.id1; o.id2 = h.id2; o.id3 = h.id3; o.id4 = h.id4;
+          o.cigar_off = blob.size();
+          blob += h.cigar;
+          blob.push_back('\0');
+        }
+    }
+  out->first[nq] = pos;
+  out->cigar_bytes = blob.size();
+  out->cigar_blob = (char *) std::malloc(std::max<size_t>(blob.size(), 1));
+  if (!out->cigar_blob) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "vsx_search_batch: host allocation failed"); }
+  std::memcpy(out->cigar_blob, blob.data(), blob.size());
+  out->pairs_aligned = pairs; out->cells_aligned = cells; out->stages = stages; out->sentinel_pairs = sentinels;
+  out->seconds_kmer = t_kmer; out->seconds_align = t_align; out->seconds_total = now_s() - t_begin;
+  return VSX_OK;
+}
+
+void vsx_hits_free(vsx_hits * h)
+{
+  if (!h) return;
+  std::free(h->first); std::free(h->hit); std::free(h->cigar_blob);
+  std::memset(h, 0, sizeof *h);
+}
+
+}  // extern "C"

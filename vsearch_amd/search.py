@@ -1,0 +1,117 @@
+"""Host-side mirror of the reference's library search API (src/core/search.hpp:88-145:
+search_session_* / search_batch) over include/vsx_search.h.
+
+    SearchSession(aligner, db_sequences, id=0.9, ...)   ~ Database + Dbindex + search_session_init
+    .search_batch(queries) -> list of per-query hit lists (best first, accepted | weak hits only)
+    .userout(queries, fields)                           ~ --userout lines of --usearch_global (for parity tests)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SearchOpts, Hits, check
+
+
+def _blob(seqs):
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    lens = np.array([len(b) for b in bs], np.uint32)
+    off = np.zeros(len(bs), np.uint64)
+    if len(bs) > 1:
+        off[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+    return b"".join(bs), off, lens
+
+
+HIT_FIELDS = [n for n, _ in _lib.Hit._fields_ if n not in ("pad", "cigar_off")]
+
+
+class SearchSession:
+    def __init__(self, aligner, db, **opts):
+        lib = _lib.load()
+        self.aligner = aligner
+        aligner._children.add(self)
+        o = SearchOpts()
+        lib.vsx_search_opts_default(C.byref(o))
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown search option {k}")
+            setattr(o, k, v)
+        self.opts = o
+        self.db = list(db)
+        blob, off, lens = _blob(self.db)
+        self._keep = (blob, off, lens)
+        self.h = C.c_void_p()
+        check(lib.vsx_searcher_create(aligner.h, C.byref(self.h), C.byref(o), len(lens),
+                                      C.cast(C.c_char_p(blob), C.c_void_p), len(blob),
+                                      off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p)),
+              "vsx_searcher_create")
+        self.stats = {}
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            _lib.load().vsx_searcher_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def candidates(self, query, cap=4096):
+        """(target, shared-kmer count) in the order search_topscores + minheap_sort hand them out"""
+        q = query.encode() if isinstance(query, str) else bytes(query)
+        t = np.zeros(cap, np.uint32)
+        c = np.zeros(cap, np.uint32)
+        n = _lib.load().vsx_search_candidates(self.h, q, len(q), t.ctypes.data_as(C.c_void_p),
+                                              c.ctypes.data_as(C.c_void_p), cap)
+        n = min(int(n), cap)
+        return list(zip(t[:n].tolist(), c[:n].tolist()))
+
+    def search_batch(self, queries):
+        lib = _lib.load()
+        blob, off, lens = _blob(queries)
+        res = Hits()
+        check(lib.vsx_search_batch(self.h, len(lens), C.cast(C.c_char_p(blob), C.c_void_p), len(blob),
+                                   off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), C.byref(res)),
+              "vsx_search_batch")
+        try:
+            cig = C.string_at(res.cigar_blob, int(res.cigar_bytes)) if res.cigar_bytes else b""
+            out = []
+            for q in range(int(res.n_queries)):
+                hs = []
+                for k in range(int(res.first[q]), int(res.first[q + 1])):
+                    h = res.hit[k]
+                    d = {n: getattr(h, n) for n in HIT_FIELDS}
+                    o = int(h.cigar_off)
+                    d["cigar"] = cig[o:cig.index(b"\0", o)].decode()
+                    hs.append(d)
+                out.append(hs)
+            self.stats = {n: getattr(res, n) for n in ("pairs_aligned", "cells_aligned", "stages", "sentinel_pairs",
+                                                        "seconds_kmer", "seconds_align", "seconds_total")}
+            return out
+        finally:
+            lib.vsx_hits_free(C.byref(res))
+
+    def userout(self, queries, qnames=None, tnames=None,
+                fields=("query", "target", "id", "alnlen", "mism", "opens", "raw", "caln")):
+        """--userout lines exactly as results_show_userout_one prints these fields (core/results.cpp:330-470)"""
+        hits = self.search_batch(queries)
+        qnames = qnames or [f"q{i}" for i in range(len(queries))]
+        tnames = tnames or [f"t{i}" for i in range(len(self.db))]
+        fmt = {
+            "query": lambda q, h: qnames[q], "target": lambda q, h: tnames[h["target"]],
+            "id": lambda q, h: "%.1f" % h["id"], "alnlen": lambda q, h: "%d" % h["internal_alignmentlength"],
+            "mism": lambda q, h: "%d" % h["mismatches"], "opens": lambda q, h: "%d" % h["internal_gaps"],
+            "exts": lambda q, h: "%d" % (h["internal_indels"] - h["internal_gaps"]),
+            "gaps": lambda q, h: "%d" % h["internal_indels"], "pairs": lambda q, h: "%d" % (h["matches"] + h["mismatches"]),
+            "pv": lambda q, h: "%d" % h["matches"], "raw": lambda q, h: "%d" % h["nwscore"], "caln": lambda q, h: h["cigar"],
+            "id0": lambda q, h: "%.1f" % h["id0"], "id1": lambda q, h: "%.1f" % h["id1"], "id2": lambda q, h: "%.1f" % h["id2"],
+            "id3": lambda q, h: "%.1f" % h["id3"], "id4": lambda q, h: "%.1f" % h["id4"],
+            "ql": lambda q, h: "%d" % len(queries[q]), "tl": lambda q, h: "%d" % len(self.db[h["target"]]),
+        }
+        lines = []
+        for q, hs in enumerate(hits):
+            for h in hs:
+                lines.append("\t".join(fmt[f](q, h) for f in fields))
+        return lines
