@@ -98,6 +98,14 @@ void vsx_hits_free(vsx_hits * h);
 int64_t vsx_search_candidates(vsx_searcher * s, const char * q, uint32_t qlen,
                               uint32_t * targets, uint32_t * counts, uint64_t cap);
 
+/* The scalar fallback the callers run on the SHRT_MAX sentinel: LinearMemoryAligner::align + alignstats
+   (core/linmemalign.cpp:694-808; call sites core/searchcore.cpp:806-832, commands/allpairs_global.cpp:447-473).
+   Host CPU, int64 arithmetic, linear memory, the reference's tie-breaks; uses the UNclamped scoring values
+   (scoring_from_options, linmemalign.cpp:99-118).  *cigar is malloc'ed. */
+int vsx_lma_align(const vsx_scoring * scoring, const char * q, uint64_t qlen, const char * t, uint64_t tlen,
+                  int64_t * score, int64_t * alnlen, int64_t * matches, int64_t * mismatches,
+                  int64_t * gaps, char ** cigar);
+
 #ifdef __cplusplus
 }
 #endif

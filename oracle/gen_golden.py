@@ -191,6 +191,25 @@ def gen_api_examples(path):
     print(f"wrote {path}: {len(search)} search rows, {len(cluster)} cluster H rows")
 
 
+def gen_lma(path, seed=77, per_scoring=40):
+    """LinearMemoryAligner::align + alignstats outputs (the callers' fallback on the SHRT_MAX sentinel)"""
+    rng = random.Random(seed)
+    cases = []
+    sets = [s for s in SCORINGS if s[0] in ("default", "distinct12", "nmismatch", "zero_terminal", "uniform10_1", "star_penalty")]
+    for name, P, nmm in sets:
+        ref = pyoracle.Reference(P, nmm)
+        for _ in range(per_scoring):
+            q, t = make_pair(rng, rng.choice(KINDS))
+            cases.append({"scoring": name, "q": q, "t": t, "exp": list(ref.lma(q, t))})
+        ref.close()
+    doc = {"generator": "oracle/gen_golden.py (reference LinearMemoryAligner via oracle/_ref/libvsref.so)",
+           "scorings": {n: {"P": list(P), "n_mismatch": nmm} for n, P, nmm in sets},
+           "fields": ["score", "alnlen", "matches", "mismatches", "gaps", "cigar"], "cases": cases}
+    with open(path, "w") as f:
+        json.dump(doc, f, separators=(",", ":"))
+    print(f"wrote {path}: {len(cases)} cases")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fuzz", type=int, default=0)
@@ -202,6 +221,7 @@ def main():
         os.makedirs(GOLD, exist_ok=True)
         gen_search16(os.path.join(GOLD, "search16_golden.json"))
         gen_api_examples(os.path.join(GOLD, "ref_api_examples.json"))
+        gen_lma(os.path.join(GOLD, "lma_golden.json"))
     if a.fuzz:
         sys.exit(1 if fuzz(a.fuzz, a.seed) else 0)
 

@@ -92,3 +92,21 @@ def test_candidate_order_matches_reference_hits(gpu_required, tmp_path):
             cands = ss.candidates(q)
             assert {f"t{t}" for t, _ in cands} == per_q.get(f"q{i}", set()), i
             assert all(cands[k][1] >= cands[k + 1][1] for k in range(len(cands) - 1))
+
+
+def test_sentinel_pairs_take_the_fallback(gpu_required, tmp_path):
+    """pairs the 16-bit aligner refuses (Q*D > 25e6 here) must come back through the linear-memory fallback
+    with the reference's hit fields (searchcore.cpp:806-832)"""
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing")
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(21)
+    anc = common.rnd_seq(rng, 9000)
+    db = [common.mutate(rng, anc, 0.03) for _ in range(3)] + [common.rnd_seq(rng, 800) for _ in range(5)]
+    qs = [common.mutate(rng, anc[1000:4200], 0.02), common.mutate(rng, db[4], 0.05)]
+    exp = run_reference(str(tmp_path), db, qs, ["--id", "0.8", "--maxaccepts", "3"])
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.8, maxaccepts=3)
+        got = ss.userout(qs, fields=FIELDS)
+        assert ss.stats["sentinel_pairs"] >= 3
+    assert got == exp, _first_diff(got, exp)

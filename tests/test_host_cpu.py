@@ -116,3 +116,48 @@ def test_workload_generator_shapes():
         assert src[k] in ti[8 * k:8 * k + 8]
         assert len(set(ti[8 * k:8 * k + 8])) == 8
     assert set(np.unique(db.numpy())) <= set(b"ACGT")
+
+
+def _lma(P, nmm, q, t):
+    import ctypes as C
+    from vsearch_amd import _lib, scoring_from_tuple
+    lib = _lib.load()
+    s = scoring_from_tuple(P, nmm)
+    v = [C.c_int64() for _ in range(5)]
+    cg = C.c_void_p()
+    rc = lib.vsx_lma_align(C.byref(s), q.encode(), len(q), t.encode(), len(t), *[C.byref(x) for x in v], C.byref(cg))
+    assert rc == 0
+    out = tuple(x.value for x in v) + (C.string_at(cg).decode(),)
+    C.CDLL(None).free(cg)
+    return out
+
+
+def test_lma_fallback_matches_reference_fixtures():
+    """host restatement of LinearMemoryAligner (the callers' fallback on the SHRT_MAX sentinel)
+    against outputs of the reference's own LMA (tests/golden/lma_golden.json)"""
+    import json
+    doc = json.load(open(os.path.join(ROOT, "tests", "golden", "lma_golden.json")))
+    bad = []
+    for c in doc["cases"]:
+        sc = doc["scorings"][c["scoring"]]
+        got = _lma(sc["P"], sc["n_mismatch"], c["q"], c["t"])
+        if list(got) != c["exp"]:
+            bad.append((c["scoring"], c["q"][:20], c["t"][:20], c["exp"], got))
+    assert not bad, bad[:2]
+    assert len(doc["cases"]) >= 200
+
+
+def test_lma_vs_live_reference():
+    import random
+    from oracle import pyoracle
+    from tests import common
+    if not pyoracle.have_ref():
+        pytest.skip("oracle/_ref not built here")
+    rng = random.Random(8)
+    for P, nmm in [(pyoracle.DEFAULT_P, False), ((3, -5, 3, 7, 11, 13, 2, 5, 1, 2, 3, 4, 2, 1), True)]:
+        ref = pyoracle.Reference(P, nmm)
+        for _ in range(250):
+            a = common.rnd_seq(rng, rng.randint(0, 200), "ACGTN")
+            b = common.mutate(rng, a, 0.2) + common.rnd_seq(rng, rng.randint(0, 40))
+            assert tuple(ref.lma(a, b)) == _lma(P, nmm, a, b), (a, b)
+        ref.close()

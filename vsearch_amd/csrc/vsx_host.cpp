@@ -157,6 +157,7 @@ extern "C" {
 
 // shared with vsx_search.cpp: one thread-local error slot for the whole library
 void vsx_internal_set_error(const char * msg) { g_err = msg ? msg : ""; }
+const vsx_scoring * vsx_internal_scoring(const vsx_ctx * ctx) { return &ctx->sc; }
 
 const char * vsx_version_string(void) { return "libvsx 0.1.0 (gfx950)"; }
 

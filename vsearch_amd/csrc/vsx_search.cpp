@@ -29,6 +29,7 @@
 #include <sched.h>
 
 extern "C" void vsx_internal_set_error(const char * msg);
+extern "C" const vsx_scoring * vsx_internal_scoring(const vsx_ctx * ctx);
 
 namespace {
 
@@ -231,6 +232,7 @@ struct QState {
 
 struct vsx_searcher {
   vsx_ctx * ctx = nullptr;
+  vsx_scoring scoring {};           // unclamped values, for the linear-memory fallback
   vsx_search_opts o {};
   std::vector<char> blob;
   std::vector<uint64_t> off;
@@ -361,6 +363,7 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
   if (opts->maxaccepts < 0 || opts->maxrejects < 0) return sfail(VSX_EINVAL, "vsx_searcher_create: negative maxaccepts/maxrejects");
   std::unique_ptr<vsx_searcher> S(new vsx_searcher);
   S->ctx = ctx;
+  S->scoring = *vsx_internal_scoring(ctx);
   S->o = *opts;
   if (S->o.weak_id > S->o.id) S->o.weak_id = S->o.id;                       // vsearch.cc:206-209
   S->w = (int) opts->wordlength;
@@ -518,23 +521,29 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
                   const uint64_t r = i++;
                   cells += (uint64_t) ql * S->len[h.target];
                   if (!live) continue;                                   // ignored hit: stays unaligned (:785, :875-878)
+                  int64_t alnlen = res.aligned[r], nm = res.matches[r], nmm = res.mismatches[r];
+                  int64_t nwscore = res.score[r], nwgaps = res.gaps[r];
+                  const int64_t dl = S->len[h.target];
                   if (res.score[r] == VSX_SCORE_SENTINEL)
                     {
+                      // the 16-bit aligner refused the pair: linear-memory aligner on the host (searchcore.cpp:806-832)
                       ++sentinels;
-                      vsx_results_free(&res);
-                      vsx_seqset_destroy(qset);
-                      return sfail(VSX_EINVAL, "vsx_search_batch: a pair needs the linear-memory fallback "
-                                               "(LinearMemoryAligner, searchcore.cpp:806-832), which this build does not provide yet");
+                      char * cg = nullptr;
+                      int lrc = vsx_lma_align(&S->scoring, qblob + qoff[w0 + k], (uint64_t) ql,
+                                              S->blob.data() + S->off[h.target], (uint64_t) dl,
+                                              &nwscore, &alnlen, &nm, &nmm, &nwgaps, &cg);
+                      if (lrc != VSX_OK) { vsx_results_free(&res); vsx_seqset_destroy(qset); return sfail(lrc, "vsx_search_batch: fallback aligner failed"); }
+                      h.cigar = cg;
+                      std::free(cg);
+                      h.fallback = true;
                     }
-                  const int64_t alnlen = res.aligned[r], nm = res.matches[r], nmm = res.mismatches[r];
-                  const int64_t dl = S->len[h.target];
+                  else h.cigar = res.cigar_blob + res.cigar_off[r];
                   h.aligned = true;
                   h.shortest = (int) std::min<int64_t>(ql, dl);
                   h.longest = (int) std::max<int64_t>(ql, dl);
-                  h.cigar = res.cigar_blob + res.cigar_off[r];
-                  h.nwscore = res.score[r];
+                  h.nwscore = (int) nwscore;
                   h.nwdiff = (int) (alnlen - nm);
-                  h.nwgaps = res.gaps[r];
+                  h.nwgaps = (int) nwgaps;
                   h.nwindels = (int) (alnlen - nm - nmm);
                   h.nwalignmentlength = (int) alnlen;
                   h.nwid = 100.0 * (double) (alnlen - h.nwdiff) / (double) alnlen;
