@@ -93,6 +93,12 @@ int vsx_search_batch(vsx_searcher * s, uint64_t n_queries, const char * qblob, u
                      const uint64_t * qoffsets, const uint32_t * qlengths, vsx_hits * out);
 void vsx_hits_free(vsx_hits * h);
 
+/* allpairs_global (commands/allpairs_global.cpp:394-527): database sequences [first, first+count) as
+   queries, each against every LATER sequence (unaligned filters applied unless acceptall); kept hits are
+   those accepted (or all with acceptall), ordered id desc, target asc.  vsx_hit.query is the database
+   sequence number.  Callers walk the database in blocks to bound the result size. */
+int vsx_allpairs_block(vsx_searcher * s, int32_t acceptall, uint64_t first, uint64_t count, vsx_hits * out);
+
 /* Candidate list of ONE query exactly as search_topscores + minheap_sort produce it (best first):
    fills up to `cap` (target, count) pairs, returns the number of candidates. For tests / tooling. */
 int64_t vsx_search_candidates(vsx_searcher * s, const char * q, uint32_t qlen,

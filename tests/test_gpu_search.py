@@ -110,3 +110,39 @@ def test_sentinel_pairs_take_the_fallback(gpu_required, tmp_path):
         got = ss.userout(qs, fields=FIELDS)
         assert ss.stats["sentinel_pairs"] >= 3
     assert got == exp, _first_diff(got, exp)
+
+
+def run_reference_allpairs(tmp, db, extra):
+    dbf, uf = os.path.join(tmp, "a.fa"), os.path.join(tmp, "ua.tsv")
+    with open(dbf, "w") as f:
+        f.write("".join(f">t{i}\n{s}\n" for i, s in enumerate(db)))
+    cmd = [REF_BIN, "--allpairs_global", dbf, "--qmask", "none", "--threads", "1",
+           "--userout", uf, "--userfields", "+".join(FIELDS), "--quiet"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    return open(uf).read().splitlines()
+
+
+@pytest.mark.parametrize("name,acceptall,opts,extra", [
+    ("id80", False, dict(id=0.8), ["--id", "0.8"]),
+    ("acceptall", True, dict(id=0.0), ["--acceptall"]),
+    ("id75_filters", False, dict(id=0.75, maxgaps=12, minsl=0.98), ["--id", "0.75", "--maxgaps", "12", "--minsl", "0.98"]),
+])
+def test_allpairs_global_matches_reference_cli(gpu_required, tmp_path, name, acceptall, opts, extra):
+    """--allpairs_global (SURVEY config 4 shape: dense all-vs-all, no k-mer heuristic)"""
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing")
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(31)
+    db, fam = common.family_db(rng, 6, 9, 400, div=0.1)
+    db += [common.rnd_seq(rng, rng.randint(100, 450)) for _ in range(6)]
+    exp = run_reference_allpairs(str(tmp_path), db, extra)
+    with Aligner() as al:
+        ss = SearchSession(al, db, **opts)
+        hits = []
+        for first in range(0, len(db), 16):            # walk the database in blocks, as a caller would
+            hits += ss.allpairs(first, min(16, len(db) - first), acceptall=acceptall)
+        names = [f"t{i}" for i in range(len(db))]
+        got = ss.userout(db, qnames=names, tnames=names, fields=FIELDS, hits=hits)
+    assert len(exp) > 10
+    assert got == exp, _first_diff(got, exp)

@@ -22,7 +22,7 @@ SYMBOLS = [
 ]
 # include/vsx_search.h
 SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
-                  "vsx_hits_free", "vsx_search_candidates", "vsx_lma_align"]
+                  "vsx_hits_free", "vsx_search_candidates", "vsx_lma_align", "vsx_allpairs_block"]
 
 
 class SearchOpts(C.Structure):
@@ -125,6 +125,7 @@ def load():
     lib.vsx_hits_free.restype = None
     lib.vsx_search_candidates.argtypes = [vp, C.c_char_p, C.c_uint32, vp, vp, C.c_uint64]
     lib.vsx_search_candidates.restype = C.c_int64
+    lib.vsx_allpairs_block.argtypes = [vp, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(Hits)]
     lib.vsx_lma_align.argtypes = [C.POINTER(Scoring), C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64] + \
         [C.POINTER(C.c_int64)] * 5 + [C.POINTER(vp)]
     _lib = lib

@@ -243,6 +243,7 @@ struct vsx_searcher {
   std::vector<uint32_t> postings;    // targets containing the k-mer, ascending
   int64_t ma = 1, mr = 32, tophits = 0, minwordmatches = 12;
   int threads = 1;
+  bool indexed = false;              // the k-mer index is built on first use (allpairs never needs it)
 };
 
 namespace {
@@ -340,6 +341,107 @@ bool advance(const vsx_searcher & S, QState & st, const char * q, int64_t qlen, 
 
 }  // namespace
 
+// Fill a hit from one alignment result (searchcore.cpp:806-857 == allpairs_global.cpp:447-508): linear-memory
+// fallback on the sentinel, derived fields, align_trim.  Returns VSX_OK or an error code.
+static int fill_hit(const vsx_searcher & S, const char * q, int64_t ql, Hit & h, const vsx_results & res, uint64_t r,
+                    uint64_t & sentinels)
+{
+  int64_t alnlen = res.aligned[r], nm = res.matches[r], nmm = res.mismatches[r];
+  int64_t nwscore = res.score[r], nwgaps = res.gaps[r];
+  const int64_t dl = S.len[h.target];
+  if (res.score[r] == VSX_SCORE_SENTINEL)
+    {
+      ++sentinels;
+      char * cg = nullptr;
+      const int rc = vsx_lma_align(&S.scoring, q, (uint64_t) ql, S.blob.data() + S.off[h.target], (uint64_t) dl,
+                                   &nwscore, &alnlen, &nm, &nmm, &nwgaps, &cg);
+      if (rc != VSX_OK) return rc;
+      h.cigar = cg;
+      std::free(cg);
+      h.fallback = true;
+    }
+  else h.cigar = res.cigar_blob + res.cigar_off[r];
+  h.aligned = true;
+  h.shortest = (int) std::min<int64_t>(ql, dl);
+  h.longest = (int) std::max<int64_t>(ql, dl);
+  h.nwscore = (int) nwscore;
+  h.nwdiff = (int) (alnlen - nm);
+  h.nwgaps = (int) nwgaps;
+  h.nwindels = (int) (alnlen - nm - nmm);
+  h.nwalignmentlength = (int) alnlen;
+  h.nwid = 100.0 * (double) (alnlen - h.nwdiff) / (double) alnlen;
+  h.matches = (int) (alnlen - h.nwdiff);
+  h.mismatches = h.nwdiff - h.nwindels;
+  align_trim(h, S.o.iddef);
+  return VSX_OK;
+}
+
+static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out)
+{
+  const uint64_t nq = kept.size();
+  uint64_t total = 0;
+  for (auto & v : kept) total += v.size();
+  out->n_queries = nq;
+  out->n_hits = total;
+  out->first = (uint64_t *) std::malloc((nq + 1) * sizeof(uint64_t));
+  out->hit = (vsx_hit *) std::malloc(std::max<uint64_t>(total, 1) * sizeof(vsx_hit));
+  std::string blob;
+  if (!out->first || !out->hit) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "host allocation failed"); }
+  uint64_t pos = 0;
+  for (uint64_t q = 0; q < nq; ++q)
+    {
+      out->first[q] = pos;
+      for (const Hit & h : kept[q])
+        {
+          vsx_hit & o = out->hit[pos++];
+          std::memset(&o, 0, sizeof o);
+          o.query = (uint32_t) q; o.target = h.target; o.count = h.count;
+          o.accepted = h.accepted; o.weak = h.weak; o.used_fallback = h.fallback;
+          o.nwscore = h.nwscore; o.nwdiff = h.nwdiff; o.nwgaps = h.nwgaps; o.nwindels = h.nwindels;
+          o.nwalignmentlength = h.nwalignmentlength; o.matches = h.matches; o.mismatches = h.mismatches;
+          o.internal_alignmentlength = h.internal_alignmentlength; o.internal_gaps = h.internal_gaps;
+          o.internal_indels = h.internal_indels;
+          o.trim_q_left = h.trim_q_left; o.trim_q_right = h.trim_q_right; o.trim_t_left = h.trim_t_left; o.trim_t_right = h.trim_t_right;
+          o.shortest = h.shortest; o.longest = h.longest;
+          o.nwid = h.nwid; o.id = h.id; o.id0 = h.id0; o.id1 = h.id1; o.id2 = h.id2; o.id3 = h.id3; o.id4 = h.id4;
+          o.cigar_off = blob.size();
+          blob += h.cigar;
+          blob.push_back('\0');
+        }
+    }
+  out->first[nq] = pos;
+  out->cigar_bytes = blob.size();
+  out->cigar_blob = (char *) std::malloc(std::max<size_t>(blob.size(), 1));
+  if (!out->cigar_blob) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "host allocation failed"); }
+  std::memcpy(out->cigar_blob, blob.data(), blob.size());
+  return VSX_OK;
+}
+
+// Dbindex::prepare + add_all_sequences (core/dbindex.cpp:163-255): count, prefix-sum, fill
+static void build_index(vsx_searcher * S)
+{
+  if (S->indexed) return;
+  const uint64_t n = S->len.size();
+  const uint64_t nk = 1ull << (2 * S->w);
+  S->kstart.assign(nk + 1, 0);
+  std::vector<uint64_t> seen(S->w < 10 ? (nk + 63) / 64 : 1, 0);
+  std::vector<uint32_t> km;
+  for (uint64_t i = 0; i < n; ++i)
+    {
+      unique_kmers(S->blob.data() + S->off[i], S->len[i], S->w, S->o.soft_mask != 0, km, seen);
+      for (uint32_t k : km) ++S->kstart[k + 1];
+    }
+  for (uint64_t k = 0; k < nk; ++k) S->kstart[k + 1] += S->kstart[k];
+  S->postings.resize(S->kstart[nk]);
+  std::vector<uint64_t> fill(S->kstart.begin(), S->kstart.end() - 1);
+  for (uint64_t i = 0; i < n; ++i)
+    {
+      unique_kmers(S->blob.data() + S->off[i], S->len[i], S->w, S->o.soft_mask != 0, km, seen);
+      for (uint32_t k : km) S->postings[fill[k]++] = (uint32_t) i;
+    }
+  S->indexed = true;
+}
+
 extern "C" {
 
 void vsx_search_opts_default(vsx_search_opts * o)
@@ -382,25 +484,6 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
   S->tophits = std::min<int64_t>(S->mr + S->ma + 8, sc);
   S->threads = opts->threads > 0 ? opts->threads : usable_cpus();
 
-  // Dbindex::prepare + add_all_sequences (core/dbindex.cpp:163-255): count, prefix-sum, fill
-  const uint64_t nk = 1ull << (2 * S->w);
-  S->kstart.assign(nk + 1, 0);
-  std::vector<uint64_t> seen(S->w < 10 ? (nk + 63) / 64 : 1, 0);
-  std::vector<uint32_t> km;
-  for (uint64_t i = 0; i < n; ++i)
-    {
-      unique_kmers(S->blob.data() + S->off[i], S->len[i], S->w, S->o.soft_mask != 0, km, seen);
-      for (uint32_t k : km) ++S->kstart[k + 1];
-    }
-  for (uint64_t k = 0; k < nk; ++k) S->kstart[k + 1] += S->kstart[k];
-  S->postings.resize(S->kstart[nk]);
-  std::vector<uint64_t> fill(S->kstart.begin(), S->kstart.end() - 1);
-  for (uint64_t i = 0; i < n; ++i)
-    {
-      unique_kmers(S->blob.data() + S->off[i], S->len[i], S->w, S->o.soft_mask != 0, km, seen);
-      for (uint32_t k : km) S->postings[fill[k]++] = (uint32_t) i;
-    }
-
   int rc = vsx_seqset_create(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths);
   if (rc != VSX_OK) return rc;
   *out = S.release();
@@ -417,6 +500,7 @@ void vsx_searcher_destroy(vsx_searcher * s)
 int64_t vsx_search_candidates(vsx_searcher * S, const char * q, uint32_t qlen, uint32_t * targets, uint32_t * counts, uint64_t cap)
 {
   if (!S || (qlen && !q)) return -1;
+  build_index(S);
   std::vector<uint16_t> cnt(S->len.size(), 0);
   std::vector<uint32_t> touched, km;
   std::vector<uint64_t> seen(S->w < 10 ? ((1ull << (2 * S->w)) + 63) / 64 : 1, 0);
@@ -434,6 +518,7 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
   for (uint64_t i = 0; i < nq; ++i)
     if (qoff[i] + qlen[i] > qbytes) return sfail(VSX_EINVAL, "vsx_search_batch: query exceeds the blob");
   const double t_begin = now_s();
+  build_index(S);
   const uint64_t window = S->o.window > 0 ? (uint64_t) S->o.window : 65536;
   std::vector<std::vector<Hit>> kept(nq);
   double t_kmer = 0, t_align = 0;
@@ -521,35 +606,10 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
                   const uint64_t r = i++;
                   cells += (uint64_t) ql * S->len[h.target];
                   if (!live) continue;                                   // ignored hit: stays unaligned (:785, :875-878)
-                  int64_t alnlen = res.aligned[r], nm = res.matches[r], nmm = res.mismatches[r];
-                  int64_t nwscore = res.score[r], nwgaps = res.gaps[r];
-                  const int64_t dl = S->len[h.target];
-                  if (res.score[r] == VSX_SCORE_SENTINEL)
-                    {
-                      // the 16-bit aligner refused the pair: linear-memory aligner on the host (searchcore.cpp:806-832)
-                      ++sentinels;
-                      char * cg = nullptr;
-                      int lrc = vsx_lma_align(&S->scoring, qblob + qoff[w0 + k], (uint64_t) ql,
-                                              S->blob.data() + S->off[h.target], (uint64_t) dl,
-                                              &nwscore, &alnlen, &nm, &nmm, &nwgaps, &cg);
-                      if (lrc != VSX_OK) { vsx_results_free(&res); vsx_seqset_destroy(qset); return sfail(lrc, "vsx_search_batch: fallback aligner failed"); }
-                      h.cigar = cg;
-                      std::free(cg);
-                      h.fallback = true;
-                    }
-                  else h.cigar = res.cigar_blob + res.cigar_off[r];
-                  h.aligned = true;
-                  h.shortest = (int) std::min<int64_t>(ql, dl);
-                  h.longest = (int) std::max<int64_t>(ql, dl);
-                  h.nwscore = (int) nwscore;
-                  h.nwdiff = (int) (alnlen - nm);
-                  h.nwgaps = (int) nwgaps;
-                  h.nwindels = (int) (alnlen - nm - nmm);
-                  h.nwalignmentlength = (int) alnlen;
-                  h.nwid = 100.0 * (double) (alnlen - h.nwdiff) / (double) alnlen;
-                  h.matches = (int) (alnlen - h.nwdiff);
-                  h.mismatches = h.nwdiff - h.nwindels;
-                  align_trim(h, S->o.iddef);
+                  {
+                    const int frc = fill_hit(*S, qblob + qoff[w0 + k], ql, h, res, r, sentinels);
+                    if (frc != VSX_OK) { vsx_results_free(&res); vsx_seqset_destroy(qset); return sfail(frc, "vsx_search_batch: fallback aligner failed"); }
+                  }
                   if (acceptable_aligned(*S, ql, h)) ++q.accepts; else ++q.rejects;
                 }
               q.finalized = (int64_t) q.hits.size();
@@ -570,43 +630,68 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
     }
 
   // ---- marshal ----
-  uint64_t total = 0;
-  for (auto & v : kept) total += v.size();
-  out->n_queries = nq;
-  out->n_hits = total;
-  out->first = (uint64_t *) std::malloc((nq + 1) * sizeof(uint64_t));
-  out->hit = (vsx_hit *) std::malloc(std::max<uint64_t>(total, 1) * sizeof(vsx_hit));
-  std::string blob;
-  if (!out->first || !out->hit) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "vsx_search_batch: host allocation failed"); }
-  uint64_t pos = 0;
-  for (uint64_t q = 0; q < nq; ++q)
-    {
-      out->first[q] = pos;
-      for (const Hit & h : kept[q])
-        {
-          vsx_hit & o = out->hit[pos++];
-          std::memset(&o, 0, sizeof o);
-          o.query = (uint32_t) q; o.target = h.target; o.count = h.count;
-          o.accepted = h.accepted; o.weak = h.weak; o.used_fallback = h.fallback;
-          o.nwscore = h.nwscore; o.nwdiff = h.nwdiff; o.nwgaps = h.nwgaps; o.nwindels = h.nwindels;
-          o.nwalignmentlength = h.nwalignmentlength; o.matches = h.matches; o.mismatches = h.mismatches;
-          o.internal_alignmentlength = h.internal_alignmentlength; o.internal_gaps = h.internal_gaps;
-          o.internal_indels = h.internal_indels;
-          o.trim_q_left = h.trim_q_left; o.trim_q_right = h.trim_q_right; o.trim_t_left = h.trim_t_left; o.trim_t_right = h.trim_t_right;
-          o.shortest = h.shortest; o.longest = h.longest;
-          o.nwid = h.nwid; o.id = h.id; o.id0 = h.id0; o.id1 = h.id1; o.id2 = h.id2; o.id3 = h.id3; o.id4 = h.id4;
-          o.cigar_off = blob.size();
-          blob += h.cigar;
-          blob.push_back('\0');
-        }
-    }
-  out->first[nq] = pos;
-  out->cigar_bytes = blob.size();
-  out->cigar_blob = (char *) std::malloc(std::max<size_t>(blob.size(), 1));
-  if (!out->cigar_blob) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "vsx_search_batch: host allocation failed"); }
-  std::memcpy(out->cigar_blob, blob.data(), blob.size());
+  {
+    const int mrc = marshal_hits(kept, out);
+    if (mrc != VSX_OK) return mrc;
+  }
   out->pairs_aligned = pairs; out->cells_aligned = cells; out->stages = stages; out->sentinel_pairs = sentinels;
   out->seconds_kmer = t_kmer; out->seconds_align = t_align; out->seconds_total = now_s() - t_begin;
+  return VSX_OK;
+}
+
+// allpairs_global (commands/allpairs_global.cpp:394-527): queries [first, first+count) of the database, each
+// against every LATER sequence that passes the unaligned filters (or all of them with acceptall); one GPU
+// plan for the whole block; hits kept if acceptall or accepted; order allpairs_hit_compare (:116-138).
+int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint64_t count, vsx_hits * out)
+{
+  if (!S || !out) return sfail(VSX_EINVAL, "vsx_allpairs_block: null argument");
+  std::memset(out, 0, sizeof *out);
+  const uint64_t n = S->len.size();
+  if (first > n || count > n - first) return sfail(VSX_EINVAL, "vsx_allpairs_block: query block out of range");
+  const double t_begin = now_s();
+  std::vector<uint32_t> pq, pt;
+  std::vector<uint64_t> qfirst(count + 1, 0);
+  for (uint64_t k = 0; k < count; ++k)
+    {
+      const uint64_t qi = first + k;
+      qfirst[k] = pq.size();
+      for (uint64_t t = qi + 1; t < n; ++t)
+        if (acceptall || acceptable_unaligned(*S, S->blob.data() + S->off[qi], S->len[qi], (uint32_t) t))
+          { pq.push_back((uint32_t) qi); pt.push_back((uint32_t) t); }
+    }
+  qfirst[count] = pq.size();
+  vsx_results res;
+  double t0 = now_s();
+  int rc = vsx_align_pairs(S->ctx, S->dbset, S->dbset, pq.size(), pq.data(), pt.data(), &res);
+  const double t_align = now_s() - t0;
+  if (rc != VSX_OK) return rc;
+  std::vector<std::vector<Hit>> kept(count);
+  uint64_t cells = 0, sentinels = 0;
+  for (uint64_t k = 0; k < count; ++k)
+    {
+      const uint64_t qi = first + k;
+      const char * q = S->blob.data() + S->off[qi];
+      const int64_t ql = S->len[qi];
+      for (uint64_t r = qfirst[k]; r < qfirst[k + 1]; ++r)
+        {
+          Hit h;
+          h.target = pt[r];
+          cells += (uint64_t) ql * S->len[h.target];
+          rc = fill_hit(*S, q, ql, h, res, r, sentinels);
+          if (rc != VSX_OK) { vsx_results_free(&res); return sfail(rc, "vsx_allpairs_block: fallback aligner failed"); }
+          if (acceptall || acceptable_aligned(*S, ql, h)) kept[k].push_back(std::move(h));
+        }
+      std::sort(kept[k].begin(), kept[k].end(), [](const Hit & a, const Hit & b) {
+        if (a.id != b.id) return a.id > b.id;
+        return a.target < b.target;
+      });
+    }
+  vsx_results_free(&res);
+  rc = marshal_hits(kept, out);
+  if (rc != VSX_OK) return rc;
+  for (uint64_t k = 0; k < out->n_hits; ++k) out->hit[k].query += (uint32_t) first;
+  out->pairs_aligned = pq.size(); out->cells_aligned = cells; out->stages = 1; out->sentinel_pairs = sentinels;
+  out->seconds_align = t_align; out->seconds_total = now_s() - t_begin;
   return VSX_OK;
 }
 

@@ -68,6 +68,14 @@ class SearchSession:
         n = min(int(n), cap)
         return list(zip(t[:n].tolist(), c[:n].tolist()))
 
+    def allpairs(self, first=0, count=None, acceptall=False):
+        """allpairs_global over database sequences [first, first+count): per-query hit lists (query = db index)"""
+        lib = _lib.load()
+        count = len(self.db) - first if count is None else count
+        res = Hits()
+        check(lib.vsx_allpairs_block(self.h, 1 if acceptall else 0, first, count, C.byref(res)), "vsx_allpairs_block")
+        return self._unpack(res)
+
     def search_batch(self, queries):
         lib = _lib.load()
         blob, off, lens = _blob(queries)
@@ -75,6 +83,10 @@ class SearchSession:
         check(lib.vsx_search_batch(self.h, len(lens), C.cast(C.c_char_p(blob), C.c_void_p), len(blob),
                                    off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), C.byref(res)),
               "vsx_search_batch")
+        return self._unpack(res)
+
+    def _unpack(self, res):
+        lib = _lib.load()
         try:
             cig = C.string_at(res.cigar_blob, int(res.cigar_bytes)) if res.cigar_bytes else b""
             out = []
@@ -94,9 +106,10 @@ class SearchSession:
             lib.vsx_hits_free(C.byref(res))
 
     def userout(self, queries, qnames=None, tnames=None,
-                fields=("query", "target", "id", "alnlen", "mism", "opens", "raw", "caln")):
+                fields=("query", "target", "id", "alnlen", "mism", "opens", "raw", "caln"), hits=None):
         """--userout lines exactly as results_show_userout_one prints these fields (core/results.cpp:330-470)"""
-        hits = self.search_batch(queries)
+        if hits is None:
+            hits = self.search_batch(queries)
         qnames = qnames or [f"q{i}" for i in range(len(queries))]
         tnames = tnames or [f"t{i}" for i in range(len(self.db))]
         fmt = {
