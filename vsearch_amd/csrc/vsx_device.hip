@@ -68,7 +68,12 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // ---------------------------------------------------------------------------------------------
 // TRACK = false drops the running H min/max (the overflow rule): the planner selects it only for tasks
 // whose score range provably stays inside (SHRT_MIN + max(go+ge), SHRT_MAX) -- see vsx_host.cpp no_overflow_possible().
-template <int R, bool GENERIC, bool TRACK>
+// CKPT = true replaces the 4 direction bits per cell by CHECKPOINTS: every step each lane stores the (H, F) pair it
+// hands to the next pipeline position (row checkpoints, 8 B) and every 16 steps its whole column state hprev[R], E[R]
+// (column checkpoints); the traceback kernel recomputes the direction bits only for the <= R x 16 tiles the path
+// crosses.  Same bytes to HBM, ~40 % fewer VALU cycles per cell (the sign-bit funnel is gone).
+#define VSX_RB 2            // row checkpoints: [2^RB-step block][lane][step in block] uint2
+template <int R, bool GENERIC, bool TRACK, bool CKPT>
 __global__ void __launch_bounds__(64)
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
@@ -219,9 +224,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   else V = a_pk_mad(a_pk_minu(ac[r] ^ code, 0x00010001u), nd, P.match_pk);
                   // onestep (:765-780)
                   const u32 h0 = sadd(Hd, V);
-                  const u32 dU = ssub(h0, F);              // sign <=> F > H      (up)
                   const u32 h1 = pmax(h0, F);
-                  const u32 dL = ssub(h1, E[r]);           // sign <=> E > H      (left)
                   h2 = pmax(h1, E[r]);
                   if (TRACK) { smn = pmin(smn, h2); smx = pmax(smx, h2); }
                   Hd = hprev[r];
@@ -230,14 +233,19 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   const u32 rq = (r == R - 1) ? rq_last : P.rq_i_pk;
                   const u32 hf = ssub(h2, qrt);
                   const u32 f = ssub(F, rt);
-                  const u32 dEU = ssub(hf, f);             // sign <=> F-R > H-QR (extend up)
-                  F = pmax(f, hf);
                   const u32 he = ssub(h2, qrq);
                   const u32 e = ssub(E[r], rq);
-                  const u32 dEL = ssub(he, e);             // sign <=> E-R > H-QR (extend left)
+                  if (!CKPT)
+                    {
+                      const u32 dU = ssub(h0, F);          // sign <=> F > H      (up)
+                      const u32 dL = ssub(h1, E[r]);       // sign <=> E > H      (left)
+                      const u32 dEU = ssub(hf, f);         // sign <=> F-R > H-QR (extend up)
+                      const u32 dEL = ssub(he, e);         // sign <=> E-R > H-QR (extend left)
+                      acc = funnel(funnel(funnel(funnel(acc, dU), dL), dEU), dEL);
+                      if ((r & 3) == 3 || r == R - 1) dw[r >> 2] = acc;
+                    }
+                  F = pmax(f, hf);
                   E[r] = pmax(e, he);
-                  acc = funnel(funnel(funnel(funnel(acc, dU), dL), dEU), dEL);
-                  if ((r & 3) == 3 || r == R - 1) dw[r >> 2] = acc;
                   // position 0 holds only rcnt0 rows: its later rows compute junk that never leaves the lane
                   if (__builtin_expect(r + 1 == rcnt0, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
                 }
@@ -262,15 +270,45 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               // [4-step block][lane][step in block][ND]: a lane's 4 consecutive steps share one 64 B line
               // (4x fewer lines for the traceback walk) while a wave-step still lands in one 4 KB window
               const size_t gt = (size_t) s * steps + t;
-              u32 * dp = dir + T.dir_off + (((gt >> 2) * 64 + lane) * 4 + (gt & 3)) * ND;
-              if (ND == 4) *reinterpret_cast<uint4 *>(dp) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
-              else if (ND == 2) *reinterpret_cast<uint2 *>(dp) = make_uint2(dw[0], dw[1]);
+              if (CKPT)
+                {
+                  u32 * rp = dir + T.dir_off + ((((gt >> VSX_RB) * 64 + lane) << VSX_RB) + (gt & ((1u << VSX_RB) - 1))) * 2;
+                  *reinterpret_cast<uint2 *>(rp) = make_uint2(outH, outF);
+                }
+              else
+                {
+                  u32 * dp = dir + T.dir_off + (((gt >> 2) * 64 + lane) * 4 + (gt & 3)) * ND;
+                  if (ND == 4) *reinterpret_cast<uint4 *>(dp) = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+                  else if (ND == 2) *reinterpret_cast<uint2 *>(dp) = make_uint2(dw[0], dw[1]);
+                  else
+                    {
+#pragma unroll
+                      for (int w = 0; w < ND; ++w) dp[w] = dw[w];
+                    }
+                }
+              if (l == 15 && s + 1 < nstrips) strip_outp[j] = make_uint2(outH, outF);
+            }
+          if (CKPT && (t & 15) == 15)
+            {
+              // column checkpoint m = t / 16 of this lane: state after its column t - l (or its border state if it has
+              // not started yet).  Layout [strip][m][lane][2R].
+              const size_t rowck_dw = (((size_t) nstrips * steps + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
+              const size_t nblk = ((size_t) steps + 15) >> 4;
+              u32 * cp = dir + T.dir_off + rowck_dw + (((size_t) s * nblk + (t >> 4)) * 64 + lane) * (2 * R);
+              if (R % 4 == 0)
+                {
+#pragma unroll
+                  for (int x = 0; x < R; x += 4)
+                    {
+                      *reinterpret_cast<uint4 *>(cp + x) = make_uint4(hprev[x], hprev[x + 1], hprev[x + 2], hprev[x + 3]);
+                      *reinterpret_cast<uint4 *>(cp + R + x) = make_uint4(E[x], E[x + 1], E[x + 2], E[x + 3]);
+                    }
+                }
               else
                 {
 #pragma unroll
-                  for (int w = 0; w < ND; ++w) dp[w] = dw[w];
+                  for (int x = 0; x < R; ++x) { cp[x] = hprev[x]; cp[R + x] = E[x]; }
                 }
-              if (l == 15 && s + 1 < nstrips) strip_outp[j] = make_uint2(outH, outF);
             }
         }
 
@@ -408,6 +446,233 @@ vsx_traceback_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Traceback for the CKPT layout: one lane per pair.  The path is followed tile by tile; a tile is the
+// part of one pipeline position (<= R rows) between two column checkpoints (<= 16 columns).  For the tile
+// under the cursor the lane recomputes the direction bits of the sub-rectangle above/left of the cursor
+// from the stored boundaries (left: column checkpoint or the left border; top: the row checkpoints of the
+// position above, or the top border) with the SAME saturating int16 arithmetic as the DP kernel, then
+// walks inside it with backtrack16's rules.  Bits live in LDS ([row][2][64 lanes] dwords).
+// ---------------------------------------------------------------------------------------------
+DEV u32 half_lo(u32 w, bool hi) { return hi ? (w >> 16) : w; }      // this pair's int16 in the LOW half (high half: don't care)
+DEV int wave_max_i32(int v)
+{
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+  return v;
+}
+
+template <int R>
+__global__ void __launch_bounds__(64)
+vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
+                        const u32 * __restrict__ pair_slot, const u32 * __restrict__ pair_ids, u32 npairs,
+                        const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
+                        const u32 * __restrict__ ck, const VsxSlotOut * __restrict__ slot,
+                        u32 * __restrict__ slab, const uint64_t * __restrict__ slab_off,
+                        u32 * __restrict__ runs, uint64_t runs_capacity, unsigned long long * cursor,
+                        VsxPairOut * __restrict__ out)
+{
+  constexpr int ND = (R + 3) / 4;
+  __shared__ int16_t Ssh[256];
+  __shared__ u32 bitsL[16 * ND * 64];              // [column in tile][dword][lane]
+  const int tid = (int) threadIdx.x;
+  for (int x = tid; x < 256; x += 64) Ssh[x] = P.matrix[x];
+  __syncthreads();
+
+  // every lane of the wave stays in the tile loop until all are done (wave-uniform bounds, shuffles)
+  const u32 k = blockIdx.x * 64 + tid;
+  const bool valid = k < npairs;
+  const u32 ts = pair_slot[valid ? k : 0];
+  const u32 task = ts >> 3, sl = ts & 7;
+  const VsxTask & T = tasks[task];
+  const VsxSlotOut so = slot[ts];
+  const bool live = valid && !so.overflow;
+
+  const int Q = (int) T.qlen;
+  const int D = (int) T.tlen[sl];
+  const int total_lanes = (Q + R - 1) / R;
+  const int rcnt0 = Q - (total_lanes - 1) * R;
+  const int nstrips = (total_lanes + 15) >> 4;
+  const size_t steps = T.steps;
+  const size_t nblk = (steps + 15) >> 4;
+  const size_t rowck_dw = (((size_t) nstrips * steps + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
+  const u32 * __restrict__ rowck = ck + T.dir_off;
+  const u32 * __restrict__ colck = ck + T.dir_off + rowck_dw;
+  const int g = (int) (sl >> 1);
+  const bool hi = (sl & 1) != 0;
+  const uint8_t * __restrict__ q = qc + T.qoff;
+  const uint8_t * __restrict__ d = tc + T.toff[sl];
+  u32 * __restrict__ my = slab + slab_off[valid ? k : 0];
+
+  auto rowck_at = [&](int Lp, int c) -> uint2 {
+    const int sp = Lp >> 4, lp = Lp & 15;
+    const size_t gt = (size_t) sp * steps + (size_t) (c + lp);
+    const u32 * p = rowck + ((((gt >> VSX_RB) * 64 + (size_t) (g * 16 + lp)) << VSX_RB) + (gt & ((1u << VSX_RB) - 1))) * 2;
+    return *reinterpret_cast<const uint2 *>(p);
+  };
+
+  int i = live ? Q - 1 : -1, j = live ? D - 1 : -1;
+  int L = total_lanes - 1;
+  int r = (L == 0 ? rcnt0 : R) - 1;
+  int op = -1;
+  u32 runlen = 0, nruns = 0;
+  u32 al = 0, ma = 0, mi = 0, ga = 0;
+  auto push = [&](int newop) {
+    if (newop == op) { ++runlen; return; }
+    if (op >= 0) my[nruns++] = (runlen << 2) | (u32) op;
+    op = newop;
+    runlen = 1;
+  };
+
+  for (;;)
+    {
+      const bool busy = (i >= 0) && (j >= 0);
+      if (!__any(busy)) break;
+
+      // ---- the tile under this lane's cursor (idle lanes recompute a harmless dummy) ----
+      const int s = L >> 4, l = L & 15;
+      const int jj = busy ? j : 0;
+      const int m = (jj + l) >> 4;
+      int c0 = 16 * m - l;
+      if (c0 < 0) c0 = 0;
+      const int i0 = (L == 0) ? 0 : rcnt0 + (L - 1) * R;
+      const bool lastpos = (L == total_lanes - 1);
+      const int rr = busy ? r : 0;
+      const int rmax = wave_max_i32(rr) | 3;                    // rows are funnelled four to a dword
+      const int cmax = wave_max_i32(jj - c0);                   // columns c0 .. c0 + cmax
+
+      // left boundary (state after column c0 - 1), low int16 half = this pair
+      u32 hp[R], ee[R], qa[R];
+      if (m == 0)
+        {
+#pragma unroll
+          for (int x = 0; x < R; ++x)
+            {
+              int ii = i0 + x; if (ii > Q - 1) ii = Q - 1;
+              const u32 hl = (u32) (uint16_t) P.hleft[ii];
+              hp[x] = hl;
+              ee[x] = ssub(hl, (ii < Q - 1) ? P.qrq_i_pk : P.qrq_r_pk);
+            }
+        }
+      else
+        {
+          const u32 * cp = colck + (((size_t) s * nblk + (size_t) (m - 1)) * 64 + (size_t) (g * 16 + l)) * (2 * R);
+#pragma unroll
+          for (int x = 0; x < R; ++x) { hp[x] = half_lo(cp[x], hi); ee[x] = half_lo(cp[R + x], hi); }
+        }
+#pragma unroll
+      for (int x = 0; x < R; ++x)
+        {
+          int ii = i0 + x; if (ii > Q - 1) ii = Q - 1;
+          qa[x] = (u32) q[ii] ;
+        }
+      u32 diag;
+      if (c0 == 0) diag = (L == 0) ? 0u : (u32) (uint16_t) P.hleft[i0 - 1];
+      else diag = (L == 0) ? (u32) (uint16_t) P.htop[c0 - 1] : half_lo(rowck_at(L - 1, c0 - 1).x, hi);
+      const u32 qrq_last = lastpos ? P.qrq_r_pk : P.qrq_i_pk;
+      const u32 rq_last = lastpos ? P.rq_r_pk : P.rq_i_pk;
+
+      // ---- recompute: same packed-int16 row body as the DP kernel, directions funnelled into bitsL ----
+      for (int cc = 0; cc <= cmax; ++cc)
+        {
+          int c = c0 + cc;
+          if (c > jj) c = jj;                                   // lanes with fewer columns repeat their last one
+          const u32 qrt = (u32) (uint16_t) ((c < D - 1) ? P.qrt_i : P.qrt_r);
+          const u32 rt = (u32) (uint16_t) ((c < D - 1) ? P.rt_i : P.rt_r);
+          u32 topH, F;
+          if (L == 0) { topH = (u32) (uint16_t) P.htop[c]; F = ssub(topH, qrt); }
+          else { const uint2 tb = rowck_at(L - 1, c); topH = half_lo(tb.x, hi); F = half_lo(tb.y, hi); }
+          const u32 b16 = (u32) d[c] * 16u;
+          u32 Hd = diag;
+          u32 acc = 0;
+#pragma unroll
+          for (int x4 = 0; x4 < R; x4 += 4)
+            {
+              if (x4 <= rmax)                                    // wave-uniform: skip the rows no lane needs
+                {
+#pragma unroll
+                  for (int y = 0; y < 4; ++y)
+                    {
+                      const int x = x4 + y;
+                      if (x < R)
+                        {
+                          const u32 V = (u32) (uint16_t) Ssh[b16 + qa[x]];
+                          const u32 h0 = sadd(Hd, V);
+                          const u32 dU = ssub(h0, F);
+                          const u32 h1 = pmax(h0, F);
+                          const u32 dL = ssub(h1, ee[x]);
+                          const u32 h2 = pmax(h1, ee[x]);
+                          Hd = hp[x];
+                          hp[x] = h2;
+                          const u32 qrq = (x == R - 1) ? qrq_last : P.qrq_i_pk;
+                          const u32 rq = (x == R - 1) ? rq_last : P.rq_i_pk;
+                          const u32 hf = ssub(h2, qrt);
+                          const u32 f = ssub(F, rt);
+                          const u32 dEU = ssub(hf, f);
+                          F = pmax(f, hf);
+                          const u32 he = ssub(h2, qrq);
+                          const u32 e = ssub(ee[x], rq);
+                          const u32 dEL = ssub(he, e);
+                          ee[x] = pmax(e, he);
+                          acc = funnel(funnel(funnel(funnel(acc, dU), dL), dEU), dEL);
+                        }
+                    }
+                  bitsL[(cc * ND + (x4 >> 2)) * 64 + tid] = acc;
+                }
+            }
+          diag = topH;
+        }
+
+      // ---- walk inside the tile (backtrack16 :1137-1211) ----
+      if (busy)
+        {
+          while (r >= 0 && j >= c0)
+            {
+              const int cw = j - c0;
+              const u32 w = bitsL[(cw * ND + (r >> 2)) * 64 + tid] & 0xffffu;
+              int rid = R - 4 * (r >> 2);
+              if (rid > 4) rid = 4;
+              const u32 bts = (w >> (16 - 4 * rid + 4 * (r & 3))) & 15u;
+              ++al;
+              if (op == 1 && (bts & 8u)) { --j; push(1); }
+              else if (op == 2 && (bts & 4u)) { --i; --r; push(2); }
+              else if (bts & 2u) { if (op != 1) ++ga; --j; push(1); }
+              else if (bts & 1u) { if (op != 2) ++ga; --i; --r; push(2); }
+              else
+                {
+                  const u32 a = q[i], c = d[j];
+                  if ((a & c) != 0 && !(P.n_mismatch && (a == 15 || c == 15))) ++ma; else ++mi;
+                  --i; --r; --j; push(0);
+                }
+            }
+          if (r < 0 && L > 0) { --L; r = (L == 0 ? rcnt0 : R) - 1; }
+        }
+    }
+  if (!valid) return;
+
+  VsxPairOut o;
+  o.pad = 0; o.nruns = 0; o.run_off = 0;
+  if (so.overflow)
+    {
+      o.score = 32767; o.aligned = 0; o.matches = 0; o.mismatches = 0; o.gaps = 0;
+      out[pair_ids[k]] = o;
+      return;
+    }
+  while (i >= 0) { ++al; if (op != 2) ++ga; --i; push(2); }
+  while (j >= 0) { ++al; if (op != 1) ++ga; --j; push(1); }
+  if (op >= 0) my[nruns++] = (runlen << 2) | (u32) op;
+
+  const unsigned long long base = atomicAdd(cursor, (unsigned long long) nruns);
+  if (base + nruns <= runs_capacity)
+    for (u32 x = 0; x < nruns; ++x) runs[base + x] = my[x];
+
+  o.score = so.score;
+  o.aligned = (uint16_t) al; o.matches = (uint16_t) ma; o.mismatches = (uint16_t) mi; o.gaps = (uint16_t) ga;
+  o.nruns = nruns;
+  o.run_off = base;
+  out[pair_ids[k]] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
 // ASCII -> 4-bit IUPAC set code (utils/maps.cpp:75-117), 16 bytes per lane; HBM-bound.
 // ---------------------------------------------------------------------------------------------
 DEV u32 map4(u32 ch)
@@ -501,38 +766,47 @@ extern "C" hipError_t vsx_launch_purity(const uint8_t * d_codes, const uint64_t 
   return hipGetLastError();
 }
 
-template <int R>
-static hipError_t launch_fwd(int generic, int track, const VsxDevParams & P, const VsxTask * d_tasks, uint32_t ntasks,
-                             const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
-                             VsxSlotOut * slot, hipStream_t st)
+template <int R, bool CK>
+static hipError_t launch_fwd2(int generic, int track, const VsxDevParams & P, const VsxTask * d_tasks, uint32_t ntasks,
+                              const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
+                              VsxSlotOut * slot, hipStream_t st)
 {
   if (generic && track)
-    hipLaunchKernelGGL((vsx_forward_kernel<R, true, true>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+    hipLaunchKernelGGL((vsx_forward_kernel<R, true, true, CK>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
   else if (generic)
-    hipLaunchKernelGGL((vsx_forward_kernel<R, true, false>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+    hipLaunchKernelGGL((vsx_forward_kernel<R, true, false, CK>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
   else if (track)
-    hipLaunchKernelGGL((vsx_forward_kernel<R, false, true>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+    hipLaunchKernelGGL((vsx_forward_kernel<R, false, true, CK>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
   else
-    hipLaunchKernelGGL((vsx_forward_kernel<R, false, false>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+    hipLaunchKernelGGL((vsx_forward_kernel<R, false, false, CK>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
   return hipGetLastError();
 }
 
-extern "C" hipError_t vsx_launch_forward(int rows, int generic, int track, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
+extern "C" hipError_t vsx_launch_forward(int rows, int generic, int track, int ckpt, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
                                          const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
                                          VsxSlotOut * slot, hipStream_t st)
 {
   if (ntasks == 0) return hipSuccess;
   switch (rows)
     {
-    case 1:  return launch_fwd<1>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 4:  return launch_fwd<4>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 8:  return launch_fwd<8>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 12: return launch_fwd<12>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 16: return launch_fwd<16>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 20: return launch_fwd<20>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 24: return launch_fwd<24>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 28: return launch_fwd<28>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 32: return launch_fwd<32>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 1:  return ckpt ? launch_fwd2<1, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<1, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 4:  return ckpt ? launch_fwd2<4, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<4, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 8:  return ckpt ? launch_fwd2<8, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<8, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 12: return ckpt ? launch_fwd2<12, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<12, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 16: return ckpt ? launch_fwd2<16, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<16, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 20: return ckpt ? launch_fwd2<20, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<20, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 24: return ckpt ? launch_fwd2<24, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<24, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 28: return ckpt ? launch_fwd2<28, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<28, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 32: return ckpt ? launch_fwd2<32, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<32, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
     default: return hipErrorInvalidValue;
     }
 }
@@ -550,4 +824,41 @@ extern "C" hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tas
                      P, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, dir, slot, slab, slab_off,
                      runs, runs_capacity, cursor, out);
   return hipGetLastError();
+}
+
+template <int R>
+static hipError_t launch_tbck(const VsxDevParams & P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
+                              const uint32_t * d_pair_ids, uint32_t npairs, const uint8_t * q, const uint8_t * t,
+                              const uint32_t * ck, const VsxSlotOut * slot, uint32_t * slab, const uint64_t * slab_off,
+                              uint32_t * runs, uint64_t cap, unsigned long long * cursor, VsxPairOut * out, hipStream_t st)
+{
+  hipLaunchKernelGGL((vsx_traceback_ck_kernel<R>), dim3((npairs + 63) / 64), dim3(64), 0, st,
+                     P, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, cap, cursor, out);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t vsx_launch_traceback_ck(int rows, VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
+                                              const uint32_t * d_pair_ids, uint32_t npairs,
+                                              const uint8_t * q, const uint8_t * t,
+                                              const uint32_t * ck, const VsxSlotOut * slot,
+                                              uint32_t * slab, const uint64_t * slab_off,
+                                              uint32_t * runs, uint64_t runs_capacity, unsigned long long * cursor,
+                                              VsxPairOut * out, hipStream_t st)
+{
+  if (npairs == 0) return hipSuccess;
+#define TBCK(RR) case RR: return launch_tbck<RR>(P, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st)
+  switch (rows)
+    {
+    TBCK(1); TBCK(4); TBCK(8); TBCK(12); TBCK(16); TBCK(20); TBCK(24); TBCK(28); TBCK(32);
+    default: return hipErrorInvalidValue;
+    }
+#undef TBCK
+}
+
+// dwords of checkpoint storage one task needs (row + column checkpoints)
+extern "C" uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t rows)
+{
+  const uint64_t rowck = (((nstrips * steps) + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
+  const uint64_t nblk = (steps + 15) >> 4;
+  return rowck + nstrips * nblk * 64 * 2 * rows;
 }

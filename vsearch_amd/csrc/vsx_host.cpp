@@ -78,6 +78,7 @@ struct vsx_ctx {
   hipStream_t stream2 = nullptr;     // traceback kernels (overlap with the next chunk's DP)
   vsx_scoring sc {};
   bool force_fallback = false;      // a score/penalty left the 16-bit range: every pair -> sentinel
+  bool ckpt = true;                 // checkpoint + tile-recompute traceback (VSX_TRACEBACK=dirs selects stored direction bits)
   int pen[12] {};                   // clamped CELL penalties: go_q_l, go_t_l, go_q_i, go_t_i, go_q_r, go_t_r, ge_*
   VsxDevParams P {};
   DevBuf<int16_t> d_htop, d_hleft, d_matrix;
@@ -99,7 +100,7 @@ struct vsx_seqset {
 
 namespace {
 
-struct Launch { int rows; int generic; int track; uint32_t first, count; };
+struct Launch { int rows; int generic; int track; uint32_t first, count; uint32_t pair_first, pair_count; };
 
 struct Chunk {
   uint32_t task_first = 0, task_count = 0;
@@ -196,6 +197,7 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   auto * c = new vsx_ctx;
   c->device = device;
   c->sc = *s;
+  if (const char * mode = std::getenv("VSX_TRACEBACK")) c->ckpt = std::strcmp(mode, "dirs") != 0;
 
   // search16_init, align_simd.cpp:1282-1376: scores must fit a CELL, each penalty SHRT_MAX/(1+CDEPTH)
   auto clamp = [&](int64_t v, int64_t lim) -> int {
@@ -516,7 +518,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       const uint64_t total_lanes = (t.qlen + pt.rows - 1) / pt.rows;
       const uint64_t nstrips = (total_lanes + 15) / 16;
       const uint64_t nd = (uint64_t) (pt.rows + 3) / 4;
-      const uint64_t dwords = ((nstrips * t.steps + 3) & ~3ull) * 64 * nd;     // [4-step block][lane][4][nd]
+      const uint64_t dwords = ctx->ckpt ? vsx_ckpt_dwords(nstrips, t.steps, (uint64_t) pt.rows)
+                                        : ((nstrips * t.steps + 3) & ~3ull) * 64 * nd;     // [4-step block][lane][4][nd]
       const uint64_t strip = nstrips > 1 ? 2ull * 4 * t.steps : 0;
       if (cur.task_count && cur.dir_dwords + dwords > budget_dwords) close_chunk();
       t.dir_off = cur.dir_dwords;
@@ -527,8 +530,9 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       const uint32_t task_index = (uint32_t) pl->tasks.size();
       if (cur.launches.empty() || cur.launches.back().rows != pt.rows || cur.launches.back().generic != pt.generic ||
           cur.launches.back().track != pt.track)
-        cur.launches.push_back(Launch {pt.rows, pt.generic, pt.track, task_index, 0});
+        cur.launches.push_back(Launch {pt.rows, pt.generic, pt.track, task_index, 0, cur.pair_first + cur.pair_count, 0});
       cur.launches.back().count++;
+      cur.launches.back().pair_count += pt.n;
       for (uint32_t s = 0; s < pt.n; ++s)
         {
           pl->pair_slot.push_back(task_index * VSX_TASK_SLOTS + s);
@@ -604,16 +608,25 @@ int vsx_plan_run(vsx_plan * pl)
       if (k >= 2) HIPCHK(hipStreamWaitEvent(st, pl->chunks[k - 2].e2, 0));      // buffer reuse
       HIPCHK(hipEventRecord(c.e0, st));
       for (const Launch & L : c.launches)
-        HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->P, pl->d_tasks.p + L.first, L.count,
+        HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, ctx->P, pl->d_tasks.p + L.first, L.count,
                                   pl->Q->d_codes.p, pl->T->d_codes.p, dir, pl->d_strip.p,
                                   pl->d_slot.p + (size_t) L.first * VSX_TASK_SLOTS, st));
       HIPCHK(hipEventRecord(c.e1, st));
       HIPCHK(hipStreamWaitEvent(st2, c.e1, 0));
       HIPCHK(hipEventRecord(c.e1b, st2));
-      HIPCHK(vsx_launch_traceback(ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + c.pair_first, pl->d_pair_ids.p + c.pair_first,
-                                  c.pair_count, pl->Q->d_codes.p, pl->T->d_codes.p, dir, pl->d_slot.p,
-                                  pl->d_slab.p, pl->d_slab_off.p + c.pair_first, pl->d_runs.p, pl->runs_capacity,
-                                  pl->d_cursor.p, pl->d_out.p, st2));
+      if (ctx->ckpt)
+        {
+          for (const Launch & L : c.launches)      // the recompute traceback is specialised on R like the DP kernel
+            HIPCHK(vsx_launch_traceback_ck(L.rows, ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
+                                           pl->d_pair_ids.p + L.pair_first, L.pair_count, pl->Q->d_codes.p, pl->T->d_codes.p,
+                                           dir, pl->d_slot.p, pl->d_slab.p, pl->d_slab_off.p + L.pair_first,
+                                           pl->d_runs.p, pl->runs_capacity, pl->d_cursor.p, pl->d_out.p, st2));
+        }
+      else
+        HIPCHK(vsx_launch_traceback(ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + c.pair_first, pl->d_pair_ids.p + c.pair_first,
+                                    c.pair_count, pl->Q->d_codes.p, pl->T->d_codes.p, dir, pl->d_slot.p,
+                                    pl->d_slab.p, pl->d_slab_off.p + c.pair_first, pl->d_runs.p, pl->runs_capacity,
+                                    pl->d_cursor.p, pl->d_out.p, st2));
       HIPCHK(hipEventRecord(c.e2, st2));
     }
   if (!pl->chunks.empty()) HIPCHK(hipStreamWaitEvent(st, pl->chunks.back().e2, 0));   // st2 is in order

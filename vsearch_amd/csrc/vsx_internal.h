@@ -68,7 +68,7 @@ hipError_t vsx_launch_purity(const uint8_t * d_codes, const uint64_t * d_off, co
                              uint64_t nseq, uint8_t * d_impure, hipStream_t st);
 // rows must be one of vsx_supported_rows(); generic != 0 selects the LDS score-table variant;
 // track == 0 selects the variant without overflow (H min/max) tracking
-hipError_t vsx_launch_forward(int rows, int generic, int track, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
+hipError_t vsx_launch_forward(int rows, int generic, int track, int ckpt, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
                               const uint8_t * d_qcodes, const uint8_t * d_tcodes,
                               uint32_t * d_dir, uint2 * d_strip, VsxSlotOut * d_slot, hipStream_t st);
 hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
@@ -78,6 +78,14 @@ hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tasks, const u
                                 uint32_t * d_slab, const uint64_t * d_slab_off,
                                 uint32_t * d_runs, uint64_t runs_capacity, unsigned long long * d_cursor,
                                 VsxPairOut * d_out, hipStream_t st);
+hipError_t vsx_launch_traceback_ck(int rows, VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
+                                   const uint32_t * d_pair_ids, uint32_t npairs,
+                                   const uint8_t * d_qcodes, const uint8_t * d_tcodes,
+                                   const uint32_t * d_ck, const VsxSlotOut * d_slot,
+                                   uint32_t * d_slab, const uint64_t * d_slab_off,
+                                   uint32_t * d_runs, uint64_t runs_capacity, unsigned long long * d_cursor,
+                                   VsxPairOut * d_out, hipStream_t st);
+uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t rows);
 const int * vsx_supported_rows(int * count);
 
 #ifdef __cplusplus
