@@ -72,7 +72,7 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // hands to the next pipeline position (row checkpoints, 8 B) and every 16 steps its whole column state hprev[R], E[R]
 // (column checkpoints); the traceback kernel recomputes the direction bits only for the <= R x 16 tiles the path
 // crosses.  Same bytes to HBM, ~40 % fewer VALU cycles per cell (the sign-bit funnel is gone).
-#define VSX_RB 2            // row checkpoints: [2^RB-step block][lane][step in block] uint2
+#define VSX_RB 1            // row checkpoints: [2^RB-step block][lane][step in block] uint2
 template <int R, bool GENERIC, bool TRACK, bool CKPT>
 __global__ void __launch_bounds__(64)
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
@@ -214,6 +214,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               u32 F = inF;
               u32 smn = 0x7FFF7FFFu, smx = 0x80008000u;
               u32 acc = 0, h2 = 0;
+              u32 xH = inH, xF = inF;                           // (H, F) entering row R-1 (R == 1: the lane's own inputs)
               u32 capH = 0, capF = 0, capmn = 0, capmx = 0;    // position 0: state after its last real row
               u32 dw[ND];
 #pragma unroll
@@ -246,6 +247,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                     }
                   F = pmax(f, hf);
                   E[r] = pmax(e, he);
+                  if (CKPT && r == R - 2) { xH = h2; xF = F; }
                   // position 0 holds only rcnt0 rows: its later rows compute junk that never leaves the lane
                   if (__builtin_expect(r + 1 == rcnt0, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
                 }
@@ -274,6 +276,15 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                 {
                   u32 * rp = dir + T.dir_off + ((((gt >> VSX_RB) * 64 + lane) << VSX_RB) + (gt & ((1u << VSX_RB) - 1))) * 2;
                   *reinterpret_cast<uint2 *>(rp) = make_uint2(outH, outF);
+                  if (lastpos)
+                    {
+                      // last-row checkpoint: lets the traceback follow the (typically long) terminal run in query row
+                      // Q-1 with one-row recomputes.  [group][column] uint2, after the column checkpoints.
+                      const size_t rowck_dw = (((size_t) nstrips * steps + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
+                      const size_t nblk = ((size_t) steps + 15) >> 4;
+                      u32 * xp = dir + T.dir_off + rowck_dw + (size_t) nstrips * nblk * 64 * (2 * R) + ((size_t) g * steps + (size_t) j) * 2;
+                      *reinterpret_cast<uint2 *>(xp) = make_uint2(xH, xF);
+                    }
                 }
               else
                 {
@@ -473,7 +484,9 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
 {
   constexpr int ND = (R + 3) / 4;
   __shared__ int16_t Ssh[256];
-  __shared__ u32 bitsL[16 * ND * 64];              // [column in tile][dword][lane]
+  __shared__ uint16_t bitsL[16 * ND * 64];         // [column in tile][4-row group][lane]: this pair's 16 direction bits
+  __shared__ u32 tbL[17 * 64];                     // top boundary of the tile, prefetched: H (low 16) | F (high 16)
+  __shared__ uint8_t symL[16 * 64];                // target symbols of the tile's columns
   const int tid = (int) threadIdx.x;
   for (int x = tid; x < 256; x += 64) Ssh[x] = P.matrix[x];
   __syncthreads();
@@ -523,6 +536,101 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
     runlen = 1;
   };
 
+  // ---- phase A: the run along the LAST query row (right-terminal gap when the target is longer than the query).
+  // One-row recomputes from the last-row checkpoints; a lane leaves the phase at the first cell whose move is not 'I'
+  // (that cell is decided again, identically, by the general loop below).  Keeps the lanes of a wave in phase.
+  if (R > 1)
+    {
+      const u32 * __restrict__ xck = colck + (size_t) nstrips * nblk * 64 * (2 * R) + (size_t) g * steps * 2;
+      const int lastL = total_lanes - 1;
+      const int sA = lastL >> 4, lA = lastL & 15;
+      const u32 qlast = live ? (u32) q[Q - 1] : 0u;
+      bool inA = live;
+      for (;;)
+        {
+          if (!__any(inA)) break;
+          const int jj = inA ? j : 0;
+          const int m = (jj + lA) >> 4;
+          int c0 = 16 * m - lA;
+          if (c0 < 0) c0 = 0;
+          const int cmax = wave_max_i32(inA ? jj - c0 : 0);
+          u32 hp1, ee1;
+          if (m == 0)
+            {
+              hp1 = (u32) (uint16_t) P.hleft[Q - 1];
+              ee1 = ssub(hp1, P.qrq_r_pk);
+            }
+          else
+            {
+              const u32 * cp = colck + (((size_t) sA * nblk + (size_t) (m - 1)) * 64 + (size_t) (g * 16 + lA)) * (2 * R);
+              hp1 = half_lo(cp[R - 1], hi);
+              ee1 = half_lo(cp[2 * R - 1], hi);
+            }
+          {
+            u32 hv[17], fv[17], sy[16];
+#pragma unroll
+            for (int cc = 0; cc < 17; ++cc)
+              {
+                int c = c0 - 1 + cc;
+                if (c > jj) c = jj;
+                if (c < 0) { hv[cc] = (u32) (uint16_t) P.hleft[Q - 2]; fv[cc] = 0; }
+                else
+                  {
+                    const uint2 tb = *reinterpret_cast<const uint2 *>(xck + (size_t) c * 2);
+                    hv[cc] = half_lo(tb.x, hi) & 0xffffu;
+                    fv[cc] = half_lo(tb.y, hi) & 0xffffu;
+                  }
+                if (cc > 0) sy[cc - 1] = (u32) d[c < 0 ? 0 : c];
+              }
+#pragma unroll
+            for (int cc = 0; cc < 17; ++cc) tbL[cc * 64 + tid] = hv[cc] | (fv[cc] << 16);
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) symL[cc * 64 + tid] = (uint8_t) sy[cc];
+          }
+          u32 diag = tbL[tid] & 0xffffu;
+          u32 nib[2] = {0u, 0u};                                 // 16 columns x 4 bits
+          for (int cc = 0; cc <= cmax; ++cc)
+            {
+              int c = c0 + cc;
+              if (c > jj) c = jj;
+              const u32 qrt = (u32) (uint16_t) ((c < D - 1) ? P.qrt_i : P.qrt_r);
+              const u32 rt = (u32) (uint16_t) ((c < D - 1) ? P.rt_i : P.rt_r);
+              const u32 tbv = tbL[(cc + 1) * 64 + tid];
+              const u32 topH = tbv & 0xffffu;
+              u32 F = tbv >> 16;
+              const u32 V = (u32) (uint16_t) Ssh[(u32) symL[cc * 64 + tid] * 16u + qlast];
+              const u32 h0 = sadd(diag, V);
+              const u32 up = (ssub(h0, F) >> 15) & 1u;
+              const u32 h1 = pmax(h0, F);
+              const u32 left = (ssub(h1, ee1) >> 15) & 1u;
+              const u32 h2 = pmax(h1, ee1);
+              hp1 = h2;
+              const u32 hf = ssub(h2, qrt), f = ssub(F, rt);
+              const u32 eu = (ssub(hf, f) >> 15) & 1u;
+              const u32 he = ssub(h2, P.qrq_r_pk), e = ssub(ee1, P.rq_r_pk);
+              const u32 el = (ssub(he, e) >> 15) & 1u;
+              ee1 = pmax(e, he);
+              const u32 n4 = (up | (left << 1) | (eu << 2) | (el << 3)) << (4 * (cc & 7));
+              if (cc < 8) nib[0] |= n4; else nib[1] |= n4;
+              diag = topH;
+            }
+          if (inA)
+            {
+              while (j >= c0)
+                {
+                  const int cw = j - c0;
+                  const u32 bts = ((cw < 8 ? nib[0] : nib[1]) >> (4 * (cw & 7))) & 15u;
+                  const bool goI = (op == 1 && (bts & 8u)) || (!(op == 2 && (bts & 4u)) && (bts & 2u));
+                  if (!goI) { inA = false; break; }
+                  ++al;
+                  if (!(op == 1 && (bts & 8u)) && op != 1) ++ga;
+                  --j; push(1);
+                }
+              if (j < 0) inA = false;
+            }
+        }
+    }
+
   for (;;)
     {
       const bool busy = (i >= 0) && (j >= 0);
@@ -537,7 +645,9 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
       const int i0 = (L == 0) ? 0 : rcnt0 + (L - 1) * R;
       const bool lastpos = (L == total_lanes - 1);
       const int rr = busy ? r : 0;
-      const int rmax = wave_max_i32(rr) | 3;                    // rows are funnelled four to a dword
+      const int rmax_raw = wave_max_i32(rr);
+      const bool one_row = (rmax_raw == 0) && (R >= 4);           // e.g. the left-terminal run in query row 0
+      const int rmax = one_row ? 0 : (rmax_raw | 3);              // rows are funnelled four to a dword
       const int cmax = wave_max_i32(jj - c0);                   // columns c0 .. c0 + cmax
 
       // left boundary (state after column c0 - 1), low int16 half = this pair
@@ -565,9 +675,38 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
           int ii = i0 + x; if (ii > Q - 1) ii = Q - 1;
           qa[x] = (u32) q[ii] ;
         }
-      u32 diag;
-      if (c0 == 0) diag = (L == 0) ? 0u : (u32) (uint16_t) P.hleft[i0 - 1];
-      else diag = (L == 0) ? (u32) (uint16_t) P.htop[c0 - 1] : half_lo(rowck_at(L - 1, c0 - 1).x, hi);
+      // top boundary for columns c0-1 .. c0+15 and the target symbols: all loads issued back to back, staged in LDS
+      {
+        u32 hv[17], fv[17], sy[16];
+#pragma unroll
+        for (int cc = 0; cc < 17; ++cc)
+          {
+            int c = c0 - 1 + cc;                                // entry 0 is the corner column c0 - 1
+            if (c > jj) c = jj;
+            if (c < 0)
+              {
+                hv[cc] = (L == 0) ? 0u : (u32) (uint16_t) P.hleft[i0 - 1];      // corner H(i0-1, -1)
+                fv[cc] = 0;
+              }
+            else if (L == 0)
+              {
+                hv[cc] = (u32) (uint16_t) P.htop[c];
+                fv[cc] = 0x10000u;                               // marker: F is derived from H and the column penalty
+              }
+            else
+              {
+                const uint2 tb = rowck_at(L - 1, c);
+                hv[cc] = half_lo(tb.x, hi) & 0xffffu;
+                fv[cc] = half_lo(tb.y, hi) & 0xffffu;
+              }
+            if (cc > 0) sy[cc - 1] = (u32) d[c < 0 ? 0 : c];
+          }
+#pragma unroll
+        for (int cc = 0; cc < 17; ++cc) tbL[cc * 64 + tid] = hv[cc] | (fv[cc] << 16);
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) symL[cc * 64 + tid] = (uint8_t) sy[cc];
+      }
+      u32 diag = tbL[tid] & 0xffffu;
       const u32 qrq_last = lastpos ? P.qrq_r_pk : P.qrq_i_pk;
       const u32 rq_last = lastpos ? P.rq_r_pk : P.rq_i_pk;
 
@@ -578,10 +717,10 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
           if (c > jj) c = jj;                                   // lanes with fewer columns repeat their last one
           const u32 qrt = (u32) (uint16_t) ((c < D - 1) ? P.qrt_i : P.qrt_r);
           const u32 rt = (u32) (uint16_t) ((c < D - 1) ? P.rt_i : P.rt_r);
-          u32 topH, F;
-          if (L == 0) { topH = (u32) (uint16_t) P.htop[c]; F = ssub(topH, qrt); }
-          else { const uint2 tb = rowck_at(L - 1, c); topH = half_lo(tb.x, hi); F = half_lo(tb.y, hi); }
-          const u32 b16 = (u32) d[c] * 16u;
+          const u32 tbv = tbL[(cc + 1) * 64 + tid];
+          const u32 topH = tbv & 0xffffu;
+          u32 F = (L == 0) ? ssub(topH, qrt) : (tbv >> 16);
+          const u32 b16 = (u32) symL[cc * 64 + tid] * 16u;
           u32 Hd = diag;
           u32 acc = 0;
 #pragma unroll
@@ -593,7 +732,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
                   for (int y = 0; y < 4; ++y)
                     {
                       const int x = x4 + y;
-                      if (x < R)
+                      if (x < R && !(one_row && y > 0))
                         {
                           const u32 V = (u32) (uint16_t) Ssh[b16 + qa[x]];
                           const u32 h0 = sadd(Hd, V);
@@ -616,7 +755,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
                           acc = funnel(funnel(funnel(funnel(acc, dU), dL), dEU), dEL);
                         }
                     }
-                  bitsL[(cc * ND + (x4 >> 2)) * 64 + tid] = acc;
+                  bitsL[(cc * ND + (x4 >> 2)) * 64 + tid] = (uint16_t) (one_row ? (acc >> 12) : acc);   // one row: its nibble sits at 12..15
                 }
             }
           diag = topH;
@@ -628,7 +767,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
           while (r >= 0 && j >= c0)
             {
               const int cw = j - c0;
-              const u32 w = bitsL[(cw * ND + (r >> 2)) * 64 + tid] & 0xffffu;
+              const u32 w = bitsL[(cw * ND + (r >> 2)) * 64 + tid];
               int rid = R - 4 * (r >> 2);
               if (rid > 4) rid = 4;
               const u32 bts = (w >> (16 - 4 * rid + 4 * (r & 3))) & 15u;
@@ -860,5 +999,5 @@ extern "C" uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t r
 {
   const uint64_t rowck = (((nstrips * steps) + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
   const uint64_t nblk = (steps + 15) >> 4;
-  return rowck + nstrips * nblk * 64 * 2 * rows;
+  return rowck + nstrips * nblk * 64 * 2 * rows + 4 * steps * 2;
 }

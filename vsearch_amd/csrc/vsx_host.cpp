@@ -487,7 +487,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
       // per buffer; two buffers are kept so the traceback of chunk k overlaps the DP of chunk k+1
-      dir_budget_bytes = std::min<uint64_t>((uint64_t) (free_b * 0.2), 24ull << 30);
+      dir_budget_bytes = std::min<uint64_t>((uint64_t) (free_b * 0.4), 128ull << 30);
     }
   const uint64_t budget_dwords = std::max<uint64_t>(dir_budget_bytes / 4, 1);
 
