@@ -104,6 +104,21 @@ int vsx_allpairs_block(vsx_searcher * s, int32_t acceptall, uint64_t first, uint
 int64_t vsx_search_candidates(vsx_searcher * s, const char * q, uint32_t qlen,
                               uint32_t * targets, uint32_t * counts, uint64_t cap);
 
+/* Greedy centroid clustering, --cluster_fast / --cluster_smallmem semantics (core/cluster.cpp:877-1125 with the
+   intra-round fix-up evaluate_extra_hits :601-856): the searcher's sequences are processed IN THE GIVEN ORDER
+   (sort them first: cluster_fast = length descending, core/db.cpp:433-450); each joins the cluster of its best
+   accepted centroid hit or founds a new cluster.  `round` sequences are searched per GPU stage (0 = 4096); the
+   result is independent of `round`.  hits.first[s]..first[s+1] holds the one hit of a member (target = its
+   centroid) and is empty for centroids; clusterno[s] is the 0-based cluster number in creation order. */
+typedef struct vsx_cluster_out {
+  uint64_t   n;
+  uint64_t   n_clusters;
+  uint32_t * clusterno;
+  vsx_hits   hits;
+} vsx_cluster_out;
+int vsx_cluster_fast(vsx_searcher * s, uint64_t round, vsx_cluster_out * out);
+void vsx_cluster_out_free(vsx_cluster_out * o);
+
 /* The scalar fallback the callers run on the SHRT_MAX sentinel: LinearMemoryAligner::align + alignstats
    (core/linmemalign.cpp:694-808; call sites core/searchcore.cpp:806-832, commands/allpairs_global.cpp:447-473).
    Host CPU, int64 arithmetic, linear memory, the reference's tie-breaks; uses the UNclamped scoring values

@@ -146,3 +146,46 @@ def test_allpairs_global_matches_reference_cli(gpu_required, tmp_path, name, acc
         got = ss.userout(db, qnames=names, tnames=names, fields=FIELDS, hits=hits)
     assert len(exp) > 10
     assert got == exp, _first_diff(got, exp)
+
+
+def run_reference_cluster(tmp, seqs, names, extra, threads=1):
+    f_in, f_uc = os.path.join(tmp, "c.fa"), os.path.join(tmp, "c.uc")
+    with open(f_in, "w") as f:
+        f.write("".join(f">{n}\n{s}\n" for n, s in zip(names, seqs)))
+    cmd = [REF_BIN, "--cluster_fast", f_in, "--qmask", "none", "--threads", str(threads), "--uc", f_uc, "--quiet"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    return open(f_uc).read().splitlines()
+
+
+@pytest.mark.parametrize("name,opts,extra,round_size", [
+    ("id97_round7", dict(id=0.97, maxrejects=8), ["--id", "0.97"], 7),
+    ("id97_round64", dict(id=0.97, maxrejects=8), ["--id", "0.97"], 64),
+    ("id90_one_round", dict(id=0.9, maxrejects=8), ["--id", "0.9"], 100000),
+    ("id94_ma3", dict(id=0.94, maxrejects=8, maxaccepts=3), ["--id", "0.94", "--maxaccepts", "3"], 50),
+])
+def test_cluster_fast_matches_reference_cli(gpu_required, tmp_path, name, opts, extra, round_size):
+    """--cluster_fast --uc (SURVEY config 3 shape: amplicon families at 2 % divergence): S/H/C records byte-identical,
+    for several round sizes (the intra-round fix-up, SURVEY 8a row 14, must make the result round-independent)."""
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing")
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(5)
+    seqs = []
+    for f in range(30):
+        anc = common.rnd_seq(rng, rng.randint(280, 320))
+        for _ in range(rng.randint(2, 14)):
+            seqs.append(common.mutate(rng, anc, rng.choice([0.01, 0.02, 0.04])))
+    seqs += [common.rnd_seq(rng, rng.randint(250, 330)) for _ in range(20)]
+    seqs += [seqs[3], seqs[3][:-2]]                                           # duplicates / near-duplicates
+    rng.shuffle(seqs)
+    names = [f"s{i:04d}" for i in range(len(seqs))]
+    # Database::sortbylength (core/db.cpp:433-450): length desc, abundance, label
+    order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), names[i]))
+    sseqs, snames = [seqs[i] for i in order], [names[i] for i in order]
+    exp = run_reference_cluster(str(tmp_path), seqs, names, extra)
+    with Aligner() as al:
+        ss = SearchSession(al, sseqs, **opts)              # cluster_fast default: --maxrejects 8 (cli.cc:4163-4167)
+        got = ss.uc_lines(snames, round=round_size)
+    assert sum(1 for l in exp if l[0] == "H") > 50
+    assert got == exp, _first_diff(got, exp)

@@ -22,7 +22,7 @@ SYMBOLS = [
 ]
 # include/vsx_search.h
 SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
-                  "vsx_hits_free", "vsx_search_candidates", "vsx_lma_align", "vsx_allpairs_block"]
+                  "vsx_hits_free", "vsx_search_candidates", "vsx_lma_align", "vsx_allpairs_block", "vsx_cluster_fast", "vsx_cluster_out_free"]
 
 
 class SearchOpts(C.Structure):
@@ -79,6 +79,10 @@ class Timing(C.Structure):
                 ("cells", C.c_uint64), ("dir_bytes", C.c_uint64)]
 
 
+class ClusterOut(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("n_clusters", C.c_uint64), ("clusterno", C.POINTER(C.c_uint32)), ("hits", Hits)]
+
+
 _lib = None
 
 
@@ -126,6 +130,9 @@ def load():
     lib.vsx_search_candidates.argtypes = [vp, C.c_char_p, C.c_uint32, vp, vp, C.c_uint64]
     lib.vsx_search_candidates.restype = C.c_int64
     lib.vsx_allpairs_block.argtypes = [vp, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(Hits)]
+    lib.vsx_cluster_fast.argtypes = [vp, C.c_uint64, C.POINTER(ClusterOut)]
+    lib.vsx_cluster_out_free.argtypes = [C.POINTER(ClusterOut)]
+    lib.vsx_cluster_out_free.restype = None
     lib.vsx_lma_align.argtypes = [C.POINTER(Scoring), C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64] + \
         [C.POINTER(C.c_int64)] * 5 + [C.POINTER(vp)]
     _lib = lib

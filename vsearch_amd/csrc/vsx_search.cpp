@@ -244,29 +244,40 @@ struct vsx_searcher {
   int64_t ma = 1, mr = 32, tophits = 0, minwordmatches = 12;
   int threads = 1;
   bool indexed = false;              // the k-mer index is built on first use (allpairs never needs it)
+  std::vector<uint8_t> is_centroid;  // clustering: which sequences are in the growing index
 };
 
 namespace {
 
+// Growing index used by clustering: only centroids are indexed (Dbindex::add_sequence, core/dbindex.cpp:125-152)
+struct IncIndex {
+  std::vector<std::vector<uint32_t>> post;      // k-mer -> centroid sequence numbers, ascending
+  uint64_t indexed = 0;
+};
+
 // search_topscores (core/searchcore.cpp:260-340) for one query; counts = zeroed per-thread scratch of size seqcount
 void candidates_for(const vsx_searcher & S, const char * q, int64_t qlen, std::vector<uint16_t> & counts,
                     std::vector<uint32_t> & touched, std::vector<uint32_t> & kmers, std::vector<uint64_t> & seen,
-                    std::vector<Cand> & out)
+                    std::vector<Cand> & out, const IncIndex * inc = nullptr)
 {
   out.clear();
   unique_kmers(q, qlen, S.w, S.o.soft_mask != 0, kmers, seen);
   touched.clear();
-  for (uint32_t k : kmers)
-    for (uint64_t p = S.kstart[k]; p < S.kstart[k + 1]; ++p)
-      {
-        uint16_t & c = counts[S.postings[p]];
-        if (c == 0) touched.push_back(S.postings[p]);
-        if (c < 32767) ++c;                                     // saturates at INT16_MAX (:306-315)
-      }
+  auto bump = [&](uint32_t t) {
+    uint16_t & c = counts[t];
+    if (c == 0) touched.push_back(t);
+    if (c < 32767) ++c;                                       // saturates at INT16_MAX (:306-315)
+  };
+  if (inc) { for (uint32_t k : kmers) for (uint32_t t : inc->post[k]) bump(t); }
+  else
+    for (uint32_t k : kmers)
+      for (uint64_t p = S.kstart[k]; p < S.kstart[k + 1]; ++p) bump(S.postings[p]);
   const uint32_t minmatches = (uint32_t) std::min<int64_t>(S.minwordmatches, (int64_t) kmers.size());   // :320
   if (minmatches == 0)
     {
-      for (uint32_t t = 0; t < S.len.size(); ++t) out.push_back(Cand {t, counts[t], S.len[t]});
+      // every INDEXED sequence qualifies (the scan runs over dbindex->getcount() entries, :323-337)
+      if (inc) { for (uint32_t t = 0; t < S.len.size(); ++t) if (S.is_centroid[t]) out.push_back(Cand {t, counts[t], S.len[t]}); }
+      else for (uint32_t t = 0; t < S.len.size(); ++t) out.push_back(Cand {t, counts[t], S.len[t]});
     }
   else
     {
@@ -414,6 +425,59 @@ static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out)
   out->cigar_blob = (char *) std::malloc(std::max<size_t>(blob.size(), 1));
   if (!out->cigar_blob) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "host allocation failed"); }
   std::memcpy(out->cigar_blob, blob.data(), blob.size());
+  return VSX_OK;
+}
+
+struct Acct { double t_align = 0; uint64_t pairs = 0, cells = 0, stages = 0, sentinels = 0; };
+
+// The staged search of a window: every open query contributes its next align_delayed batch, all batches go to the
+// GPU as one plan, then the reference's bookkeeping (:782-878) is replayed per query.  qseq/qlen/qidx map a window
+// slot to its sequence, length and index inside `qset`.
+template <typename FSeq, typename FLen, typename FIdx>
+static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qseq, FLen qlen, FIdx qidx,
+                      const vsx_seqset * qset, Acct & acct)
+{
+  const uint64_t wn = st.size();
+  std::vector<uint32_t> open(wn);
+  for (uint64_t k = 0; k < wn; ++k) open[k] = (uint32_t) k;
+  std::vector<uint32_t> pq, pt;
+  while (!open.empty())
+    {
+      pq.clear(); pt.clear();
+      std::vector<uint32_t> waiting;
+      for (uint32_t k : open)
+        if (advance(S, st[k], qseq(k), qlen(k), qidx(k), pq, pt)) waiting.push_back(k);
+      if (waiting.empty()) break;
+      ++acct.stages;
+      const double t0 = now_s();
+      vsx_results res;
+      int rc = vsx_align_pairs(S.ctx, qset, S.dbset, pq.size(), pq.data(), pt.data(), &res);
+      acct.t_align += now_s() - t0;
+      if (rc != VSX_OK) return rc;
+      acct.pairs += pq.size();
+      for (uint32_t k : waiting)
+        {
+          QState & q = st[k];
+          const int64_t ql = qlen(k);
+          uint64_t i = q.req_first;
+          for (size_t x = (size_t) q.finalized; x < q.hits.size(); ++x)
+            {
+              Hit & h = q.hits[x];
+              const bool live = (q.rejects < S.mr) && (q.accepts < S.ma);
+              if (h.rejected) { if (live) ++q.rejects; continue; }
+              const uint64_t r = i++;
+              acct.cells += (uint64_t) ql * S.len[h.target];
+              if (!live) continue;                                   // ignored hit: stays unaligned (:785, :875-878)
+              const int frc = fill_hit(S, qseq(k), ql, h, res, r, acct.sentinels);
+              if (frc != VSX_OK) { vsx_results_free(&res); return sfail(frc, "search: fallback aligner failed"); }
+              if (acceptable_aligned(S, ql, h)) ++q.accepts; else ++q.rejects;
+            }
+          q.finalized = (int64_t) q.hits.size();
+          q.delayed = 0;
+        }
+      vsx_results_free(&res);
+      open.swap(waiting);
+    }
   return VSX_OK;
 }
 
@@ -573,51 +637,14 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
         if (rc != VSX_OK) return rc;
       }
 
-      // ---- stages: every open query contributes its next align_delayed batch ----
-      std::vector<uint32_t> open(wn);
-      for (uint64_t k = 0; k < wn; ++k) open[k] = (uint32_t) k;
-      std::vector<uint32_t> pq, pt;
-      while (!open.empty())
-        {
-          pq.clear(); pt.clear();
-          std::vector<uint32_t> waiting;
-          for (uint32_t k : open)
-            if (advance(*S, st[k], qblob + qoff[w0 + k], qlen[w0 + k], k, pq, pt)) waiting.push_back(k);
-          if (waiting.empty()) break;
-          ++stages;
-          t0 = now_s();
-          vsx_results res;
-          int rc = vsx_align_pairs(S->ctx, qset, S->dbset, pq.size(), pq.data(), pt.data(), &res);
-          t_align += now_s() - t0;
-          if (rc != VSX_OK) { vsx_seqset_destroy(qset); return rc; }
-          pairs += pq.size();
-
-          // ---- align_delayed bookkeeping (:782-878), sequential per query, reference order ----
-          for (uint32_t k : waiting)
-            {
-              QState & q = st[k];
-              const int64_t ql = qlen[w0 + k];
-              uint64_t i = q.req_first;
-              for (size_t x = (size_t) q.finalized; x < q.hits.size(); ++x)
-                {
-                  Hit & h = q.hits[x];
-                  const bool live = (q.rejects < S->mr) && (q.accepts < S->ma);
-                  if (h.rejected) { if (live) ++q.rejects; continue; }
-                  const uint64_t r = i++;
-                  cells += (uint64_t) ql * S->len[h.target];
-                  if (!live) continue;                                   // ignored hit: stays unaligned (:785, :875-878)
-                  {
-                    const int frc = fill_hit(*S, qblob + qoff[w0 + k], ql, h, res, r, sentinels);
-                    if (frc != VSX_OK) { vsx_results_free(&res); vsx_seqset_destroy(qset); return sfail(frc, "vsx_search_batch: fallback aligner failed"); }
-                  }
-                  if (acceptable_aligned(*S, ql, h)) ++q.accepts; else ++q.rejects;
-                }
-              q.finalized = (int64_t) q.hits.size();
-              q.delayed = 0;
-            }
-          vsx_results_free(&res);
-          open.swap(waiting);
-        }
+      {
+        Acct acct;
+        const int src = run_stages(*S, st, [&](uint64_t k) { return qblob + qoff[w0 + k]; },
+                                   [&](uint64_t k) { return (int64_t) qlen[w0 + k]; },
+                                   [&](uint64_t k) { return (uint32_t) k; }, qset, acct);
+        t_align += acct.t_align; pairs += acct.pairs; cells += acct.cells; stages += acct.stages; sentinels += acct.sentinels;
+        if (src != VSX_OK) { vsx_seqset_destroy(qset); return src; }
+      }
       vsx_seqset_destroy(qset);
 
       // ---- search_joinhits (:1028-1052): accepted | weak, ordered by hit_compare_byid ----
@@ -693,6 +720,246 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
   out->pairs_aligned = pq.size(); out->cells_aligned = cells; out->stages = 1; out->sentinel_pairs = sentinels;
   out->seconds_align = t_align; out->seconds_total = now_s() - t_begin;
   return VSX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cluster_fast / cluster_smallmem-style greedy centroid clustering (core/cluster.cpp:877-1031 cluster_core_parallel,
+// :601-856 evaluate_extra_hits).  Sequences are processed in the given order (the caller sorts: --cluster_fast =
+// length descending, Database::sortbylength core/db.cpp:433-450).  A ROUND of `round` sequences is searched against
+// the centroids known at the start of the round (one staged GPU search, as vsx_search_batch); the sequential
+// reconciliation then replays the reference's intra-round fix-up: sequences of the same round that became centroids
+// are inserted into the hit list by shared k-mers and the accept loop is re-run from the top.  The reference
+// proves (and the survey verified) that the result does not depend on the round size, i.e. equals the serial
+// algorithm; the (query, new-centroid) alignments the fix-up may need are aligned speculatively in one GPU batch.
+// ---------------------------------------------------------------------------------------------------------
+static bool enough_kmers(const vsx_searcher & S, uint32_t shared, uint32_t kmersamplecount)     // searchcore.cpp:251-257
+{
+  return ((int64_t) shared >= S.minwordmatches) || (shared >= kmersamplecount);
+}
+
+int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
+{
+  if (!S || !out) return sfail(VSX_EINVAL, "vsx_cluster_fast: null argument");
+  std::memset(out, 0, sizeof *out);
+  const double t_begin = now_s();
+  const uint64_t n = S->len.size();
+  if (round == 0) round = 4096;
+  const uint64_t nk = 1ull << (2 * S->w);
+  IncIndex inc;
+  inc.post.assign(nk, {});
+  S->is_centroid.assign(n, 0);
+  std::vector<uint32_t> clusterno(n, 0);
+  std::vector<std::vector<Hit>> kept(n);
+  uint32_t nclusters = 0;
+  Acct acct;
+  double t_kmer = 0;
+  const int64_t hit_capacity = std::min<int64_t>(S->ma + S->mr - 1, S->tophits);
+
+  const int nth = std::max(1, S->threads);
+  struct Scratch { std::vector<uint16_t> counts; std::vector<uint32_t> touched, km; std::vector<uint64_t> seen; };
+  std::vector<Scratch> scratch((size_t) nth);
+  for (auto & sc : scratch)
+    {
+      sc.counts.assign(n, 0);
+      sc.seen.assign(S->w < 10 ? (nk + 63) / 64 : 1, 0);
+    }
+  auto seq_of = [&](uint64_t seqno) { return S->blob.data() + S->off[seqno]; };
+
+  for (uint64_t s0 = 0; s0 < n; s0 += round)
+    {
+      const uint64_t wn = std::min<uint64_t>(round, n - s0);
+      std::vector<QState> st(wn);
+      std::vector<std::vector<uint32_t>> kmers(wn);
+
+      // ---- phase 1a: k-mer candidates against the centroid index as of the round start ----
+      double t0 = now_s();
+      {
+        std::atomic<uint64_t> next {0};
+        auto work = [&](int tid) {
+          Scratch & sc = scratch[(size_t) tid];
+          for (;;)
+            {
+              const uint64_t k = next.fetch_add(1);
+              if (k >= wn) break;
+              candidates_for(*S, seq_of(s0 + k), S->len[s0 + k], sc.counts, sc.touched, sc.km, sc.seen, st[k].cands, &inc);
+              kmers[k] = sc.km;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto & th : pool) th.join();
+      }
+      t_kmer += now_s() - t0;
+
+      // ---- phase 1b: staged GPU search (queries and targets both live in the database sequence set) ----
+      int rc = run_stages(*S, st, [&](uint64_t k) { return seq_of(s0 + k); }, [&](uint64_t k) { return (int64_t) S->len[s0 + k]; },
+                          [&](uint64_t k) { return (uint32_t) (s0 + k); }, S->dbset, acct);
+      if (rc != VSX_OK) return rc;
+
+      // ---- phase 1c: intra-round shared k-mer counts (unique_count_shared, core/unique.cpp:356-395) and the
+      //      speculative alignments of (member i, earlier member k) pairs that the fix-up could ask for ----
+      t0 = now_s();
+      struct Near { uint32_t k, shared; int64_t res; };            // res = index into the speculative results, -1 none
+      std::vector<std::vector<Near>> near(wn);
+      std::vector<uint32_t> sq, stg;
+      {
+        std::vector<std::vector<uint32_t>> lpost(nk);               // round-local: k-mer -> earlier members
+        std::vector<uint16_t> cnt(wn, 0);
+        std::vector<uint32_t> touched;
+        for (uint64_t i = 0; i < wn; ++i)
+          {
+            touched.clear();
+            for (uint32_t km : kmers[i])
+              for (uint32_t k : lpost[km]) { if (cnt[k]++ == 0) touched.push_back(k); }
+            std::sort(touched.begin(), touched.end());
+            for (uint32_t k : touched)
+              {
+                Near nr {k, cnt[k], -1};
+                cnt[k] = 0;
+                if (enough_kmers(*S, nr.shared, (uint32_t) kmers[i].size()) &&
+                    acceptable_unaligned(*S, seq_of(s0 + i), S->len[s0 + i], (uint32_t) (s0 + k)))
+                  {
+                    nr.res = (int64_t) sq.size();
+                    sq.push_back((uint32_t) (s0 + i));
+                    stg.push_back((uint32_t) (s0 + k));
+                  }
+                near[i].push_back(nr);
+              }
+            for (uint32_t km : kmers[i]) lpost[km].push_back((uint32_t) i);
+          }
+      }
+      t_kmer += now_s() - t0;
+      vsx_results spec;
+      std::memset(&spec, 0, sizeof spec);
+      if (!sq.empty())
+        {
+          t0 = now_s();
+          rc = vsx_align_pairs(S->ctx, S->dbset, S->dbset, sq.size(), sq.data(), stg.data(), &spec);
+          acct.t_align += now_s() - t0;
+          if (rc != VSX_OK) return rc;
+          acct.pairs += sq.size();
+        }
+
+      // ---- phase 2: sequential reconciliation in processing order ----
+      std::vector<uint32_t> extras;                                  // round members that became centroids, in order
+      for (uint64_t i = 0; i < wn; ++i)
+        {
+          const uint64_t seqno = s0 + i;
+          QState & q = st[i];
+          const int64_t ql = S->len[seqno];
+          std::vector<Hit> & hits = q.hits;
+
+          // evaluate_extra_hits (:601-856)
+          int added = 0;
+          {
+            size_t np = 0;                                           // near[i] is sorted by k, extras is increasing too
+            for (uint32_t k : extras)
+              {
+                while (np < near[i].size() && near[i][np].k < k) ++np;
+                const uint32_t shared = (np < near[i].size() && near[i][np].k == k) ? near[i][np].shared : 0;
+                if (!enough_kmers(*S, shared, (uint32_t) kmers[i].size())) continue;
+                const uint32_t length = S->len[s0 + k];
+                int64_t x = (int64_t) hits.size();
+                while (x > 0 && ((hits[(size_t) x - 1].count < shared) ||
+                                 (hits[(size_t) x - 1].count == shared && S->len[hits[(size_t) x - 1].target] > length)))
+                  --x;
+                if (x < hit_capacity)
+                  {
+                    if ((int64_t) hits.size() >= hit_capacity) hits.pop_back();
+                    Hit h;
+                    h.target = (uint32_t) (s0 + k);
+                    h.count = shared;
+                    hits.insert(hits.begin() + x, std::move(h));
+                    ++added;
+                  }
+              }
+          }
+          if (added != 0)
+            {
+              q.rejects = 0; q.accepts = 0;
+              for (Hit & h : hits) { h.accepted = false; h.rejected = false; }
+              for (size_t t = 0; (q.accepts < S->ma) && (q.rejects < S->mr) && (t < hits.size()); ++t)
+                {
+                  Hit & h = hits[t];
+                  if (!h.aligned)
+                    {
+                      if (acceptable_unaligned(*S, seq_of(seqno), ql, h.target))
+                        {
+                          // single-target alignment (:743): taken from the speculative batch when it is there
+                          int64_t ri = -1;
+                          if (h.target >= s0 && h.target < s0 + wn)
+                            for (const Near & nr : near[i]) if (nr.k == h.target - s0) { ri = nr.res; break; }
+                          vsx_results one;
+                          std::memset(&one, 0, sizeof one);
+                          const vsx_results * rp = &spec;
+                          if (ri < 0)
+                            {
+                              const uint32_t a = (uint32_t) seqno, b = h.target;
+                              rc = vsx_align_pairs(S->ctx, S->dbset, S->dbset, 1, &a, &b, &one);
+                              if (rc != VSX_OK) { vsx_results_free(&spec); return rc; }
+                              ++acct.pairs;
+                              rp = &one; ri = 0;
+                            }
+                          acct.cells += (uint64_t) ql * S->len[h.target];
+                          rc = fill_hit(*S, seq_of(seqno), ql, h, *rp, (uint64_t) ri, acct.sentinels);
+                          vsx_results_free(&one);
+                          if (rc != VSX_OK) { vsx_results_free(&spec); return sfail(rc, "vsx_cluster_fast: fallback aligner failed"); }
+                        }
+                      else { h.rejected = true; ++q.rejects; }
+                    }
+                  if (!h.rejected)
+                    {
+                      if (acceptable_aligned(*S, ql, h)) ++q.accepts; else ++q.rejects;
+                    }
+                }
+              // delete all undetermined hits from the first one on (:841-854)
+              size_t cut = hits.size();
+              for (size_t t = hits.size(); t-- > 0;)
+                if (!hits[t].accepted && !hits[t].rejected) cut = t;
+              hits.resize(cut);
+            }
+
+          // search_findbest2_byid (searchcore.cpp:960-991): first minimum under hit_compare_byid, must be accepted
+          const Hit * best = nullptr;
+          for (const Hit & h : hits) if (!best || hit_compare_byid(h, *best) < 0) best = &h;
+          if (best && !best->accepted) best = nullptr;
+          if (best)
+            {
+              clusterno[seqno] = clusterno[best->target];
+              kept[seqno].push_back(*best);
+            }
+          else
+            {
+              clusterno[seqno] = nclusters++;
+              extras.push_back((uint32_t) i);
+              S->is_centroid[seqno] = 1;
+              for (uint32_t km : kmers[i]) inc.post[km].push_back((uint32_t) seqno);    // Dbindex::add_sequence (:1009)
+              ++inc.indexed;
+            }
+        }
+      vsx_results_free(&spec);
+    }
+
+  int rc = marshal_hits(kept, &out->hits);
+  if (rc != VSX_OK) return rc;
+  out->n = n;
+  out->n_clusters = nclusters;
+  out->clusterno = (uint32_t *) std::malloc(std::max<uint64_t>(n, 1) * sizeof(uint32_t));
+  if (!out->clusterno) { vsx_hits_free(&out->hits); return sfail(VSX_ENOMEM, "vsx_cluster_fast: host allocation failed"); }
+  std::memcpy(out->clusterno, clusterno.data(), n * sizeof(uint32_t));
+  out->hits.pairs_aligned = acct.pairs; out->hits.cells_aligned = acct.cells; out->hits.stages = acct.stages;
+  out->hits.sentinel_pairs = acct.sentinels; out->hits.seconds_kmer = t_kmer; out->hits.seconds_align = acct.t_align;
+  out->hits.seconds_total = now_s() - t_begin;
+  return VSX_OK;
+}
+
+void vsx_cluster_out_free(vsx_cluster_out * o)
+{
+  if (!o) return;
+  vsx_hits_free(&o->hits);
+  std::free(o->clusterno);
+  std::memset(o, 0, sizeof *o);
 }
 
 void vsx_hits_free(vsx_hits * h)

@@ -76,6 +76,51 @@ class SearchSession:
         check(lib.vsx_allpairs_block(self.h, 1 if acceptall else 0, first, count, C.byref(res)), "vsx_allpairs_block")
         return self._unpack(res)
 
+    def cluster_fast(self, round=0):
+        """greedy centroid clustering of the session's sequences in their given order (sort them first).
+        -> (clusterno list, per-sequence hit dict or None, number of clusters)"""
+        lib = _lib.load()
+        res = _lib.ClusterOut()
+        check(lib.vsx_cluster_fast(self.h, int(round), C.byref(res)), "vsx_cluster_fast")
+        try:
+            n = int(res.n)
+            cno = [int(res.clusterno[k]) for k in range(n)]
+            hits = res.hits
+            cig = C.string_at(hits.cigar_blob, int(hits.cigar_bytes)) if hits.cigar_bytes else b""
+            per = []
+            for q in range(n):
+                a, b = int(hits.first[q]), int(hits.first[q + 1])
+                if a == b:
+                    per.append(None)
+                    continue
+                h = hits.hit[a]
+                d = {nm: getattr(h, nm) for nm in HIT_FIELDS}
+                o = int(h.cigar_off)
+                d["cigar"] = cig[o:cig.index(b"\0", o)].decode()
+                per.append(d)
+            self.stats = {nm: getattr(hits, nm) for nm in ("pairs_aligned", "cells_aligned", "stages", "sentinel_pairs",
+                                                             "seconds_kmer", "seconds_align", "seconds_total")}
+            return cno, per, int(res.n_clusters)
+        finally:
+            lib.vsx_cluster_out_free(C.byref(res))
+
+    def uc_lines(self, names, round=0):
+        """the --uc file of --cluster_fast: S/H records in processing order, then one C record per cluster
+        (core/results.cpp:274-327, core/cluster.cpp:513-547, :1366-1378)"""
+        cno, per, ncl = self.cluster_fast(round)
+        lines, size, centroid = [], [0] * ncl, [None] * ncl
+        for s, (c, h) in enumerate(zip(cno, per)):
+            size[c] += 1
+            if h is None:
+                centroid[c] = s
+                lines.append(f"S\t{c}\t{len(self.db[s])}\t*\t*\t*\t*\t*\t{names[s]}\t*")
+            else:
+                aln = "=" if h["matches"] == h["internal_alignmentlength"] else h["cigar"]
+                lines.append(f"H\t{c}\t{len(self.db[s])}\t{h['id']:.1f}\t+\t0\t0\t{aln}\t{names[s]}\t{names[h['target']]}")
+        for c in range(ncl):
+            lines.append(f"C\t{c}\t{size[c]}\t*\t*\t*\t*\t*\t{names[centroid[c]]}\t*")
+        return lines
+
     def search_batch(self, queries):
         lib = _lib.load()
         blob, off, lens = _blob(queries)
