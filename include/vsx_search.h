@@ -119,6 +119,21 @@ typedef struct vsx_cluster_out {
 int vsx_cluster_fast(vsx_searcher * s, uint64_t round, vsx_cluster_out * out);
 void vsx_cluster_out_free(vsx_cluster_out * o);
 
+/* Star multiple alignment / profile / consensus of ONE cluster from the members' CIGARs (core/msa.cpp:569-613;
+   no DP).  seqs[0] is the centroid (cigars[0] ignored), members follow with the CIGAR of (query = member,
+   target = centroid) exactly as vsx_cluster_fast reports it.  rows: n_rows = n + 1 NUL-terminated strings of alnlen
+   columns each (centroid, members, then the consensus row with '+' outside the centroid and '-' where gaps win);
+   profile: alnlen x 6 counts in the order A C G T N gap (msa.cpp:92-141); consensus: the un-gapped majority sequence. */
+typedef struct vsx_msa_out {
+  uint64_t   alnlen, n_rows, conslen;
+  char     * rows;
+  char     * consensus;
+  uint64_t * profile;
+} vsx_msa_out;
+int vsx_msa(uint32_t n, const char * const * seqs, const uint32_t * lens, const char * const * cigars,
+            const uint64_t * abundances /* NULL = all 1 */, vsx_msa_out * out);
+void vsx_msa_out_free(vsx_msa_out * o);
+
 /* The scalar fallback the callers run on the SHRT_MAX sentinel: LinearMemoryAligner::align + alignstats
    (core/linmemalign.cpp:694-808; call sites core/searchcore.cpp:806-832, commands/allpairs_global.cpp:447-473).
    Host CPU, int64 arithmetic, linear memory, the reference's tie-breaks; uses the UNclamped scoring values

@@ -189,3 +189,60 @@ def test_cluster_fast_matches_reference_cli(gpu_required, tmp_path, name, opts, 
         got = ss.uc_lines(snames, round=round_size)
     assert sum(1 for l in exp if l[0] == "H") > 50
     assert got == exp, _first_diff(got, exp)
+
+
+def _wrap(seq, width=80):
+    return [seq[i:i + width] for i in range(0, len(seq), width)] or [""]
+
+
+def test_cluster_msa_consensus_profile_match_reference_cli(gpu_required, tmp_path):
+    """--cluster_fast --msaout --consout --profile: the CIGARs we store per member must drive the reference's star MSA,
+    consensus and profile to byte-identical files (the consumer of the CIGAR contract)."""
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing")
+    from vsearch_amd import Aligner, SearchSession, msa
+    rng = random.Random(17)
+    seqs = []
+    for f in range(8):
+        anc = common.rnd_seq(rng, rng.randint(150, 200))
+        for _ in range(rng.randint(1, 9)):
+            seqs.append(common.mutate(rng, anc, rng.choice([0.02, 0.06])))
+    seqs.append(common.mutate(rng, seqs[0], 0.03, "ACGTNRY"))
+    rng.shuffle(seqs)
+    names = [f"s{i:03d}" for i in range(len(seqs))]
+    order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), names[i]))
+    sseqs, snames = [seqs[i] for i in order], [names[i] for i in order]
+    tmp = str(tmp_path)
+    f_in = os.path.join(tmp, "m.fa")
+    with open(f_in, "w") as f:
+        f.write("".join(f">{n}\n{s}\n" for n, s in zip(names, seqs)))
+    p = subprocess.run([REF_BIN, "--cluster_fast", f_in, "--id", "0.85", "--qmask", "none", "--threads", "1", "--quiet",
+                        "--msaout", tmp + "/m.msa", "--consout", tmp + "/m.cons", "--profile", tmp + "/m.prof"],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    with Aligner() as al:
+        ss = SearchSession(al, sseqs, id=0.85, maxrejects=8)
+        cno, per, ncl = ss.cluster_fast(round=16)
+    members = [[] for _ in range(ncl)]
+    for s, c in enumerate(cno):
+        members[c].append(s)                       # ascending seqno: the centroid comes first
+    msa_lines, cons_lines, prof_lines = [], [], []
+    for c in range(ncl):
+        m = members[c]
+        assert per[m[0]] is None
+        res = msa([sseqs[s] for s in m], [None] + [per[s]["cigar"] for s in m[1:]])
+        msa_lines.append("")
+        for k, s in enumerate(m):
+            msa_lines.append(">" + ("*" if k == 0 else "") + snames[s])
+            msa_lines += _wrap(res["rows"][k])
+        msa_lines.append(">consensus")
+        msa_lines += _wrap(res["rows"][-1])
+        cons_lines.append(f">centroid={snames[m[0]]};seqs={len(m)}")
+        cons_lines += _wrap(res["consensus"])
+        prof_lines.append(f">centroid={snames[m[0]]};seqs={len(m)}")
+        for i, (ch, pr) in enumerate(zip(res["rows"][-1], res["profile"])):
+            prof_lines.append("\t".join([str(i), ch] + [str(pr[k]) for k in (0, 1, 2, 3, 5, 4)]))
+        prof_lines.append("")
+    assert msa_lines == open(tmp + "/m.msa").read().splitlines()
+    assert cons_lines == open(tmp + "/m.cons").read().splitlines()
+    assert prof_lines == open(tmp + "/m.prof").read().splitlines()

@@ -22,7 +22,7 @@ SYMBOLS = [
 ]
 # include/vsx_search.h
 SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
-                  "vsx_hits_free", "vsx_search_candidates", "vsx_lma_align", "vsx_allpairs_block", "vsx_cluster_fast", "vsx_cluster_out_free"]
+                  "vsx_hits_free", "vsx_search_candidates", "vsx_lma_align", "vsx_allpairs_block", "vsx_cluster_fast", "vsx_cluster_out_free", "vsx_msa", "vsx_msa_out_free"]
 
 
 class SearchOpts(C.Structure):
@@ -83,6 +83,11 @@ class ClusterOut(C.Structure):
     _fields_ = [("n", C.c_uint64), ("n_clusters", C.c_uint64), ("clusterno", C.POINTER(C.c_uint32)), ("hits", Hits)]
 
 
+class MsaOut(C.Structure):
+    _fields_ = [("alnlen", C.c_uint64), ("n_rows", C.c_uint64), ("conslen", C.c_uint64), ("rows", C.POINTER(C.c_char)),
+                ("consensus", C.POINTER(C.c_char)), ("profile", C.POINTER(C.c_uint64))]
+
+
 _lib = None
 
 
@@ -133,6 +138,9 @@ def load():
     lib.vsx_cluster_fast.argtypes = [vp, C.c_uint64, C.POINTER(ClusterOut)]
     lib.vsx_cluster_out_free.argtypes = [C.POINTER(ClusterOut)]
     lib.vsx_cluster_out_free.restype = None
+    lib.vsx_msa.argtypes = [C.c_uint32, vp, vp, vp, vp, C.POINTER(MsaOut)]
+    lib.vsx_msa_out_free.argtypes = [C.POINTER(MsaOut)]
+    lib.vsx_msa_out_free.restype = None
     lib.vsx_lma_align.argtypes = [C.POINTER(Scoring), C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64] + \
         [C.POINTER(C.c_int64)] * 5 + [C.POINTER(vp)]
     _lib = lib

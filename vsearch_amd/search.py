@@ -173,3 +173,25 @@ class SearchSession:
             for h in hs:
                 lines.append("\t".join(fmt[f](q, h) for f in fields))
         return lines
+
+
+def msa(seqs, cigars):
+    """star MSA / profile / consensus of one cluster (core/msa.cpp): seqs[0] = centroid, cigars[i] = member i vs centroid.
+    -> dict(rows=[centroid, members..., consensus row], consensus=str, profile=[[A,C,G,T,N,gap] per column])"""
+    lib = _lib.load()
+    n = len(seqs)
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+    cs = [(c.encode() if isinstance(c, str) else c) if c is not None else b"" for c in cigars]
+    sp = (C.c_char_p * n)(*bs)
+    cp = (C.c_char_p * n)(*cs)
+    lens = (C.c_uint32 * n)(*[len(b) for b in bs])
+    out = _lib.MsaOut()
+    check(lib.vsx_msa(n, sp, lens, cp, None, C.byref(out)), "vsx_msa")
+    try:
+        L = int(out.alnlen)
+        raw = C.string_at(out.rows, int(out.n_rows) * (L + 1))
+        rows = [raw[k * (L + 1):k * (L + 1) + L].decode() for k in range(int(out.n_rows))]
+        prof = [[int(out.profile[i * 6 + k]) for k in range(6)] for i in range(L)]
+        return dict(rows=rows, consensus=C.string_at(out.consensus, int(out.conslen)).decode(), profile=prof)
+    finally:
+        lib.vsx_msa_out_free(C.byref(out))
