@@ -157,7 +157,7 @@ def main():
             "cells_per_step_per_gpu": cells,
         },
         "roofline": {
-            "kernel": "vsx_forward_kernel<16,false,false,true>",
+            "kernel": "vsx_forward_kernel<16,true,false,true>",
             "bound": "valu-int16",
             "achieved": round(achieved, 3),
             "peak": round(PEAK_INT16_TOPS, 2),

@@ -80,7 +80,9 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    u32 * __restrict__ dir, uint2 * strip, VsxSlotOut * __restrict__ slot_out)
 {
   constexpr int ND = (R + 3) / 4;                  // direction dwords per lane per step
-  __shared__ u32 W[GENERIC ? 4096 : 1];            // W[a][bA][bB] = {S[bA][a], S[bB][a]}
+  // GENERIC: query profile in LDS, QP[target code][row of the strip] = S[code][query symbol of the row] (int16).
+  // Any IUPAC / unknown symbol on either side is handled by construction; one v_perm_b32 per row packs the two targets.
+  __shared__ __attribute__((aligned(16))) int16_t QP[GENERIC ? 16 * 16 * R : 8];
 
   const VsxTask & T = tasks[blockIdx.x];
   const int lane = (int) threadIdx.x;
@@ -90,6 +92,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   const int Q = (int) T.qlen;
   const int total_lanes = (Q + R - 1) / R;         // pipeline positions holding query rows
   const int rcnt0 = Q - (total_lanes - 1) * R;     // rows in position 0 (1..R); all others hold R
+  const int rc0 = __builtin_amdgcn_readfirstlane(rcnt0);   // provably scalar: keeps the per-row capture test on the SALU
   const int nstrips = (total_lanes + 15) >> 4;
   const int steps = (int) T.steps;
 
@@ -102,16 +105,6 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   const uint8_t * __restrict__ tB = tc + T.toff[2 * g + 1];
   const uint8_t * __restrict__ qq = qc + T.qoff;
 
-  if (GENERIC)
-    {
-      for (int idx = lane; idx < 4096; idx += 64)
-        {
-          const int a = idx >> 8, bA = (idx >> 4) & 15, bB = idx & 15;
-          W[idx] = ((u32) (uint16_t) P.matrix[bA * 16 + a]) | ((u32) (uint16_t) P.matrix[bB * 16 + a] << 16);
-        }
-      __syncthreads();
-    }
-
   u32 hmin = 0, hmax = 0;      // running min(0, H...) / max(0, H...) of align_simd.cpp:810-811,772-773
   u32 score = 0;
 
@@ -121,6 +114,24 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       const bool lane_on = (L < total_lanes) && (Dpg > 0);
       const bool first = (L == 0);
       const int i0 = first ? 0 : rcnt0 + (L - 1) * R;
+
+      if (GENERIC)
+        {
+          __syncthreads();                           // previous strip's readers are done
+          for (int idx = lane; idx < 16 * 16 * R; idx += 64)
+            {
+              const int code = idx / (16 * R), row = idx % (16 * R);
+              const int Lr = 16 * s + row / R, rr = row % R;
+              int v = 0;
+              if (Lr < total_lanes && !(Lr == 0 && rr >= rcnt0))
+                {
+                  const int gi = (Lr == 0) ? rr : rcnt0 + (Lr - 1) * R + rr;
+                  v = P.matrix[code * 16 + (int) qq[gi]];
+                }
+              QP[idx] = (int16_t) v;
+            }
+          __syncthreads();
+        }
 
       // ---- per-lane row state: left border (aligncolumns_first :844-859, :881-887) ----
       u32 hprev[R];      // H(i, j-1): left neighbour, next column's diagonal for row i+1
@@ -132,7 +143,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           int i = i0 + r;
           if (i > Q - 1) i = Q - 1;                // dummy rows (skipped or idle lanes): any valid address
           const u32 a = qq[i];
-          ac[r] = GENERIC ? (a << 8) : (a | (a << 16));
+          ac[r] = a | (a << 16);
           const u32 hl = pack16(P.hleft[i]);
           hprev[r] = hl;
           E[r] = ssub(hl, (i < Q - 1) ? P.qrq_i_pk : P.qrq_r_pk);
@@ -209,7 +220,9 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           if (lane_on && j >= 0 && j < Dpg)
             {
               const u32 code = sym & 0x000F000Fu;
-              const u32 bcol = GENERIC ? (((code & 0xFu) << 4) | (code >> 16)) : 0u;
+              const int16_t * qpA = QP + (code & 0xFu) * (16 * R) + l * R;      // GENERIC only
+              const int16_t * qpB = QP + (code >> 16) * (16 * R) + l * R;
+              u32 pa = 0, pb = 0;                                               // two rows' scores per dword
               u32 Hd = diag;
               u32 F = inF;
               u32 smn = 0x7FFF7FFFu, smx = 0x80008000u;
@@ -221,7 +234,22 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               for (int r = 0; r < R; ++r)
                 {
                   u32 V;
-                  if (GENERIC) V = W[ac[r] | bcol];
+                  if (GENERIC)
+                    {
+                      if (R % 4 == 0)
+                        {
+                          if ((r & 3) == 0)
+                            {
+                              const uint2 va = *reinterpret_cast<const uint2 *>(qpA + r);
+                              const uint2 vb = *reinterpret_cast<const uint2 *>(qpB + r);
+                              pa = va.x; pb = vb.x;
+                              ac[r + 1] = va.y; ac[r + 2] = vb.y;             // rows r+2, r+3 (ac[] is free in this variant)
+                            }
+                          else if ((r & 3) == 2) { pa = ac[r - 1]; pb = ac[r]; }
+                          V = (r & 1) ? __builtin_amdgcn_perm(pb, pa, 0x07060302u) : __builtin_amdgcn_perm(pb, pa, 0x05040100u);
+                        }
+                      else V = (u32) (uint16_t) qpA[r] | ((u32) (uint16_t) qpB[r] << 16);
+                    }
                   else V = a_pk_mad(a_pk_minu(ac[r] ^ code, 0x00010001u), nd, P.match_pk);
                   // onestep (:765-780)
                   const u32 h0 = sadd(Hd, V);
@@ -249,7 +277,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   E[r] = pmax(e, he);
                   if (CKPT && r == R - 2) { xH = h2; xF = F; }
                   // position 0 holds only rcnt0 rows: its later rows compute junk that never leaves the lane
-                  if (__builtin_expect(r + 1 == rcnt0, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
+                  if (__builtin_expect(rc0 == r + 1, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
                 }
               const u32 hl = first ? capH : h2;
               F = first ? capF : F;

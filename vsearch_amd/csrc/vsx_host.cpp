@@ -457,7 +457,10 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       std::stable_sort(gpu_pairs.begin() + b, gpu_pairs.begin() + e,
                        [&](uint32_t x, uint32_t y) { return targets->len[tidx[x]] > targets->len[tidx[y]]; });
       const int rows = pick_rows((int) queries->len[q]);
-      const int generic = queries->impure[q] ? 1 : 0;
+      // substitution scores: LDS query profile by default (handles every symbol); VSX_SCORE=arith selects the XOR/min/mad
+      // variant for queries made of A/C/G/T(U) only (kept for A/B measurements)
+      static const bool arith = std::getenv("VSX_SCORE") && std::strcmp(std::getenv("VSX_SCORE"), "arith") == 0;
+      const int generic = (queries->impure[q] || !arith) ? 1 : 0;
       for (size_t x = b; x < e; x += VSX_TASK_SLOTS)
         {
           ProtoTask pt {};
