@@ -45,6 +45,32 @@
 #define I_SAD16(x)    "v_sad_u16 " #x ", " #x ", %16, %17\n"
 #define I_MAD_I32_I16(x) "v_mad_i32_i16 " #x ", " #x ", %16, %17\n"
 
+#define I_SUB32(x)    "v_sub_u32 " #x ", " #x ", %16\n"
+#define I_SUBREV32(x) "v_subrev_u32 " #x ", " #x ", %16\n"
+#define I_MIN32(x)    "v_min_i32 " #x ", " #x ", %16\n"
+#define I_MAXU32(x)   "v_max_u32 " #x ", " #x ", %16\n"
+#define I_ASHR32(x)   "v_ashrrev_i32 " #x ", 31, " #x "\n"
+#define I_AND32(x)    "v_and_b32 " #x ", " #x ", %16\n"
+#define I_OR32(x)     "v_or_b32 " #x ", " #x ", %16\n"
+#define I_LSHL32(x)   "v_lshlrev_b32 " #x ", 1, " #x "\n"
+#define I_ADDCO(x)    "v_add_co_u32 " #x ", vcc, " #x ", %16\n"
+#define I_ADDC(x)     "v_addc_co_u32 " #x ", vcc, " #x ", %16, vcc\n"
+#define I_MIN16(x)    "v_min_i16 " #x ", " #x ", %16\n"
+#define I_ADDU16(x)   "v_add_u16 " #x ", " #x ", %16\n"
+#define I_SUBU16(x)   "v_sub_u16 " #x ", " #x ", %16\n"
+#define I_CMP32(x)    "v_cmp_lt_i32 vcc, " #x ", %16\n"
+#define I_LSHLADD(x)  "v_lshl_add_u32 " #x ", " #x ", 1, %16\n"
+#define I_MADU24(x)   "v_mad_u32_u24 " #x ", " #x ", %16, %17\n"
+#define I_MULU24(x)   "v_mul_u32_u24 " #x ", " #x ", %16\n"
+#define I_SUBI32C(x)  "v_sub_i32 " #x ", " #x ", %16 clamp\n"
+#define I_MED3(x)     "v_med3_i32 " #x ", " #x ", %16, %17\n"
+#define I_BFE(x)      "v_bfe_u32 " #x ", " #x ", 8, 8\n"
+#define I_ADDSDWA(x)  "v_add_u32_sdwa " #x ", " #x ", %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define I_MAX16SDWA(x) "v_max_i16_sdwa " #x ", " #x ", %16 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1\n"
+#define I_MOVDPP(x)   "v_mov_b32_dpp " #x ", %16 row_ror:15 row_mask:0xf bank_mask:0xf\n"
+#define I_ADDDPP(x)   "v_add_u32_dpp " #x ", %16, " #x " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define I_MOV64(x)    "v_mov_b64 %18, %19\n"
+
 #define DEFK(NAME, INS) \
   __global__ void __launch_bounds__(256) NAME(int iters, int * out, int seed) { \
     int r[16]; int b = seed + threadIdx.x, c = seed * 7 + 3; \
@@ -84,6 +110,31 @@ DEFK(k_dot2, I_DOT2)
 DEFK(k_sad16, I_SAD16)
 DEFK(k_mad_i32_i16, I_MAD_I32_I16)
 
+DEFK(k2_sub32, I_SUB32)
+DEFK(k2_subrev32, I_SUBREV32)
+DEFK(k2_min32, I_MIN32)
+DEFK(k2_maxu32, I_MAXU32)
+DEFK(k2_ashr32, I_ASHR32)
+DEFK(k2_and32, I_AND32)
+DEFK(k2_or32, I_OR32)
+DEFK(k2_lshl32, I_LSHL32)
+DEFK(k2_addco, I_ADDCO)
+DEFK(k2_addc, I_ADDC)
+DEFK(k2_min16, I_MIN16)
+DEFK(k2_addu16, I_ADDU16)
+DEFK(k2_subu16, I_SUBU16)
+DEFK(k2_cmp32, I_CMP32)
+DEFK(k2_lshladd, I_LSHLADD)
+DEFK(k2_madu24, I_MADU24)
+DEFK(k2_mulu24, I_MULU24)
+DEFK(k2_subi32c, I_SUBI32C)
+DEFK(k2_med3, I_MED3)
+DEFK(k2_bfe, I_BFE)
+DEFK(k2_addsdwa, I_ADDSDWA)
+DEFK(k2_max16sdwa, I_MAX16SDWA)
+DEFK(k2_movdpp, I_MOVDPP)
+DEFK(k2_adddpp, I_ADDDPP)
+
 typedef void (*kfn)(int, int *, int);
 
 static void run(const char * name, kfn k, int waves_per_simd)
@@ -112,10 +163,12 @@ int main()
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
   printf("device %s  CUs %d  clock %d kHz  arch %s\n", p.name, p.multiProcessorCount, p.clockRate, p.gcnArchName);
 #define R(NAME) run(#NAME, NAME, 4);
+  if (getenv("UB_NEW")) { R(k2_sub32) R(k2_subrev32) R(k2_min32) R(k2_maxu32) R(k2_ashr32) R(k2_and32) R(k2_or32) R(k2_lshl32) R(k2_addco) R(k2_addc) R(k2_min16) R(k2_addu16) R(k2_subu16) R(k2_cmp32) R(k2_lshladd) R(k2_madu24) R(k2_mulu24) R(k2_subi32c) R(k2_med3) R(k2_bfe) R(k2_addsdwa) R(k2_max16sdwa) R(k2_movdpp) R(k2_adddpp) return 0; }
   R(k_pk_add) R(k_pk_sub) R(k_pk_max) R(k_pk_min) R(k_pk_lshr) R(k_pk_ashr) R(k_pk_mad) R(k_pk_mul)
   R(k_xor) R(k_andor) R(k_lshr) R(k_bfi) R(k_lshlor) R(k_add32) R(k_add3) R(k_max32) R(k_max3_32)
   R(k_add16) R(k_max16) R(k_max3_16) R(k_dpp) R(k_perm) R(k_cndmask) R(k_cmp16) R(k_mov) R(k_alignbit)
   R(k_dot2) R(k_sad16) R(k_mad_i32_i16)
+  if (getenv("UB_NEW")) { R(k2_sub32) R(k2_subrev32) R(k2_min32) R(k2_maxu32) R(k2_ashr32) R(k2_and32) R(k2_or32) R(k2_lshl32) R(k2_addco) R(k2_addc) R(k2_min16) R(k2_addu16) R(k2_subu16) R(k2_cmp32) R(k2_lshladd) R(k2_madu24) R(k2_mulu24) R(k2_subi32c) R(k2_med3) R(k2_bfe) R(k2_addsdwa) R(k2_max16sdwa) R(k2_movdpp) R(k2_adddpp) return 0; }
   run("k_pk_add", k_pk_add, 1); run("k_pk_add", k_pk_add, 2); run("k_pk_add", k_pk_add, 8);
   run("k_xor", k_xor, 1); run("k_xor", k_xor, 2); run("k_xor", k_xor, 8);
   return 0;

@@ -500,7 +500,48 @@ DEV int wave_max_i32(int v)
   return v;
 }
 
-template <int R>
+// Arithmetic of the tile recompute.  PACKED = the DP kernel's saturating v_pk_*_i16 (this pair in the LOW int16 half,
+// sign bits funnelled to the right); FAST16 = for tasks whose scores provably never saturate (the planner's TRACK = 0
+// class, vsx_host.cpp no_overflow_possible()): values biased by 0x8000 into unsigned 16 bits, so the half-rate-free VOP2
+// forms v_add_u16 / v_sub_u16 / v_max_u16 (2 cycles per wave, measured: profiles/r01_ubench_valu.txt) give the same
+// numbers as the clamped packed ops (4 cycles), the comparison a > b is the sign of an exact 32-bit v_sub_u32, and one
+// v_alignbit_b32 shifts that sign into the direction word.
+template <bool FAST> struct TbOps;
+template <> struct TbOps<false>
+{
+  static DEV u32 in(u32 lo16) { return lo16; }
+  static DEV u32 score(int16_t v) { return (u32) (uint16_t) v; }
+  static DEV u32 add(u32 a, u32 b) { return sadd(a, b); }
+  static DEV u32 sub(u32 a, u32 b) { return ssub(a, b); }
+  static DEV u32 max(u32 a, u32 b) { return pmax(a, b); }
+  static DEV u32 dif(u32 a, u32 b) { return ssub(a, b); }                 // sign of a - b in bit 15
+  static DEV u32 neg(u32 d) { return (d >> 15) & 1u; }
+  static DEV u32 fun(u32 acc, u32 d) { return funnel(acc, d); }           // first row of a group ends in the LOW nibble
+  static DEV u32 one_row_word(u32 acc) { return acc >> 12; }
+  static DEV u32 nibble(u32 w, int rows_in_group, int y) { return (w >> (16 - 4 * rows_in_group + 4 * y)) & 15u; }
+  static constexpr u32 UP = 1, LEFT = 2, EXT_UP = 4, EXT_LEFT = 8;
+};
+template <> struct TbOps<true>
+{
+  // no value ever leaves (0, 65535) in this class, so plain 32-bit add/sub ARE the 16-bit results (v_add_u32 / v_sub_u32,
+  // 2 cycles); only the maximum needs the 16-bit form (v_max_u16 is full rate, v_max_u32 is not)
+  static DEV u32 in(u32 lo16) { return (lo16 & 0xffffu) ^ 0x8000u; }
+  static DEV u32 score(int16_t v) { return (u32) (int) v; }              // sign-extended addend
+  static DEV u32 add(u32 a, u32 b) { return a + b; }
+  static DEV u32 sub(u32 a, u32 b) { return a - b; }
+  static DEV u32 max(u32 a, u32 b) { return (u32) __builtin_elementwise_max((unsigned short) a, (unsigned short) b); }
+  static DEV u32 dif(u32 a, u32 b) { return a - b; }                      // exact sign in bit 31
+  static DEV u32 neg(u32 d) { return d >> 31; }
+  static DEV u32 fun(u32 acc, u32 d) { return __builtin_amdgcn_alignbit(acc, d, 31); }   // (acc << 1) | sign(d)
+  static DEV u32 one_row_word(u32 acc) { return acc << 12; }
+  static DEV u32 nibble(u32 w, int rows_in_group, int y) { return (w >> (4 * (rows_in_group - 1 - y))) & 15u; }
+  static constexpr u32 UP = 8, LEFT = 4, EXT_UP = 2, EXT_LEFT = 1;
+};
+
+typedef u32 u32_unaligned __attribute__((aligned(1)));
+struct __attribute__((aligned(4))) Quad { u32 x, y, z, w; };
+
+template <int R, bool FAST>
 __global__ void __launch_bounds__(64)
 vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                         const u32 * __restrict__ pair_slot, const u32 * __restrict__ pair_ids, u32 npairs,
@@ -510,10 +551,12 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
                         u32 * __restrict__ runs, uint64_t runs_capacity, unsigned long long * cursor,
                         VsxPairOut * __restrict__ out)
 {
+  typedef TbOps<FAST> A;
+  static_assert(VSX_RB == 1, "the tile staging below reads row checkpoints as two-step (16-byte) pairs");
   constexpr int ND = (R + 3) / 4;
   __shared__ int16_t Ssh[256];
   __shared__ uint16_t bitsL[16 * ND * 64];         // [column in tile][4-row group][lane]: this pair's 16 direction bits
-  __shared__ u32 tbL[17 * 64];                     // top boundary of the tile, prefetched: H (low 16) | F (high 16)
+  __shared__ u32 tbL[19 * 64];                     // top boundary of the tile: H (low 16) | F (high 16); entry cc + 1 = column c0 - 1 + cc
   __shared__ uint8_t symL[16 * 64];                // target symbols of the tile's columns
   const int tid = (int) threadIdx.x;
   for (int x = tid; x < 256; x += 64) Ssh[x] = P.matrix[x];
@@ -535,20 +578,47 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
   const int nstrips = (total_lanes + 15) >> 4;
   const size_t steps = T.steps;
   const size_t nblk = (steps + 15) >> 4;
-  const size_t rowck_dw = (((size_t) nstrips * steps + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
+  const size_t rowsteps = ((size_t) nstrips * steps + 1) & ~(size_t) 1;
+  const size_t rowck_dw = rowsteps * 128;
   const u32 * __restrict__ rowck = ck + T.dir_off;
   const u32 * __restrict__ colck = ck + T.dir_off + rowck_dw;
   const int g = (int) (sl >> 1);
   const bool hi = (sl & 1) != 0;
+  const u32 half_sel = hi ? 0x07060302u : 0x05040100u;           // v_perm_b32(F, H, sel) = this pair's H | F << 16
+  const u32 bias2 = FAST ? 0x80008000u : 0u;
+  const u32 qrt_i16 = (u32) (uint16_t) P.qrt_i, qrt_r16 = (u32) (uint16_t) P.qrt_r;     // column penalties (target-side gaps)
+  const u32 rt_i16 = (u32) (uint16_t) P.rt_i, rt_r16 = (u32) (uint16_t) P.rt_r;
   const uint8_t * __restrict__ q = qc + T.qoff;
   const uint8_t * __restrict__ d = tc + T.toff[sl];
   u32 * __restrict__ my = slab + slab_off[valid ? k : 0];
 
-  auto rowck_at = [&](int Lp, int c) -> uint2 {
-    const int sp = Lp >> 4, lp = Lp & 15;
-    const size_t gt = (size_t) sp * steps + (size_t) (c + lp);
-    const u32 * p = rowck + ((((gt >> VSX_RB) * 64 + (size_t) (g * 16 + lp)) << VSX_RB) + (gt & ((1u << VSX_RB) - 1))) * 2;
-    return *reinterpret_cast<const uint2 *>(p);
+  // 18 consecutive checkpoint steps, stored as two-step pairs `stride` dwords apart, land in tbL[1 ..]: entry cc + 1 is
+  // step gstart + cc (cc = 0 .. 16).  Pairs outside [0, maxpair] are clamped (their entries are never used).
+  auto stage_top = [&](const u32 * base, size_t stride, long gstart, long maxpair) {
+    const long p0 = gstart >> 1;                               // floor, also for gstart = -1
+    const int par = (int) (gstart - 2 * p0);
+    Quad v[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+      {
+        long p = p0 + e;
+        p = p < 0 ? 0 : (p > maxpair ? maxpair : p);
+        v[e] = *reinterpret_cast<const Quad *>(base + (size_t) p * stride);
+      }
+    u32 * dst = tbL + (1 - par) * 64 + tid;
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+      {
+        dst[(2 * e) * 64] = __builtin_amdgcn_perm(v[e].y, v[e].x, half_sel) ^ bias2;
+        dst[(2 * e + 1) * 64] = __builtin_amdgcn_perm(v[e].w, v[e].z, half_sel) ^ bias2;
+      }
+  };
+  auto stage_symbols = [&](int c0) {
+    u32 w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = *reinterpret_cast<const u32_unaligned *>(d + c0 + 4 * e);   // 16 B of slack follow the codes
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) symL[cc * 64 + tid] = (uint8_t) ((w[cc >> 2] >> (8 * (cc & 3))) & 15u);
   };
 
   int i = live ? Q - 1 : -1, j = live ? D - 1 : -1;
@@ -556,13 +626,14 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
   int r = (L == 0 ? rcnt0 : R) - 1;
   int op = -1;
   u32 runlen = 0, nruns = 0;
-  u32 al = 0, ma = 0, mi = 0, ga = 0;
-  auto push = [&](int newop) {
-    if (newop == op) { ++runlen; return; }
+  u32 al = 0, ga = 0;
+  auto push_n = [&](int newop, u32 n) {
+    if (newop == op) { runlen += n; return; }
     if (op >= 0) my[nruns++] = (runlen << 2) | (u32) op;
     op = newop;
-    runlen = 1;
+    runlen = n;
   };
+  auto push = [&](int newop) { push_n(newop, 1u); };
 
   // ---- phase A: the run along the LAST query row (right-terminal gap when the target is longer than the query).
   // One-row recomputes from the last-row checkpoints; a lane leaves the phase at the first cell whose move is not 'I'
@@ -572,7 +643,9 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
       const u32 * __restrict__ xck = colck + (size_t) nstrips * nblk * 64 * (2 * R) + (size_t) g * steps * 2;
       const int lastL = total_lanes - 1;
       const int sA = lastL >> 4, lA = lastL & 15;
-      const u32 qlast = live ? (u32) q[Q - 1] : 0u;
+      const u32 qlast = live ? ((u32) q[Q - 1] & 15u) : 0u;
+      const u32 pen_qrq = FAST ? (P.qrq_r_pk & 0xffffu) : P.qrq_r_pk;
+      const u32 pen_rq = FAST ? (P.rq_r_pk & 0xffffu) : P.rq_r_pk;
       bool inA = live;
       for (;;)
         {
@@ -581,63 +654,44 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
           const int m = (jj + lA) >> 4;
           int c0 = 16 * m - lA;
           if (c0 < 0) c0 = 0;
-          const int cmax = wave_max_i32(inA ? jj - c0 : 0);
+          const int cmax = __builtin_amdgcn_readfirstlane(wave_max_i32(inA ? jj - c0 : 0));
           u32 hp1, ee1;
           if (m == 0)
             {
-              hp1 = (u32) (uint16_t) P.hleft[Q - 1];
-              ee1 = ssub(hp1, P.qrq_r_pk);
+              hp1 = A::in((u32) (uint16_t) P.hleft[Q - 1]);
+              ee1 = A::sub(hp1, pen_qrq);
             }
           else
             {
               const u32 * cp = colck + (((size_t) sA * nblk + (size_t) (m - 1)) * 64 + (size_t) (g * 16 + lA)) * (2 * R);
-              hp1 = half_lo(cp[R - 1], hi);
-              ee1 = half_lo(cp[2 * R - 1], hi);
+              hp1 = A::in(half_lo(cp[R - 1], hi));
+              ee1 = A::in(half_lo(cp[2 * R - 1], hi));
             }
-          {
-            u32 hv[17], fv[17], sy[16];
-#pragma unroll
-            for (int cc = 0; cc < 17; ++cc)
-              {
-                int c = c0 - 1 + cc;
-                if (c > jj) c = jj;
-                if (c < 0) { hv[cc] = (u32) (uint16_t) P.hleft[Q - 2]; fv[cc] = 0; }
-                else
-                  {
-                    const uint2 tb = *reinterpret_cast<const uint2 *>(xck + (size_t) c * 2);
-                    hv[cc] = half_lo(tb.x, hi) & 0xffffu;
-                    fv[cc] = half_lo(tb.y, hi) & 0xffffu;
-                  }
-                if (cc > 0) sy[cc - 1] = (u32) d[c < 0 ? 0 : c];
-              }
-#pragma unroll
-            for (int cc = 0; cc < 17; ++cc) tbL[cc * 64 + tid] = hv[cc] | (fv[cc] << 16);
-#pragma unroll
-            for (int cc = 0; cc < 16; ++cc) symL[cc * 64 + tid] = (uint8_t) sy[cc];
-          }
-          u32 diag = tbL[tid] & 0xffffu;
+          stage_top(xck, 4, (long) c0 - 1, (long) ((steps >> 1) - 1));
+          if (c0 == 0) tbL[64 + tid] = A::in((u32) (uint16_t) P.hleft[Q - 2]);     // corner H(Q-2, -1); its F is never used
+          stage_symbols(c0);
+          u32 diag = tbL[64 + tid] & 0xffffu;
           u32 nib[2] = {0u, 0u};                                 // 16 columns x 4 bits
           for (int cc = 0; cc <= cmax; ++cc)
             {
-              int c = c0 + cc;
-              if (c > jj) c = jj;
-              const u32 qrt = (u32) (uint16_t) ((c < D - 1) ? P.qrt_i : P.qrt_r);
-              const u32 rt = (u32) (uint16_t) ((c < D - 1) ? P.rt_i : P.rt_r);
-              const u32 tbv = tbL[(cc + 1) * 64 + tid];
+              const int c = c0 + cc;
+              const u32 qrt = (c < D - 1) ? qrt_i16 : qrt_r16;
+              const u32 rt = (c < D - 1) ? rt_i16 : rt_r16;
+              const u32 tbv = tbL[(cc + 2) * 64 + tid];
               const u32 topH = tbv & 0xffffu;
               u32 F = tbv >> 16;
-              const u32 V = (u32) (uint16_t) Ssh[(u32) symL[cc * 64 + tid] * 16u + qlast];
-              const u32 h0 = sadd(diag, V);
-              const u32 up = (ssub(h0, F) >> 15) & 1u;
-              const u32 h1 = pmax(h0, F);
-              const u32 left = (ssub(h1, ee1) >> 15) & 1u;
-              const u32 h2 = pmax(h1, ee1);
+              const u32 V = A::score(Ssh[(u32) symL[cc * 64 + tid] * 16u + qlast]);
+              const u32 h0 = A::add(diag, V);
+              const u32 up = A::neg(A::dif(h0, F));
+              const u32 h1 = A::max(h0, F);
+              const u32 left = A::neg(A::dif(h1, ee1));
+              const u32 h2 = A::max(h1, ee1);
               hp1 = h2;
-              const u32 hf = ssub(h2, qrt), f = ssub(F, rt);
-              const u32 eu = (ssub(hf, f) >> 15) & 1u;
-              const u32 he = ssub(h2, P.qrq_r_pk), e = ssub(ee1, P.rq_r_pk);
-              const u32 el = (ssub(he, e) >> 15) & 1u;
-              ee1 = pmax(e, he);
+              const u32 hf = A::sub(h2, qrt), f = A::sub(F, rt);
+              const u32 eu = A::neg(A::dif(hf, f));
+              const u32 he = A::sub(h2, pen_qrq), e = A::sub(ee1, pen_rq);
+              const u32 el = A::neg(A::dif(he, e));
+              ee1 = A::max(e, he);
               const u32 n4 = (up | (left << 1) | (eu << 2) | (el << 3)) << (4 * (cc & 7));
               if (cc < 8) nib[0] |= n4; else nib[1] |= n4;
               diag = topH;
@@ -673,123 +727,118 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
       const int i0 = (L == 0) ? 0 : rcnt0 + (L - 1) * R;
       const bool lastpos = (L == total_lanes - 1);
       const int rr = busy ? r : 0;
-      const int rmax_raw = wave_max_i32(rr);
+      const int rmax_raw = __builtin_amdgcn_readfirstlane(wave_max_i32(rr));
       const bool one_row = (rmax_raw == 0) && (R >= 4);           // e.g. the left-terminal run in query row 0
       const int rmax = one_row ? 0 : (rmax_raw | 3);              // rows are funnelled four to a dword
-      const int cmax = wave_max_i32(jj - c0);                   // columns c0 .. c0 + cmax
+      const int cmax = __builtin_amdgcn_readfirstlane(wave_max_i32(jj - c0));     // columns c0 .. c0 + cmax
 
-      // left boundary (state after column c0 - 1), low int16 half = this pair
+      // top boundary for columns c0-1 .. c0+15 (entry 1 is the corner column c0 - 1) and the target symbols
+      if (L == 0)
+        {
+#pragma unroll
+          for (int cc = 0; cc < 17; ++cc)
+            {
+              int c = c0 - 1 + cc;
+              if (c > jj) c = jj;
+              tbL[(cc + 1) * 64 + tid] = (c < 0) ? A::in(0u) : A::in((u32) (uint16_t) P.htop[c]);   // F is derived from H below
+            }
+        }
+      else
+        {
+          const int Lp = L - 1;
+          const int sp = Lp >> 4, lp = Lp & 15;
+          stage_top(rowck + (size_t) (g * 16 + lp) * 4, 256, (long) ((size_t) sp * steps) + (long) (c0 - 1 + lp),
+                    (long) (rowsteps >> 1) - 1);
+          if (c0 == 0) tbL[64 + tid] = A::in((u32) (uint16_t) P.hleft[i0 - 1]);     // corner H(i0-1, -1)
+        }
+      stage_symbols(c0);
+
+      // left boundary (state after column c0 - 1)
       u32 hp[R], ee[R], qa[R];
+      const u32 qrq_i = FAST ? (P.qrq_i_pk & 0xffffu) : P.qrq_i_pk;
+      const u32 rq_i = FAST ? (P.rq_i_pk & 0xffffu) : P.rq_i_pk;
+      const u32 qrq_last = lastpos ? (FAST ? (P.qrq_r_pk & 0xffffu) : P.qrq_r_pk) : qrq_i;
+      const u32 rq_last = lastpos ? (FAST ? (P.rq_r_pk & 0xffffu) : P.rq_r_pk) : rq_i;
       if (m == 0)
         {
 #pragma unroll
           for (int x = 0; x < R; ++x)
             {
               int ii = i0 + x; if (ii > Q - 1) ii = Q - 1;
-              const u32 hl = (u32) (uint16_t) P.hleft[ii];
+              const u32 hl = A::in((u32) (uint16_t) P.hleft[ii]);
               hp[x] = hl;
-              ee[x] = ssub(hl, (ii < Q - 1) ? P.qrq_i_pk : P.qrq_r_pk);
+              ee[x] = A::sub(hl, (ii < Q - 1) ? qrq_i : (FAST ? (P.qrq_r_pk & 0xffffu) : P.qrq_r_pk));
             }
         }
       else
         {
           const u32 * cp = colck + (((size_t) s * nblk + (size_t) (m - 1)) * 64 + (size_t) (g * 16 + l)) * (2 * R);
 #pragma unroll
-          for (int x = 0; x < R; ++x) { hp[x] = half_lo(cp[x], hi); ee[x] = half_lo(cp[R + x], hi); }
+          for (int x = 0; x < R; ++x) { hp[x] = A::in(half_lo(cp[x], hi)); ee[x] = A::in(half_lo(cp[R + x], hi)); }
         }
-#pragma unroll
-      for (int x = 0; x < R; ++x)
-        {
-          int ii = i0 + x; if (ii > Q - 1) ii = Q - 1;
-          qa[x] = (u32) q[ii] ;
-        }
-      // top boundary for columns c0-1 .. c0+15 and the target symbols: all loads issued back to back, staged in LDS
       {
-        u32 hv[17], fv[17], sy[16];
+        u32 w[(R + 3) / 4];
 #pragma unroll
-        for (int cc = 0; cc < 17; ++cc)
-          {
-            int c = c0 - 1 + cc;                                // entry 0 is the corner column c0 - 1
-            if (c > jj) c = jj;
-            if (c < 0)
-              {
-                hv[cc] = (L == 0) ? 0u : (u32) (uint16_t) P.hleft[i0 - 1];      // corner H(i0-1, -1)
-                fv[cc] = 0;
-              }
-            else if (L == 0)
-              {
-                hv[cc] = (u32) (uint16_t) P.htop[c];
-                fv[cc] = 0x10000u;                               // marker: F is derived from H and the column penalty
-              }
-            else
-              {
-                const uint2 tb = rowck_at(L - 1, c);
-                hv[cc] = half_lo(tb.x, hi) & 0xffffu;
-                fv[cc] = half_lo(tb.y, hi) & 0xffffu;
-              }
-            if (cc > 0) sy[cc - 1] = (u32) d[c < 0 ? 0 : c];
-          }
+        for (int e = 0; e < (R + 3) / 4; ++e) w[e] = *reinterpret_cast<const u32_unaligned *>(q + i0 + 4 * e);   // slack: see stage_symbols
 #pragma unroll
-        for (int cc = 0; cc < 17; ++cc) tbL[cc * 64 + tid] = hv[cc] | (fv[cc] << 16);
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) symL[cc * 64 + tid] = (uint8_t) sy[cc];
+        for (int x = 0; x < R; ++x) qa[x] = (w[x >> 2] >> (8 * (x & 3))) & 15u;
       }
-      u32 diag = tbL[tid] & 0xffffu;
-      const u32 qrq_last = lastpos ? P.qrq_r_pk : P.qrq_i_pk;
-      const u32 rq_last = lastpos ? P.rq_r_pk : P.rq_i_pk;
+      u32 diag = tbL[64 + tid] & 0xffffu;
 
-      // ---- recompute: same packed-int16 row body as the DP kernel, directions funnelled into bitsL ----
+      // ---- recompute: the DP kernel's row body, directions funnelled into bitsL ----
       for (int cc = 0; cc <= cmax; ++cc)
         {
-          int c = c0 + cc;
-          if (c > jj) c = jj;                                   // lanes with fewer columns repeat their last one
-          const u32 qrt = (u32) (uint16_t) ((c < D - 1) ? P.qrt_i : P.qrt_r);
-          const u32 rt = (u32) (uint16_t) ((c < D - 1) ? P.rt_i : P.rt_r);
-          const u32 tbv = tbL[(cc + 1) * 64 + tid];
+          const int c = c0 + cc;
+          const u32 qrt = (c < D - 1) ? qrt_i16 : qrt_r16;
+          const u32 rt = (c < D - 1) ? rt_i16 : rt_r16;
+          const u32 tbv = tbL[(cc + 2) * 64 + tid];
           const u32 topH = tbv & 0xffffu;
-          u32 F = (L == 0) ? ssub(topH, qrt) : (tbv >> 16);
+          u32 F = (L == 0) ? A::sub(topH, qrt) : (tbv >> 16);
           const u32 b16 = (u32) symL[cc * 64 + tid] * 16u;
           u32 Hd = diag;
           u32 acc = 0;
-#pragma unroll
-          for (int x4 = 0; x4 < R; x4 += 4)
+          auto row = [&](int x) {
+            const u32 V = A::score(Ssh[b16 + qa[x]]);
+            const u32 h0 = A::add(Hd, V);
+            const u32 dU = A::dif(h0, F);
+            const u32 h1 = A::max(h0, F);
+            const u32 dL = A::dif(h1, ee[x]);
+            const u32 h2 = A::max(h1, ee[x]);
+            Hd = hp[x];
+            hp[x] = h2;
+            const u32 qrq = (x == R - 1) ? qrq_last : qrq_i;
+            const u32 rq = (x == R - 1) ? rq_last : rq_i;
+            const u32 hf = A::sub(h2, qrt);
+            const u32 f = A::sub(F, rt);
+            const u32 dEU = A::dif(hf, f);
+            F = A::max(f, hf);
+            const u32 he = A::sub(h2, qrq);
+            const u32 e = A::sub(ee[x], rq);
+            const u32 dEL = A::dif(he, e);
+            ee[x] = A::max(e, he);
+            acc = A::fun(A::fun(A::fun(A::fun(acc, dU), dL), dEU), dEL);
+          };
+          if (one_row)                                           // wave-uniform (SGPR) branches throughout
             {
-              if (x4 <= rmax)                                    // wave-uniform: skip the rows no lane needs
-                {
+              row(0);
+              bitsL[(cc * ND) * 64 + tid] = (uint16_t) A::one_row_word(acc);
+            }
+          else
+            {
 #pragma unroll
-                  for (int y = 0; y < 4; ++y)
-                    {
-                      const int x = x4 + y;
-                      if (x < R && !(one_row && y > 0))
-                        {
-                          const u32 V = (u32) (uint16_t) Ssh[b16 + qa[x]];
-                          const u32 h0 = sadd(Hd, V);
-                          const u32 dU = ssub(h0, F);
-                          const u32 h1 = pmax(h0, F);
-                          const u32 dL = ssub(h1, ee[x]);
-                          const u32 h2 = pmax(h1, ee[x]);
-                          Hd = hp[x];
-                          hp[x] = h2;
-                          const u32 qrq = (x == R - 1) ? qrq_last : P.qrq_i_pk;
-                          const u32 rq = (x == R - 1) ? rq_last : P.rq_i_pk;
-                          const u32 hf = ssub(h2, qrt);
-                          const u32 f = ssub(F, rt);
-                          const u32 dEU = ssub(hf, f);
-                          F = pmax(f, hf);
-                          const u32 he = ssub(h2, qrq);
-                          const u32 e = ssub(ee[x], rq);
-                          const u32 dEL = ssub(he, e);
-                          ee[x] = pmax(e, he);
-                          acc = funnel(funnel(funnel(funnel(acc, dU), dL), dEU), dEL);
-                        }
-                    }
-                  bitsL[(cc * ND + (x4 >> 2)) * 64 + tid] = (uint16_t) (one_row ? (acc >> 12) : acc);   // one row: its nibble sits at 12..15
-                }
+              for (int x4 = 0; x4 < R; x4 += 4)
+                if (x4 <= rmax)                                  // skip the rows no lane needs
+                  {
+#pragma unroll
+                    for (int y = 0; y < 4; ++y)
+                      if (x4 + y < R) row(x4 + y);
+                    bitsL[(cc * ND + (x4 >> 2)) * 64 + tid] = (uint16_t) acc;
+                  }
             }
           diag = topH;
         }
 
-      // ---- walk inside the tile (backtrack16 :1137-1211) ----
+      // ---- walk inside the tile (backtrack16 :1137-1211); matches are counted from the finished CIGAR below ----
       if (busy)
         {
           while (r >= 0 && j >= c0)
@@ -798,18 +847,13 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
               const u32 w = bitsL[(cw * ND + (r >> 2)) * 64 + tid];
               int rid = R - 4 * (r >> 2);
               if (rid > 4) rid = 4;
-              const u32 bts = (w >> (16 - 4 * rid + 4 * (r & 3))) & 15u;
+              const u32 bts = A::nibble(w, rid, r & 3);
               ++al;
-              if (op == 1 && (bts & 8u)) { --j; push(1); }
-              else if (op == 2 && (bts & 4u)) { --i; --r; push(2); }
-              else if (bts & 2u) { if (op != 1) ++ga; --j; push(1); }
-              else if (bts & 1u) { if (op != 2) ++ga; --i; --r; push(2); }
-              else
-                {
-                  const u32 a = q[i], c = d[j];
-                  if ((a & c) != 0 && !(P.n_mismatch && (a == 15 || c == 15))) ++ma; else ++mi;
-                  --i; --r; --j; push(0);
-                }
+              if (op == 1 && (bts & A::EXT_LEFT)) { --j; push(1); }
+              else if (op == 2 && (bts & A::EXT_UP)) { --i; --r; push(2); }
+              else if (bts & A::LEFT) { if (op != 1) ++ga; --j; push(1); }
+              else if (bts & A::UP) { if (op != 2) ++ga; --i; --r; push(2); }
+              else { --i; --r; --j; push(0); }
             }
           if (r < 0 && L > 0) { --L; r = (L == 0 ? rcnt0 : R) - 1; }
         }
@@ -824,9 +868,44 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
       out[pair_ids[k]] = o;
       return;
     }
-  while (i >= 0) { ++al; if (op != 2) ++ga; --i; push(2); }
-  while (j >= 0) { ++al; if (op != 1) ++ga; --j; push(1); }
+  if (i >= 0) { al += (u32) (i + 1); if (op != 2) ++ga; push_n(2, (u32) (i + 1)); }     // left-terminal runs
+  if (j >= 0) { al += (u32) (j + 1); if (op != 1) ++ga; push_n(1, (u32) (j + 1)); }
   if (op >= 0) my[nruns++] = (runlen << 2) | (u32) op;
+
+  // matches / mismatches of the M runs (the walk above makes no dependent global loads): replay the runs from the end
+  u32 ma = 0, mi = 0;
+  {
+    int qi = Q - 1, tj = D - 1;
+    for (u32 x = 0; x < nruns; ++x)
+      {
+        const u32 w = my[x];
+        const int len = (int) (w >> 2);
+        const u32 o2 = w & 3u;
+        if (o2 == 0)
+          {
+            for (int b = 0; b < len; b += 8)
+              {
+                u32 av[8], cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                  {
+                    const int kk = (b + u < len) ? b + u : len - 1;
+                    av[u] = q[qi - kk];
+                    cv[u] = d[tj - kk];
+                  }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                  if (b + u < len)
+                    {
+                      if ((av[u] & cv[u]) != 0 && !(P.n_mismatch && (av[u] == 15 || cv[u] == 15))) ++ma; else ++mi;
+                    }
+              }
+            qi -= len; tj -= len;
+          }
+        else if (o2 == 1) tj -= len;
+        else qi -= len;
+      }
+  }
 
   const unsigned long long base = atomicAdd(cursor, (unsigned long long) nruns);
   if (base + nruns <= runs_capacity)
@@ -993,18 +1072,18 @@ extern "C" hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tas
   return hipGetLastError();
 }
 
-template <int R>
+template <int R, bool FAST>
 static hipError_t launch_tbck(const VsxDevParams & P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
                               const uint32_t * d_pair_ids, uint32_t npairs, const uint8_t * q, const uint8_t * t,
                               const uint32_t * ck, const VsxSlotOut * slot, uint32_t * slab, const uint64_t * slab_off,
                               uint32_t * runs, uint64_t cap, unsigned long long * cursor, VsxPairOut * out, hipStream_t st)
 {
-  hipLaunchKernelGGL((vsx_traceback_ck_kernel<R>), dim3((npairs + 63) / 64), dim3(64), 0, st,
+  hipLaunchKernelGGL((vsx_traceback_ck_kernel<R, FAST>), dim3((npairs + 63) / 64), dim3(64), 0, st,
                      P, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, cap, cursor, out);
   return hipGetLastError();
 }
 
-extern "C" hipError_t vsx_launch_traceback_ck(int rows, VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
+extern "C" hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
                                               const uint32_t * d_pair_ids, uint32_t npairs,
                                               const uint8_t * q, const uint8_t * t,
                                               const uint32_t * ck, const VsxSlotOut * slot,
@@ -1013,7 +1092,8 @@ extern "C" hipError_t vsx_launch_traceback_ck(int rows, VsxDevParams P, const Vs
                                               VsxPairOut * out, hipStream_t st)
 {
   if (npairs == 0) return hipSuccess;
-#define TBCK(RR) case RR: return launch_tbck<RR>(P, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st)
+#define TBCK(RR) case RR: return fast16 ? launch_tbck<RR, true>(P, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
+                                        : launch_tbck<RR, false>(P, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st)
   switch (rows)
     {
     TBCK(1); TBCK(4); TBCK(8); TBCK(12); TBCK(16); TBCK(20); TBCK(24); TBCK(28); TBCK(32);

@@ -78,6 +78,7 @@ struct vsx_ctx {
   hipStream_t stream2 = nullptr;     // traceback kernels (overlap with the next chunk's DP)
   vsx_scoring sc {};
   bool force_fallback = false;      // a score/penalty left the 16-bit range: every pair -> sentinel
+  bool tb_packed = false;           // VSX_TB_ARITH=packed: recompute tiles with the saturating packed ops even for TRACK = 0 tasks
   bool ckpt = true;                 // checkpoint + tile-recompute traceback (VSX_TRACEBACK=dirs selects stored direction bits)
   int pen[12] {};                   // clamped CELL penalties: go_q_l, go_t_l, go_q_i, go_t_i, go_q_r, go_t_r, ge_*
   VsxDevParams P {};
@@ -198,6 +199,7 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   c->device = device;
   c->sc = *s;
   if (const char * mode = std::getenv("VSX_TRACEBACK")) c->ckpt = std::strcmp(mode, "dirs") != 0;
+  if (const char * mode = std::getenv("VSX_TB_ARITH")) c->tb_packed = std::strcmp(mode, "packed") == 0;
 
   // search16_init, align_simd.cpp:1282-1376: scores must fit a CELL, each penalty SHRT_MAX/(1+CDEPTH)
   auto clamp = [&](int64_t v, int64_t lim) -> int {
@@ -620,7 +622,7 @@ int vsx_plan_run(vsx_plan * pl)
       if (ctx->ckpt)
         {
           for (const Launch & L : c.launches)      // the recompute traceback is specialised on R like the DP kernel
-            HIPCHK(vsx_launch_traceback_ck(L.rows, ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
+            HIPCHK(vsx_launch_traceback_ck(L.rows, (L.track == 0 && !ctx->tb_packed) ? 1 : 0, ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
                                            pl->d_pair_ids.p + L.pair_first, L.pair_count, pl->Q->d_codes.p, pl->T->d_codes.p,
                                            dir, pl->d_slot.p, pl->d_slab.p, pl->d_slab_off.p + L.pair_first,
                                            pl->d_runs.p, pl->runs_capacity, pl->d_cursor.p, pl->d_out.p, st2));

@@ -78,7 +78,8 @@ hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tasks, const u
                                 uint32_t * d_slab, const uint64_t * d_slab_off,
                                 uint32_t * d_runs, uint64_t runs_capacity, unsigned long long * d_cursor,
                                 VsxPairOut * d_out, hipStream_t st);
-hipError_t vsx_launch_traceback_ck(int rows, VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
+// fast16: the tasks never saturate (planner's TRACK = 0 class) -> biased-u16 VOP2 arithmetic in the tile recompute
+hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
                                    const uint32_t * d_pair_ids, uint32_t npairs,
                                    const uint8_t * d_qcodes, const uint8_t * d_tcodes,
                                    const uint32_t * d_ck, const VsxSlotOut * d_slot,
