@@ -135,6 +135,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
 
       // ---- per-lane row state: left border (aligncolumns_first :844-859, :881-887) ----
       u32 hprev[R];      // H(i, j-1): left neighbour, next column's diagonal for row i+1
+      u32 hnext[R];      // its ping-pong partner
       u32 E[R];          // E(i, j)
       u32 ac[R];         // query symbol of the row (fast: code in both halves; generic: code << 8)
 #pragma unroll
@@ -146,6 +147,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           ac[r] = a | (a << 16);
           const u32 hl = pack16(P.hleft[i]);
           hprev[r] = hl;
+          hnext[r] = hl;     // a lane that has not started yet must find its border state in either array
           E[r] = ssub(hl, (i < Q - 1) ? P.qrq_i_pk : P.qrq_r_pk);
         }
       u32 diag = first ? 0u : pack16(P.hleft[i0 - 1]);    // H(i0-1, -1); Htop(-1) = 0 (:1895)
@@ -173,8 +175,9 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       };
       prefetch(0);
 
-      for (int t = 0; t < steps; ++t)
-        {
+      // one pipeline step; reads the left-neighbour row state from hin[] and writes hout[] (the caller ping-pongs the two
+      // arrays over an even number of steps, so no per-step register copies remain)
+      auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R]) __attribute__((always_inline)) {
           if ((t & 15) == 0)
             {
               // build the feed block for columns 16k..16k+15 (lane l describes column 16k+l)
@@ -256,8 +259,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   const u32 h1 = pmax(h0, F);
                   h2 = pmax(h1, E[r]);
                   if (TRACK) { smn = pmin(smn, h2); smx = pmax(smx, h2); }
-                  Hd = hprev[r];
-                  hprev[r] = h2;
+                  Hd = hin[r];
+                  hout[r] = h2;
                   const u32 qrq = (r == R - 1) ? qrq_last : P.qrq_i_pk;
                   const u32 rq = (r == R - 1) ? rq_last : P.rq_i_pk;
                   const u32 hf = ssub(h2, qrt);
@@ -339,16 +342,22 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
 #pragma unroll
                   for (int x = 0; x < R; x += 4)
                     {
-                      *reinterpret_cast<uint4 *>(cp + x) = make_uint4(hprev[x], hprev[x + 1], hprev[x + 2], hprev[x + 3]);
+                      *reinterpret_cast<uint4 *>(cp + x) = make_uint4(hout[x], hout[x + 1], hout[x + 2], hout[x + 3]);
                       *reinterpret_cast<uint4 *>(cp + R + x) = make_uint4(E[x], E[x + 1], E[x + 2], E[x + 3]);
                     }
                 }
               else
                 {
 #pragma unroll
-                  for (int x = 0; x < R; ++x) { cp[x] = hprev[x]; cp[R + x] = E[x]; }
+                  for (int x = 0; x < R; ++x) { cp[x] = hout[x]; cp[R + x] = E[x]; }
                 }
             }
+      };
+      // steps is odd (padded length + 15): the extra step finds every lane past its last column
+      for (int t = 0; t < steps; t += 2)
+        {
+          step(t, hprev, hnext);
+          step(t + 1, hnext, hprev);
         }
 
       if (s + 1 < nstrips)
