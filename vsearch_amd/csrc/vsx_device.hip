@@ -80,6 +80,14 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    u32 * __restrict__ dir, uint2 * strip, VsxSlotOut * __restrict__ slot_out)
 {
   constexpr int ND = (R + 3) / 4;                  // direction dwords per lane per step
+  // TOPPAD: pipeline position 0 holds fewer than R query rows.  In this class its spare slots sit ABOVE the real rows and
+  // are made transparent -- each dummy row reproduces the top border chain, H = Htop(j), via a constant profile score
+  // -ge (query-left extension) and a diagonal seeded with -go, so the first real row sees exactly Htop(j-1), Htop(j) and
+  // F = Htop(j) - QR_t(j) -- and every position hands (H, F) over from its compile-time row R-1: no per-row capture.
+  // Needs the LDS profile (a per-row constant score), no min/max tracking (the dummies would pollute it) and
+  // QR_q(interior) >= ge (the planner checks both, vsx_host.cpp no_overflow_possible()).  The traceback of this class
+  // (vsx_traceback_ck_kernel<R, true>) uses the same slot layout.
+  constexpr bool TOPPAD = CKPT && GENERIC && !TRACK;
   // GENERIC: query profile in LDS, QP[target code][row of the strip] = S[code][query symbol of the row] (int16).
   // Any IUPAC / unknown symbol on either side is handled by construction; one v_perm_b32 per row packs the two targets.
   __shared__ __attribute__((aligned(16))) int16_t QP[GENERIC ? 16 * 16 * R : 8];
@@ -113,7 +121,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       const int L = 16 * s + l;                    // global pipeline position
       const bool lane_on = (L < total_lanes) && (Dpg > 0);
       const bool first = (L == 0);
-      const int i0 = first ? 0 : rcnt0 + (L - 1) * R;
+      const int pad = TOPPAD ? R - rcnt0 : 0;    // dummy slots above the rows of position 0
+      const int i0 = first ? -pad : rcnt0 + (L - 1) * R;
 
       if (GENERIC)
         {
@@ -123,9 +132,10 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               const int code = idx / (16 * R), row = idx % (16 * R);
               const int Lr = 16 * s + row / R, rr = row % R;
               int v = 0;
-              if (Lr < total_lanes && !(Lr == 0 && rr >= rcnt0))
+              if (TOPPAD && Lr == 0 && rr < pad) v = -P.top_step;
+              else if (Lr < total_lanes && (TOPPAD || !(Lr == 0 && rr >= rcnt0)))
                 {
-                  const int gi = (Lr == 0) ? rr : rcnt0 + (Lr - 1) * R + rr;
+                  const int gi = (Lr == 0) ? rr - pad : rcnt0 + (Lr - 1) * R + rr;
                   v = P.matrix[code * 16 + (int) qq[gi]];
                 }
               QP[idx] = (int16_t) v;
@@ -142,15 +152,23 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       for (int r = 0; r < R; ++r)
         {
           int i = i0 + r;
-          if (i > Q - 1) i = Q - 1;                // dummy rows (skipped or idle lanes): any valid address
+          const bool dummy = TOPPAD && first && r < pad;
+          if (i > Q - 1) i = Q - 1;                // junk rows (skipped or idle lanes): any valid address
+          if (i < 0) i = 0;
           const u32 a = qq[i];
           ac[r] = a | (a << 16);
-          const u32 hl = pack16(P.hleft[i]);
+          u32 hl = pack16(P.hleft[i]);
+          u32 e0 = ssub(hl, (i < Q - 1) ? P.qrq_i_pk : P.qrq_r_pk);
+          if (dummy)
+            {
+              hl = (r == pad - 1) ? 0u : pack16(-P.top_open);                       // Htop(-1) = 0 for the first real row's diagonal
+              e0 = ssub(pack16(-P.top_open - P.top_step), P.qrq_i_pk);               // <= Htop(0), stays below the chain
+            }
           hprev[r] = hl;
           hnext[r] = hl;     // a lane that has not started yet must find its border state in either array
-          E[r] = ssub(hl, (i < Q - 1) ? P.qrq_i_pk : P.qrq_r_pk);
+          E[r] = e0;
         }
-      u32 diag = first ? 0u : pack16(P.hleft[i0 - 1]);    // H(i0-1, -1); Htop(-1) = 0 (:1895)
+      u32 diag = first ? ((TOPPAD && pad > 0) ? pack16(-P.top_open) : 0u) : pack16(P.hleft[i0 - 1]);   // H(i0-1, -1); Htop(-1) = 0 (:1895)
       // query-gap penalties of row R-1: only the globally last row uses the right-end pair (:836-897)
       const bool lastpos = (L == total_lanes - 1);
       const u32 qrq_last = lastpos ? P.qrq_r_pk : P.qrq_i_pk;
@@ -280,12 +298,12 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   E[r] = pmax(e, he);
                   if (CKPT && r == R - 2) { xH = h2; xF = F; }
                   // position 0 holds only rcnt0 rows: its later rows compute junk that never leaves the lane
-                  if (__builtin_expect(rc0 == r + 1, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
+                  if (!TOPPAD && __builtin_expect(rc0 == r + 1, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
                 }
-              const u32 hl = first ? capH : h2;
-              F = first ? capF : F;
-              smn = first ? capmn : smn;
-              smx = first ? capmx : smx;
+              const u32 hl = (!TOPPAD && first) ? capH : h2;
+              F = (!TOPPAD && first) ? capF : F;
+              smn = (!TOPPAD && first) ? capmn : smn;
+              smx = (!TOPPAD && first) ? capmx : smx;
               outH = hl;
               outF = F;
               diag = inH;
@@ -563,12 +581,14 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
   typedef TbOps<FAST> A;
   static_assert(VSX_RB == 1, "the tile staging below reads row checkpoints as two-step (16-byte) pairs");
   constexpr int ND = (R + 3) / 4;
-  __shared__ int16_t Ssh[256];
+  constexpr bool TOPPAD = FAST;                    // slot layout of position 0, see vsx_forward_kernel
+  __shared__ int16_t Ssh[512];                     // S[target code][query code], row stride 32; query "code" 16 = a dummy row
   __shared__ uint16_t bitsL[16 * ND * 64];         // [column in tile][4-row group][lane]: this pair's 16 direction bits
   __shared__ u32 tbL[19 * 64];                     // top boundary of the tile: H (low 16) | F (high 16); entry cc + 1 = column c0 - 1 + cc
   __shared__ uint8_t symL[16 * 64];                // target symbols of the tile's columns
   const int tid = (int) threadIdx.x;
-  for (int x = tid; x < 256; x += 64) Ssh[x] = P.matrix[x];
+  for (int x = tid; x < 512; x += 64)
+    Ssh[x] = ((x & 31) < 16) ? P.matrix[(x >> 5) * 16 + (x & 15)] : (int16_t) -P.top_step;
   __syncthreads();
 
   // every lane of the wave stays in the tile loop until all are done (wave-uniform bounds, shuffles)
@@ -584,6 +604,8 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
   const int D = (int) T.tlen[sl];
   const int total_lanes = (Q + R - 1) / R;
   const int rcnt0 = Q - (total_lanes - 1) * R;
+  const int pad = TOPPAD ? R - rcnt0 : 0;
+  const int rtop0 = TOPPAD ? R : rcnt0;            // slots of position 0
   const int nstrips = (total_lanes + 15) >> 4;
   const size_t steps = T.steps;
   const size_t nblk = (steps + 15) >> 4;
@@ -625,14 +647,14 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
   auto stage_symbols = [&](int c0) {
     u32 w[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = *reinterpret_cast<const u32_unaligned *>(d + c0 + 4 * e);   // 16 B of slack follow the codes
+    for (int e = 0; e < 4; ++e) w[e] = *reinterpret_cast<const u32_unaligned *>(d + c0 + 4 * e);   // VSX_CODE_SLACK bytes follow the codes
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) symL[cc * 64 + tid] = (uint8_t) ((w[cc >> 2] >> (8 * (cc & 3))) & 15u);
   };
 
   int i = live ? Q - 1 : -1, j = live ? D - 1 : -1;
   int L = total_lanes - 1;
-  int r = (L == 0 ? rcnt0 : R) - 1;
+  int r = (L == 0 ? rtop0 : R) - 1;
   int op = -1;
   u32 runlen = 0, nruns = 0;
   u32 al = 0, ga = 0;
@@ -689,7 +711,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
               const u32 tbv = tbL[(cc + 2) * 64 + tid];
               const u32 topH = tbv & 0xffffu;
               u32 F = tbv >> 16;
-              const u32 V = A::score(Ssh[(u32) symL[cc * 64 + tid] * 16u + qlast]);
+              const u32 V = A::score(Ssh[(u32) symL[cc * 64 + tid] * 32u + qlast]);
               const u32 h0 = A::add(diag, V);
               const u32 up = A::neg(A::dif(h0, F));
               const u32 h1 = A::max(h0, F);
@@ -733,7 +755,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
       const int m = (jj + l) >> 4;
       int c0 = 16 * m - l;
       if (c0 < 0) c0 = 0;
-      const int i0 = (L == 0) ? 0 : rcnt0 + (L - 1) * R;
+      const int i0 = (L == 0) ? -pad : rcnt0 + (L - 1) * R;
       const bool lastpos = (L == total_lanes - 1);
       const int rr = busy ? r : 0;
       const int rmax_raw = __builtin_amdgcn_readfirstlane(wave_max_i32(rr));
@@ -749,7 +771,8 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
             {
               int c = c0 - 1 + cc;
               if (c > jj) c = jj;
-              tbL[(cc + 1) * 64 + tid] = (c < 0) ? A::in(0u) : A::in((u32) (uint16_t) P.htop[c]);   // F is derived from H below
+              const u32 corner = (TOPPAD && pad > 0) ? (u32) (uint16_t) (-P.top_open) : 0u;       // see the DP kernel's diag seed
+              tbL[(cc + 1) * 64 + tid] = (c < 0) ? A::in(corner) : A::in((u32) (uint16_t) P.htop[c]);   // F is derived from H below
             }
         }
       else
@@ -774,9 +797,18 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
           for (int x = 0; x < R; ++x)
             {
               int ii = i0 + x; if (ii > Q - 1) ii = Q - 1;
+              if (ii < 0) ii = 0;
               const u32 hl = A::in((u32) (uint16_t) P.hleft[ii]);
               hp[x] = hl;
               ee[x] = A::sub(hl, (ii < Q - 1) ? qrq_i : (FAST ? (P.qrq_r_pk & 0xffffu) : P.qrq_r_pk));
+            }
+          if (TOPPAD && L == 0 && pad > 0)                       // border state of the dummy rows, as seeded by the DP kernel
+            {
+              const u32 hd = A::in((u32) (uint16_t) (-P.top_open));
+              const u32 ed = A::sub(A::in((u32) (uint16_t) (-P.top_open - P.top_step)), qrq_i);
+#pragma unroll
+              for (int x = 0; x < R - 1; ++x)
+                if (x < pad) { hp[x] = (x == pad - 1) ? A::in(0u) : hd; ee[x] = ed; }
             }
         }
       else
@@ -788,9 +820,16 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
       {
         u32 w[(R + 3) / 4];
 #pragma unroll
-        for (int e = 0; e < (R + 3) / 4; ++e) w[e] = *reinterpret_cast<const u32_unaligned *>(q + i0 + 4 * e);   // slack: see stage_symbols
+        for (int e = 0; e < (R + 3) / 4; ++e) w[e] = *reinterpret_cast<const u32_unaligned *>(q + i0 + 4 * e);   // VSX_CODE_SLACK on both sides
 #pragma unroll
-        for (int x = 0; x < R; ++x) qa[x] = (w[x >> 2] >> (8 * (x & 3))) & 15u;
+        for (int x = 0; x < R; ++x)
+          qa[x] = (w[x >> 2] >> (8 * (x & 3))) & 15u;
+        if (TOPPAD && L == 0)
+          {
+#pragma unroll
+            for (int x = 0; x < R - 1; ++x)
+              if (x < pad) qa[x] = 16u;                                                   // dummy row: score -ge
+          }
       }
       u32 diag = tbL[64 + tid] & 0xffffu;
 
@@ -803,7 +842,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
           const u32 tbv = tbL[(cc + 2) * 64 + tid];
           const u32 topH = tbv & 0xffffu;
           u32 F = (L == 0) ? A::sub(topH, qrt) : (tbv >> 16);
-          const u32 b16 = (u32) symL[cc * 64 + tid] * 16u;
+          const u32 b16 = (u32) symL[cc * 64 + tid] * 32u;
           u32 Hd = diag;
           u32 acc = 0;
           auto row = [&](int x) {
@@ -850,7 +889,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
       // ---- walk inside the tile (backtrack16 :1137-1211); matches are counted from the finished CIGAR below ----
       if (busy)
         {
-          while (r >= 0 && j >= c0)
+          while (r >= 0 && j >= c0 && (!TOPPAD || i >= 0))
             {
               const int cw = j - c0;
               const u32 w = bitsL[(cw * ND + (r >> 2)) * 64 + tid];
@@ -864,7 +903,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
               else if (bts & A::UP) { if (op != 2) ++ga; --i; --r; push(2); }
               else { --i; --r; --j; push(0); }
             }
-          if (r < 0 && L > 0) { --L; r = (L == 0 ? rcnt0 : R) - 1; }
+          if (r < 0 && L > 0) { --L; r = (L == 0 ? rtop0 : R) - 1; }
         }
     }
   if (!valid) return;

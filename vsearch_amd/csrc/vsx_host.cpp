@@ -78,7 +78,7 @@ struct vsx_ctx {
   hipStream_t stream2 = nullptr;     // traceback kernels (overlap with the next chunk's DP)
   vsx_scoring sc {};
   bool force_fallback = false;      // a score/penalty left the 16-bit range: every pair -> sentinel
-  bool tb_packed = false;           // VSX_TB_ARITH=packed: recompute tiles with the saturating packed ops even for TRACK = 0 tasks
+  bool tb_packed = false;           // VSX_TB_ARITH=packed: plan every task into the TRACK = 1 class (saturating packed ops, capture layout)
   bool ckpt = true;                 // checkpoint + tile-recompute traceback (VSX_TRACEBACK=dirs selects stored direction bits)
   int pen[12] {};                   // clamped CELL penalties: go_q_l, go_t_l, go_q_i, go_t_i, go_q_r, go_t_r, ge_*
   VsxDevParams P {};
@@ -92,7 +92,8 @@ struct vsx_seqset {
   uint64_t bytes = 0;
   std::vector<uint64_t> off;
   std::vector<uint32_t> len;
-  DevBuf<uint8_t> d_codes;
+  DevBuf<uint8_t> d_codes;          // VSX_CODE_SLACK bytes | codes | VSX_CODE_SLACK bytes: the traceback stages rows/columns with unaligned dword loads
+  uint8_t * codes() const { return d_codes.p + VSX_CODE_SLACK; }
   DevBuf<uint64_t> d_off;
   DevBuf<uint32_t> d_len;
   std::vector<uint8_t> impure;      // lazily computed on the device (vsx_purity_kernel)
@@ -226,6 +227,7 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   P.qrt_r = gotr + getr; P.rt_r = getr;
   P.match = match; P.mismatch = mism;
   P.n_mismatch = s->n_mismatch ? 1 : 0;
+  P.top_open = goql; P.top_step = geql;
   int pmax = 0;
   for (int v : {goql + geql, goqi + geqi, goqr + geqr, gotl + getl, goti + geti, gotr + getr}) pmax = std::max(pmax, v);
   P.smin = -32768 + pmax;                                       // compute_score_min :1432-1444
@@ -303,7 +305,7 @@ static int seqset_common(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const voi
   DevBuf<uint8_t> staging;
   const uint8_t * d_ascii = static_cast<const uint8_t *>(blob);
   do {
-    if ((e = s->d_codes.alloc(blob_bytes + 16)) != hipSuccess) break;
+    if ((e = s->d_codes.alloc(blob_bytes + 2 * VSX_CODE_SLACK)) != hipSuccess) break;
     if ((e = s->d_off.alloc(n)) != hipSuccess) break;
     if ((e = s->d_len.alloc(n)) != hipSuccess) break;
     if (n)
@@ -317,7 +319,7 @@ static int seqset_common(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const voi
         if ((e = hipMemcpyAsync(staging.p, blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
         d_ascii = staging.p;
       }
-    if ((e = vsx_launch_encode(d_ascii, s->d_codes.p, blob_bytes, ctx->stream)) != hipSuccess) break;
+    if ((e = vsx_launch_encode(d_ascii, s->codes(), blob_bytes, ctx->stream)) != hipSuccess) break;
     e = hipStreamSynchronize(ctx->stream);
   } while (false);
   if (e != hipSuccess)
@@ -357,7 +359,7 @@ static int ensure_impure(vsx_seqset * s)
   HIPCHK(hipSetDevice(ctx->device));
   DevBuf<uint8_t> d_flags;
   HIPCHK(d_flags.alloc(s->n));
-  HIPCHK(vsx_launch_purity(s->d_codes.p, s->d_off.p, s->d_len.p, s->n, d_flags.p, ctx->stream));
+  HIPCHK(vsx_launch_purity(s->codes(), s->d_off.p, s->d_len.p, s->n, d_flags.p, ctx->stream));
   s->impure.assign(s->n, 0);
   if (s->n) HIPCHK(hipMemcpyAsync(s->impure.data(), d_flags.p, s->n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -381,6 +383,7 @@ static bool no_overflow_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
       if (ctx->pen[k] < 0) return false;
       if (k < 6) G = std::max<int64_t>(G, ctx->pen[k]); else B = std::max<int64_t>(B, ctx->pen[k]);
     }
+  if (ctx->pen[2] + ctx->pen[8] < ctx->pen[6]) return false;     // TOPPAD dummy rows need QR_q(interior) >= ge(query left)
   const int64_t Dp = (D + 3) & ~3ll;
   return 4 * G + (Q + Dp + 16) * B < 32000;
 }
@@ -474,7 +477,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
               pt.pair[s] = gpu_pairs[x + s];
               dmax = std::max(dmax, targets->len[tidx[pt.pair[s]]]);
             }
-          pt.track = no_overflow_possible(ctx, queries->len[q], dmax) ? 0 : 1;
+          pt.track = (!ctx->tb_packed && no_overflow_possible(ctx, queries->len[q], dmax)) ? 0 : 1;
           protos.push_back(pt);
         }
       b = e;
@@ -614,7 +617,7 @@ int vsx_plan_run(vsx_plan * pl)
       HIPCHK(hipEventRecord(c.e0, st));
       for (const Launch & L : c.launches)
         HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, ctx->P, pl->d_tasks.p + L.first, L.count,
-                                  pl->Q->d_codes.p, pl->T->d_codes.p, dir, pl->d_strip.p,
+                                  pl->Q->codes(), pl->T->codes(), dir, pl->d_strip.p,
                                   pl->d_slot.p + (size_t) L.first * VSX_TASK_SLOTS, st));
       HIPCHK(hipEventRecord(c.e1, st));
       HIPCHK(hipStreamWaitEvent(st2, c.e1, 0));
@@ -622,14 +625,14 @@ int vsx_plan_run(vsx_plan * pl)
       if (ctx->ckpt)
         {
           for (const Launch & L : c.launches)      // the recompute traceback is specialised on R like the DP kernel
-            HIPCHK(vsx_launch_traceback_ck(L.rows, (L.track == 0 && !ctx->tb_packed) ? 1 : 0, ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
-                                           pl->d_pair_ids.p + L.pair_first, L.pair_count, pl->Q->d_codes.p, pl->T->d_codes.p,
+            HIPCHK(vsx_launch_traceback_ck(L.rows, (L.track == 0 && L.generic != 0) ? 1 : 0, ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
+                                           pl->d_pair_ids.p + L.pair_first, L.pair_count, pl->Q->codes(), pl->T->codes(),
                                            dir, pl->d_slot.p, pl->d_slab.p, pl->d_slab_off.p + L.pair_first,
                                            pl->d_runs.p, pl->runs_capacity, pl->d_cursor.p, pl->d_out.p, st2));
         }
       else
         HIPCHK(vsx_launch_traceback(ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + c.pair_first, pl->d_pair_ids.p + c.pair_first,
-                                    c.pair_count, pl->Q->d_codes.p, pl->T->d_codes.p, dir, pl->d_slot.p,
+                                    c.pair_count, pl->Q->codes(), pl->T->codes(), dir, pl->d_slot.p,
                                     pl->d_slab.p, pl->d_slab_off.p + c.pair_first, pl->d_runs.p, pl->runs_capacity,
                                     pl->d_cursor.p, pl->d_out.p, st2));
       HIPCHK(hipEventRecord(c.e2, st2));

@@ -10,6 +10,7 @@
 #define VSX_MAX_SEQLEN_SUM 65535LL        // reference core/align_simd.cpp:89
 #define VSX_MAX_SEQLEN_PRODUCT 25000000LL // reference core/align_simd.cpp:88
 #define VSX_TABLE_LEN (65536 + 64)
+#define VSX_CODE_SLACK 64          // readable bytes before and after a sequence set's 4-bit codes
 
 // Device-side constants derived from the 14 post-fixup penalties (reference search16_init,
 // core/align_simd.cpp:1282-1376 and the QR/R vectors at :1629-1649).  "pk" = the int16 value
@@ -23,6 +24,7 @@ struct VsxDevParams {
   int32_t  match, mismatch;
   int32_t  smin;                  // overflow threshold, compute_score_min (:1432-1444)
   int32_t  n_mismatch;
+  int32_t  top_open, top_step;    // go / ge of a query-left terminal gap: Htop(j) = -(go + (j + 1) ge); the dummy rows of TOPPAD
   const int16_t * htop;           // H(-1, j), j >= 0: top border chain (:1895-1910, :2043-2051)
   const int16_t * hleft;          // H(i, -1), i >= 0: left border chain (:844-859, :881-887)
   const int16_t * matrix;         // 16x16 score matrix S[target code][query code] (:1319-1342)
