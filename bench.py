@@ -31,7 +31,26 @@ import torch  # noqa: E402
 # (MI355X_MICROARCH.md: 256 CUs, 4 SIMDs/CU, 2400 MHz; VOP3P issues at 16 lanes/clk/SIMD -- measured with
 #  vsearch_amd/csrc/ubench_valu.hip: 69-73 T int16-ops/s, profiles/r01_ubench_valu.txt)
 PEAK_INT16_TOPS = 256 * 4 * 16 * 2 * 2.4e9 / 1e12
-OPS_PER_CELL = 15        # reference onestep (align_simd.cpp:765-780): SURVEY.md 8(d)
+OPS_PER_CELL = 15        # reference onestep (align_simd.cpp:765-780): SURVEY.md 8(d) -- the ALGORITHMIC figure `frac` uses
+# What the checkpointing DP kernel really issues per cell: score pack + add + 2 max + 4 sub + 2 max = 10 int16 ops (the 4
+# direction compares run only on the tiles the traceback crosses, the min/max tracking only for tasks that can overflow).
+# `frac_executed` prices the same kernel time with this count: it is the honest "how busy is the VALU" number.
+EXEC_OPS_PER_CELL = 10
+
+
+def traffic_from_profile(a, world):
+    """HBM bytes per DP-kernel launch from the committed PMC passes (profiles/r01_traffic.json, written by
+    profiles/summarize.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS command); counters cannot be
+    collected from inside the timed run, so the figure is only reported for the workload it was measured on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+        w = t["workload"]
+        if world == 1 and all(getattr(a, k) == w[k] for k in ("queries", "qlen", "db", "dlen", "cands")):
+            return t["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def parse():
@@ -164,10 +183,12 @@ def main():
             "unit": "Tops/s",
             "frac": round(achieved / PEAK_INT16_TOPS, 4),
             "ops_per_cell": OPS_PER_CELL,
+            "frac_executed": round(achieved * EXEC_OPS_PER_CELL / OPS_PER_CELL / PEAK_INT16_TOPS, 4),
+            "ops_per_cell_executed": EXEC_OPS_PER_CELL,
             "kernel_ms_avg": round(fwd_avg_ms, 3),
             "kernel_launches": fwd_launches,
             "kernel_gcups": round(cells_per_launch / (fwd_avg_ms * 1e-3) / 1e9, 1),
-            "traffic": None,
+            "traffic": traffic_from_profile(a, world),
             "hbm_algorithmic_bytes_per_launch": int(tm.dir_bytes / max(1, tm.forward_launches)),
             "hbm_algorithmic_GBps": round(tm.dir_bytes / max(1, tm.forward_launches) / (fwd_avg_ms * 1e-3) / 1e9, 1),
         },

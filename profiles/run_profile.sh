@@ -24,3 +24,4 @@ find $WORK -name "*.csv" | xargs ls -la | head -30
 python $REPO/profiles/summarize.py $WORK > $OUT/summary.txt 2>&1
 for f in $(find $WORK -name "*kernel_stats.csv"); do cp $f $OUT/; done
 cat $OUT/summary.txt
+cp $WORK/traffic.json $OUT/ 2>/dev/null

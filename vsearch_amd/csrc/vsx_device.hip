@@ -566,6 +566,7 @@ template <> struct TbOps<true>
 };
 
 typedef u32 u32_unaligned __attribute__((aligned(1)));
+typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
 struct __attribute__((aligned(4))) Quad { u32 x, y, z, w; };
 
 template <int R, bool FAST>
@@ -931,22 +932,26 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
         const u32 o2 = w & 3u;
         if (o2 == 0)
           {
+            // eight cells per trip: the symbols are the 8 bytes ENDING at q[qi - b] / d[tj - b] (unaligned 64-bit loads, the
+            // code buffers have slack in front); byte u of a chunk is cell kk = 7 - u of the trip
             for (int b = 0; b < len; b += 8)
               {
-                u32 av[8], cv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
+                const int rem = (len - b < 8) ? len - b : 8;
+                const unsigned long long aw = *reinterpret_cast<const u64_unaligned *>(q + (qi - b - 7));
+                const unsigned long long cw = *reinterpret_cast<const u64_unaligned *>(d + (tj - b - 7));
+                const unsigned long long ones = 0x0101010101010101ull;
+                const unsigned long long x = aw & cw;
+                unsigned long long t = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;            // codes share a nucleotide
+                if (P.n_mismatch)
                   {
-                    const int kk = (b + u < len) ? b + u : len - 1;
-                    av[u] = q[qi - kk];
-                    cv[u] = d[tj - kk];
+                    const unsigned long long a15 = aw & (aw >> 1) & (aw >> 2) & (aw >> 3);
+                    const unsigned long long c15 = cw & (cw >> 1) & (cw >> 2) & (cw >> 3);
+                    t &= ~(a15 | c15);                                                         // N never matches (:1191-1206)
                   }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                  if (b + u < len)
-                    {
-                      if ((av[u] & cv[u]) != 0 && !(P.n_mismatch && (av[u] == 15 || cv[u] == 15))) ++ma; else ++mi;
-                    }
+                t &= ~0ull << (8 * (8 - rem));
+                const u32 m8 = (u32) __builtin_popcountll(t);
+                ma += m8;
+                mi += (u32) rem - m8;
               }
             qi -= len; tj -= len;
           }
