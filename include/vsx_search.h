@@ -104,6 +104,25 @@ int vsx_allpairs_block(vsx_searcher * s, int32_t acceptall, uint64_t first, uint
 int64_t vsx_search_candidates(vsx_searcher * s, const char * q, uint32_t qlen,
                               uint32_t * targets, uint32_t * counts, uint64_t cap);
 
+/* Candidate lists of a BATCH of queries (search_topscores + heap order, core/searchcore.cpp:260-340,
+   core/minheap.cpp:82-146): best first, at most maxaccepts + maxrejects + 8 per query.  device != 0 counts on the GPU
+   (vsx_kmer.hip: tiled LDS counters over a device-resident index), 0 on host threads; both give identical lists.
+   All arrays are malloc()'d; release with vsx_candidates_free. */
+typedef struct vsx_candidates {
+  uint64_t   n_queries;
+  uint64_t * start;            /* n_queries + 1 */
+  uint32_t * target;
+  uint32_t * count;
+  double     seconds;          /* wall time of the call (host k-mer extraction + counting + ranking) */
+  double     kernel_ms;        /* device counting kernel(s), hipEvents; 0 on the host path */
+  double     index_build_ms;   /* device index build, paid on first use */
+  uint64_t   index_postings;   /* entries of the index */
+  uint64_t   postings_streamed;/* counter increments of this call = postings read */
+} vsx_candidates;
+int vsx_search_candidates_batch(vsx_searcher * s, int32_t device, uint64_t n, const char * qblob, uint64_t qbytes,
+                                const uint64_t * qoff, const uint32_t * qlen, vsx_candidates * out);
+void vsx_candidates_free(vsx_candidates * c);
+
 /* Greedy centroid clustering, --cluster_fast / --cluster_smallmem semantics (core/cluster.cpp:877-1125 with the
    intra-round fix-up evaluate_extra_hits :601-856): the searcher's sequences are processed IN THE GIVEN ORDER
    (sort them first: cluster_fast = length descending, core/db.cpp:433-450); each joins the cluster of its best

@@ -246,3 +246,56 @@ def test_cluster_msa_consensus_profile_match_reference_cli(gpu_required, tmp_pat
     assert msa_lines == open(tmp + "/m.msa").read().splitlines()
     assert cons_lines == open(tmp + "/m.cons").read().splitlines()
     assert prof_lines == open(tmp + "/m.prof").read().splitlines()
+
+
+# ---- k-mer candidate counting on the device (vsx_kmer.hip) vs the host restatement of search_topscores ----
+def _kmer_case(rng, n_fam, per_fam, L, nq, qlen, iupac=0.0, **opts):
+    db, _ = common.family_db(rng, n_fam, per_fam, L, div=0.08)
+    if iupac:
+        db = ["".join((rng.choice("RYSWKMBDHVN") if rng.random() < iupac else ch) for ch in s) for s in db]
+    db += ["", "A", "ACGTACG", common.rnd_seq(rng, 9), common.rnd_seq(rng, 40)]            # shorter than a word / barely longer
+    qs, _ = common.queries_from_db(rng, db[:n_fam * per_fam], nq, qlen)
+    qs += ["", "ACG", common.rnd_seq(rng, 8), "N" * 50, common.rnd_seq(rng, 700)]
+    return db, qs, opts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    dict(seed=1, n_fam=20, per_fam=8, L=300, nq=40, qlen=150),
+    dict(seed=2, n_fam=10, per_fam=10, L=400, nq=30, qlen=200, iupac=0.01),
+    dict(seed=3, n_fam=12, per_fam=6, L=250, nq=25, qlen=120, wordlength=5),
+    dict(seed=4, n_fam=12, per_fam=6, L=250, nq=25, qlen=120, wordlength=3, minwordmatches=2),
+    dict(seed=5, n_fam=15, per_fam=8, L=300, nq=30, qlen=100, maxaccepts=3, maxrejects=5),
+    dict(seed=6, n_fam=6, per_fam=6, L=200, nq=10, qlen=80, minwordmatches=0),            # every sequence qualifies: host path
+])
+def test_device_kmer_candidates_equal_host(gpu_required, case):
+    from vsearch_amd import Aligner, SearchSession
+    case = dict(case)
+    rng = random.Random(case.pop("seed"))
+    db, qs, opts = _kmer_case(rng, **case)
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.5, **opts)
+        host = ss.candidates_batch(qs, device=False)
+        dev = ss.candidates_batch(qs, device=True)
+        assert ss.kmer_stats["index_postings"] > 0
+    assert len(host) == len(dev) == len(qs)
+    assert sum(len(h) for h in host) > 0
+    for k, (h, d) in enumerate(zip(host, dev)):
+        assert h == d, (k, h[:5], d[:5])
+
+
+@pytest.mark.gpu
+def test_device_kmer_multi_tile(gpu_required):
+    """more than 2^15 sequences: several counter tiles per query, candidates from every tile"""
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(77)
+    anc = [common.rnd_seq(rng, 120) for _ in range(700)]
+    db = [common.mutate(rng, anc[i % 700], 0.05) for i in range(70_000)]
+    qs = [common.mutate(rng, db[i], 0.02) for i in (0, 1, 32767, 32768, 40000, 65535, 65536, 69999)]
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.5, maxaccepts=2, maxrejects=200)
+        host = ss.candidates_batch(qs, device=False)
+        dev = ss.candidates_batch(qs, device=True)
+    assert host == dev
+    assert all(len(h) >= 50 for h in host)
+    assert any(t >= 65536 for h in host for t, _ in h) and any(t < 32768 for h in host for t, _ in h)

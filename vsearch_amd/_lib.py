@@ -22,7 +22,14 @@ SYMBOLS = [
 ]
 # include/vsx_search.h
 SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
-                  "vsx_hits_free", "vsx_search_candidates", "vsx_lma_align", "vsx_allpairs_block", "vsx_cluster_fast", "vsx_cluster_out_free", "vsx_msa", "vsx_msa_out_free"]
+                  "vsx_hits_free", "vsx_search_candidates", "vsx_search_candidates_batch", "vsx_candidates_free", "vsx_lma_align", "vsx_allpairs_block", "vsx_cluster_fast", "vsx_cluster_out_free", "vsx_msa", "vsx_msa_out_free"]
+
+
+class Candidates(C.Structure):
+    """vsx_candidates (include/vsx_search.h)"""
+    _fields_ = [("n_queries", C.c_uint64), ("start", C.POINTER(C.c_uint64)), ("target", C.POINTER(C.c_uint32)),
+                ("count", C.POINTER(C.c_uint32)), ("seconds", C.c_double), ("kernel_ms", C.c_double),
+                ("index_build_ms", C.c_double), ("index_postings", C.c_uint64), ("postings_streamed", C.c_uint64)]
 
 
 class SearchOpts(C.Structure):
@@ -134,6 +141,9 @@ def load():
     lib.vsx_hits_free.restype = None
     lib.vsx_search_candidates.argtypes = [vp, C.c_char_p, C.c_uint32, vp, vp, C.c_uint64]
     lib.vsx_search_candidates.restype = C.c_int64
+    lib.vsx_search_candidates_batch.argtypes = [vp, C.c_int32, C.c_uint64, vp, C.c_uint64, vp, vp, C.POINTER(Candidates)]
+    lib.vsx_candidates_free.argtypes = [C.POINTER(Candidates)]
+    lib.vsx_candidates_free.restype = None
     lib.vsx_allpairs_block.argtypes = [vp, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(Hits)]
     lib.vsx_cluster_fast.argtypes = [vp, C.c_uint64, C.POINTER(ClusterOut)]
     lib.vsx_cluster_out_free.argtypes = [C.POINTER(ClusterOut)]

@@ -161,6 +161,12 @@ extern "C" {
 // shared with vsx_search.cpp: one thread-local error slot for the whole library
 void vsx_internal_set_error(const char * msg) { g_err = msg ? msg : ""; }
 const vsx_scoring * vsx_internal_scoring(const vsx_ctx * ctx) { return &ctx->sc; }
+int vsx_internal_device(const vsx_ctx * ctx) { return ctx->device; }
+hipStream_t vsx_internal_stream(const vsx_ctx * ctx) { return ctx->stream; }
+void vsx_internal_seqset_device(const vsx_seqset * s, const uint8_t ** codes, const uint64_t ** off, const uint32_t ** len, uint64_t * n)
+{
+  *codes = s->codes(); *off = s->d_off.p; *len = s->d_len.p; *n = s->n;
+}
 
 const char * vsx_version_string(void) { return "libvsx 0.1.0 (gfx950)"; }
 

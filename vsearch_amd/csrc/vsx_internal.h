@@ -91,6 +91,19 @@ hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams P, const V
 uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t rows);
 const int * vsx_supported_rows(int * count);
 
+// launchers implemented in vsx_kmer.hip (k-mer candidate counting)
+hipError_t vsx_kmer_launch_sweep(int fill, const uint8_t * codes, const uint64_t * off, const uint32_t * len,
+                                 uint32_t nseq, int w, uint32_t ntiles, uint32_t * bucket_count,
+                                 const uint64_t * bucket_start, uint32_t * postings, hipStream_t st);
+hipError_t vsx_kmer_launch_count(const uint32_t * postings, const uint64_t * bucket_start, uint32_t ntiles,
+                                 uint32_t nseq, uint32_t nslots, const uint64_t * qk_start, const uint32_t * qk,
+                                 const uint32_t * minmatch, const uint32_t * qlist, void * rec, uint32_t cap,
+                                 uint32_t * qcount, hipStream_t st);
+hipError_t vsx_kmer_launch_select(const void * rec, uint32_t cap, const uint32_t * qcount, uint32_t nslots,
+                                  uint32_t keep, void * dense, unsigned long long * cursor, uint64_t capacity,
+                                  void * sel_m_n, uint64_t * sel_off, hipStream_t st);
+uint32_t vsx_kmer_tile_shift(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,33 @@
+// vsx_kmer.h -- host-side handle of the device k-mer index (vsx_kmer.hip / vsx_kmer_host.cpp); internal C++ API used by
+// the dispatch layer (vsx_search.cpp).
+#ifndef VSX_KMER_H
+#define VSX_KMER_H
+
+#include <stdint.h>
+#include <vector>
+#include "../../include/vsx.h"
+
+struct VsxKmerRec { uint32_t query, target, count, pad; };     // one candidate: count >= the query's minmatches
+struct VsxKmerIndex;
+
+struct VsxKmerStats {
+  double build_ms = 0;            // index build (two sweeps + prefix sum), device time + the small D2H/H2D of the bucket table
+  double count_ms = 0;            // last vsx_kmer_count_batch: kernel time (hipEvents)
+  uint64_t postings = 0;          // entries in the index
+  uint64_t increments = 0;        // last batch: counter updates = postings streamed
+  uint64_t records = 0;           // last batch: candidates emitted
+  uint64_t index_bytes = 0;
+};
+
+// words of length w (3..8) over the sequence set's 4-bit codes; ambiguous symbols poison the words that cover them
+int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIndex ** out);
+void vsx_kmer_index_destroy(VsxKmerIndex * ix);
+// qk_start[nq + 1] / qk[]: each query's unique words; minmatch[q] = threshold, 0xffffffff = skip the query.
+// recs: (query, target, count) with count >= minmatch[query], unordered.
+// keep = size of the reference's heap (tophits): per query the device keeps every record whose count is >= the
+// keep-th largest count (a superset of the heap under any tie-break); the caller applies the total order.
+int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_start, const uint32_t * qk,
+                         const uint32_t * minmatch, uint32_t keep, std::vector<VsxKmerRec> & recs);
+const VsxKmerStats * vsx_kmer_stats(const VsxKmerIndex * ix);
+
+#endif

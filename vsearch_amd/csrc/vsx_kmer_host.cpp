@@ -1,0 +1,228 @@
+// vsx_kmer_host.cpp -- builds and drives the device k-mer index (kernels: vsx_kmer.hip).
+#include "vsx_kmer.h"
+#include "vsx_internal.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+
+extern "C" void vsx_internal_set_error(const char * msg);
+extern "C" int vsx_internal_device(const vsx_ctx * ctx);
+extern "C" hipStream_t vsx_internal_stream(const vsx_ctx * ctx);
+extern "C" void vsx_internal_seqset_device(const vsx_seqset * s, const uint8_t ** codes, const uint64_t ** off,
+                                           const uint32_t ** len, uint64_t * n);
+
+namespace {
+
+int kfail(int code, const char * what, hipError_t e)
+{
+  std::string m = std::string(what) + ": " + hipGetErrorString(e);
+  vsx_internal_set_error(m.c_str());
+  return code;
+}
+
+template <typename T> struct Buf {
+  T * p = nullptr;
+  size_t n = 0;
+  ~Buf() { if (p) (void) hipFree(p); }
+  hipError_t alloc(size_t count)
+  {
+    if (p) { (void) hipFree(p); p = nullptr; n = 0; }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  hipError_t ensure(size_t count) { return (p && count <= n) ? hipSuccess : alloc(count); }
+};
+
+}  // namespace
+
+struct VsxKmerIndex {
+  vsx_ctx * ctx = nullptr;
+  int device = 0;
+  hipStream_t st = nullptr;
+  int w = 8;
+  uint32_t nseq = 0, ntiles = 0;
+  uint64_t nbuckets = 0;
+  Buf<uint64_t> d_start;          // nbuckets + 1
+  Buf<uint32_t> d_post;
+  // per-batch scratch, grown on demand
+  Buf<uint64_t> d_qk_start;
+  Buf<uint32_t> d_qk, d_minmatch;
+  Buf<uint64_t> d_rec, d_dense, d_sel_mn, d_sel_off;    // uint2 records (target, count); (kept, seen) per slot
+  Buf<uint32_t> d_qcount;
+  Buf<unsigned long long> d_cursor;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  VsxKmerStats stats;
+  std::vector<uint64_t> word_total;   // postings per word over all tiles
+  ~VsxKmerIndex()
+  {
+    if (e0) (void) hipEventDestroy(e0);
+    if (e1) (void) hipEventDestroy(e1);
+  }
+};
+
+#define KCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return kfail(e_ == hipErrorOutOfMemory ? VSX_ENOMEM : VSX_EHIP, #x, e_); } while (0)
+
+int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIndex ** out)
+{
+  if (!ctx || !db || !out) { vsx_internal_set_error("vsx_kmer_index_create: null argument"); return VSX_EINVAL; }
+  *out = nullptr;
+  if (w < 3 || w > 8) { vsx_internal_set_error("vsx_kmer_index_create: device index supports word lengths 3..8"); return VSX_EINVAL; }
+  const uint8_t * codes; const uint64_t * off; const uint32_t * len; uint64_t n;
+  vsx_internal_seqset_device(db, &codes, &off, &len, &n);
+  if (n >= (1ull << 31)) { vsx_internal_set_error("vsx_kmer_index_create: too many sequences"); return VSX_EINVAL; }
+  std::unique_ptr<VsxKmerIndex> ix(new VsxKmerIndex);
+  ix->ctx = ctx; ix->device = vsx_internal_device(ctx); ix->st = vsx_internal_stream(ctx); ix->w = w;
+  KCHK(hipSetDevice(ix->device));
+  KCHK(hipEventCreate(&ix->e0));
+  KCHK(hipEventCreate(&ix->e1));
+  const uint32_t shift = vsx_kmer_tile_shift();
+  ix->nseq = (uint32_t) n;
+  ix->ntiles = std::max<uint32_t>(1, (uint32_t) ((n + (1ull << shift) - 1) >> shift));
+  ix->nbuckets = (1ull << (2 * w)) * ix->ntiles;
+
+  Buf<uint32_t> d_count;
+  KCHK(d_count.alloc(ix->nbuckets));
+  KCHK(ix->d_start.alloc(ix->nbuckets + 1));
+  KCHK(hipEventRecord(ix->e0, ix->st));
+  KCHK(hipMemsetAsync(d_count.p, 0, ix->nbuckets * 4, ix->st));
+  KCHK(vsx_kmer_launch_sweep(0, codes, off, len, ix->nseq, w, ix->ntiles, d_count.p, nullptr, nullptr, ix->st));
+  // bucket table: exclusive prefix sum on the host (4^w x ntiles entries: 8 MB for 1 M sequences, w = 8)
+  std::vector<uint32_t> cnt(ix->nbuckets);
+  KCHK(hipMemcpyAsync(cnt.data(), d_count.p, ix->nbuckets * 4, hipMemcpyDeviceToHost, ix->st));
+  KCHK(hipStreamSynchronize(ix->st));
+  std::vector<uint64_t> start(ix->nbuckets + 1);
+  uint64_t acc = 0;
+  for (uint64_t b = 0; b < ix->nbuckets; ++b) { start[b] = acc; acc += cnt[b]; }
+  start[ix->nbuckets] = acc;
+  ix->word_total.resize(1ull << (2 * w));
+  for (uint64_t k = 0; k < ix->word_total.size(); ++k) ix->word_total[k] = start[(k + 1) * ix->ntiles] - start[k * ix->ntiles];
+  KCHK(ix->d_post.alloc(acc));
+  KCHK(hipMemcpyAsync(ix->d_start.p, start.data(), (ix->nbuckets + 1) * 8, hipMemcpyHostToDevice, ix->st));
+  KCHK(hipMemsetAsync(d_count.p, 0, ix->nbuckets * 4, ix->st));
+  KCHK(vsx_kmer_launch_sweep(1, codes, off, len, ix->nseq, w, ix->ntiles, d_count.p, ix->d_start.p, ix->d_post.p, ix->st));
+  KCHK(hipEventRecord(ix->e1, ix->st));
+  KCHK(hipStreamSynchronize(ix->st));
+  float ms = 0;
+  KCHK(hipEventElapsedTime(&ms, ix->e0, ix->e1));
+  ix->stats.build_ms = ms;
+  ix->stats.postings = acc;
+  ix->stats.index_bytes = acc * 4 + (ix->nbuckets + 1) * 8;
+  KCHK(ix->d_cursor.alloc(1));
+  *out = ix.release();
+  return VSX_OK;
+}
+
+void vsx_kmer_index_destroy(VsxKmerIndex * ix)
+{
+  if (!ix) return;
+  (void) hipSetDevice(ix->device);
+  delete ix;
+}
+
+const VsxKmerStats * vsx_kmer_stats(const VsxKmerIndex * ix) { return ix ? &ix->stats : nullptr; }
+
+namespace {
+
+// one counting + selection pass over `nslots` query slots (slot -> query through qlist, or identity); appends to recs
+int count_pass(VsxKmerIndex * ix, uint32_t nslots, const uint32_t * d_qlist, const std::vector<uint32_t> * h_qlist, uint32_t cap,
+               uint32_t keep, std::vector<VsxKmerRec> & recs, std::vector<uint32_t> & overflow, uint32_t & overflow_max, float & ms_total)
+{
+  KCHK(ix->d_rec.ensure((size_t) nslots * cap));
+  KCHK(ix->d_qcount.ensure(nslots));
+  KCHK(ix->d_sel_mn.ensure(nslots));
+  KCHK(ix->d_sel_off.ensure(nslots));
+  KCHK(hipMemsetAsync(ix->d_qcount.p, 0, (size_t) nslots * 4, ix->st));
+  KCHK(hipEventRecord(ix->e0, ix->st));
+  KCHK(vsx_kmer_launch_count(ix->d_post.p, ix->d_start.p, ix->ntiles, ix->nseq, nslots, ix->d_qk_start.p, ix->d_qk.p,
+                             ix->d_minmatch.p, d_qlist, ix->d_rec.p, cap, ix->d_qcount.p, ix->st));
+  uint64_t capacity = std::max<uint64_t>(ix->d_dense.n, std::max<uint64_t>(1u << 20, (uint64_t) nslots * 128));
+  unsigned long long produced = 0;
+  for (int attempt = 0; attempt < 2; ++attempt)
+    {
+      KCHK(ix->d_dense.ensure(capacity));
+      KCHK(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), ix->st));
+      KCHK(vsx_kmer_launch_select(ix->d_rec.p, cap, ix->d_qcount.p, nslots, keep, ix->d_dense.p, ix->d_cursor.p, ix->d_dense.n,
+                                  ix->d_sel_mn.p, ix->d_sel_off.p, ix->st));
+      KCHK(hipEventRecord(ix->e1, ix->st));
+      KCHK(hipMemcpyAsync(&produced, ix->d_cursor.p, sizeof produced, hipMemcpyDeviceToHost, ix->st));
+      KCHK(hipStreamSynchronize(ix->st));
+      if (produced <= ix->d_dense.n) break;
+      capacity = produced;
+      if (attempt == 1) { vsx_internal_set_error("vsx_kmer_count_batch: selection buffer overflow"); return VSX_EHIP; }
+    }
+  float ms = 0;
+  KCHK(hipEventElapsedTime(&ms, ix->e0, ix->e1));
+  ms_total += ms;
+  std::vector<uint64_t> mn(nslots), off(nslots);
+  std::vector<uint64_t> dense(produced);
+  KCHK(hipMemcpy(mn.data(), ix->d_sel_mn.p, (size_t) nslots * 8, hipMemcpyDeviceToHost));
+  KCHK(hipMemcpy(off.data(), ix->d_sel_off.p, (size_t) nslots * 8, hipMemcpyDeviceToHost));
+  if (produced) KCHK(hipMemcpy(dense.data(), ix->d_dense.p, produced * 8, hipMemcpyDeviceToHost));
+  const size_t before = recs.size();
+  recs.reserve(before + produced);
+  for (uint32_t s = 0; s < nslots; ++s)
+    {
+      const uint32_t m = (uint32_t) (mn[s] & 0xffffffffu), n = (uint32_t) (mn[s] >> 32);
+      const uint32_t q = h_qlist ? (*h_qlist)[s] : s;
+      if (m == 0xffffffffu) { overflow.push_back(q); overflow_max = std::max(overflow_max, n); continue; }
+      for (uint32_t x = 0; x < m; ++x)
+        {
+          const uint64_t w = dense[off[s] + x];                        // uint2 (target, count), little endian
+          recs.push_back(VsxKmerRec {q, (uint32_t) (w & 0xffffffffu), (uint32_t) (w >> 32), 0});
+        }
+    }
+  ix->stats.records += recs.size() - before;
+  return VSX_OK;
+}
+
+}  // namespace
+
+int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_start, const uint32_t * qk,
+                         const uint32_t * minmatch, uint32_t keep, std::vector<VsxKmerRec> & recs)
+{
+  recs.clear();
+  if (!ix || (nq && (!qk_start || !minmatch))) { vsx_internal_set_error("vsx_kmer_count_batch: null argument"); return VSX_EINVAL; }
+  if (nq == 0 || ix->nseq == 0) return VSX_OK;
+  if (nq >= (1ull << 22)) { vsx_internal_set_error("vsx_kmer_count_batch: at most 4 M queries per batch"); return VSX_EINVAL; }
+  KCHK(hipSetDevice(ix->device));
+  const uint64_t nk = qk_start[nq];
+  {
+    uint64_t inc = 0;
+    for (uint64_t x = 0; x < nk; ++x) inc += ix->word_total[qk[x]];
+    ix->stats.increments = inc;
+  }
+  ix->stats.records = 0;
+  KCHK(ix->d_qk_start.ensure(nq + 1));
+  KCHK(ix->d_qk.ensure(nk));
+  KCHK(ix->d_minmatch.ensure(nq));
+  KCHK(hipMemcpyAsync(ix->d_qk_start.p, qk_start, (nq + 1) * 8, hipMemcpyHostToDevice, ix->st));
+  if (nk) KCHK(hipMemcpyAsync(ix->d_qk.p, qk, nk * 4, hipMemcpyHostToDevice, ix->st));
+  KCHK(hipMemcpyAsync(ix->d_minmatch.p, minmatch, nq * 4, hipMemcpyHostToDevice, ix->st));
+  float ms = 0;
+  std::vector<uint32_t> overflow;
+  uint32_t overflow_max = 0;
+  const uint32_t cap = 1024;                                // records per query region in the first pass (8 KB)
+  int rc = count_pass(ix, (uint32_t) nq, nullptr, nullptr, cap, keep, recs, overflow, overflow_max, ms);
+  if (rc != VSX_OK) return rc;
+  if (!overflow.empty())
+    {
+      // queries with more than `cap` sequences at or above their threshold (low-complexity words): a second pass over
+      // just these, with regions of the size the first pass measured
+      Buf<uint32_t> d_qlist;
+      KCHK(d_qlist.alloc(overflow.size()));
+      KCHK(hipMemcpyAsync(d_qlist.p, overflow.data(), overflow.size() * 4, hipMemcpyHostToDevice, ix->st));
+      std::vector<uint32_t> again;
+      uint32_t again_max = 0;
+      const std::vector<uint32_t> list = overflow;
+      rc = count_pass(ix, (uint32_t) list.size(), d_qlist.p, &list, overflow_max, keep, recs, again, again_max, ms);
+      if (rc != VSX_OK) return rc;
+      if (!again.empty()) { vsx_internal_set_error("vsx_kmer_count_batch: record region overflow in the second pass"); return VSX_EHIP; }
+    }
+  ix->stats.count_ms = ms;
+  return VSX_OK;
+}

@@ -10,6 +10,7 @@
 //   align_trim               core/searchcore.cpp:343-464 ; hit order :133-179, :1028-1052
 #include "../../include/vsx_search.h"
 #include "vsx_internal.h"
+#include "vsx_kmer.h"
 
 #include <algorithm>
 #include <atomic>
@@ -244,6 +245,8 @@ struct vsx_searcher {
   int64_t ma = 1, mr = 32, tophits = 0, minwordmatches = 12;
   int threads = 1;
   bool indexed = false;              // the k-mer index is built on first use (allpairs never needs it)
+  VsxKmerIndex * kidx = nullptr;     // device index (vsx_kmer.hip), built on first use by the batch search
+  std::vector<uint64_t> word_total;  // postings per word (statistics of the device index)
   std::vector<uint8_t> is_centroid;  // clustering: which sequences are in the growing index
 };
 
@@ -506,6 +509,113 @@ static void build_index(vsx_searcher * S)
   S->indexed = true;
 }
 
+// The device path covers what the tiled 16-bit counters can hold: word lengths 3..8, hard masking (words are derived from
+// the 4-bit codes), at least one sequence.  VSX_KMER=host forces the host threads.
+static bool device_kmer_ok(const vsx_searcher & S)
+{
+  static const bool forced_host = std::getenv("VSX_KMER") && std::strcmp(std::getenv("VSX_KMER"), "host") == 0;
+  return !forced_host && S.w >= 3 && S.w <= 8 && S.o.soft_mask == 0 && !S.len.empty();
+}
+
+struct KmerAcct { double kernel_ms = 0, build_ms = 0; uint64_t streamed = 0, postings = 0; };
+
+// search_topscores for a batch: cands[k] = candidate list of query k, best first, <= tophits entries.
+template <typename FSeq, typename FLen>
+static int batch_candidates(vsx_searcher * S, bool device, uint64_t nq, FSeq qseq, FLen qlen,
+                            std::vector<std::vector<Cand>> & cands, KmerAcct & acct)
+{
+  cands.assign(nq, {});
+  const int nth = std::max(1, S->threads);
+  const uint64_t nwords = 1ull << (2 * S->w);
+  auto parallel = [&](auto && fn) {
+    std::atomic<uint64_t> next {0};
+    auto work = [&](int tid) { for (;;) { const uint64_t k = next.fetch_add(1); if (k >= nq) break; fn(tid, k); } };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto & th : pool) th.join();
+  };
+
+  if (!device)
+    {
+      build_index(S);
+      struct Scratch { std::vector<uint16_t> counts; std::vector<uint32_t> touched, km; std::vector<uint64_t> seen; };
+      std::vector<Scratch> scratch((size_t) nth);
+      for (auto & sc : scratch)
+        {
+          sc.counts.assign(S->len.size(), 0);
+          sc.seen.assign(S->w < 10 ? (nwords + 63) / 64 : 1, 0);
+        }
+      parallel([&](int tid, uint64_t k) {
+        Scratch & sc = scratch[(size_t) tid];
+        candidates_for(*S, qseq(k), qlen(k), sc.counts, sc.touched, sc.km, sc.seen, cands[k]);
+      });
+      return VSX_OK;
+    }
+
+  if (!S->kidx)
+    {
+      const int rc = vsx_kmer_index_create(S->ctx, S->dbset, S->w, &S->kidx);
+      if (rc != VSX_OK) return rc;
+      acct.build_ms = vsx_kmer_stats(S->kidx)->build_ms;
+    }
+  acct.postings = vsx_kmer_stats(S->kidx)->postings;
+
+  // 1. unique words per query (host threads; unique_count, core/unique.cpp:155-352)
+  std::vector<std::vector<uint32_t>> words(nq);
+  {
+    std::vector<std::vector<uint64_t>> seen((size_t) nth, std::vector<uint64_t>((nwords + 63) / 64, 0));
+    parallel([&](int tid, uint64_t k) { unique_kmers(qseq(k), qlen(k), S->w, false, words[k], seen[(size_t) tid]); });
+  }
+  // 2. CSR + thresholds (:320); queries the 16-bit tile counters cannot serve go to the host path
+  std::vector<uint64_t> qk_start(nq + 1, 0);
+  std::vector<uint32_t> minmatch(nq);
+  std::vector<uint64_t> fallback;
+  for (uint64_t k = 0; k < nq; ++k)
+    {
+      const uint64_t nk = words[k].size();
+      const uint64_t mm = (uint64_t) std::min<int64_t>(S->minwordmatches, (int64_t) nk);
+      if (mm == 0 || nk > 32767) { minmatch[k] = 0xffffffffu; fallback.push_back(k); qk_start[k + 1] = qk_start[k]; continue; }
+      minmatch[k] = (uint32_t) mm;
+      qk_start[k + 1] = qk_start[k] + nk;
+    }
+  std::vector<uint32_t> qk(qk_start[nq]);
+  for (uint64_t k = 0; k < nq; ++k)
+    if (minmatch[k] != 0xffffffffu) std::copy(words[k].begin(), words[k].end(), qk.begin() + (int64_t) qk_start[k]);
+  // 3. count on the device
+  std::vector<VsxKmerRec> recs;
+  const int rc = vsx_kmer_count_batch(S->kidx, nq, qk_start.data(), qk.data(), minmatch.data(), (uint32_t) std::max<int64_t>(S->tophits, 1), recs);
+  if (rc != VSX_OK) return rc;
+  acct.kernel_ms += vsx_kmer_stats(S->kidx)->count_ms;
+  acct.streamed += vsx_kmer_stats(S->kidx)->increments;
+  // 4. bucket by query, then the heap's total order (count desc, length asc, seqno asc) and size
+  std::vector<uint64_t> first(nq + 1, 0);
+  for (const VsxKmerRec & r : recs) ++first[r.query + 1];
+  for (uint64_t k = 0; k < nq; ++k) first[k + 1] += first[k];
+  std::vector<Cand> flat(recs.size());
+  {
+    std::vector<uint64_t> fill(first.begin(), first.end() - 1);
+    for (const VsxKmerRec & r : recs) flat[fill[r.query]++] = Cand {r.target, r.count, S->len[r.target]};
+  }
+  parallel([&](int, uint64_t k) {
+    if (minmatch[k] == 0xffffffffu) return;
+    std::vector<Cand> & out = cands[k];
+    out.assign(flat.begin() + (int64_t) first[k], flat.begin() + (int64_t) first[k + 1]);
+    const size_t keep = std::min<size_t>(out.size(), (size_t) S->tophits);
+    std::partial_sort(out.begin(), out.begin() + (int64_t) keep, out.end(), cand_better);
+    out.resize(keep);
+  });
+  if (!fallback.empty())
+    {
+      build_index(S);
+      std::vector<uint16_t> counts(S->len.size(), 0);
+      std::vector<uint32_t> touched, km;
+      std::vector<uint64_t> seen(S->w < 10 ? (nwords + 63) / 64 : 1, 0);
+      for (uint64_t k : fallback) candidates_for(*S, qseq(k), qlen(k), counts, touched, km, seen, cands[k]);
+    }
+  return VSX_OK;
+}
+
 extern "C" {
 
 void vsx_search_opts_default(vsx_search_opts * o)
@@ -557,6 +667,7 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
 void vsx_searcher_destroy(vsx_searcher * s)
 {
   if (!s) return;
+  vsx_kmer_index_destroy(s->kidx);
   vsx_seqset_destroy(s->dbset);
   delete s;
 }
@@ -574,6 +685,50 @@ int64_t vsx_search_candidates(vsx_searcher * S, const char * q, uint32_t qlen, u
   return (int64_t) c.size();
 }
 
+int vsx_search_candidates_batch(vsx_searcher * S, int32_t device, uint64_t nq, const char * qblob, uint64_t qbytes,
+                                const uint64_t * qoff, const uint32_t * qlen, vsx_candidates * out)
+{
+  if (!S || !out || (nq && (!qblob || !qoff || !qlen))) return sfail(VSX_EINVAL, "vsx_search_candidates_batch: null argument");
+  std::memset(out, 0, sizeof *out);
+  for (uint64_t i = 0; i < nq; ++i)
+    if (qoff[i] + qlen[i] > qbytes) return sfail(VSX_EINVAL, "vsx_search_candidates_batch: query exceeds the blob");
+  if (device && !device_kmer_ok(*S))
+    return sfail(VSX_EINVAL, "vsx_search_candidates_batch: the device path needs wordlength 3..8, hard masking, a non-empty database");
+  const double t0 = now_s();
+  std::vector<std::vector<Cand>> cands;
+  KmerAcct acct;
+  const int rc = batch_candidates(S, device != 0, nq, [&](uint64_t k) { return qblob + qoff[k]; },
+                                  [&](uint64_t k) { return (int64_t) qlen[k]; }, cands, acct);
+  if (rc != VSX_OK) return rc;
+  uint64_t total = 0;
+  for (auto & c : cands) total += c.size();
+  out->n_queries = nq;
+  out->start = (uint64_t *) std::malloc((nq + 1) * sizeof(uint64_t));
+  out->target = (uint32_t *) std::malloc(std::max<uint64_t>(total, 1) * sizeof(uint32_t));
+  out->count = (uint32_t *) std::malloc(std::max<uint64_t>(total, 1) * sizeof(uint32_t));
+  if (!out->start || !out->target || !out->count) { vsx_candidates_free(out); return sfail(VSX_ENOMEM, "vsx_search_candidates_batch: out of memory"); }
+  uint64_t p = 0;
+  for (uint64_t k = 0; k < nq; ++k)
+    {
+      out->start[k] = p;
+      for (const Cand & c : cands[k]) { out->target[p] = c.target; out->count[p] = c.count; ++p; }
+    }
+  out->start[nq] = p;
+  out->seconds = now_s() - t0;
+  out->kernel_ms = acct.kernel_ms;
+  out->index_build_ms = acct.build_ms;
+  out->index_postings = acct.postings;
+  out->postings_streamed = acct.streamed;
+  return VSX_OK;
+}
+
+void vsx_candidates_free(vsx_candidates * c)
+{
+  if (!c) return;
+  std::free(c->start); std::free(c->target); std::free(c->count);
+  std::memset(c, 0, sizeof *c);
+}
+
 int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t qbytes, const uint64_t * qoff,
                      const uint32_t * qlen, vsx_hits * out)
 {
@@ -582,44 +737,27 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
   for (uint64_t i = 0; i < nq; ++i)
     if (qoff[i] + qlen[i] > qbytes) return sfail(VSX_EINVAL, "vsx_search_batch: query exceeds the blob");
   const double t_begin = now_s();
-  build_index(S);
   const uint64_t window = S->o.window > 0 ? (uint64_t) S->o.window : 65536;
   std::vector<std::vector<Hit>> kept(nq);
   double t_kmer = 0, t_align = 0;
   uint64_t pairs = 0, cells = 0, stages = 0, sentinels = 0;
 
-  // per-thread k-mer scratch
-  const int nth = std::max(1, S->threads);
-  struct Scratch { std::vector<uint16_t> counts; std::vector<uint32_t> touched, km; std::vector<uint64_t> seen; };
-  std::vector<Scratch> scratch((size_t) nth);
-  for (auto & sc : scratch)
-    {
-      sc.counts.assign(S->len.size(), 0);
-      sc.seen.assign(S->w < 10 ? ((1ull << (2 * S->w)) + 63) / 64 : 1, 0);
-    }
+  const bool dev_kmer = device_kmer_ok(*S);
+  KmerAcct kacct;
 
   for (uint64_t w0 = 0; w0 < nq; w0 += window)
     {
       const uint64_t wn = std::min<uint64_t>(window, nq - w0);
       std::vector<QState> st(wn);
 
-      // ---- k-mer heuristic for the whole window (host threads; SURVEY 8f "next #1" moves this to the GPU) ----
+      // ---- k-mer heuristic for the whole window: device counters (vsx_kmer.hip) or host threads ----
       double t0 = now_s();
       {
-        std::atomic<uint64_t> next {0};
-        auto work = [&](int tid) {
-          Scratch & sc = scratch[(size_t) tid];
-          for (;;)
-            {
-              const uint64_t k = next.fetch_add(1);
-              if (k >= wn) break;
-              candidates_for(*S, qblob + qoff[w0 + k], qlen[w0 + k], sc.counts, sc.touched, sc.km, sc.seen, st[k].cands);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto & th : pool) th.join();
+        std::vector<std::vector<Cand>> cands;
+        const int krc = batch_candidates(S, dev_kmer, wn, [&](uint64_t k) { return qblob + qoff[w0 + k]; },
+                                         [&](uint64_t k) { return (int64_t) qlen[w0 + k]; }, cands, kacct);
+        if (krc != VSX_OK) return krc;
+        for (uint64_t k = 0; k < wn; ++k) st[k].cands = std::move(cands[k]);
       }
       t_kmer += now_s() - t0;
 

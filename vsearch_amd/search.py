@@ -68,6 +68,27 @@ class SearchSession:
         n = min(int(n), cap)
         return list(zip(t[:n].tolist(), c[:n].tolist()))
 
+    def candidates_batch(self, queries, device=True):
+        """per-query [(target, count)] lists, best first (search_topscores + heap order) -- counted on the GPU
+        (device=True, vsx_kmer.hip) or by the host restatement; self.kmer_stats holds the timings of the call"""
+        lib = _lib.load()
+        blob, off, lens = _blob(queries)
+        res = _lib.Candidates()
+        check(lib.vsx_search_candidates_batch(self.h, 1 if device else 0, len(lens), C.cast(C.c_char_p(blob), C.c_void_p),
+                                              len(blob), off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                                              C.byref(res)), "vsx_search_candidates_batch")
+        try:
+            n = int(res.n_queries)
+            start = np.ctypeslib.as_array(res.start, shape=(n + 1,)).copy()
+            tot = int(start[n])
+            tg = np.ctypeslib.as_array(res.target, shape=(max(tot, 1),))[:tot].copy()
+            ct = np.ctypeslib.as_array(res.count, shape=(max(tot, 1),))[:tot].copy()
+            self.kmer_stats = {k: getattr(res, k) for k in ("seconds", "kernel_ms", "index_build_ms", "index_postings",
+                                                            "postings_streamed")}
+            return [list(zip(tg[start[k]:start[k + 1]].tolist(), ct[start[k]:start[k + 1]].tolist())) for k in range(n)]
+        finally:
+            lib.vsx_candidates_free(C.byref(res))
+
     def allpairs(self, first=0, count=None, acceptall=False):
         """allpairs_global over database sequences [first, first+count): per-query hit lists (query = db index)"""
         lib = _lib.load()
