@@ -98,10 +98,13 @@ def main():
                 if best is None or st["kernel_ms"] < best["kernel_ms"]:
                     best = st
             nh = min(a.host_queries, a.queries)
-            run(0, 1)                                   # builds the host index (not part of the timed host sample)
-            hstart, htg, hct, hst = run(0, nh)
-            same = bool(np.array_equal(start[:nh + 1], hstart) and np.array_equal(tg[:hstart[nh]], htg)
-                        and np.array_equal(ct[:hstart[nh]], hct))
+            if nh > 0:
+                run(0, 1)                               # builds the host index (not part of the timed host sample)
+                hstart, htg, hct, hst = run(0, nh)
+                same = bool(np.array_equal(start[:nh + 1], hstart) and np.array_equal(tg[:hstart[nh]], htg)
+                            and np.array_equal(ct[:hstart[nh]], hct))
+            else:
+                hst, same = {"seconds": float("inf")}, None
             # does the source member lead its query's list? (sanity of the synthetic workload, not a parity statement)
             lead = float(np.mean(tg[start[:-1][start[1:] > start[:-1]]] == src[start[1:] > start[:-1]]))
             bytes_streamed = best["postings_streamed"] * 4

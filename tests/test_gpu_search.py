@@ -299,3 +299,18 @@ def test_device_kmer_multi_tile(gpu_required):
     assert host == dev
     assert all(len(h) >= 50 for h in host)
     assert any(t >= 65536 for h in host for t, _ in h) and any(t < 32768 for h in host for t, _ in h)
+
+
+@pytest.mark.gpu
+def test_device_kmer_region_overflow_second_pass(gpu_required, monkeypatch):
+    """a record region smaller than a query's candidate count must trigger the exact-size second pass"""
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(5)
+    db, _ = common.family_db(rng, 6, 30, 300, div=0.05)
+    qs, _ = common.queries_from_db(rng, db, 20, 150)
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.5, maxaccepts=4, maxrejects=16)
+        host = ss.candidates_batch(qs, device=False)
+        monkeypatch.setenv("VSX_KMER_CAP", "3")
+        dev = ss.candidates_batch(qs, device=True)
+    assert host == dev and max(len(h) for h in host) > 3

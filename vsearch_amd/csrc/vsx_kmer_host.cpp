@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -206,9 +207,13 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
   float ms = 0;
   std::vector<uint32_t> overflow;
   uint32_t overflow_max = 0;
-  const uint32_t cap = 1024;                                // records per query region in the first pass (8 KB)
+  // records per query region in the first pass: at 1 M x 1 kbp a 250-bp query has ~5 000 sequences with >= 12 shared
+  // words (chance runs of shared 11..13-mers), so 8 192 x 8 B = 64 KB per query; HBM is plentiful (100 k queries = 6.5 GB)
+  uint32_t cap = nq <= (1u << 18) ? 8192 : 2048;
+  if (const char * c = std::getenv("VSX_KMER_CAP")) cap = (uint32_t) std::max(1, std::atoi(c));      // tests: force the second pass
   int rc = count_pass(ix, (uint32_t) nq, nullptr, nullptr, cap, keep, recs, overflow, overflow_max, ms);
   if (rc != VSX_OK) return rc;
+  if (std::getenv("VSX_KMER_DEBUG")) std::fprintf(stderr, "kmer: %zu of %llu queries overflowed cap %u (max %u records), %.1f ms\n", overflow.size(), (unsigned long long) nq, cap, overflow_max, ms);
   if (!overflow.empty())
     {
       // queries with more than `cap` sequences at or above their threshold (low-complexity words): a second pass over
