@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--qlen", type=int, default=250)
     ap.add_argument("--host-queries", type=int, default=1000)
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--e2e", type=int, default=0, help="also run vsx_search_batch (--usearch_global --id 0.9) on the first N queries")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_kmer.py needs a GPU (no CPU fallback)")
@@ -107,6 +108,18 @@ def main():
                 hst, same = {"seconds": float("inf")}, None
             # does the source member lead its query's list? (sanity of the synthetic workload, not a parity statement)
             lead = float(np.mean(tg[start[:-1][start[1:] > start[:-1]]] == src[start[1:] > start[:-1]]))
+            e2e = None
+            if a.e2e > 0:
+                ne = min(a.e2e, a.queries)
+                hits = _lib.Hits()
+                t0 = time.perf_counter()
+                check(lib.vsx_search_batch(h, ne, C.cast(C.c_char_p(q_blob), C.c_void_p), len(q_blob), vp(q_off), vp(q_len),
+                                           C.byref(hits)), "vsx_search_batch")
+                t_e2e = time.perf_counter() - t0
+                e2e = {"queries": ne, "seconds": round(t_e2e, 3), "queries_per_s": round(ne / t_e2e, 1),
+                       "pairs_aligned": int(hits.pairs_aligned), "cells_aligned": int(hits.cells_aligned), "stages": int(hits.stages),
+                       "hits": int(hits.n_hits), "seconds_kmer": round(hits.seconds_kmer, 3), "seconds_align": round(hits.seconds_align, 3)}
+                lib.vsx_hits_free(C.byref(hits))
             bytes_streamed = best["postings_streamed"] * 4
             gbps = bytes_streamed / (best["kernel_ms"] * 1e-3) / 1e9
             out = {
@@ -130,6 +143,8 @@ def main():
                 "parity_lists_equal_on_sample": same,
                 "gen_s": round(t_gen, 1), "create_s": round(t_create, 1),
             }
+            if e2e:
+                out["usearch_global_end_to_end"] = e2e
         finally:
             lib.vsx_searcher_destroy(h)
     print(json.dumps(out))

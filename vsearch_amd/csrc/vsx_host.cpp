@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <chrono>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -70,6 +72,84 @@ struct DevBuf {
   hipError_t ensure(size_t count) { return (count <= n && p) ? hipSuccess : alloc(count); }
 };
 
+
+// Scratch pool: hipMalloc/hipFree of the multi-GB checkpoint, slab and run buffers cost seconds per plan (page-table
+// set-up), far more than the kernels of a 500 k-pair stage.  A context keeps the blocks its finished plans give back and
+// hands them to the next plan (best fit).  VSX_POOL=0 disables it; vsx_destroy frees everything.
+struct PoolBlock { void * p; size_t bytes; };
+struct ScratchPool {
+  std::vector<PoolBlock> free_blocks;
+  std::mutex mu;
+  bool enabled = true;
+  hipError_t get(size_t bytes, void ** out, size_t * got)
+  {
+    if (bytes == 0) bytes = 1;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      size_t best = SIZE_MAX;
+      for (size_t k = 0; k < free_blocks.size(); ++k)
+        if (free_blocks[k].bytes >= bytes && (best == SIZE_MAX || free_blocks[k].bytes < free_blocks[best].bytes)) best = k;
+      if (best != SIZE_MAX)
+        {
+          *out = free_blocks[best].p; *got = free_blocks[best].bytes;
+          free_blocks.erase(free_blocks.begin() + (long) best);
+          return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) { trim(); (void) hipGetLastError(); e = hipMalloc(out, bytes); }
+    if (e == hipSuccess) *got = bytes;
+    return e;
+  }
+  void put(void * p, size_t bytes)
+  {
+    if (!p) return;
+    if (!enabled) { (void) hipFree(p); return; }
+    std::lock_guard<std::mutex> lk(mu);
+    free_blocks.push_back(PoolBlock {p, bytes});
+    while (free_blocks.size() > 12)                       // bound the number of idle blocks: drop the smallest
+      {
+        size_t m = 0;
+        for (size_t k = 1; k < free_blocks.size(); ++k) if (free_blocks[k].bytes < free_blocks[m].bytes) m = k;
+        (void) hipFree(free_blocks[m].p);
+        free_blocks.erase(free_blocks.begin() + (long) m);
+      }
+  }
+  size_t idle_bytes()
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    size_t t = 0;
+    for (const PoolBlock & b : free_blocks) t += b.bytes;
+    return t;
+  }
+  void trim()
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (PoolBlock & b : free_blocks) (void) hipFree(b.p);
+    free_blocks.clear();
+  }
+};
+
+template <typename T>
+struct PoolBuf {
+  T * p = nullptr;
+  size_t n = 0, bytes = 0;
+  ScratchPool * pool = nullptr;
+  ~PoolBuf() { release(); }
+  void release() { if (p && pool) pool->put(p, bytes); else if (p) (void) hipFree(p); p = nullptr; n = 0; bytes = 0; }
+  hipError_t alloc(ScratchPool * pl, size_t count)
+  {
+    release();
+    pool = pl;
+    if (count == 0) count = 1;
+    void * q = nullptr;
+    size_t got = 0;
+    hipError_t e = pl->get(count * sizeof(T), &q, &got);
+    if (e == hipSuccess) { p = static_cast<T *>(q); n = count; bytes = got; }
+    return e;
+  }
+};
+
 }  // namespace
 
 struct vsx_ctx {
@@ -83,6 +163,7 @@ struct vsx_ctx {
   int pen[12] {};                   // clamped CELL penalties: go_q_l, go_t_l, go_q_i, go_t_i, go_q_r, go_t_r, ge_*
   VsxDevParams P {};
   DevBuf<int16_t> d_htop, d_hleft, d_matrix;
+  ScratchPool pool;
 };
 
 struct vsx_seqset {
@@ -131,7 +212,8 @@ struct vsx_plan {
   uint64_t cells = 0, dir_bytes_total = 0;
 
   DevBuf<VsxTask> d_tasks;
-  DevBuf<uint32_t> d_pair_slot, d_pair_ids, d_dir[2], d_slab, d_runs;   // two direction buffers: chunk k uses k & 1
+  DevBuf<uint32_t> d_pair_slot, d_pair_ids;
+  PoolBuf<uint32_t> d_dir[2], d_slab, d_runs;   // two direction buffers: chunk k uses k & 1; pooled per context
   DevBuf<uint64_t> d_slab_off;
   DevBuf<uint2> d_strip;
   DevBuf<VsxSlotOut> d_slot;
@@ -206,6 +288,7 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   c->device = device;
   c->sc = *s;
   if (const char * mode = std::getenv("VSX_TRACEBACK")) c->ckpt = std::strcmp(mode, "dirs") != 0;
+  if (const char * mode = std::getenv("VSX_POOL")) c->pool.enabled = std::strcmp(mode, "0") != 0;
   if (const char * mode = std::getenv("VSX_TB_ARITH")) c->tb_packed = std::strcmp(mode, "packed") == 0;
 
   // search16_init, align_simd.cpp:1282-1376: scores must fit a CELL, each penalty SHRT_MAX/(1+CDEPTH)
@@ -287,6 +370,7 @@ void vsx_destroy(vsx_ctx * c)
   (void) hipSetDevice(c->device);
   if (c->stream) { (void) hipStreamSynchronize(c->stream); (void) hipStreamDestroy(c->stream); }
   if (c->stream2) { (void) hipStreamSynchronize(c->stream2); (void) hipStreamDestroy(c->stream2); }
+  c->pool.trim();
   delete c;
 }
 
@@ -501,6 +585,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
       // per buffer; two buffers are kept so the traceback of chunk k overlaps the DP of chunk k+1
+      free_b += ctx->pool.idle_bytes();                     // blocks this context can hand straight back
       dir_budget_bytes = std::min<uint64_t>((uint64_t) (free_b * 0.4), 128ull << 30);
     }
   const uint64_t budget_dwords = std::max<uint64_t>(dir_budget_bytes / 4, 1);
@@ -578,11 +663,11 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   HIPCHK(pl->d_slot.alloc(pl->tasks.size() * VSX_TASK_SLOTS));
   HIPCHK(pl->d_out.alloc(n_pairs));
   HIPCHK(pl->d_cursor.alloc(1));
-  HIPCHK(pl->d_dir[0].alloc(max_dir));
-  if (pl->chunks.size() > 1) HIPCHK(pl->d_dir[1].alloc(max_dir));
+  HIPCHK(pl->d_dir[0].alloc(&ctx->pool, max_dir));
+  if (pl->chunks.size() > 1) HIPCHK(pl->d_dir[1].alloc(&ctx->pool, max_dir));
   HIPCHK(pl->d_strip.alloc(max_strip));
-  HIPCHK(pl->d_slab.alloc(max_slab));
-  HIPCHK(pl->d_runs.alloc(pl->runs_capacity));
+  HIPCHK(pl->d_slab.alloc(&ctx->pool, max_slab));
+  HIPCHK(pl->d_runs.alloc(&ctx->pool, pl->runs_capacity));
   if (!pl->tasks.empty())
     HIPCHK(hipMemcpyAsync(pl->d_tasks.p, pl->tasks.data(), pl->tasks.size() * sizeof(VsxTask), hipMemcpyHostToDevice, ctx->stream));
   if (ngp)
@@ -705,7 +790,7 @@ int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
     {
       // the dense run buffer was sized for typical alignments; size it exactly and run again
       pl->runs_capacity = used + 1;
-      HIPCHK(pl->d_runs.alloc(pl->runs_capacity));
+      HIPCHK(pl->d_runs.alloc(&pl->ctx->pool, pl->runs_capacity));
       if ((rc = vsx_plan_run(pl)) != VSX_OK) return rc;
       if ((rc = vsx_plan_sync(pl, nullptr)) != VSX_OK) return rc;
       HIPCHK(hipMemcpy(&used, pl->d_cursor.p, sizeof used, hipMemcpyDeviceToHost));
@@ -784,12 +869,21 @@ void vsx_plan_destroy(vsx_plan * pl)
 int vsx_align_pairs(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
                     const uint32_t * qidx, const uint32_t * tidx, vsx_results * out)
 {
+  static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   vsx_plan * pl = nullptr;
   int rc = vsx_plan_create(ctx, &pl, queries, targets, n_pairs, qidx, tidx, 0);
   if (rc != VSX_OK) return rc;
+  const double t1 = now();
   rc = vsx_plan_run(pl);
-  if (rc == VSX_OK) rc = vsx_plan_fetch(pl, out);
+  double t2 = t1, t3 = t1;
+  if (rc == VSX_OK) { rc = vsx_plan_sync(pl, nullptr); t2 = now(); }
+  if (rc == VSX_OK) { rc = vsx_plan_fetch(pl, out); t3 = now(); }
   vsx_plan_destroy(pl);
+  if (timing)
+    std::fprintf(stderr, "vsx_align_pairs: %llu pairs: plan %.3f s, run+sync %.3f s, fetch %.3f s, destroy %.3f s\n",
+                 (unsigned long long) n_pairs, t1 - t0, t2 - t1, t3 - t2, now() - t3);
   return rc;
 }
 
