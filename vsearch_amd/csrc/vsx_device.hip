@@ -20,6 +20,7 @@
 // A second kernel walks the stored direction bits (one lane per pair) and emits the alignment
 // statistics and run-length CIGAR exactly as backtrack16 does.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "vsx_internal.h"
 
 typedef unsigned int u32;
@@ -74,7 +75,7 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // crosses.  Same bytes to HBM, ~40 % fewer VALU cycles per cell (the sign-bit funnel is gone).
 #define VSX_RB 1            // row checkpoints: [2^RB-step block][lane][step in block] uint2
 template <int R, bool GENERIC, bool TRACK, bool CKPT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 16 ? 4 : 1, 8)))
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
                    u32 * __restrict__ dir, uint2 * strip, VsxSlotOut * __restrict__ slot_out)
@@ -113,6 +114,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   const uint8_t * __restrict__ tB = tc + T.toff[2 * g + 1];
   const uint8_t * __restrict__ qq = qc + T.qoff;
 
+  const u32 qrt_i_pk = pack16(P.qrt_i);
   u32 hmin = 0, hmax = 0;      // running min(0, H...) / max(0, H...) of align_simd.cpp:810-811,772-773
   u32 score = 0;
 
@@ -251,6 +253,11 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               u32 xH = inH, xF = inF;                           // (H, F) entering row R-1 (R == 1: the lane's own inputs)
               u32 capH = 0, capF = 0, capmn = 0, capmx = 0;    // position 0: state after its last real row
               u32 dw[ND];
+              // SHARED: the interior query-row and target-column gap penalties coincide (planner flag P.share_sub) and no
+              // lane of the wave is in a last / padded column this step, so H - QR is the same number for E and for F in
+              // every row but R-1: 9 instead of 10 instructions per lane-row.
+              auto rows = [&](auto shared_tag) __attribute__((always_inline)) {
+              constexpr bool SHARED = decltype(shared_tag)::value;
 #pragma unroll
               for (int r = 0; r < R; ++r)
                 {
@@ -281,9 +288,9 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   hout[r] = h2;
                   const u32 qrq = (r == R - 1) ? qrq_last : P.qrq_i_pk;
                   const u32 rq = (r == R - 1) ? rq_last : P.rq_i_pk;
-                  const u32 hf = ssub(h2, qrt);
-                  const u32 f = ssub(F, rt);
                   const u32 he = ssub(h2, qrq);
+                  const u32 hf = (SHARED && r < R - 1) ? he : ssub(h2, qrt);
+                  const u32 f = ssub(F, rt);
                   const u32 e = ssub(E[r], rq);
                   if (!CKPT)
                     {
@@ -300,6 +307,9 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   // position 0 holds only rcnt0 rows: its later rows compute junk that never leaves the lane
                   if (!TOPPAD && __builtin_expect(rc0 == r + 1, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
                 }
+              };
+              if (CKPT && P.share_sub && !__any(qrt != qrt_i_pk)) rows(std::true_type {});
+              else rows(std::false_type {});
               const u32 hl = (!TOPPAD && first) ? capH : h2;
               F = (!TOPPAD && first) ? capF : F;
               smn = (!TOPPAD && first) ? capmn : smn;

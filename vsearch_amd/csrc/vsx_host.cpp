@@ -317,6 +317,7 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   P.match = match; P.mismatch = mism;
   P.n_mismatch = s->n_mismatch ? 1 : 0;
   P.top_open = goql; P.top_step = geql;
+  P.share_sub = (goqi + geqi == goti + geti && !std::getenv("VSX_NO_SHARE_SUB")) ? 1 : 0;
   int pmax = 0;
   for (int v : {goql + geql, goqi + geqi, goqr + geqr, gotl + getl, goti + geti, gotr + getr}) pmax = std::max(pmax, v);
   P.smin = -32768 + pmax;                                       // compute_score_min :1432-1444

@@ -24,6 +24,7 @@ struct VsxDevParams {
   int32_t  match, mismatch;
   int32_t  smin;                  // overflow threshold, compute_score_min (:1432-1444)
   int32_t  n_mismatch;
+  int32_t  share_sub;             // 1: QR_q(interior) == QR_t(interior): the DP kernel shares one H - QR per row (see `rows`)
   int32_t  top_open, top_step;    // go / ge of a query-left terminal gap: Htop(j) = -(go + (j + 1) ge); the dummy rows of TOPPAD
   const int16_t * htop;           // H(-1, j), j >= 0: top border chain (:1895-1910, :2043-2051)
   const int16_t * hleft;          // H(i, -1), i >= 0: left border chain (:844-859, :881-887)
