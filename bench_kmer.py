@@ -111,12 +111,17 @@ def main():
             e2e = None
             if a.e2e > 0:
                 ne = min(a.e2e, a.queries)
-                hits = _lib.Hits()
-                t0 = time.perf_counter()
-                check(lib.vsx_search_batch(h, ne, C.cast(C.c_char_p(q_blob), C.c_void_p), len(q_blob), vp(q_off), vp(q_len),
-                                           C.byref(hits)), "vsx_search_batch")
-                t_e2e = time.perf_counter() - t0
-                e2e = {"queries": ne, "seconds": round(t_e2e, 3), "queries_per_s": round(ne / t_e2e, 1),
+                t_first = None
+                for rep in range(2):                      # the first call also pays the one-time hipMalloc of the scratch pool
+                    hits = _lib.Hits()
+                    t0 = time.perf_counter()
+                    check(lib.vsx_search_batch(h, ne, C.cast(C.c_char_p(q_blob), C.c_void_p), len(q_blob), vp(q_off), vp(q_len),
+                                               C.byref(hits)), "vsx_search_batch")
+                    t_e2e = time.perf_counter() - t0
+                    if rep == 0:
+                        t_first = t_e2e
+                        lib.vsx_hits_free(C.byref(hits))
+                e2e = {"queries": ne, "seconds_first_call": round(t_first, 3), "seconds": round(t_e2e, 3), "queries_per_s": round(ne / t_e2e, 1),
                        "pairs_aligned": int(hits.pairs_aligned), "cells_aligned": int(hits.cells_aligned), "stages": int(hits.stages),
                        "hits": int(hits.n_hits), "seconds_kmer": round(hits.seconds_kmer, 3), "seconds_align": round(hits.seconds_align, 3)}
                 lib.vsx_hits_free(C.byref(hits))

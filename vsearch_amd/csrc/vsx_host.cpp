@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sched.h>
+#include <thread>
 #include <mutex>
 #include <chrono>
 #include <memory>
@@ -243,6 +245,21 @@ extern "C" {
 // shared with vsx_search.cpp: one thread-local error slot for the whole library
 void vsx_internal_set_error(const char * msg) { g_err = msg ? msg : ""; }
 const vsx_scoring * vsx_internal_scoring(const vsx_ctx * ctx) { return &ctx->sc; }
+int vsx_internal_usable_cpus(void)
+{
+  // CPUs this process may really use: affinity mask, capped by a cgroup v2 CPU quota
+  int n = (int) std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+  if (FILE * f = std::fopen("/sys/fs/cgroup/cpu.max", "r"))
+    {
+      char q[32]; long long period = 0;
+      if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0)
+        n = std::min<int>(n, (int) std::max<long long>(1, std::atoll(q) / period));
+      std::fclose(f);
+    }
+  return std::max(1, n);
+}
 int vsx_internal_device(const vsx_ctx * ctx) { return ctx->device; }
 hipStream_t vsx_internal_stream(const vsx_ctx * ctx) { return ctx->stream; }
 void vsx_internal_seqset_device(const vsx_seqset * s, const uint8_t ** codes, const uint64_t ** off, const uint32_t ** len, uint64_t * n)
@@ -814,26 +831,53 @@ int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
   if (!out->score || !out->aligned || !out->matches || !out->mismatches || !out->gaps || !out->cigar_off)
     { vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: host allocation failed"); }
 
-  std::string blob;
-  blob.reserve(used * 3 + n + 16);
-  size_t hc = 0;
-  for (uint64_t k = 0; k < n; ++k)
-    {
-      const VsxPairOut & o = pl->is_gpu[k] ? dev[k] : pl->host_out[k];
-      out->score[k] = o.score;
-      out->aligned[k] = o.aligned;
-      out->matches[k] = o.matches;
-      out->mismatches[k] = o.mismatches;
-      out->gaps[k] = o.gaps;
-      out->cigar_off[k] = blob.size();
-      if (pl->is_gpu[k]) { if (o.nruns) append_cigar(blob, runs.data() + o.run_off, o.nruns); }
-      else if (hc < pl->host_cigar_pair.size() && pl->host_cigar_pair[hc] == k) blob += pl->host_cigar[hc++];
-      blob.push_back('\0');
-    }
-  out->cigar_bytes = blob.size();
-  out->cigar_blob = (char *) std::malloc(std::max<size_t>(blob.size(), 1));
+  // statistics + CIGAR text: contiguous slices of the pair list are formatted by host threads, then concatenated
+  const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) vsx_internal_usable_cpus(), n / 4096));
+  std::vector<std::string> part((size_t) nth);
+  std::vector<uint64_t> lo((size_t) nth + 1);
+  for (int t = 0; t <= nth; ++t) lo[(size_t) t] = n * (uint64_t) t / (uint64_t) nth;
+  // pairs answered on the host with a CIGAR (Q == 0 closed form) are rare: index them once
+  auto work = [&](int t) {
+    std::string & b = part[(size_t) t];
+    b.reserve((size_t) ((used * 3 + n) / (uint64_t) nth + 64));
+    size_t hc = (size_t) (std::lower_bound(pl->host_cigar_pair.begin(), pl->host_cigar_pair.end(), (uint32_t) lo[(size_t) t]) -
+                          pl->host_cigar_pair.begin());
+    for (uint64_t k = lo[(size_t) t]; k < lo[(size_t) t + 1]; ++k)
+      {
+        const VsxPairOut & o = pl->is_gpu[k] ? dev[k] : pl->host_out[k];
+        out->score[k] = o.score;
+        out->aligned[k] = o.aligned;
+        out->matches[k] = o.matches;
+        out->mismatches[k] = o.mismatches;
+        out->gaps[k] = o.gaps;
+        out->cigar_off[k] = b.size();                              // slice-relative, rebased below
+        if (pl->is_gpu[k]) { if (o.nruns) append_cigar(b, runs.data() + o.run_off, o.nruns); }
+        else if (hc < pl->host_cigar_pair.size() && pl->host_cigar_pair[hc] == k) b += pl->host_cigar[hc++];
+        b.push_back('\0');
+      }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto & th : pool) th.join();
+  }
+  size_t total = 0;
+  std::vector<size_t> base((size_t) nth);
+  for (int t = 0; t < nth; ++t) { base[(size_t) t] = total; total += part[(size_t) t].size(); }
+  out->cigar_bytes = total;
+  out->cigar_blob = (char *) std::malloc(std::max<size_t>(total, 1));
   if (!out->cigar_blob) { vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: host allocation failed"); }
-  std::memcpy(out->cigar_blob, blob.data(), blob.size());
+  {
+    auto place = [&](int t) {
+      std::memcpy(out->cigar_blob + base[(size_t) t], part[(size_t) t].data(), part[(size_t) t].size());
+      for (uint64_t k = lo[(size_t) t]; k < lo[(size_t) t + 1]; ++k) out->cigar_off[k] += base[(size_t) t];
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nth; ++t) pool.emplace_back(place, t);
+    place(0);
+    for (auto & th : pool) th.join();
+  }
   return VSX_OK;
 }
 
