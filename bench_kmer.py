@@ -7,7 +7,7 @@ of its own:
   python bench_kmer.py [--db 1000000 --dlen 1000 --queries 100000 --qlen 250 --host-queries 1000]
 
 value      = candidate lists per second of the counting kernel (index resident, query words resident)
-roofline   = HBM: bytes of postings streamed (4 B per counter increment) / kernel time vs 8 TB/s
+roofline   = HBM: bytes of postings streamed (2 B per counter increment) / kernel time vs 8 TB/s
 cpu_baseline = the host path (vsx_search.cpp candidates_for, all usable cores) on the first --host-queries queries, whose
              lists are also compared with the device's (parity at full database size).
 """
@@ -125,7 +125,7 @@ def main():
                        "pairs_aligned": int(hits.pairs_aligned), "cells_aligned": int(hits.cells_aligned), "stages": int(hits.stages),
                        "hits": int(hits.n_hits), "seconds_kmer": round(hits.seconds_kmer, 3), "seconds_align": round(hits.seconds_align, 3)}
                 lib.vsx_hits_free(C.byref(hits))
-            bytes_streamed = best["postings_streamed"] * 4
+            bytes_streamed = best["postings_streamed"] * 2          # 16-bit tile-local indices
             gbps = bytes_streamed / (best["kernel_ms"] * 1e-3) / 1e9
             out = {
                 "metric": "k-mer candidate lists per second (search_topscores: count + threshold, device kernel)",
@@ -136,7 +136,7 @@ def main():
                 "kernel_ms": round(best["kernel_ms"], 3),
                 "call_s_incl_host": round(best["seconds"], 3),
                 "index": {"build_ms": round(first["index_build_ms"], 1), "postings": int(first["index_postings"]),
-                          "bytes": int(first["index_postings"]) * 4},
+                          "bytes": int(first["index_postings"]) * 2},
                 "increments_per_s": round(best["postings_streamed"] / (best["kernel_ms"] * 1e-3), 1),
                 "roofline": {"kernel": "vsx_kmer_count_kernel", "bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0,
                              "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": None,

@@ -5,7 +5,9 @@
 // top-N heap) and the index it walks (core/dbindex.cpp:125-255, core/unique.cpp:155-352) by HBM/LDS-bound integer
 // kernels.  No MFMA: this is a sparse count, not a contraction.
 //
-//   index   = postings grouped by (word, TILE of 2^15 consecutive sequence numbers): a CSR over 4^w x ntiles buckets.
+//   index   = postings grouped by (word, TILE of 2^15 consecutive sequence numbers): a CSR over 4^w x ntiles buckets of
+//             16-BIT tile-local sequence indices, two per dword (an odd bucket ends in the 0xFFFF sentinel) -- half the
+//             bytes of sequence numbers, and the count kernel is bound by exactly this stream.
 //             Built on the device from the 4-bit codes in two sweeps (count, fill); the order inside a bucket is
 //             arbitrary (counting commutes), so no sort is needed.
 //   count   = one 1024-thread block per (query, tile): 2^15 16-bit counters live in 64 KB of LDS; the query's unique words
@@ -57,7 +59,7 @@ template <bool FILL>
 __global__ void __launch_bounds__(256)
 vsx_kmer_sweep_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict__ off, const u32 * __restrict__ len, u32 nseq,
                       int w, u32 ntiles, u32 * __restrict__ bucket_count, const u64 * __restrict__ bucket_start,
-                      u32 * __restrict__ postings)
+                      uint16_t * __restrict__ postings)
 {
   extern __shared__ u32 bm_all[];                       // 4 waves x (4^w / 32) words
   const int lane = (int) (threadIdx.x & 63), wave = (int) (threadIdx.x >> 6);
@@ -81,7 +83,7 @@ vsx_kmer_sweep_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict
             {
               const size_t b = (size_t) word * ntiles + tile;
               const u32 slot = atomicAdd(&bucket_count[b], 1u);
-              if (FILL) postings[bucket_start[b] + slot] = seq;
+              if (FILL) postings[2 * bucket_start[b] + slot] = (uint16_t) (seq & (KM_TILE - 1));   // bucket_start counts dwords
             }
         }
     }
@@ -173,7 +175,7 @@ vsx_kmer_count_kernel(const u32 * __restrict__ postings, const u64 * __restrict_
                 if (i < wend)
                   {
                     while (i >= hi) { ++e; lo = hi; hi = pre[e + 1]; r0 = rs[e]; }
-                    s[u] = postings[r0 + (i - lo)];
+                    s[u] = postings[r0 + (i - lo)];               // two tile-local indices
                   }
               }
           };
@@ -187,7 +189,11 @@ vsx_kmer_count_kernel(const u32 * __restrict__ postings, const u64 * __restrict_
               if (more) fetch(i0, nxt);
 #pragma unroll
               for (int u = 0; u < KM_UNROLL; ++u)
-                if (cur[u] != 0xffffffffu) { const u32 x = cur[u] - base; atomicAdd(&cnt[x >> 1], 1u << ((x & 1u) * 16)); }
+                {
+                  const u32 x0 = cur[u] & 0xffffu, x1 = cur[u] >> 16;
+                  if (x0 != 0xffffu) atomicAdd(&cnt[x0 >> 1], 1u << ((x0 & 1u) * 16));
+                  if (x1 != 0xffffu) atomicAdd(&cnt[x1 >> 1], 1u << ((x1 & 1u) * 16));
+                }
               if (!more) break;
 #pragma unroll
               for (int u = 0; u < KM_UNROLL; ++u) cur[u] = nxt[u];
@@ -271,17 +277,17 @@ vsx_kmer_select_kernel(const uint2 * __restrict__ rec, u32 cap, const u32 * __re
 
 extern "C" hipError_t vsx_kmer_launch_sweep(int fill, const uint8_t * codes, const uint64_t * off, const uint32_t * len,
                                             uint32_t nseq, int w, uint32_t ntiles, uint32_t * bucket_count,
-                                            const uint64_t * bucket_start, uint32_t * postings, hipStream_t st)
+                                            const uint64_t * bucket_start, uint32_t * postings, hipStream_t st)   // postings: dwords of two 16-bit indices
 {
   if (nseq == 0) return hipSuccess;
   const size_t lds = (size_t) 4 * (((1u << (2 * w)) >> 5) ? ((1u << (2 * w)) >> 5) : 1) * 4;
   const dim3 grid((nseq + 3) / 4), block(256);
   if (fill)
     hipLaunchKernelGGL(vsx_kmer_sweep_kernel<true>, grid, block, lds, st, codes, (const u64 *) off, len, nseq, w, ntiles,
-                       bucket_count, (const u64 *) bucket_start, postings);
+                       bucket_count, (const u64 *) bucket_start, (uint16_t *) postings);
   else
     hipLaunchKernelGGL(vsx_kmer_sweep_kernel<false>, grid, block, lds, st, codes, (const u64 *) off, len, nseq, w, ntiles,
-                       bucket_count, (const u64 *) bucket_start, postings);
+                       bucket_count, (const u64 *) bucket_start, (uint16_t *) postings);
   return hipGetLastError();
 }
 

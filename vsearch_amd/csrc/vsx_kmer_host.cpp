@@ -98,11 +98,19 @@ int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIn
   KCHK(hipStreamSynchronize(ix->st));
   std::vector<uint64_t> start(ix->nbuckets + 1);
   uint64_t acc = 0;
-  for (uint64_t b = 0; b < ix->nbuckets; ++b) { start[b] = acc; acc += cnt[b]; }
+  // a bucket holds 16-bit tile-local indices, two per dword: start[] counts DWORDS, odd buckets end in a 0xFFFF sentinel
+  uint64_t entries = 0;
+  ix->word_total.assign(1ull << (2 * w), 0);
+  for (uint64_t b = 0; b < ix->nbuckets; ++b)
+    {
+      start[b] = acc;
+      acc += (cnt[b] + 1u) / 2u;
+      entries += cnt[b];
+      ix->word_total[b / ix->ntiles] += cnt[b];
+    }
   start[ix->nbuckets] = acc;
-  ix->word_total.resize(1ull << (2 * w));
-  for (uint64_t k = 0; k < ix->word_total.size(); ++k) ix->word_total[k] = start[(k + 1) * ix->ntiles] - start[k * ix->ntiles];
   KCHK(ix->d_post.alloc(acc));
+  KCHK(hipMemsetAsync(ix->d_post.p, 0xff, acc * 4, ix->st));
   KCHK(hipMemcpyAsync(ix->d_start.p, start.data(), (ix->nbuckets + 1) * 8, hipMemcpyHostToDevice, ix->st));
   KCHK(hipMemsetAsync(d_count.p, 0, ix->nbuckets * 4, ix->st));
   KCHK(vsx_kmer_launch_sweep(1, codes, off, len, ix->nseq, w, ix->ntiles, d_count.p, ix->d_start.p, ix->d_post.p, ix->st));
@@ -111,7 +119,7 @@ int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIn
   float ms = 0;
   KCHK(hipEventElapsedTime(&ms, ix->e0, ix->e1));
   ix->stats.build_ms = ms;
-  ix->stats.postings = acc;
+  ix->stats.postings = entries;
   ix->stats.index_bytes = acc * 4 + (ix->nbuckets + 1) * 8;
   KCHK(ix->d_cursor.alloc(1));
   *out = ix.release();
