@@ -74,7 +74,26 @@ typedef struct vsx_results {
   uint64_t * cigar_off;
   char     * cigar_blob;
   uint64_t   cigar_bytes;
+  uint8_t  * verdict;      /* NULL unless the plan has a filter: VSX_VERDICT_* per pair */
 } vsx_results;
+
+/* Device-side accept filter: align_trim (core/searchcore.cpp:343-464) + search_acceptable_aligned (:664-737) evaluated by
+   the traceback kernel on the finished alignment, with the reference's double expressions.  A REJECTED pair keeps its
+   statistics but gets no CIGAR (its runs never leave the device): all-vs-all and large candidate batches return only
+   what the caller will keep.  Pairs the 16-bit aligner refuses (sentinel) stay UNDECIDED for the caller's fallback. */
+#define VSX_VERDICT_UNDECIDED 0
+#define VSX_VERDICT_ACCEPTED  1
+#define VSX_VERDICT_WEAK      2   /* rejected, but id >= weak_id and all other tests passed: reported as a weak hit */
+#define VSX_VERDICT_REJECTED  3
+typedef struct vsx_filter {
+  int32_t iddef;            /* 0..4, --iddef */
+  int32_t leftjust, rightjust;
+  int32_t pad;
+  double  id, weak_id, maxid, mid, query_cov, target_cov;
+  int64_t maxsubs, maxgaps, mincols, maxdiffs;
+} vsx_filter;
+/* before vsx_plan_run; NULL removes the filter.  Needs the default (checkpoint) traceback. */
+int vsx_plan_set_filter(vsx_plan * plan, const vsx_filter * f);
 
 /* Timing of the last vsx_plan_run, measured with hipEvents on the plan's stream. */
 typedef struct vsx_timing {
@@ -136,6 +155,9 @@ int vsx_plan_export_hits(vsx_plan * plan, void * d_dst, uint64_t dst_bytes);
 void vsx_plan_destroy(vsx_plan * plan);
 
 /* Convenience: create + run + fetch + destroy. */
+int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets,
+                             uint64_t n_pairs, const uint32_t * qidx, const uint32_t * tidx,
+                             const vsx_filter * filter, vsx_results * out);
 int vsx_align_pairs(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets,
                     uint64_t n_pairs, const uint32_t * qidx, const uint32_t * tidx,
                     vsx_results * out);

@@ -136,3 +136,86 @@ def test_size_guard_and_sentinels(gpu_required):
         assert al.align("", "") == (0, 0, 0, 0, 0, "")
         assert al.align("", "ACGT") == (-5, 4, 0, 0, 4, "4I")
         assert al.align("", "A") == (-2, 1, 0, 0, 1, "1I")
+
+
+# ---- device-side accept filter (vsx_filter) vs a Python restatement of align_trim + search_acceptable_aligned ----
+def _verdict_py(q, t, row, f):
+    """core/searchcore.cpp:343-464 (align_trim) + :664-737 (search_acceptable_aligned), evaluated on one result row"""
+    import re
+    score, al, ma, mi, ga, cigar = row
+    runs = [(int(n) if n else 1, op) for n, op in re.findall(r"(\d*)([MID])", cigar)]
+    tql = ttl = tqr = ttr = 0
+    if runs and runs[0][1] != "M":
+        if runs[0][1] == "D": tql = runs[0][0]
+        else: ttl = runs[0][0]
+    if runs and runs[-1][1] != "M":
+        if runs[-1][1] == "D": tqr = runs[-1][0]
+        else: ttr = runs[-1][0]
+    if tql >= al: tqr = 0
+    if ttl >= al: ttr = 0
+    indels = al - ma - mi
+    ial = al - tql - ttl - tqr - ttr
+    iindels = indels - tql - ttl - tqr - ttr
+    igaps = ga - (1 if tql + ttl > 0 else 0) - (1 if tqr + ttr > 0 else 0)
+    Q, D = len(q), len(t)
+    shortest, longest = min(Q, D), max(Q, D)
+    iddef = f["iddef"]
+    if iddef == 0: idv = 100.0 * ma / shortest if shortest > 0 else 0.0
+    elif iddef == 2: idv = 100.0 * ma / ial if ial > 0 else 0.0
+    elif iddef == 3: idv = max(0.0, 100.0 * (1.0 - (1.0 * (mi + ga) / longest)))
+    else: idv = 100.0 * ma / al if al > 0 else 0.0
+    ok = (idv >= 100.0 * f["weak_id"] and mi <= f["maxsubs"] and igaps <= f["maxgaps"] and ial >= f["mincols"]
+          and (not f["leftjust"] or tql + ttl == 0) and (not f["rightjust"] or tqr + ttr == 0)
+          and ma + mi >= f["query_cov"] * Q and ma + mi >= f["target_cov"] * float(D) and idv <= 100.0 * f["maxid"]
+          and (ma + mi > 0 and 100.0 * ma / (ma + mi) >= f["mid"]) and mi + iindels <= f["maxdiffs"])
+    if not ok:
+        return 3
+    return 1 if idv >= 100.0 * f["id"] else 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flt", [
+    dict(iddef=2, id=0.9, weak_id=0.8),
+    dict(iddef=0, id=0.85, weak_id=0.85, maxgaps=2, maxsubs=20),
+    dict(iddef=1, id=0.8, weak_id=0.5, mincols=100, maxdiffs=30, query_cov=0.7),
+    dict(iddef=3, id=0.7, weak_id=0.6, leftjust=1, target_cov=0.3),
+    dict(iddef=4, id=0.95, weak_id=0.9, rightjust=1, maxid=0.99, mid=90.0),
+])
+def test_device_filter_matches_restatement(gpu_required, flt):
+    from vsearch_amd import Aligner
+    rng = random.Random(99)
+    qs, ts = [], []
+    for _ in range(600):
+        L = rng.randint(60, 400)
+        a = common.rnd_seq(rng, L)
+        b = common.mutate(rng, a, rng.choice([0.0, 0.02, 0.05, 0.1, 0.2, 0.35]))
+        r = rng.random()
+        if r < 0.3:
+            b = common.rnd_seq(rng, rng.randint(0, 40)) + b + common.rnd_seq(rng, rng.randint(0, 40))     # terminal gaps
+        elif r < 0.5:
+            a = common.rnd_seq(rng, rng.randint(0, 30)) + a
+        qs.append(a)
+        ts.append(b)
+    full = dict(iddef=2, id=0.0, weak_id=0.0, maxid=1.0, mid=0.0, query_cov=0.0, target_cov=0.0, maxsubs=2 ** 31 - 1,
+                maxgaps=2 ** 31 - 1, mincols=0, maxdiffs=2 ** 31 - 1, leftjust=0, rightjust=0)
+    full.update(flt)
+    idx = np.arange(len(qs), dtype=np.uint32)
+    with Aligner() as al:
+        Q, T = al.sequences(qs), al.sequences(ts)
+        plain = al.align_pairs(Q, T, idx, idx)
+        p = al.plan(Q, T, idx, idx)
+        p.set_filter(**full)
+        p.run()
+        got = p.fetch()
+        p.close()
+    assert got.verdict is not None and plain.verdict is None
+    seen = set()
+    for k in range(len(qs)):
+        exp = _verdict_py(qs[k], ts[k], plain.row(k), full)
+        assert int(got.verdict[k]) == exp, (k, exp, int(got.verdict[k]), plain.row(k))
+        seen.add(exp)
+        if exp == 3:
+            assert got.cigar[k] == "" and got.row(k)[:5] == plain.row(k)[:5]
+        else:
+            assert got.row(k) == plain.row(k)
+    assert len(seen) >= 2, seen

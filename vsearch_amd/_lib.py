@@ -18,7 +18,7 @@ SYMBOLS = [
     "vsx_version_string", "vsx_device_count", "vsx_last_error", "vsx_create", "vsx_destroy",
     "vsx_seqset_create", "vsx_seqset_create_from_device", "vsx_seqset_destroy", "vsx_seqset_count",
     "vsx_plan_create", "vsx_plan_run", "vsx_plan_sync", "vsx_plan_fetch", "vsx_plan_export_hits", "vsx_plan_destroy",
-    "vsx_align_pairs", "vsx_results_free",
+    "vsx_align_pairs", "vsx_align_pairs_filtered", "vsx_plan_set_filter", "vsx_results_free",
 ]
 # include/vsx_search.h
 SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
@@ -77,7 +77,15 @@ class Results(C.Structure):
     _fields_ = [("n_pairs", C.c_uint64), ("score", C.POINTER(C.c_int16)), ("aligned", C.POINTER(C.c_uint16)),
                 ("matches", C.POINTER(C.c_uint16)), ("mismatches", C.POINTER(C.c_uint16)),
                 ("gaps", C.POINTER(C.c_uint16)), ("cigar_off", C.POINTER(C.c_uint64)),
-                ("cigar_blob", C.POINTER(C.c_char)), ("cigar_bytes", C.c_uint64)]
+                ("cigar_blob", C.POINTER(C.c_char)), ("cigar_bytes", C.c_uint64), ("verdict", C.POINTER(C.c_uint8))]
+
+
+class Filter(C.Structure):
+    """vsx_filter (include/vsx.h): device-side align_trim + search_acceptable_aligned"""
+    _fields_ = [("iddef", C.c_int32), ("leftjust", C.c_int32), ("rightjust", C.c_int32), ("pad", C.c_int32),
+                ("id", C.c_double), ("weak_id", C.c_double), ("maxid", C.c_double), ("mid", C.c_double),
+                ("query_cov", C.c_double), ("target_cov", C.c_double),
+                ("maxsubs", C.c_int64), ("maxgaps", C.c_int64), ("mincols", C.c_int64), ("maxdiffs", C.c_int64)]
 
 
 class Timing(C.Structure):
@@ -129,6 +137,8 @@ def load():
     lib.vsx_plan_destroy.argtypes = [vp]
     lib.vsx_plan_destroy.restype = None
     lib.vsx_align_pairs.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.POINTER(Results)]
+    lib.vsx_align_pairs_filtered.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.POINTER(Filter), C.POINTER(Results)]
+    lib.vsx_plan_set_filter.argtypes = [vp, C.POINTER(Filter)]
     lib.vsx_results_free.argtypes = [C.POINTER(Results)]
     lib.vsx_results_free.restype = None
     lib.vsx_search_opts_default.argtypes = [C.POINTER(SearchOpts)]

@@ -57,6 +57,9 @@ class AlignmentResults:
         off = cp(res.cigar_off, np.uint64)
         blob = C.string_at(res.cigar_blob, int(res.cigar_bytes)) if res.cigar_bytes else b""
         self.cigar = [blob[int(o):blob.index(b"\0", int(o))].decode() for o in off]
+        # VSX_VERDICT_* per pair when the plan carried a filter (0 undecided, 1 accepted, 2 weak, 3 rejected)
+        self.verdict = (np.ctypeslib.as_array(res.verdict, shape=(n,)).astype(np.uint8, copy=True)
+                        if (n and bool(res.verdict)) else None)
 
     def __len__(self):
         return len(self.score)
@@ -128,6 +131,18 @@ class Plan:
         check(_lib.load().vsx_plan_create(aligner.h, C.byref(self.h), queries.h, targets.h, self.qidx.size,
                                           _ptr(self.qidx), _ptr(self.tidx), int(dir_budget_bytes)),
               "vsx_plan_create")
+
+    def set_filter(self, **kw):
+        """device-side accept filter (vsx_filter): iddef, id, weak_id, maxid, mid, query_cov, target_cov, maxsubs, maxgaps,
+        mincols, maxdiffs, leftjust, rightjust; call before run().  No arguments = defaults that accept everything."""
+        f = _lib.Filter()
+        f.iddef, f.id, f.weak_id, f.maxid = 2, 0.0, 0.0, 1.0
+        f.maxsubs = f.maxgaps = f.maxdiffs = 2 ** 31 - 1
+        for k, v in kw.items():
+            if not hasattr(f, k):
+                raise TypeError(f"unknown filter field {k}")
+            setattr(f, k, v)
+        check(_lib.load().vsx_plan_set_filter(self.h, C.byref(f)), "vsx_plan_set_filter")
 
     def run(self):
         check(_lib.load().vsx_plan_run(self.h), "vsx_plan_run")

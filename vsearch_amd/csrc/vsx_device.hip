@@ -579,9 +579,41 @@ typedef u32 u32_unaligned __attribute__((aligned(1)));
 typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
 struct __attribute__((aligned(4))) Quad { u32 x, y, z, w; };
 
+// align_trim (core/searchcore.cpp:343-464) + search_acceptable_aligned (:664-737) on the finished alignment, with the
+// reference's double expressions (no contraction: every product feeds a comparison or a quotient, never a sum).
+// first_text / last_text: the first and last run of the CIGAR in TEXT order, (length << 2) | op, op 0 = M, 1 = I, 2 = D.
+#pragma clang fp contract(off)
+DEV u32 accept_verdict(const VsxFilterDev & F, int Q, int D, int al, int ma, int mi, int ga, u32 first_text, u32 last_text)
+{
+  int tql = 0, ttl = 0, tqr = 0, ttr = 0;
+  if ((first_text & 3u) != 0u) { if ((first_text & 3u) == 2u) tql = (int) (first_text >> 2); else ttl = (int) (first_text >> 2); }
+  if ((last_text & 3u) != 0u) { if ((last_text & 3u) == 2u) tqr = (int) (last_text >> 2); else ttr = (int) (last_text >> 2); }
+  if (tql >= al) tqr = 0;
+  if (ttl >= al) ttr = 0;
+  const int indels = al - ma - mi;
+  const int ial = al - tql - ttl - tqr - ttr;
+  const int iindels = indels - tql - ttl - tqr - ttr;
+  const int igaps = ga - ((tql + ttl) > 0 ? 1 : 0) - ((tqr + ttr) > 0 ? 1 : 0);
+  const int shortest = Q < D ? Q : D, longest = Q < D ? D : Q;
+  double id;
+  switch (F.iddef)
+    {
+    case 0: id = shortest > 0 ? 100.0 * ma / shortest : 0.0; break;
+    case 2: id = ial > 0 ? 100.0 * ma / ial : 0.0; break;
+    case 3: { const double x = 100.0 * (1.0 - (1.0 * (mi + ga) / longest)); id = x > 0.0 ? x : 0.0; } break;
+    default: id = al > 0 ? 100.0 * ma / al : 0.0; break;          // 1 and 4
+    }
+  const bool pass = (id >= 100.0 * F.weak_id) && (mi <= F.maxsubs) && (igaps <= F.maxgaps) && (ial >= F.mincols) &&
+                    ((F.leftjust == 0) || (tql + ttl == 0)) && ((F.rightjust == 0) || (tqr + ttr == 0)) &&
+                    (ma + mi >= F.query_cov * Q) && (ma + mi >= F.target_cov * (double) D) && (id <= 100.0 * F.maxid) &&
+                    (100.0 * ma / (ma + mi) >= F.mid) && (mi + iindels <= F.maxdiffs);
+  if (!pass) return 3u;
+  return (id >= 100.0 * F.id) ? 1u : 2u;
+}
+
 template <int R, bool FAST>
 __global__ void __launch_bounds__(64)
-vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
+vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTask * __restrict__ tasks,
                         const u32 * __restrict__ pair_slot, const u32 * __restrict__ pair_ids, u32 npairs,
                         const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
                         const u32 * __restrict__ ck, const VsxSlotOut * __restrict__ slot,
@@ -970,12 +1002,17 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks
       }
   }
 
+  u32 verdict = 0;
+  if (FL.enabled && nruns > 0) verdict = accept_verdict(FL, Q, D, (int) al, (int) ma, (int) mi, (int) ga, my[nruns - 1], my[0]);
+  if (verdict == 3u) nruns = 0;                          // rejected: the runs never leave the device
+
   const unsigned long long base = atomicAdd(cursor, (unsigned long long) nruns);
   if (base + nruns <= runs_capacity)
     for (u32 x = 0; x < nruns; ++x) runs[base + x] = my[x];
 
   o.score = so.score;
   o.aligned = (uint16_t) al; o.matches = (uint16_t) ma; o.mismatches = (uint16_t) mi; o.gaps = (uint16_t) ga;
+  o.pad = (uint16_t) verdict;
   o.nruns = nruns;
   o.run_off = base;
   out[pair_ids[k]] = o;
@@ -1136,17 +1173,17 @@ extern "C" hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tas
 }
 
 template <int R, bool FAST>
-static hipError_t launch_tbck(const VsxDevParams & P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
+static hipError_t launch_tbck(const VsxDevParams & P, const VsxFilterDev & F, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
                               const uint32_t * d_pair_ids, uint32_t npairs, const uint8_t * q, const uint8_t * t,
                               const uint32_t * ck, const VsxSlotOut * slot, uint32_t * slab, const uint64_t * slab_off,
                               uint32_t * runs, uint64_t cap, unsigned long long * cursor, VsxPairOut * out, hipStream_t st)
 {
   hipLaunchKernelGGL((vsx_traceback_ck_kernel<R, FAST>), dim3((npairs + 63) / 64), dim3(64), 0, st,
-                     P, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, cap, cursor, out);
+                     P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, cap, cursor, out);
   return hipGetLastError();
 }
 
-extern "C" hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
+extern "C" hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams P, VsxFilterDev F, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
                                               const uint32_t * d_pair_ids, uint32_t npairs,
                                               const uint8_t * q, const uint8_t * t,
                                               const uint32_t * ck, const VsxSlotOut * slot,
@@ -1155,8 +1192,8 @@ extern "C" hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams
                                               VsxPairOut * out, hipStream_t st)
 {
   if (npairs == 0) return hipSuccess;
-#define TBCK(RR) case RR: return fast16 ? launch_tbck<RR, true>(P, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
-                                        : launch_tbck<RR, false>(P, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st)
+#define TBCK(RR) case RR: return fast16 ? launch_tbck<RR, true>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
+                                        : launch_tbck<RR, false>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st)
   switch (rows)
     {
     TBCK(1); TBCK(4); TBCK(8); TBCK(12); TBCK(16); TBCK(20); TBCK(24); TBCK(28); TBCK(32);

@@ -202,6 +202,7 @@ struct vsx_plan {
   const vsx_seqset * Q = nullptr;
   const vsx_seqset * T = nullptr;
   uint64_t n_pairs = 0;
+  VsxFilterDev filter {};                // accept filter evaluated by the traceback kernel (enabled == 0: none)
   std::vector<VsxPairOut> host_out;      // closed-form / sentinel pairs pre-filled; GPU pairs overwritten on fetch
   std::vector<uint8_t> is_gpu;
   std::vector<std::string> host_cigar;   // only for the Q == 0 closed form
@@ -708,6 +709,21 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   return VSX_OK;
 }
 
+int vsx_plan_set_filter(vsx_plan * pl, const vsx_filter * f)
+{
+  if (!pl) return fail(VSX_EINVAL, "vsx_plan_set_filter: null plan");
+  pl->filter = VsxFilterDev {};
+  if (!f) return VSX_OK;
+  if (!pl->ctx->ckpt) return fail(VSX_EINVAL, "vsx_plan_set_filter: needs the checkpoint traceback (VSX_TRACEBACK=dirs is set)");
+  if (f->iddef < 0 || f->iddef > 4) return fail(VSX_EINVAL, "vsx_plan_set_filter: iddef must be 0..4");
+  VsxFilterDev & d = pl->filter;
+  d.enabled = 1; d.iddef = f->iddef; d.leftjust = f->leftjust; d.rightjust = f->rightjust;
+  d.id = f->id; d.weak_id = f->weak_id; d.maxid = f->maxid; d.mid = f->mid; d.query_cov = f->query_cov; d.target_cov = f->target_cov;
+  d.maxsubs = f->maxsubs; d.maxgaps = f->maxgaps; d.mincols = f->mincols; d.maxdiffs = f->maxdiffs;
+  pl->ran = false;
+  return VSX_OK;
+}
+
 int vsx_plan_run(vsx_plan * pl)
 {
   if (!pl) return fail(VSX_EINVAL, "vsx_plan_run: null plan");
@@ -734,7 +750,7 @@ int vsx_plan_run(vsx_plan * pl)
       if (ctx->ckpt)
         {
           for (const Launch & L : c.launches)      // the recompute traceback is specialised on R like the DP kernel
-            HIPCHK(vsx_launch_traceback_ck(L.rows, (L.track == 0 && L.generic != 0) ? 1 : 0, ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
+            HIPCHK(vsx_launch_traceback_ck(L.rows, (L.track == 0 && L.generic != 0) ? 1 : 0, ctx->P, pl->filter, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
                                            pl->d_pair_ids.p + L.pair_first, L.pair_count, pl->Q->codes(), pl->T->codes(),
                                            dir, pl->d_slot.p, pl->d_slab.p, pl->d_slab_off.p + L.pair_first,
                                            pl->d_runs.p, pl->runs_capacity, pl->d_cursor.p, pl->d_out.p, st2));
@@ -828,7 +844,8 @@ int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
   out->mismatches = (uint16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
   out->gaps = (uint16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
   out->cigar_off = (uint64_t *) std::malloc(std::max<uint64_t>(n, 1) * 8);
-  if (!out->score || !out->aligned || !out->matches || !out->mismatches || !out->gaps || !out->cigar_off)
+  out->verdict = pl->filter.enabled ? (uint8_t *) std::malloc(std::max<uint64_t>(n, 1)) : nullptr;
+  if (!out->score || !out->aligned || !out->matches || !out->mismatches || !out->gaps || !out->cigar_off || (pl->filter.enabled && !out->verdict))
     { vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: host allocation failed"); }
 
   // statistics + CIGAR text: contiguous slices of the pair list are formatted by host threads, then concatenated
@@ -850,6 +867,7 @@ int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
         out->matches[k] = o.matches;
         out->mismatches[k] = o.mismatches;
         out->gaps[k] = o.gaps;
+        if (out->verdict) out->verdict[k] = pl->is_gpu[k] ? (uint8_t) o.pad : (uint8_t) VSX_VERDICT_UNDECIDED;
         out->cigar_off[k] = b.size();                              // slice-relative, rebased below
         if (pl->is_gpu[k]) { if (o.nruns) append_cigar(b, runs.data() + o.run_off, o.nruns); }
         else if (hc < pl->host_cigar_pair.size() && pl->host_cigar_pair[hc] == k) b += pl->host_cigar[hc++];
@@ -914,12 +932,19 @@ void vsx_plan_destroy(vsx_plan * pl)
 int vsx_align_pairs(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
                     const uint32_t * qidx, const uint32_t * tidx, vsx_results * out)
 {
+  return vsx_align_pairs_filtered(ctx, queries, targets, n_pairs, qidx, tidx, nullptr, out);
+}
+
+int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
+                             const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, vsx_results * out)
+{
   static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   vsx_plan * pl = nullptr;
   int rc = vsx_plan_create(ctx, &pl, queries, targets, n_pairs, qidx, tidx, 0);
   if (rc != VSX_OK) return rc;
+  if (filter && ctx->ckpt) { rc = vsx_plan_set_filter(pl, filter); if (rc != VSX_OK) { vsx_plan_destroy(pl); return rc; } }
   const double t1 = now();
   rc = vsx_plan_run(pl);
   double t2 = t1, t3 = t1;
@@ -936,7 +961,7 @@ void vsx_results_free(vsx_results * r)
 {
   if (!r) return;
   std::free(r->score); std::free(r->aligned); std::free(r->matches); std::free(r->mismatches);
-  std::free(r->gaps); std::free(r->cigar_off); std::free(r->cigar_blob);
+  std::free(r->gaps); std::free(r->cigar_off); std::free(r->cigar_blob); std::free(r->verdict);
   std::memset(r, 0, sizeof *r);
 }
 

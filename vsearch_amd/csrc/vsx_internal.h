@@ -46,6 +46,13 @@ struct VsxTask {
   uint32_t pad;
 };
 
+// Accept filter evaluated in the traceback epilogue (include/vsx.h vsx_filter); enabled == 0: every pair is kept.
+struct VsxFilterDev {
+  int32_t enabled, iddef, leftjust, rightjust;
+  double  id, weak_id, maxid, mid, query_cov, target_cov;
+  int64_t maxsubs, maxgaps, mincols, maxdiffs;
+};
+
 // Per (task, slot) output of the DP kernel.
 struct VsxSlotOut {
   int16_t  score;
@@ -56,7 +63,7 @@ struct VsxSlotOut {
 struct VsxPairOut {
   int16_t  score;
   uint16_t aligned, matches, mismatches, gaps;
-  uint16_t pad;
+  uint16_t pad;           // verdict of the accept filter (VSX_VERDICT_*), 0 without a filter
   uint32_t nruns;
   uint64_t run_off;       // offset into the dense run buffer (unordered allocation)
 };
@@ -82,7 +89,7 @@ hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tasks, const u
                                 uint32_t * d_runs, uint64_t runs_capacity, unsigned long long * d_cursor,
                                 VsxPairOut * d_out, hipStream_t st);
 // fast16: the tasks never saturate (planner's TRACK = 0 class) -> biased-u16 VOP2 arithmetic in the tile recompute
-hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
+hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams P, VsxFilterDev F, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
                                    const uint32_t * d_pair_ids, uint32_t npairs,
                                    const uint8_t * d_qcodes, const uint8_t * d_tcodes,
                                    const uint32_t * d_ck, const VsxSlotOut * d_slot,

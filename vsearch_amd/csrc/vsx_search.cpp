@@ -355,6 +355,19 @@ bool advance(const vsx_searcher & S, QState & st, const char * q, int64_t qlen, 
 
 }  // namespace
 
+// the searcher's acceptance options as the device filter (include/vsx.h): the traceback kernel then decides every pair
+// itself and only accepted / weak hits come back with a CIGAR
+static vsx_filter make_filter(const vsx_searcher & S)
+{
+  const vsx_search_opts & o = S.o;
+  vsx_filter f;
+  std::memset(&f, 0, sizeof f);
+  f.iddef = o.iddef; f.leftjust = o.leftjust; f.rightjust = o.rightjust;
+  f.id = o.id; f.weak_id = o.weak_id; f.maxid = o.maxid; f.mid = o.mid; f.query_cov = o.query_cov; f.target_cov = o.target_cov;
+  f.maxsubs = o.maxsubs; f.maxgaps = o.maxgaps; f.mincols = o.mincols; f.maxdiffs = o.maxdiffs;
+  return f;
+}
+
 // Fill a hit from one alignment result (searchcore.cpp:806-857 == allpairs_global.cpp:447-508): linear-memory
 // fallback on the sentinel, derived fields, align_trim.  Returns VSX_OK or an error code.
 static int fill_hit(const vsx_searcher & S, const char * q, int64_t ql, Hit & h, const vsx_results & res, uint64_t r,
@@ -454,7 +467,8 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
       ++acct.stages;
       const double t0 = now_s();
       vsx_results res;
-      int rc = vsx_align_pairs(S.ctx, qset, S.dbset, pq.size(), pq.data(), pt.data(), &res);
+      const vsx_filter flt = make_filter(S);
+      int rc = vsx_align_pairs_filtered(S.ctx, qset, S.dbset, pq.size(), pq.data(), pt.data(), &flt, &res);
       acct.t_align += now_s() - t0;
       if (rc != VSX_OK) return rc;
       acct.pairs += pq.size();
@@ -471,9 +485,20 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
               const uint64_t r = i++;
               acct.cells += (uint64_t) ql * S.len[h.target];
               if (!live) continue;                                   // ignored hit: stays unaligned (:785, :875-878)
+              const uint8_t verdict = res.verdict ? res.verdict[r] : (uint8_t) VSX_VERDICT_UNDECIDED;
+              if (verdict == VSX_VERDICT_REJECTED)
+                {
+                  // decided on the device (align_trim + search_acceptable_aligned): not reported, no CIGAR fetched
+                  h.aligned = true; h.rejected = true; h.weak = false;
+                  ++q.rejects;
+                  continue;
+                }
               const int frc = fill_hit(S, qseq(k), ql, h, res, r, acct.sentinels);
               if (frc != VSX_OK) { vsx_results_free(&res); return sfail(frc, "search: fallback aligner failed"); }
-              if (acceptable_aligned(S, ql, h)) ++q.accepts; else ++q.rejects;
+              const bool acc = acceptable_aligned(S, ql, h);
+              if (verdict != VSX_VERDICT_UNDECIDED && (acc != (verdict == VSX_VERDICT_ACCEPTED) || (!acc && !h.weak)))
+                { vsx_results_free(&res); return sfail(VSX_EHIP, "search: device and host accept filters disagree"); }
+              if (acc) ++q.accepts; else ++q.rejects;
             }
           q.finalized = (int64_t) q.hits.size();
           q.delayed = 0;
@@ -827,7 +852,8 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
   qfirst[count] = pq.size();
   vsx_results res;
   double t0 = now_s();
-  int rc = vsx_align_pairs(S->ctx, S->dbset, S->dbset, pq.size(), pq.data(), pt.data(), &res);
+  const vsx_filter flt = make_filter(*S);
+  int rc = vsx_align_pairs_filtered(S->ctx, S->dbset, S->dbset, pq.size(), pq.data(), pt.data(), acceptall ? nullptr : &flt, &res);
   const double t_align = now_s() - t0;
   if (rc != VSX_OK) return rc;
   std::vector<std::vector<Hit>> kept(count);
@@ -842,9 +868,14 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
           Hit h;
           h.target = pt[r];
           cells += (uint64_t) ql * S->len[h.target];
+          const uint8_t verdict = res.verdict ? res.verdict[r] : (uint8_t) VSX_VERDICT_UNDECIDED;
+          if (verdict == VSX_VERDICT_REJECTED || verdict == VSX_VERDICT_WEAK) continue;      // only accepted hits are kept (:509-527)
           rc = fill_hit(*S, q, ql, h, res, r, sentinels);
           if (rc != VSX_OK) { vsx_results_free(&res); return sfail(rc, "vsx_allpairs_block: fallback aligner failed"); }
-          if (acceptall || acceptable_aligned(*S, ql, h)) kept[k].push_back(std::move(h));
+          const bool acc = acceptall || acceptable_aligned(*S, ql, h);
+          if (verdict == VSX_VERDICT_ACCEPTED && !acc)
+            { vsx_results_free(&res); return sfail(VSX_EHIP, "vsx_allpairs_block: device and host accept filters disagree"); }
+          if (acc) kept[k].push_back(std::move(h));
         }
       std::sort(kept[k].begin(), kept[k].end(), [](const Hit & a, const Hit & b) {
         if (a.id != b.id) return a.id > b.id;
