@@ -559,51 +559,82 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       pl->cells += (uint64_t) Q * (uint64_t) D;
     }
 
-  // ---- group by query -> tasks of <= 8 targets, similar lengths together ----
-  std::stable_sort(gpu_pairs.begin(), gpu_pairs.end(), [&](uint32_t a, uint32_t b) { return qidx[a] < qidx[b]; });
+  // ---- group by query -> tasks of <= 8 targets, similar lengths together (host threads over query groups) ----
+  auto by_query = [&](uint32_t a, uint32_t b) { return qidx[a] < qidx[b]; };
+  if (!std::is_sorted(gpu_pairs.begin(), gpu_pairs.end(), by_query)) std::stable_sort(gpu_pairs.begin(), gpu_pairs.end(), by_query);
   struct ProtoTask { uint32_t q; int rows; int generic; int track; uint32_t n; uint32_t pair[8]; };
-  std::vector<ProtoTask> protos;
+  std::vector<size_t> group_begin;                       // start of every query's run in gpu_pairs, plus the end
   for (size_t b = 0; b < gpu_pairs.size();)
     {
-      size_t e = b;
+      group_begin.push_back(b);
       const uint32_t q = qidx[gpu_pairs[b]];
+      size_t e = b;
       while (e < gpu_pairs.size() && qidx[gpu_pairs[e]] == q) ++e;
-      std::stable_sort(gpu_pairs.begin() + b, gpu_pairs.begin() + e,
-                       [&](uint32_t x, uint32_t y) { return targets->len[tidx[x]] > targets->len[tidx[y]]; });
-      const int rows = pick_rows((int) queries->len[q]);
-      // substitution scores: LDS query profile by default (handles every symbol); VSX_SCORE=arith selects the XOR/min/mad
-      // variant for queries made of A/C/G/T(U) only (kept for A/B measurements)
-      static const bool arith = std::getenv("VSX_SCORE") && std::strcmp(std::getenv("VSX_SCORE"), "arith") == 0;
-      const int generic = (queries->impure[q] || !arith) ? 1 : 0;
-      for (size_t x = b; x < e; x += VSX_TASK_SLOTS)
-        {
-          ProtoTask pt {};
-          pt.q = q; pt.rows = rows; pt.generic = generic;
-          pt.n = (uint32_t) std::min<size_t>(VSX_TASK_SLOTS, e - x);
-          uint32_t dmax = 0;
-          for (uint32_t s = 0; s < pt.n; ++s)
-            {
-              pt.pair[s] = gpu_pairs[x + s];
-              dmax = std::max(dmax, targets->len[tidx[pt.pair[s]]]);
-            }
-          pt.track = (!ctx->tb_packed && no_overflow_possible(ctx, queries->len[q], dmax)) ? 0 : 1;
-          protos.push_back(pt);
-        }
       b = e;
     }
+  group_begin.push_back(gpu_pairs.size());
+  // substitution scores: LDS query profile by default (handles every symbol); VSX_SCORE=arith selects the XOR/min/mad
+  // variant for queries made of A/C/G/T(U) only (kept for A/B measurements)
+  static const bool arith = std::getenv("VSX_SCORE") && std::strcmp(std::getenv("VSX_SCORE"), "arith") == 0;
+  const size_t ngroups = group_begin.size() - 1;
+  const int nth = (int) std::max<size_t>(1, std::min<size_t>((size_t) vsx_internal_usable_cpus(), gpu_pairs.size() / 65536));
+  std::vector<std::vector<ProtoTask>> part((size_t) nth);
+  auto work = [&](int t) {
+    // contiguous ranges of groups with about the same number of pairs
+    const size_t p_lo = gpu_pairs.size() * (size_t) t / (size_t) nth, p_hi = gpu_pairs.size() * (size_t) (t + 1) / (size_t) nth;
+    const size_t g_lo = (size_t) (std::lower_bound(group_begin.begin(), group_begin.end() - 1, p_lo) - group_begin.begin());
+    const size_t g_hi = (t == nth - 1) ? ngroups : (size_t) (std::lower_bound(group_begin.begin(), group_begin.end() - 1, p_hi) - group_begin.begin());
+    std::vector<ProtoTask> & outp = part[(size_t) t];
+    for (size_t g = g_lo; g < g_hi; ++g)
+      {
+        const size_t b = group_begin[g], e = group_begin[g + 1];
+        const uint32_t q = qidx[gpu_pairs[b]];
+        std::stable_sort(gpu_pairs.begin() + (long) b, gpu_pairs.begin() + (long) e,
+                         [&](uint32_t x, uint32_t y) { return targets->len[tidx[x]] > targets->len[tidx[y]]; });
+        const int rows = pick_rows((int) queries->len[q]);
+        const int generic = (queries->impure[q] || !arith) ? 1 : 0;
+        for (size_t x = b; x < e; x += VSX_TASK_SLOTS)
+          {
+            ProtoTask pt {};
+            pt.q = q; pt.rows = rows; pt.generic = generic;
+            pt.n = (uint32_t) std::min<size_t>(VSX_TASK_SLOTS, e - x);
+            uint32_t dmax = 0;
+            for (uint32_t sidx = 0; sidx < pt.n; ++sidx)
+              {
+                pt.pair[sidx] = gpu_pairs[x + sidx];
+                dmax = std::max(dmax, targets->len[tidx[pt.pair[sidx]]]);
+              }
+            pt.track = (!ctx->tb_packed && no_overflow_possible(ctx, queries->len[q], dmax)) ? 0 : 1;
+            outp.push_back(pt);
+          }
+      }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto & th : pool) th.join();
+  }
+  std::vector<ProtoTask> protos;
+  {
+    size_t total = 0;
+    for (auto & v : part) total += v.size();
+    protos.reserve(total);
+    for (auto & v : part) protos.insert(protos.end(), v.begin(), v.end());
+  }
   // kernel classes together (one launch per class and chunk)
-  std::stable_sort(protos.begin(), protos.end(), [](const ProtoTask & a, const ProtoTask & b) {
+  auto by_class = [](const ProtoTask & a, const ProtoTask & b) {
     if (a.rows != b.rows) return a.rows < b.rows;
     if (a.generic != b.generic) return a.generic < b.generic;
     return a.track < b.track;
-  });
+  };
+  if (!std::is_sorted(protos.begin(), protos.end(), by_class)) std::stable_sort(protos.begin(), protos.end(), by_class);
 
   // ---- direction-buffer budget ----
   if (dir_budget_bytes == 0)
     {
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
-      // per buffer; two buffers are kept so the traceback of chunk k overlaps the DP of chunk k+1
       free_b += ctx->pool.idle_bytes();                     // blocks this context can hand straight back
       dir_budget_bytes = std::min<uint64_t>((uint64_t) (free_b * 0.4), 128ull << 30);
     }
@@ -682,8 +713,9 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   HIPCHK(pl->d_slot.alloc(pl->tasks.size() * VSX_TASK_SLOTS));
   HIPCHK(pl->d_out.alloc(n_pairs));
   HIPCHK(pl->d_cursor.alloc(1));
+  // one checkpoint buffer, reused chunk after chunk: overlapping chunk k's traceback with chunk k+1's DP bought nothing
+  // (both are issue-bound), while a second buffer doubled a multi-second hipMalloc
   HIPCHK(pl->d_dir[0].alloc(&ctx->pool, max_dir));
-  if (pl->chunks.size() > 1) HIPCHK(pl->d_dir[1].alloc(&ctx->pool, max_dir));
   HIPCHK(pl->d_strip.alloc(max_strip));
   HIPCHK(pl->d_slab.alloc(&ctx->pool, max_slab));
   HIPCHK(pl->d_runs.alloc(&ctx->pool, pl->runs_capacity));
@@ -732,13 +764,12 @@ int vsx_plan_run(vsx_plan * pl)
   hipStream_t st = ctx->stream, st2 = ctx->stream2;
   HIPCHK(hipMemsetAsync(pl->d_cursor.p, 0, sizeof(unsigned long long), st));
   HIPCHK(hipEventRecord(pl->ev_begin, st));
-  // DP kernels run back to back on `st`; each chunk's traceback runs on `st2` as soon as its DP is done and
-  // overlaps the next chunk's DP (VALU-bound vs HBM-latency-bound).  Chunk k owns direction buffer k & 1.
+  // per chunk: DP kernels on `st`, then its traceback on `st2`; the next chunk's DP waits for it (one checkpoint buffer)
   for (size_t k = 0; k < pl->chunks.size(); ++k)
     {
       Chunk & c = pl->chunks[k];
-      uint32_t * dir = pl->d_dir[k & 1].p;
-      if (k >= 2) HIPCHK(hipStreamWaitEvent(st, pl->chunks[k - 2].e2, 0));      // buffer reuse
+      uint32_t * dir = pl->d_dir[0].p;
+      if (k >= 1) HIPCHK(hipStreamWaitEvent(st, pl->chunks[k - 1].e2, 0));      // buffer reuse: the previous traceback is done
       HIPCHK(hipEventRecord(c.e0, st));
       for (const Launch & L : c.launches)
         HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, ctx->P, pl->d_tasks.p + L.first, L.count,
