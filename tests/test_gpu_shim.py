@@ -1,0 +1,136 @@
+"""-m gpu: the drop-in proof.  oracle/_ref/vsearch_vsx is the REFERENCE CLI (every translation unit of torognes/vsearch
+compiled in place by oracle/Makefile) with exactly one unit swapped: src/core/align_simd.cpp is replaced by
+shim/vsx_search16_shim.cpp, which defines the same four symbols (search16_init/exit/qprep/search16) on top of libvsx.so.
+Every command that reaches the aligner must write byte-identical output files to the unmodified CLI
+(oracle/_ref/vsearch_ref): same hits, %id, CIGARs, alignments, clusters, consensus sequences."""
+import os
+import random
+import subprocess
+
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "vsearch_ref")
+VSX_BIN = os.path.join(ROOT, "oracle", "_ref", "vsearch_vsx")
+FIELDS = "query+target+id+alnlen+mism+opens+exts+raw+caln+qlo+qhi+tlo+thi+id0+id1+id2+id3+id4+qrow+trow"
+
+
+def _fasta(path, seqs, prefix):
+    with open(path, "w") as f:
+        f.write("".join(f">{prefix}{i};size={1 + (i * 7) % 5}\n{s}\n" for i, s in enumerate(seqs)))
+
+
+def _run_both(tmp, args_of):
+    """args_of(outdir) -> (argv tail, [output file names]); runs both binaries, returns {name: (ref bytes, vsx bytes)}"""
+    res = {}
+    for tag, exe in (("ref", REF_BIN), ("vsx", VSX_BIN)):
+        out = os.path.join(tmp, tag)
+        os.makedirs(out, exist_ok=True)
+        argv, files = args_of(out)
+        p = subprocess.run([exe] + argv + ["--quiet"], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (tag, p.stderr[-2000:])
+        for name in files:
+            with open(os.path.join(out, name), "rb") as f:
+                data = f.read()
+            # --alnout / --uchimealns echo the command line: neutralise the binary name and the output directory
+            data = data.replace(exe.encode(), b"VSEARCH").replace(out.encode(), b"OUT")
+            res.setdefault(name, {})[tag] = data
+    return res
+
+
+def _check(res):
+    for name, d in res.items():
+        assert len(d["ref"]) > 0, name
+        if d["ref"] != d["vsx"]:
+            a, b = d["ref"].splitlines(), d["vsx"].splitlines()
+            for i, (x, y) in enumerate(zip(a, b)):
+                assert x == y, f"{name} line {i}:\n ref {x[:300]}\n vsx {y[:300]}"
+            assert len(a) == len(b), f"{name}: {len(a)} vs {len(b)} lines"
+
+
+@pytest.fixture
+def binaries(gpu_required):
+    for b in (REF_BIN, VSX_BIN):
+        if not os.path.exists(b):
+            pytest.fail(f"{b} missing: run `make -C oracle ref_full ref_shim` in the build container (it travels with the repo)")
+
+
+def _inputs(seed):
+    rng = random.Random(seed)
+    db, _ = common.family_db(rng, 12, 8, 380, div=0.07)
+    db += [common.rnd_seq(rng, rng.randint(150, 450)) for _ in range(15)]
+    db += [common.mutate(rng, db[5], 0.03, "ACGTN"), common.mutate(rng, db[9], 0.03, "ACGTRYKM")]
+    qs, _ = common.queries_from_db(rng, db, 60, 170)
+    qs += [common.mutate(rng, db[rng.randrange(len(db))], 0.06) for _ in range(15)]
+    qs += [common.rnd_seq(rng, 90), "ACGT" * 25]
+    return db, qs
+
+
+@pytest.mark.parametrize("extra", [
+    ["--id", "0.9"],
+    ["--id", "0.7", "--maxaccepts", "3", "--maxrejects", "16", "--strand", "both"],
+    ["--id", "0.8", "--maxaccepts", "0", "--maxrejects", "0", "--gapopen", "10I/3E", "--gapext", "1I/1E", "--mismatch", "-2"],
+], ids=["id90", "both_strands", "custom_scoring_all_hits"])
+def test_usearch_global_through_the_shim(binaries, tmp_path, extra):
+    db, qs = _inputs(41)
+    _fasta(tmp_path / "db.fa", db, "t")
+    _fasta(tmp_path / "q.fa", qs, "q")
+
+    def args(out):
+        return (["--usearch_global", str(tmp_path / "q.fa"), "--db", str(tmp_path / "db.fa"), "--qmask", "none", "--dbmask", "none",
+                 "--threads", "1", "--userout", os.path.join(out, "u.tsv"), "--userfields", FIELDS,
+                 "--alnout", os.path.join(out, "aln.txt"), "--uc", os.path.join(out, "hits.uc"),
+                 "--samout", os.path.join(out, "hits.sam")] + extra, ["u.tsv", "aln.txt", "hits.uc", "hits.sam"])
+    _check(_run_both(str(tmp_path), args))
+
+
+def test_cluster_fast_through_the_shim(binaries, tmp_path):
+    rng = random.Random(8)
+    seqs, _ = common.family_db(rng, 10, 9, 300, div=0.04)
+    seqs += [common.rnd_seq(rng, rng.randint(200, 350)) for _ in range(10)]
+    rng.shuffle(seqs)
+    _fasta(tmp_path / "in.fa", seqs, "s")
+
+    def args(out):
+        return (["--cluster_fast", str(tmp_path / "in.fa"), "--id", "0.9", "--qmask", "none", "--threads", "1", "--sizein", "--sizeout",
+                 "--uc", os.path.join(out, "c.uc"), "--centroids", os.path.join(out, "cent.fa"),
+                 "--msaout", os.path.join(out, "msa.fa"), "--consout", os.path.join(out, "cons.fa"),
+                 "--profile", os.path.join(out, "prof.txt")], ["c.uc", "cent.fa", "msa.fa", "cons.fa", "prof.txt"])
+    _check(_run_both(str(tmp_path), args))
+
+
+def test_allpairs_global_through_the_shim(binaries, tmp_path):
+    rng = random.Random(13)
+    seqs, _ = common.family_db(rng, 5, 7, 260, div=0.08)
+    _fasta(tmp_path / "in.fa", seqs, "s")
+
+    def args(out):
+        return (["--allpairs_global", str(tmp_path / "in.fa"), "--id", "0.75", "--qmask", "none", "--threads", "1",
+                 "--userout", os.path.join(out, "u.tsv"), "--userfields", FIELDS, "--alnout", os.path.join(out, "aln.txt")],
+                ["u.tsv", "aln.txt"])
+    _check(_run_both(str(tmp_path), args))
+
+
+def test_uchime_ref_through_the_shim(binaries, tmp_path):
+    """chimera detection aligns query segments against parents with search16 (chimera.cpp:1899-2078)"""
+    rng = random.Random(21)
+    parents = [common.rnd_seq(rng, 400) for _ in range(6)]
+    qs = []
+    for _ in range(12):
+        a, b = rng.sample(range(6), 2)
+        cut = rng.randint(120, 280)
+        qs.append(common.mutate(rng, parents[a][:cut] + parents[b][cut:], 0.01))
+    qs += [common.mutate(rng, parents[k], 0.02) for k in range(6)]
+    _fasta(tmp_path / "ref.fa", parents, "p")
+    _fasta(tmp_path / "q.fa", qs, "q")
+
+    def args(out):
+        return (["--uchime_ref", str(tmp_path / "q.fa"), "--db", str(tmp_path / "ref.fa"), "--qmask", "none", "--dbmask", "none",
+                 "--threads", "1", "--uchimeout", os.path.join(out, "uchime.tsv"), "--uchimealns", os.path.join(out, "alns.txt"),
+                 "--chimeras", os.path.join(out, "chim.fa"), "--nonchimeras", os.path.join(out, "non.fa")],
+                ["uchime.tsv", "alns.txt", "chim.fa", "non.fa"])
+    _check(_run_both(str(tmp_path), args))
