@@ -50,6 +50,10 @@ typedef struct vsx_search_opts {
   int32_t selfid;
   int32_t threads;          /* host threads for the k-mer heuristic; 0 = all usable CPUs          */
   int64_t window;           /* queries advanced together; 0 = default (65536)                     */
+  uint32_t gap_infinite;    /* '*' gap penalties (cli.cc:307-384): bit k = penalty k is infinite, k in the order of
+                               vsx_scoring after match/mismatch (0..5 open q_l t_l q_i t_i q_r t_r, 6..11 extension);
+                               an alignment using a forbidden gap class is rejected (searchcore.cpp:621-660) */
+  uint32_t pad;
 } vsx_search_opts;
 
 void vsx_search_opts_default(vsx_search_opts * o);

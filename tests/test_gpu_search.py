@@ -314,3 +314,27 @@ def test_device_kmer_region_overflow_second_pass(gpu_required, monkeypatch):
         monkeypatch.setenv("VSX_KMER_CAP", "3")
         dev = ss.candidates_batch(qs, device=True)
     assert host == dev and max(len(h) for h in host) > 3
+
+
+def test_infinite_gap_penalties_match_reference_cli(gpu_required, tmp_path):
+    """--gapext "2I/*E": terminal gaps longer than one are forbidden (cli.cc:203-228, searchcore.cpp:621-660); every pair
+    takes the linear-memory fallback (search16 refuses penalties beyond the 16-bit range, align_simd.cpp:1463-1479)"""
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing")
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(4242)
+    db, _ = common.family_db(rng, 6, 6, 220, div=0.05)
+    qs = [common.mutate(rng, db[rng.randrange(len(db))], 0.04) for _ in range(25)]
+    qs += [db[3][2:], db[8][:-3], "A" + db[11], db[20][1:-1]]                       # terminal gaps of 2, 3, 1, 1+1
+    exp = run_reference(str(tmp_path), db, qs, ["--id", "0.8", "--maxaccepts", "3", "--gapext", "2I/*E"])
+    INF = 2 ** 31 - 1
+    # post-fixup values (vsearch.cc:250-259): open -= extension
+    scoring = (2, -4, 2 - INF, 2 - INF, 18, 18, 2 - INF, 2 - INF, INF, INF, 2, 2, INF, INF)
+    mask = (1 << 6) | (1 << 7) | (1 << 10) | (1 << 11)
+    with Aligner(scoring=scoring) as al:
+        ss = SearchSession(al, db, id=0.8, maxaccepts=3, gap_infinite=mask)
+        got = ss.userout(qs, fields=FIELDS)
+        stats = dict(ss.stats)
+    assert len(exp) > 10
+    assert got == exp, _first_diff(got, exp)
+    assert stats["sentinel_pairs"] > 0 and stats["pairs_aligned"] > 0

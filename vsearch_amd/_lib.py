@@ -41,7 +41,7 @@ class SearchOpts(C.Structure):
                 ("leftjust", C.c_int32), ("rightjust", C.c_int32),
                 ("minqt", C.c_double), ("maxqt", C.c_double), ("minsl", C.c_double), ("maxsl", C.c_double),
                 ("idprefix", C.c_int64), ("idsuffix", C.c_int64), ("selfid", C.c_int32), ("threads", C.c_int32),
-                ("window", C.c_int64)]
+                ("window", C.c_int64), ("gap_infinite", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class Hit(C.Structure):

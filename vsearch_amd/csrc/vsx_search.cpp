@@ -309,11 +309,38 @@ bool acceptable_unaligned(const vsx_searcher & S, const char * q, int64_t qlen, 
          ((o.selfid == 0) || (qlen != dlen) || (seqcmp(q, d, qlen) != 0));
 }
 
-// search_acceptable_aligned, core/searchcore.cpp:664-737 (finite penalties, no unoise)
+// alignment_uses_forbidden_gap, core/searchcore.cpp:621-660: an 'I' run is a query gap, a 'D' run a target gap; the first
+// CIGAR op is left-terminal, the last right-terminal, any other interior.  An infinite open penalty forbids the class, an
+// infinite extension penalty forbids runs longer than one.
+bool uses_forbidden_gap(const std::string & cigar, uint32_t mask)
+{
+  const char * p = cigar.c_str();
+  bool first = true;
+  while (*p)
+    {
+      long long run = 1; int scan = 0;
+      std::sscanf(p, "%lld%n", &run, &scan);
+      p += scan;
+      const char op = *p++;
+      if (op == 'I' || op == 'D')
+        {
+          const bool right = (*p == 0);
+          const int cls = first ? 0 : (right ? 4 : 2);            // left, right, interior -> bit of the query-side open penalty
+          const int bit = cls + (op == 'I' ? 0 : 1);
+          if (mask & (1u << bit)) return true;
+          if ((mask & (1u << (6 + bit))) && run > 1) return true;
+        }
+      first = false;
+    }
+  return false;
+}
+
+// search_acceptable_aligned, core/searchcore.cpp:664-737 (no unoise)
 bool acceptable_aligned(const vsx_searcher & S, int64_t qlen, Hit & h)
 {
   const vsx_search_opts & o = S.o;
   if ((h.id >= 100.0 * o.weak_id) && (h.mismatches <= o.maxsubs) && (h.internal_gaps <= o.maxgaps) &&
+      ((o.gap_infinite == 0) || !uses_forbidden_gap(h.cigar, o.gap_infinite)) &&
       (h.internal_alignmentlength >= o.mincols) &&
       ((o.leftjust == 0) || (h.trim_q_left + h.trim_t_left == 0)) &&
       ((o.rightjust == 0) || (h.trim_q_right + h.trim_t_right == 0)) &&
@@ -468,7 +495,8 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
       const double t0 = now_s();
       vsx_results res;
       const vsx_filter flt = make_filter(S);
-      int rc = vsx_align_pairs_filtered(S.ctx, qset, S.dbset, pq.size(), pq.data(), pt.data(), &flt, &res);
+      // with '*' penalties every pair takes the linear-memory fallback and the forbidden-gap test: nothing for the device to decide
+      int rc = vsx_align_pairs_filtered(S.ctx, qset, S.dbset, pq.size(), pq.data(), pt.data(), S.o.gap_infinite ? nullptr : &flt, &res);
       acct.t_align += now_s() - t0;
       if (rc != VSX_OK) return rc;
       acct.pairs += pq.size();
@@ -853,7 +881,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
   vsx_results res;
   double t0 = now_s();
   const vsx_filter flt = make_filter(*S);
-  int rc = vsx_align_pairs_filtered(S->ctx, S->dbset, S->dbset, pq.size(), pq.data(), pt.data(), acceptall ? nullptr : &flt, &res);
+  int rc = vsx_align_pairs_filtered(S->ctx, S->dbset, S->dbset, pq.size(), pq.data(), pt.data(), (acceptall || S->o.gap_infinite) ? nullptr : &flt, &res);
   const double t_align = now_s() - t0;
   if (rc != VSX_OK) return rc;
   std::vector<std::vector<Hit>> kept(count);
