@@ -53,7 +53,8 @@ typedef struct vsx_search_opts {
   uint32_t gap_infinite;    /* '*' gap penalties (cli.cc:307-384): bit k = penalty k is infinite, k in the order of
                                vsx_scoring after match/mismatch (0..5 open q_l t_l q_i t_i q_r t_r, 6..11 extension);
                                an alignment using a forbidden gap class is rejected (searchcore.cpp:621-660) */
-  uint32_t pad;
+  uint32_t strand_both;     /* 0: --strand plus (default); 1: --strand both -- the reverse complement of every query is
+                               searched as well (search.cpp:200-214), hits of both strands are joined (searchcore.cpp:1028-1052) */
 } vsx_search_opts;
 
 void vsx_search_opts_default(vsx_search_opts * o);
@@ -63,7 +64,7 @@ typedef struct vsx_hit {
   uint32_t query;           /* index into the batch                                               */
   uint32_t target;          /* database sequence number                                           */
   uint32_t count;           /* shared unique k-mers (candidate rank key)                          */
-  uint8_t  accepted, weak, used_fallback, pad;
+  uint8_t  accepted, weak, used_fallback, strand;   /* strand: 0 = plus, 1 = minus (the query's reverse complement matched) */
   int32_t  nwscore, nwdiff, nwgaps, nwindels, nwalignmentlength;
   int32_t  matches, mismatches;
   int32_t  internal_alignmentlength, internal_gaps, internal_indels;

@@ -338,3 +338,33 @@ def test_infinite_gap_penalties_match_reference_cli(gpu_required, tmp_path):
     assert len(exp) > 10
     assert got == exp, _first_diff(got, exp)
     assert stats["sentinel_pairs"] > 0 and stats["pairs_aligned"] > 0
+
+
+def test_strand_both_matches_reference_cli(gpu_required, tmp_path):
+    """--strand both: reverse-complemented queries are searched too and the hits of both strands are joined"""
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing")
+    from vsearch_amd import Aligner, SearchSession
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "R": "Y", "Y": "R", "N": "N", "K": "M", "M": "K"}
+    rng = random.Random(606)
+    db, _ = common.family_db(rng, 10, 6, 300, div=0.06)
+    qs, _ = common.queries_from_db(rng, db, 40, 150)
+    for k in range(0, len(qs), 2):                                    # every other query is given on the minus strand
+        qs[k] = "".join(comp[c] for c in reversed(qs[k]))
+    qs.append(common.mutate(rng, db[4], 0.03, "ACGTRYN"))
+    flds = FIELDS + ["qstrand"]
+    dbf, qf, uf = str(tmp_path / "db.fa"), str(tmp_path / "q.fa"), str(tmp_path / "u.tsv")
+    with open(dbf, "w") as f:
+        f.write("".join(f">t{i}\n{s}\n" for i, s in enumerate(db)))
+    with open(qf, "w") as f:
+        f.write("".join(f">q{i}\n{s}\n" for i, s in enumerate(qs)))
+    p = subprocess.run([REF_BIN, "--usearch_global", qf, "--db", dbf, "--qmask", "none", "--dbmask", "none", "--threads", "1",
+                        "--userout", uf, "--userfields", "+".join(flds), "--quiet", "--id", "0.8", "--maxaccepts", "2",
+                        "--strand", "both"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    exp = open(uf).read().splitlines()
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.8, maxaccepts=2, strand_both=1)
+        got = ss.userout(qs, fields=flds)
+    assert sum(1 for l in exp if l.endswith("-")) > 10 and sum(1 for l in exp if l.endswith("+")) > 10
+    assert got == exp, _first_diff(got, exp)

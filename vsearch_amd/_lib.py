@@ -41,12 +41,12 @@ class SearchOpts(C.Structure):
                 ("leftjust", C.c_int32), ("rightjust", C.c_int32),
                 ("minqt", C.c_double), ("maxqt", C.c_double), ("minsl", C.c_double), ("maxsl", C.c_double),
                 ("idprefix", C.c_int64), ("idsuffix", C.c_int64), ("selfid", C.c_int32), ("threads", C.c_int32),
-                ("window", C.c_int64), ("gap_infinite", C.c_uint32), ("pad", C.c_uint32)]
+                ("window", C.c_int64), ("gap_infinite", C.c_uint32), ("strand_both", C.c_uint32)]
 
 
 class Hit(C.Structure):
     _fields_ = [("query", C.c_uint32), ("target", C.c_uint32), ("count", C.c_uint32),
-                ("accepted", C.c_uint8), ("weak", C.c_uint8), ("used_fallback", C.c_uint8), ("pad", C.c_uint8),
+                ("accepted", C.c_uint8), ("weak", C.c_uint8), ("used_fallback", C.c_uint8), ("strand", C.c_uint8),
                 ("nwscore", C.c_int32), ("nwdiff", C.c_int32), ("nwgaps", C.c_int32), ("nwindels", C.c_int32),
                 ("nwalignmentlength", C.c_int32), ("matches", C.c_int32), ("mismatches", C.c_int32),
                 ("internal_alignmentlength", C.c_int32), ("internal_gaps", C.c_int32), ("internal_indels", C.c_int32),

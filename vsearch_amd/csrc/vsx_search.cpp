@@ -55,6 +55,20 @@ int usable_cpus()
   return std::max(1, n);
 }
 
+// chrmap_complement, utils/maps.cpp:121-150: IUPAC complement, case kept for the letters that have one, everything else 'N'
+inline char complement(unsigned char c)
+{
+  static const char up[] = "TVGHNNCDNNMNKNNNNYSAABWNRN";    // complement of 'A' .. 'Z'
+  if (c >= 'A' && c <= 'Z') return up[c - 'A'];
+  if (c >= 'a' && c <= 'z')
+    {
+      const char u = up[c - 'a'];
+      const bool kept = std::strchr("abcdghkmnrstuvwy", (int) c) != nullptr;       // letters whose row entry is lower case
+      return kept ? (char) (u | 0x20) : 'N';
+    }
+  return 'N';
+}
+
 // utils/maps.cpp: chrmap_2bit (:156-186), chrmap_mask_ambig (:208-236), chrmap_mask_lower (:239-267), chrmap_4bit
 inline unsigned map2(unsigned char c)
 {
@@ -141,7 +155,7 @@ inline bool cand_better(const Cand & a, const Cand & b)
 
 struct Hit {
   uint32_t target = 0, count = 0;
-  bool accepted = false, rejected = false, aligned = false, weak = false, fallback = false;
+  bool accepted = false, rejected = false, aligned = false, weak = false, fallback = false, minus = false;
   int nwscore = 0, nwdiff = 0, nwgaps = 0, nwindels = 0, nwalignmentlength = 0, matches = 0, mismatches = 0;
   int internal_alignmentlength = 0, internal_gaps = 0, internal_indels = 0;
   int trim_q_left = 0, trim_q_right = 0, trim_t_left = 0, trim_t_right = 0, trim_aln_left = 0, trim_aln_right = 0;
@@ -450,7 +464,7 @@ static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out)
           vsx_hit & o = out->hit[pos++];
           std::memset(&o, 0, sizeof o);
           o.query = (uint32_t) q; o.target = h.target; o.count = h.count;
-          o.accepted = h.accepted; o.weak = h.weak; o.used_fallback = h.fallback;
+          o.accepted = h.accepted; o.weak = h.weak; o.used_fallback = h.fallback; o.strand = h.minus ? 1 : 0;
           o.nwscore = h.nwscore; o.nwdiff = h.nwdiff; o.nwgaps = h.nwgaps; o.nwindels = h.nwindels;
           o.nwalignmentlength = h.nwalignmentlength; o.matches = h.matches; o.mismatches = h.mismatches;
           o.internal_alignmentlength = h.internal_alignmentlength; o.internal_gaps = h.internal_gaps;
@@ -798,51 +812,75 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
   const bool dev_kmer = device_kmer_ok(*S);
   KmerAcct kacct;
 
+  const bool both = S->o.strand_both != 0;
   for (uint64_t w0 = 0; w0 < nq; w0 += window)
     {
       const uint64_t wn = std::min<uint64_t>(window, nq - w0);
-      std::vector<QState> st(wn);
+      // --strand both: state k < wn searches query w0 + k, state wn + k its reverse complement (search.cpp:200-214)
+      const uint64_t ns = both ? 2 * wn : wn;
+      std::vector<QState> st(ns);
+
+      // ---- the window's sequences in one blob: the queries, then (both strands) their reverse complements ----
+      uint64_t mn = qoff[w0], hi = qoff[w0];
+      for (uint64_t k = 0; k < wn; ++k) { mn = std::min(mn, qoff[w0 + k]); hi = std::max(hi, qoff[w0 + k] + qlen[w0 + k]); }
+      std::vector<uint64_t> lo(ns);
+      std::vector<uint32_t> ln(ns);
+      std::string rc;
+      for (uint64_t k = 0; k < wn; ++k) { lo[k] = qoff[w0 + k] - mn; ln[k] = qlen[w0 + k]; }
+      if (both)
+        {
+          uint64_t tot = 0;
+          for (uint64_t k = 0; k < wn; ++k) tot += qlen[w0 + k];
+          rc.resize(tot);
+          uint64_t p = 0;
+          for (uint64_t k = 0; k < wn; ++k)
+            {
+              const char * q = qblob + qoff[w0 + k];
+              const uint32_t L = qlen[w0 + k];
+              lo[wn + k] = (hi - mn) + p; ln[wn + k] = L;
+              for (uint32_t x = 0; x < L; ++x) rc[p + x] = complement((unsigned char) q[L - 1 - x]);
+              p += L;
+            }
+        }
+      std::string joined;
+      const char * wblob = qblob + mn;
+      if (both) { joined.assign(qblob + mn, hi - mn); joined += rc; wblob = joined.data(); }
+      auto seq_of = [&](uint64_t k) { return wblob + lo[k]; };
 
       // ---- k-mer heuristic for the whole window: device counters (vsx_kmer.hip) or host threads ----
       double t0 = now_s();
       {
         std::vector<std::vector<Cand>> cands;
-        const int krc = batch_candidates(S, dev_kmer, wn, [&](uint64_t k) { return qblob + qoff[w0 + k]; },
-                                         [&](uint64_t k) { return (int64_t) qlen[w0 + k]; }, cands, kacct);
+        const int krc = batch_candidates(S, dev_kmer, ns, seq_of, [&](uint64_t k) { return (int64_t) ln[k]; }, cands, kacct);
         if (krc != VSX_OK) return krc;
-        for (uint64_t k = 0; k < wn; ++k) st[k].cands = std::move(cands[k]);
+        for (uint64_t k = 0; k < ns; ++k) st[k].cands = std::move(cands[k]);
       }
       t_kmer += now_s() - t0;
 
-      // ---- the window's queries as a device sequence set ----
+      // ---- the window's sequences as a device sequence set ----
       vsx_seqset * qset = nullptr;
       {
-        std::vector<uint64_t> lo(wn);
-        const uint64_t base = qoff[w0];
-        uint64_t hi = base;
-        for (uint64_t k = 0; k < wn; ++k) { lo[k] = qoff[w0 + k]; hi = std::max(hi, qoff[w0 + k] + qlen[w0 + k]); }
-        uint64_t mn = base;
-        for (uint64_t k = 0; k < wn; ++k) mn = std::min(mn, lo[k]);
-        for (uint64_t k = 0; k < wn; ++k) lo[k] -= mn;
-        int rc = vsx_seqset_create(S->ctx, &qset, wn, qblob + mn, hi - mn, lo.data(), qlen + w0);
-        if (rc != VSX_OK) return rc;
+        int rc2 = vsx_seqset_create(S->ctx, &qset, ns, wblob, (hi - mn) + rc.size(), lo.data(), ln.data());
+        if (rc2 != VSX_OK) return rc2;
       }
 
       {
         Acct acct;
-        const int src = run_stages(*S, st, [&](uint64_t k) { return qblob + qoff[w0 + k]; },
-                                   [&](uint64_t k) { return (int64_t) qlen[w0 + k]; },
+        const int src = run_stages(*S, st, seq_of, [&](uint64_t k) { return (int64_t) ln[k]; },
                                    [&](uint64_t k) { return (uint32_t) k; }, qset, acct);
         t_align += acct.t_align; pairs += acct.pairs; cells += acct.cells; stages += acct.stages; sentinels += acct.sentinels;
         if (src != VSX_OK) { vsx_seqset_destroy(qset); return src; }
       }
       vsx_seqset_destroy(qset);
 
-      // ---- search_joinhits (:1028-1052): accepted | weak, ordered by hit_compare_byid ----
+      // ---- search_joinhits (:1028-1052): accepted | weak of the plus strand, then of the minus strand, ordered by
+      //      hit_compare_byid ----
       for (uint64_t k = 0; k < wn; ++k)
         {
           std::vector<Hit> & dst = kept[w0 + k];
           for (Hit & h : st[k].hits) if (h.accepted || h.weak) dst.push_back(std::move(h));
+          if (both)
+            for (Hit & h : st[wn + k].hits) if (h.accepted || h.weak) { h.minus = true; dst.push_back(std::move(h)); }
           std::sort(dst.begin(), dst.end(), [](const Hit & a, const Hit & b) { return hit_compare_byid(a, b) < 0; });
         }
     }

@@ -187,6 +187,7 @@ class SearchSession:
             "pv": lambda q, h: "%d" % h["matches"], "raw": lambda q, h: "%d" % h["nwscore"], "caln": lambda q, h: h["cigar"],
             "id0": lambda q, h: "%.1f" % h["id0"], "id1": lambda q, h: "%.1f" % h["id1"], "id2": lambda q, h: "%.1f" % h["id2"],
             "id3": lambda q, h: "%.1f" % h["id3"], "id4": lambda q, h: "%.1f" % h["id4"],
+            "qstrand": lambda q, h: "-" if h.get("strand") else "+",
             "ql": lambda q, h: "%d" % len(queries[q]), "tl": lambda q, h: "%d" % len(self.db[h["target"]]),
         }
         lines = []
