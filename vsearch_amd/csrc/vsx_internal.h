@@ -101,7 +101,7 @@ const int * vsx_supported_rows(int * count);
 
 // launchers implemented in vsx_kmer.hip (k-mer candidate counting)
 hipError_t vsx_kmer_launch_sweep(int fill, const uint8_t * codes, const uint64_t * off, const uint32_t * len,
-                                 uint32_t nseq, int w, uint32_t ntiles, uint32_t * bucket_count,
+                                 const uint32_t * seq_list, uint32_t nseq, int w, uint32_t ntiles, uint32_t * bucket_count,
                                  const uint64_t * bucket_start, uint32_t * postings, hipStream_t st);
 hipError_t vsx_kmer_launch_count(const uint32_t * postings, const uint64_t * bucket_start, uint32_t ntiles,
                                  uint32_t nseq, uint32_t nslots, const uint64_t * qk_start, const uint32_t * qk,

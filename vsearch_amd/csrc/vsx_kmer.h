@@ -21,13 +21,17 @@ struct VsxKmerStats {
 
 // words of length w (3..8) over the sequence set's 4-bit codes; ambiguous symbols poison the words that cover them
 int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIndex ** out);
+// an index with nothing in it yet; vsx_kmer_index_rebuild(ix, list, n) (re)builds it over the listed sequences of `db`
+// (index position i = sequence list[i]; targets in the records are POSITIONS) or, with list == nullptr, over all of them.
+int vsx_kmer_index_create_empty(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIndex ** out);
+int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_list);
 void vsx_kmer_index_destroy(VsxKmerIndex * ix);
 // qk_start[nq + 1] / qk[]: each query's unique words; minmatch[q] = threshold, 0xffffffff = skip the query.
 // recs: (query, target, count) with count >= minmatch[query], unordered.
 // keep = size of the reference's heap (tophits): per query the device keeps every record whose count is >= the
 // keep-th largest count (a superset of the heap under any tie-break); the caller applies the total order.
 int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_start, const uint32_t * qk,
-                         const uint32_t * minmatch, uint32_t keep, std::vector<VsxKmerRec> & recs);
+                         const uint32_t * minmatch, uint32_t keep, std::vector<VsxKmerRec> & recs, uint32_t cap_hint = 0);
 const VsxKmerStats * vsx_kmer_stats(const VsxKmerIndex * ix);
 
 #endif

@@ -57,7 +57,8 @@ __device__ __forceinline__ bool word_at(const uint8_t * __restrict__ s, int p, i
 // A word counts once per sequence (unique_count): first setter of the word's bit in a per-wave LDS bitmap emits.
 template <bool FILL>
 __global__ void __launch_bounds__(256)
-vsx_kmer_sweep_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict__ off, const u32 * __restrict__ len, u32 nseq,
+vsx_kmer_sweep_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict__ off, const u32 * __restrict__ len,
+                      const u32 * __restrict__ seq_list, u32 nseq,
                       int w, u32 ntiles, u32 * __restrict__ bucket_count, const u64 * __restrict__ bucket_start,
                       uint16_t * __restrict__ postings)
 {
@@ -66,10 +67,11 @@ vsx_kmer_sweep_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict
   const u32 words = (1u << (2 * w)) >> 5;
   u32 * bm = bm_all + (size_t) wave * (words ? words : 1);
   for (u32 x = lane; x < (words ? words : 1); x += 64) bm[x] = 0;
-  const u32 seq = blockIdx.x * 4 + wave;
+  const u32 seq = blockIdx.x * 4 + wave;                 // position in the index
   if (seq >= nseq) return;
-  const uint8_t * __restrict__ s = codes + off[seq];
-  const int L = (int) len[seq];
+  const u32 sid = seq_list ? seq_list[seq] : seq;        // sequence of the set it stands for (subset index: clustering)
+  const uint8_t * __restrict__ s = codes + off[sid];
+  const int L = (int) len[sid];
   const u32 tile = seq >> KM_TILE_SHIFT;
   for (int p0 = 0; p0 + w <= L; p0 += 64)
     {
@@ -276,17 +278,17 @@ vsx_kmer_select_kernel(const uint2 * __restrict__ rec, u32 cap, const u32 * __re
 }
 
 extern "C" hipError_t vsx_kmer_launch_sweep(int fill, const uint8_t * codes, const uint64_t * off, const uint32_t * len,
-                                            uint32_t nseq, int w, uint32_t ntiles, uint32_t * bucket_count,
+                                            const uint32_t * seq_list, uint32_t nseq, int w, uint32_t ntiles, uint32_t * bucket_count,
                                             const uint64_t * bucket_start, uint32_t * postings, hipStream_t st)   // postings: dwords of two 16-bit indices
 {
   if (nseq == 0) return hipSuccess;
   const size_t lds = (size_t) 4 * (((1u << (2 * w)) >> 5) ? ((1u << (2 * w)) >> 5) : 1) * 4;
   const dim3 grid((nseq + 3) / 4), block(256);
   if (fill)
-    hipLaunchKernelGGL(vsx_kmer_sweep_kernel<true>, grid, block, lds, st, codes, (const u64 *) off, len, nseq, w, ntiles,
+    hipLaunchKernelGGL(vsx_kmer_sweep_kernel<true>, grid, block, lds, st, codes, (const u64 *) off, len, seq_list, nseq, w, ntiles,
                        bucket_count, (const u64 *) bucket_start, (uint16_t *) postings);
   else
-    hipLaunchKernelGGL(vsx_kmer_sweep_kernel<false>, grid, block, lds, st, codes, (const u64 *) off, len, nseq, w, ntiles,
+    hipLaunchKernelGGL(vsx_kmer_sweep_kernel<false>, grid, block, lds, st, codes, (const u64 *) off, len, seq_list, nseq, w, ntiles,
                        bucket_count, (const u64 *) bucket_start, (uint16_t *) postings);
   return hipGetLastError();
 }

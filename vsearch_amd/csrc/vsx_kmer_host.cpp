@@ -43,13 +43,16 @@ template <typename T> struct Buf {
 
 struct VsxKmerIndex {
   vsx_ctx * ctx = nullptr;
+  const vsx_seqset * db = nullptr;
   int device = 0;
   hipStream_t st = nullptr;
   int w = 8;
   uint32_t nseq = 0, ntiles = 0;
   uint64_t nbuckets = 0;
   Buf<uint64_t> d_start;          // nbuckets + 1
-  Buf<uint32_t> d_post;
+  Buf<uint32_t> d_post, d_count, d_list;
+  std::vector<uint32_t> h_count;
+  std::vector<uint64_t> h_start;
   // per-batch scratch, grown on demand
   Buf<uint64_t> d_qk_start;
   Buf<uint32_t> d_qk, d_minmatch;
@@ -73,34 +76,73 @@ int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIn
   if (!ctx || !db || !out) { vsx_internal_set_error("vsx_kmer_index_create: null argument"); return VSX_EINVAL; }
   *out = nullptr;
   if (w < 3 || w > 8) { vsx_internal_set_error("vsx_kmer_index_create: device index supports word lengths 3..8"); return VSX_EINVAL; }
-  const uint8_t * codes; const uint64_t * off; const uint32_t * len; uint64_t n;
-  vsx_internal_seqset_device(db, &codes, &off, &len, &n);
-  if (n >= (1ull << 31)) { vsx_internal_set_error("vsx_kmer_index_create: too many sequences"); return VSX_EINVAL; }
   std::unique_ptr<VsxKmerIndex> ix(new VsxKmerIndex);
-  ix->ctx = ctx; ix->device = vsx_internal_device(ctx); ix->st = vsx_internal_stream(ctx); ix->w = w;
+  ix->ctx = ctx; ix->db = db; ix->device = vsx_internal_device(ctx); ix->st = vsx_internal_stream(ctx); ix->w = w;
   KCHK(hipSetDevice(ix->device));
   KCHK(hipEventCreate(&ix->e0));
   KCHK(hipEventCreate(&ix->e1));
+  KCHK(ix->d_cursor.alloc(1));
+  const int rc = vsx_kmer_index_rebuild(ix.get(), nullptr, 0);
+  if (rc != VSX_OK) return rc;
+  *out = ix.release();
+  return VSX_OK;
+}
+
+int vsx_kmer_index_create_empty(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIndex ** out)
+{
+  if (!ctx || !db || !out) { vsx_internal_set_error("vsx_kmer_index_create_empty: null argument"); return VSX_EINVAL; }
+  *out = nullptr;
+  if (w < 3 || w > 8) { vsx_internal_set_error("vsx_kmer_index_create_empty: device index supports word lengths 3..8"); return VSX_EINVAL; }
+  std::unique_ptr<VsxKmerIndex> ix(new VsxKmerIndex);
+  ix->ctx = ctx; ix->db = db; ix->device = vsx_internal_device(ctx); ix->st = vsx_internal_stream(ctx); ix->w = w;
+  KCHK(hipSetDevice(ix->device));
+  KCHK(hipEventCreate(&ix->e0));
+  KCHK(hipEventCreate(&ix->e1));
+  KCHK(ix->d_cursor.alloc(1));
+  *out = ix.release();
+  return VSX_OK;
+}
+
+// (Re)build the index over the whole sequence set (list == nullptr) or over the listed sequences: index position i stands
+// for sequence list[i].  Buffers are reused and only ever grow (clustering rebuilds once per round).
+int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_list)
+{
+  if (!ix) { vsx_internal_set_error("vsx_kmer_index_rebuild: null index"); return VSX_EINVAL; }
+  const uint8_t * codes; const uint64_t * off; const uint32_t * len; uint64_t n_all;
+  vsx_internal_seqset_device(ix->db, &codes, &off, &len, &n_all);
+  const uint64_t n = list ? n_list : n_all;
+  if (n >= (1ull << 31)) { vsx_internal_set_error("vsx_kmer_index_rebuild: too many sequences"); return VSX_EINVAL; }
+  KCHK(hipSetDevice(ix->device));
+  const int w = ix->w;
   const uint32_t shift = vsx_kmer_tile_shift();
   ix->nseq = (uint32_t) n;
   ix->ntiles = std::max<uint32_t>(1, (uint32_t) ((n + (1ull << shift) - 1) >> shift));
   ix->nbuckets = (1ull << (2 * w)) * ix->ntiles;
-
-  Buf<uint32_t> d_count;
-  KCHK(d_count.alloc(ix->nbuckets));
-  KCHK(ix->d_start.alloc(ix->nbuckets + 1));
+  ix->word_total.assign(1ull << (2 * w), 0);
+  ix->stats.postings = 0;
+  if (n == 0) return VSX_OK;
+  const uint32_t * d_list = nullptr;
+  if (list)
+    {
+      KCHK(ix->d_list.ensure(n));
+      KCHK(hipMemcpyAsync(ix->d_list.p, list, n * 4, hipMemcpyHostToDevice, ix->st));
+      d_list = ix->d_list.p;
+    }
+  KCHK(ix->d_count.ensure(ix->nbuckets));
+  KCHK(ix->d_start.ensure(ix->nbuckets + 1));
   KCHK(hipEventRecord(ix->e0, ix->st));
-  KCHK(hipMemsetAsync(d_count.p, 0, ix->nbuckets * 4, ix->st));
-  KCHK(vsx_kmer_launch_sweep(0, codes, off, len, ix->nseq, w, ix->ntiles, d_count.p, nullptr, nullptr, ix->st));
+  KCHK(hipMemsetAsync(ix->d_count.p, 0, ix->nbuckets * 4, ix->st));
+  KCHK(vsx_kmer_launch_sweep(0, codes, off, len, d_list, ix->nseq, w, ix->ntiles, ix->d_count.p, nullptr, nullptr, ix->st));
   // bucket table: exclusive prefix sum on the host (4^w x ntiles entries: 8 MB for 1 M sequences, w = 8)
-  std::vector<uint32_t> cnt(ix->nbuckets);
-  KCHK(hipMemcpyAsync(cnt.data(), d_count.p, ix->nbuckets * 4, hipMemcpyDeviceToHost, ix->st));
+  std::vector<uint32_t> & cnt = ix->h_count;
+  cnt.resize(ix->nbuckets);
+  KCHK(hipMemcpyAsync(cnt.data(), ix->d_count.p, ix->nbuckets * 4, hipMemcpyDeviceToHost, ix->st));
   KCHK(hipStreamSynchronize(ix->st));
-  std::vector<uint64_t> start(ix->nbuckets + 1);
+  std::vector<uint64_t> & start = ix->h_start;
+  start.resize(ix->nbuckets + 1);
   uint64_t acc = 0;
   // a bucket holds 16-bit tile-local indices, two per dword: start[] counts DWORDS, odd buckets end in a 0xFFFF sentinel
   uint64_t entries = 0;
-  ix->word_total.assign(1ull << (2 * w), 0);
   for (uint64_t b = 0; b < ix->nbuckets; ++b)
     {
       start[b] = acc;
@@ -109,11 +151,11 @@ int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIn
       ix->word_total[b / ix->ntiles] += cnt[b];
     }
   start[ix->nbuckets] = acc;
-  KCHK(ix->d_post.alloc(acc));
-  KCHK(hipMemsetAsync(ix->d_post.p, 0xff, acc * 4, ix->st));
+  KCHK(ix->d_post.ensure(acc));
+  if (acc) KCHK(hipMemsetAsync(ix->d_post.p, 0xff, acc * 4, ix->st));
   KCHK(hipMemcpyAsync(ix->d_start.p, start.data(), (ix->nbuckets + 1) * 8, hipMemcpyHostToDevice, ix->st));
-  KCHK(hipMemsetAsync(d_count.p, 0, ix->nbuckets * 4, ix->st));
-  KCHK(vsx_kmer_launch_sweep(1, codes, off, len, ix->nseq, w, ix->ntiles, d_count.p, ix->d_start.p, ix->d_post.p, ix->st));
+  KCHK(hipMemsetAsync(ix->d_count.p, 0, ix->nbuckets * 4, ix->st));
+  KCHK(vsx_kmer_launch_sweep(1, codes, off, len, d_list, ix->nseq, w, ix->ntiles, ix->d_count.p, ix->d_start.p, ix->d_post.p, ix->st));
   KCHK(hipEventRecord(ix->e1, ix->st));
   KCHK(hipStreamSynchronize(ix->st));
   float ms = 0;
@@ -121,8 +163,6 @@ int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIn
   ix->stats.build_ms = ms;
   ix->stats.postings = entries;
   ix->stats.index_bytes = acc * 4 + (ix->nbuckets + 1) * 8;
-  KCHK(ix->d_cursor.alloc(1));
-  *out = ix.release();
   return VSX_OK;
 }
 
@@ -192,7 +232,7 @@ int count_pass(VsxKmerIndex * ix, uint32_t nslots, const uint32_t * d_qlist, con
 }  // namespace
 
 int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_start, const uint32_t * qk,
-                         const uint32_t * minmatch, uint32_t keep, std::vector<VsxKmerRec> & recs)
+                         const uint32_t * minmatch, uint32_t keep, std::vector<VsxKmerRec> & recs, uint32_t cap_hint)
 {
   recs.clear();
   if (!ix || (nq && (!qk_start || !minmatch))) { vsx_internal_set_error("vsx_kmer_count_batch: null argument"); return VSX_EINVAL; }
@@ -217,7 +257,7 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
   uint32_t overflow_max = 0;
   // records per query region in the first pass: at 1 M x 1 kbp a 250-bp query has ~5 000 sequences with >= 12 shared
   // words (chance runs of shared 11..13-mers), so 8 192 x 8 B = 64 KB per query; HBM is plentiful (100 k queries = 6.5 GB)
-  uint32_t cap = nq <= (1u << 18) ? 8192 : 2048;
+  uint32_t cap = cap_hint ? cap_hint : (nq <= (1u << 18) ? 8192 : 2048);
   if (const char * c = std::getenv("VSX_KMER_CAP")) cap = (uint32_t) std::max(1, std::atoi(c));      // tests: force the second pass
   int rc = count_pass(ix, (uint32_t) nq, nullptr, nullptr, cap, keep, recs, overflow, overflow_max, ms);
   if (rc != VSX_OK) return rc;

@@ -586,6 +586,73 @@ static bool device_kmer_ok(const vsx_searcher & S)
 
 struct KmerAcct { double kernel_ms = 0, build_ms = 0; uint64_t streamed = 0, postings = 0; };
 
+// Count the queries' words against a device index and rank: words[k] = unique words of query k; `map` translates index
+// positions to sequence numbers (subset index) or is null; keep = heap size.  cands[k] = (target, count, length) best first
+// (rank == true: the heap's total order, cut to `keep`) or all records in position order (rank == false).  Queries the
+// 16-bit tile counters cannot serve (threshold 0, > 32767 words) are listed in `fallback` and left empty.
+static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vector<uint32_t> * map, uint64_t nq,
+                       const std::vector<std::vector<uint32_t>> & words, uint32_t keep, uint32_t cap_hint, bool rank,
+                       std::vector<std::vector<Cand>> & cands, std::vector<uint64_t> & fallback, KmerAcct & acct)
+{
+  // CSR + thresholds (:320)
+  std::vector<uint64_t> qk_start(nq + 1, 0);
+  std::vector<uint32_t> minmatch(nq);
+  for (uint64_t k = 0; k < nq; ++k)
+    {
+      const uint64_t nk = words[k].size();
+      const uint64_t mm = (uint64_t) std::min<int64_t>(S->minwordmatches, (int64_t) nk);
+      if (mm == 0 || nk > 32767) { minmatch[k] = 0xffffffffu; fallback.push_back(k); qk_start[k + 1] = qk_start[k]; continue; }
+      minmatch[k] = (uint32_t) mm;
+      qk_start[k + 1] = qk_start[k] + nk;
+    }
+  std::vector<uint32_t> qk(qk_start[nq]);
+  for (uint64_t k = 0; k < nq; ++k)
+    if (minmatch[k] != 0xffffffffu) std::copy(words[k].begin(), words[k].end(), qk.begin() + (int64_t) qk_start[k]);
+  // count on the device
+  std::vector<VsxKmerRec> recs;
+  const int rc = vsx_kmer_count_batch(ix, nq, qk_start.data(), qk.data(), minmatch.data(), keep, recs, cap_hint);
+  if (rc != VSX_OK) return rc;
+  acct.kernel_ms += vsx_kmer_stats(ix)->count_ms;
+  acct.streamed += vsx_kmer_stats(ix)->increments;
+  // bucket by query, then the heap's total order (count desc, length asc, seqno asc) and size
+  std::vector<uint64_t> first(nq + 1, 0);
+  for (const VsxKmerRec & r : recs) ++first[r.query + 1];
+  for (uint64_t k = 0; k < nq; ++k) first[k + 1] += first[k];
+  std::vector<Cand> flat(recs.size());
+  {
+    std::vector<uint64_t> fill(first.begin(), first.end() - 1);
+    for (const VsxKmerRec & r : recs)
+      {
+        const uint32_t t = map ? (*map)[r.target] : r.target;
+        flat[fill[r.query]++] = Cand {t, r.count, S->len[t]};
+      }
+  }
+  const int nth = std::max(1, S->threads);
+  std::atomic<uint64_t> next {0};
+  auto work = [&]() {
+    for (;;)
+      {
+        const uint64_t k = next.fetch_add(1);
+        if (k >= nq) break;
+        if (minmatch[k] == 0xffffffffu) continue;
+        std::vector<Cand> & out = cands[k];
+        out.assign(flat.begin() + (int64_t) first[k], flat.begin() + (int64_t) first[k + 1]);
+        if (rank)
+          {
+            const size_t kp = std::min<size_t>(out.size(), (size_t) keep);
+            std::partial_sort(out.begin(), out.begin() + (int64_t) kp, out.end(), cand_better);
+            out.resize(kp);
+          }
+        else std::sort(out.begin(), out.end(), [](const Cand & a, const Cand & b) { return a.target < b.target; });
+      }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nth; ++t) pool.emplace_back(work);
+  work();
+  for (auto & th : pool) th.join();
+  return VSX_OK;
+}
+
 // search_topscores for a batch: cands[k] = candidate list of query k, best first, <= tophits entries.
 template <typename FSeq, typename FLen>
 static int batch_candidates(vsx_searcher * S, bool device, uint64_t nq, FSeq qseq, FLen qlen,
@@ -634,44 +701,11 @@ static int batch_candidates(vsx_searcher * S, bool device, uint64_t nq, FSeq qse
     std::vector<std::vector<uint64_t>> seen((size_t) nth, std::vector<uint64_t>((nwords + 63) / 64, 0));
     parallel([&](int tid, uint64_t k) { unique_kmers(qseq(k), qlen(k), S->w, false, words[k], seen[(size_t) tid]); });
   }
-  // 2. CSR + thresholds (:320); queries the 16-bit tile counters cannot serve go to the host path
-  std::vector<uint64_t> qk_start(nq + 1, 0);
-  std::vector<uint32_t> minmatch(nq);
   std::vector<uint64_t> fallback;
-  for (uint64_t k = 0; k < nq; ++k)
-    {
-      const uint64_t nk = words[k].size();
-      const uint64_t mm = (uint64_t) std::min<int64_t>(S->minwordmatches, (int64_t) nk);
-      if (mm == 0 || nk > 32767) { minmatch[k] = 0xffffffffu; fallback.push_back(k); qk_start[k + 1] = qk_start[k]; continue; }
-      minmatch[k] = (uint32_t) mm;
-      qk_start[k + 1] = qk_start[k] + nk;
-    }
-  std::vector<uint32_t> qk(qk_start[nq]);
-  for (uint64_t k = 0; k < nq; ++k)
-    if (minmatch[k] != 0xffffffffu) std::copy(words[k].begin(), words[k].end(), qk.begin() + (int64_t) qk_start[k]);
-  // 3. count on the device
-  std::vector<VsxKmerRec> recs;
-  const int rc = vsx_kmer_count_batch(S->kidx, nq, qk_start.data(), qk.data(), minmatch.data(), (uint32_t) std::max<int64_t>(S->tophits, 1), recs);
-  if (rc != VSX_OK) return rc;
-  acct.kernel_ms += vsx_kmer_stats(S->kidx)->count_ms;
-  acct.streamed += vsx_kmer_stats(S->kidx)->increments;
-  // 4. bucket by query, then the heap's total order (count desc, length asc, seqno asc) and size
-  std::vector<uint64_t> first(nq + 1, 0);
-  for (const VsxKmerRec & r : recs) ++first[r.query + 1];
-  for (uint64_t k = 0; k < nq; ++k) first[k + 1] += first[k];
-  std::vector<Cand> flat(recs.size());
   {
-    std::vector<uint64_t> fill(first.begin(), first.end() - 1);
-    for (const VsxKmerRec & r : recs) flat[fill[r.query]++] = Cand {r.target, r.count, S->len[r.target]};
+    const int rc = device_rank(S, S->kidx, nullptr, nq, words, (uint32_t) std::max<int64_t>(S->tophits, 1), 0, true, cands, fallback, acct);
+    if (rc != VSX_OK) return rc;
   }
-  parallel([&](int, uint64_t k) {
-    if (minmatch[k] == 0xffffffffu) return;
-    std::vector<Cand> & out = cands[k];
-    out.assign(flat.begin() + (int64_t) first[k], flat.begin() + (int64_t) first[k + 1]);
-    const size_t keep = std::min<size_t>(out.size(), (size_t) S->tophits);
-    std::partial_sort(out.begin(), out.begin() + (int64_t) keep, out.end(), cand_better);
-    out.resize(keep);
-  });
   if (!fallback.empty())
     {
       build_index(S);
@@ -1000,14 +1034,67 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
     }
   auto seq_of = [&](uint64_t seqno) { return S->blob.data() + S->off[seqno]; };
 
+  // device k-mer counting (vsx_kmer.hip): one index over the centroids, rebuilt when a round added some, and one over the
+  // members of the current round (the intra-round shared-word counts of evaluate_extra_hits)
+  const bool dev_kmer = device_kmer_ok(*S);
+  struct IxDel { void operator()(VsxKmerIndex * p) const { vsx_kmer_index_destroy(p); } };
+  std::unique_ptr<VsxKmerIndex, IxDel> cix, rix;
+  std::vector<uint32_t> centroid_list;                   // sequence numbers of the centroids, ascending
+  size_t cix_built = 0;
+  KmerAcct kacct;
+  if (dev_kmer)
+    {
+      VsxKmerIndex * a = nullptr, * b = nullptr;
+      int irc = vsx_kmer_index_create_empty(S->ctx, S->dbset, S->w, &a);
+      cix.reset(a);
+      if (irc == VSX_OK) { irc = vsx_kmer_index_create_empty(S->ctx, S->dbset, S->w, &b); rix.reset(b); }
+      if (irc != VSX_OK) return irc;
+    }
+
   for (uint64_t s0 = 0; s0 < n; s0 += round)
     {
       const uint64_t wn = std::min<uint64_t>(round, n - s0);
       std::vector<QState> st(wn);
       std::vector<std::vector<uint32_t>> kmers(wn);
+      std::vector<uint64_t> fallback;                        // round members the device counters cannot serve
 
       // ---- phase 1a: k-mer candidates against the centroid index as of the round start ----
       double t0 = now_s();
+      if (dev_kmer)
+        {
+          {
+            std::atomic<uint64_t> next {0};
+            auto work = [&](int tid) {
+              for (;;)
+                {
+                  const uint64_t k = next.fetch_add(1);
+                  if (k >= wn) break;
+                  unique_kmers(seq_of(s0 + k), S->len[s0 + k], S->w, false, kmers[k], scratch[(size_t) tid].seen);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+            work(0);
+            for (auto & th : pool) th.join();
+          }
+          if (centroid_list.size() != cix_built)
+            {
+              const int irc = vsx_kmer_index_rebuild(cix.get(), centroid_list.data(), centroid_list.size());
+              if (irc != VSX_OK) return irc;
+              cix_built = centroid_list.size();
+            }
+          std::vector<std::vector<Cand>> cands(wn);
+          const int krc = device_rank(S, cix.get(), &centroid_list, wn, kmers, (uint32_t) std::max<int64_t>(S->tophits, 1), 1024, true,
+                                      cands, fallback, kacct);
+          if (krc != VSX_OK) return krc;
+          for (uint64_t k = 0; k < wn; ++k) st[k].cands = std::move(cands[k]);
+          for (uint64_t k : fallback)
+            {
+              Scratch & sc = scratch[0];
+              candidates_for(*S, seq_of(s0 + k), S->len[s0 + k], sc.counts, sc.touched, sc.km, sc.seen, st[k].cands, &inc);
+            }
+        }
+      else
       {
         std::atomic<uint64_t> next {0};
         auto work = [&](int tid) {
@@ -1038,6 +1125,33 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       struct Near { uint32_t k, shared; int64_t res; };            // res = index into the speculative results, -1 none
       std::vector<std::vector<Near>> near(wn);
       std::vector<uint32_t> sq, stg;
+      if (dev_kmer && fallback.empty())
+        {
+          // the same counting problem on the device: members of the round against an index of the round
+          std::vector<uint32_t> round_list(wn);
+          for (uint64_t i = 0; i < wn; ++i) round_list[i] = (uint32_t) (s0 + i);
+          const int irc = vsx_kmer_index_rebuild(rix.get(), round_list.data(), wn);
+          if (irc != VSX_OK) return irc;
+          std::vector<std::vector<Cand>> nc(wn);
+          std::vector<uint64_t> none;
+          const int krc = device_rank(S, rix.get(), &round_list, wn, kmers, 0xffffffffu, 1024, false, nc, none, kacct);
+          if (krc != VSX_OK) return krc;
+          for (uint64_t i = 0; i < wn; ++i)
+            for (const Cand & c : nc[i])                              // ascending target
+              {
+                const uint32_t k = (uint32_t) (c.target - s0);
+                if (k >= i) break;                                    // only earlier members can have become centroids
+                Near nr {k, c.count, -1};
+                if (acceptable_unaligned(*S, seq_of(s0 + i), S->len[s0 + i], (uint32_t) (s0 + k)))
+                  {
+                    nr.res = (int64_t) sq.size();
+                    sq.push_back((uint32_t) (s0 + i));
+                    stg.push_back((uint32_t) (s0 + k));
+                  }
+                near[i].push_back(nr);
+              }
+        }
+      else
       {
         std::vector<std::vector<uint32_t>> lpost(nk);               // round-local: k-mer -> earlier members
         std::vector<uint16_t> cnt(wn, 0);
@@ -1170,6 +1284,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
               extras.push_back((uint32_t) i);
               S->is_centroid[seqno] = 1;
               for (uint32_t km : kmers[i]) inc.post[km].push_back((uint32_t) seqno);    // Dbindex::add_sequence (:1009)
+              centroid_list.push_back((uint32_t) seqno);
               ++inc.indexed;
             }
         }
