@@ -92,6 +92,10 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   // GENERIC: query profile in LDS, QP[target code][row of the strip] = S[code][query symbol of the row] (int16).
   // Any IUPAC / unknown symbol on either side is handled by construction; one v_perm_b32 per row packs the two targets.
   __shared__ __attribute__((aligned(16))) int16_t QP[GENERIC ? 16 * 16 * R : 8];
+  // feed block of the column pipeline: [lane group][column of the 16-block] (sym, QR_t, R_t, H) and F -- written once per 16
+  // steps by the 16 lanes of a group, read back one column per step for lane 0 (replaces five v_mov_b32_dpp row_ror rotations)
+  __shared__ uint4 FEED4[4 * 16];
+  __shared__ u32 FEEDF[4 * 16], FEEDN[GENERIC ? 1 : 4 * 16];
 
   const VsxTask & T = tasks[blockIdx.x];
   const int lane = (int) threadIdx.x;
@@ -228,16 +232,21 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   f_H = rawS.x;                        // handed over by the previous strip's last lane
                   f_F = rawS.y;
                 }
+              FEED4[g * 16 + l] = make_uint4(f_sym, f_qrt, f_rt, f_H);
+              FEEDF[g * 16 + l] = f_F;
+              if (!GENERIC) FEEDN[g * 16 + l] = f_nd;
               prefetch((t >> 4) + 1);
             }
 
           // ---- systolic shift (all lanes, full EXEC) ----
-          sym = dpp_shr1(f_sym, sym);   f_sym = dpp_rol1(f_sym);
-          nd  = dpp_shr1(f_nd, nd);     f_nd  = dpp_rol1(f_nd);
-          qrt = dpp_shr1(f_qrt, qrt);   f_qrt = dpp_rol1(f_qrt);
-          rt  = dpp_shr1(f_rt, rt);     f_rt  = dpp_rol1(f_rt);
-          const u32 inH = dpp_shr1(f_H, outH);   f_H = dpp_rol1(f_H);
-          const u32 inF = dpp_shr1(f_F, outF);   f_F = dpp_rol1(f_F);
+          const uint4 fv = FEED4[g * 16 + (t & 15)];
+          const u32 fF = FEEDF[g * 16 + (t & 15)];
+          sym = dpp_shr1(fv.x, sym);
+          if (!GENERIC) nd = dpp_shr1(FEEDN[g * 16 + (t & 15)], nd);
+          qrt = dpp_shr1(fv.y, qrt);
+          rt  = dpp_shr1(fv.z, rt);
+          const u32 inH = dpp_shr1(fv.w, outH);
+          const u32 inF = dpp_shr1(fF, outF);
 
           const int j = t - l;
           if (lane_on && j >= 0 && j < Dpg)
