@@ -201,7 +201,10 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
 
       // one pipeline step; reads the left-neighbour row state from hin[] and writes hout[] (the caller ping-pongs the two
       // arrays over an even number of steps, so no per-step register copies remain)
-      auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R]) __attribute__((always_inline)) {
+      // INTERIOR (phase A of the strip, see the loops below): no lane of the wave has reached a last / padded column yet, so
+      // the column penalties are the interior constants (not pipelined), H - QR is shared by E and F, no score capture.
+      auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R], auto interior_tag) __attribute__((always_inline)) {
+          constexpr bool INTERIOR = decltype(interior_tag)::value;
           if ((t & 15) == 0)
             {
               // build the feed block for columns 16k..16k+15 (lane l describes column 16k+l)
@@ -243,8 +246,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           const u32 fF = FEEDF[g * 16 + (t & 15)];
           sym = dpp_shr1(fv.x, sym);
           if (!GENERIC) nd = dpp_shr1(FEEDN[g * 16 + (t & 15)], nd);
-          qrt = dpp_shr1(fv.y, qrt);
-          rt  = dpp_shr1(fv.z, rt);
+          if (!INTERIOR) { qrt = dpp_shr1(fv.y, qrt); rt = dpp_shr1(fv.z, rt); }
           const u32 inH = dpp_shr1(fv.w, outH);
           const u32 inF = dpp_shr1(fF, outF);
 
@@ -317,7 +319,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   if (!TOPPAD && __builtin_expect(rc0 == r + 1, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
                 }
               };
-              if (CKPT && P.share_sub && !__any(qrt != qrt_i_pk)) rows(std::true_type {});
+              if (INTERIOR) rows(std::true_type {});
               else rows(std::false_type {});
               const u32 hl = (!TOPPAD && first) ? capH : h2;
               F = (!TOPPAD && first) ? capF : F;
@@ -334,8 +336,11 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   hmin = pmin(hmin, a_bfi_v(vm, smn, 0x7FFF7FFFu));
                   hmax = pmax(hmax, a_bfi_v(vm, smx, 0x80008000u));
                 }
-              const u32 lm = a_pk_ashr15(sym << 7);     // bit 8 (column == D-1)
-              score = a_bfi_v(lm, hl, score);            // S[(D+3)%4] of the last row (:1835-1836)
+              if (!INTERIOR)
+                {
+                  const u32 lm = a_pk_ashr15(sym << 7);     // bit 8 (column == D-1)
+                  score = a_bfi_v(lm, hl, score);            // S[(D+3)%4] of the last row (:1835-1836)
+                }
 
               // [4-step block][lane][step in block][ND]: a lane's 4 consecutive steps share one 64 B line
               // (4x fewer lines for the traceback walk) while a wave-step still lands in one 4 KB window
@@ -391,10 +396,31 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
             }
       };
       // steps is odd (padded length + 15): the extra step finds every lane past its last column
-      for (int t = 0; t < steps; t += 2)
+      // Phase A: steps before ANY lane of the wave reaches column D - 1 of one of its targets (lane l works on column
+      // t - l <= t): every column in flight is interior.  Needs QR_q(interior) == QR_t(interior) for the shared
+      // subtraction (planner flag); the checkpoint kernels only.  Phase B: the general step for the rest.
+      int t_switch = 0;
+      if (CKPT && P.share_sub)
         {
-          step(t, hprev, hnext);
-          step(t + 1, hnext, hprev);
+          int dmin = 0x7fffffff;
+          if (DA > 0 && DA < dmin) dmin = DA;
+          if (DB > 0 && DB < dmin) dmin = DB;
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(dmin, m, 64); dmin = o < dmin ? o : dmin; }
+          t_switch = __builtin_amdgcn_readfirstlane(dmin == 0x7fffffff ? 0 : dmin - 1) & ~1;
+          if (t_switch > steps) t_switch = steps & ~1;
+        }
+      int t = 0;
+      qrt = qrt_i_pk; rt = pack16(P.rt_i);
+      for (; t < t_switch; t += 2)
+        {
+          step(t, hprev, hnext, std::true_type {});
+          step(t + 1, hnext, hprev, std::true_type {});
+        }
+      for (; t < steps; t += 2)
+        {
+          step(t, hprev, hnext, std::false_type {});
+          step(t + 1, hnext, hprev, std::false_type {});
         }
 
       if (s + 1 < nstrips)
