@@ -203,8 +203,11 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       // arrays over an even number of steps, so no per-step register copies remain)
       // INTERIOR (phase A of the strip, see the loops below): no lane of the wave has reached a last / padded column yet, so
       // the column penalties are the interior constants (not pipelined), H - QR is shared by E and F, no score capture.
-      auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R], auto interior_tag) __attribute__((always_inline)) {
+      u32 pendH = 0, pendF = 0;                    // row checkpoint of the even step, stored together with the odd step's
+      bool pend_on = false;
+      auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R], auto interior_tag, auto odd_tag) __attribute__((always_inline)) {
           constexpr bool INTERIOR = decltype(interior_tag)::value;
+          constexpr bool ODD = decltype(odd_tag)::value;
           if ((t & 15) == 0)
             {
               // build the feed block for columns 16k..16k+15 (lane l describes column 16k+l)
@@ -251,7 +254,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           const u32 inF = dpp_shr1(fF, outF);
 
           const int j = t - l;
-          if (lane_on && j >= 0 && j < Dpg)
+          const bool active = lane_on && j >= 0 && j < Dpg;
+          if (active)
             {
               const u32 code = sym & 0x000F000Fu;
               const int16_t * qpA = QP + (code & 0xFu) * (16 * R) + l * R;      // GENERIC only
@@ -347,8 +351,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               const size_t gt = (size_t) s * steps + t;
               if (CKPT)
                 {
-                  u32 * rp = dir + T.dir_off + ((((gt >> VSX_RB) * 64 + lane) << VSX_RB) + (gt & ((1u << VSX_RB) - 1))) * 2;
-                  *reinterpret_cast<uint2 *>(rp) = make_uint2(outH, outF);
+                  if (!ODD) { pendH = outH; pendF = outF; }             // stored by the odd step below
                   if (lastpos)
                     {
                       // last-row checkpoint: lets the traceback follow the (typically long) terminal run in query row
@@ -372,30 +375,44 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                 }
               if (l == 15 && s + 1 < nstrips) strip_outp[j] = make_uint2(outH, outF);
             }
+          if (CKPT)
+            {
+              // row checkpoints [two-step pair][lane][2] uint2: one 16-byte store per lane and pair, so a wave writes
+              // 1 KB of full lines (steps is even: a pair never straddles two strips); halves that were not active hold junk
+              // nobody reads
+              if (!ODD) pend_on = active;
+              else if (pend_on || active)
+                {
+                  const size_t pair = ((size_t) s * steps + (size_t) t) >> 1;
+                  u32 * rp = dir + T.dir_off + (pair * 64 + lane) * 4;
+                  *reinterpret_cast<uint4 *>(rp) = make_uint4(pendH, pendF, outH, outF);
+                }
+            }
           if (CKPT && (t & 15) == 15)
             {
               // column checkpoint m = t / 16 of this lane: state after its column t - l (or its border state if it has
-              // not started yet).  Layout [strip][m][lane][2R].
+              // not started yet).  Layout [strip][m][block of 4 rows: hprev blocks, then E blocks][lane][4]: every store
+              // instruction of the wave writes 1 KB of full lines (R = 1: [strip][m][lane][2]).
               const size_t rowck_dw = (((size_t) nstrips * steps + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
               const size_t nblk = ((size_t) steps + 15) >> 4;
-              u32 * cp = dir + T.dir_off + rowck_dw + (((size_t) s * nblk + (t >> 4)) * 64 + lane) * (2 * R);
+              u32 * cb = dir + T.dir_off + rowck_dw + ((size_t) s * nblk + (t >> 4)) * 64 * (2 * R);
               if (R % 4 == 0)
                 {
 #pragma unroll
                   for (int x = 0; x < R; x += 4)
                     {
-                      *reinterpret_cast<uint4 *>(cp + x) = make_uint4(hout[x], hout[x + 1], hout[x + 2], hout[x + 3]);
-                      *reinterpret_cast<uint4 *>(cp + R + x) = make_uint4(E[x], E[x + 1], E[x + 2], E[x + 3]);
+                      *reinterpret_cast<uint4 *>(cb + ((x >> 2) * 64 + lane) * 4) = make_uint4(hout[x], hout[x + 1], hout[x + 2], hout[x + 3]);
+                      *reinterpret_cast<uint4 *>(cb + (((R + x) >> 2) * 64 + lane) * 4) = make_uint4(E[x], E[x + 1], E[x + 2], E[x + 3]);
                     }
                 }
               else
                 {
+                  u32 * cp = cb + lane * (2 * R);
 #pragma unroll
                   for (int x = 0; x < R; ++x) { cp[x] = hout[x]; cp[R + x] = E[x]; }
                 }
             }
       };
-      // steps is odd (padded length + 15): the extra step finds every lane past its last column
       // Phase A: steps before ANY lane of the wave reaches column D - 1 of one of its targets (lane l works on column
       // t - l <= t): every column in flight is interior.  Needs QR_q(interior) == QR_t(interior) for the shared
       // subtraction (planner flag); the checkpoint kernels only.  Phase B: the general step for the rest.
@@ -414,13 +431,13 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       qrt = qrt_i_pk; rt = pack16(P.rt_i);
       for (; t < t_switch; t += 2)
         {
-          step(t, hprev, hnext, std::true_type {});
-          step(t + 1, hnext, hprev, std::true_type {});
+          step(t, hprev, hnext, std::true_type {}, std::false_type {});
+          step(t + 1, hnext, hprev, std::true_type {}, std::true_type {});
         }
       for (; t < steps; t += 2)
         {
-          step(t, hprev, hnext, std::false_type {});
-          step(t + 1, hnext, hprev, std::false_type {});
+          step(t, hprev, hnext, std::false_type {}, std::false_type {});
+          step(t + 1, hnext, hprev, std::false_type {}, std::true_type {});
         }
 
       if (s + 1 < nstrips)
@@ -691,6 +708,11 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   const size_t rowck_dw = rowsteps * 128;
   const u32 * __restrict__ rowck = ck + T.dir_off;
   const u32 * __restrict__ colck = ck + T.dir_off + rowck_dw;
+  // column checkpoint element x (0 .. 2R-1: hprev[R], E[R]) of pipeline lane `lanepos`, strip sp, 16-step block mb
+  auto colck_at = [&](int sp, int mb, int lanepos, int x) -> u32 {
+    const u32 * cb = colck + ((size_t) sp * nblk + (size_t) mb) * 64 * (2 * R);
+    return (R % 4 == 0) ? cb[((size_t) (x >> 2) * 64 + (size_t) lanepos) * 4 + (x & 3)] : cb[(size_t) lanepos * (2 * R) + x];
+  };
   const int g = (int) (sl >> 1);
   const bool hi = (sl & 1) != 0;
   const u32 half_sel = hi ? 0x07060302u : 0x05040100u;           // v_perm_b32(F, H, sel) = this pair's H | F << 16
@@ -772,9 +794,8 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
             }
           else
             {
-              const u32 * cp = colck + (((size_t) sA * nblk + (size_t) (m - 1)) * 64 + (size_t) (g * 16 + lA)) * (2 * R);
-              hp1 = A::in(half_lo(cp[R - 1], hi));
-              ee1 = A::in(half_lo(cp[2 * R - 1], hi));
+              hp1 = A::in(half_lo(colck_at(sA, m - 1, g * 16 + lA, R - 1), hi));
+              ee1 = A::in(half_lo(colck_at(sA, m - 1, g * 16 + lA, 2 * R - 1), hi));
             }
           stage_top(xck, 4, (long) c0 - 1, (long) ((steps >> 1) - 1));
           if (c0 == 0) tbL[64 + tid] = A::in((u32) (uint16_t) P.hleft[Q - 2]);     // corner H(Q-2, -1); its F is never used
@@ -891,9 +912,34 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         }
       else
         {
-          const u32 * cp = colck + (((size_t) s * nblk + (size_t) (m - 1)) * 64 + (size_t) (g * 16 + l)) * (2 * R);
+          if (R % 4 == 0)
+            {
+              const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * 64 * (2 * R) + (size_t) (g * 16 + l) * 4;
+              Quad hq[R / 4 ? R / 4 : 1], eq[R / 4 ? R / 4 : 1];
 #pragma unroll
-          for (int x = 0; x < R; ++x) { hp[x] = A::in(half_lo(cp[x], hi)); ee[x] = A::in(half_lo(cp[R + x], hi)); }
+              for (int b = 0; b < R / 4; ++b)
+                {
+                  hq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * 256);
+                  eq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) (R / 4 + b) * 256);
+                }
+#pragma unroll
+              for (int b = 0; b < R / 4; ++b)
+                {
+                  hp[4 * b] = A::in(half_lo(hq[b].x, hi)); hp[4 * b + 1] = A::in(half_lo(hq[b].y, hi));
+                  hp[4 * b + 2] = A::in(half_lo(hq[b].z, hi)); hp[4 * b + 3] = A::in(half_lo(hq[b].w, hi));
+                  ee[4 * b] = A::in(half_lo(eq[b].x, hi)); ee[4 * b + 1] = A::in(half_lo(eq[b].y, hi));
+                  ee[4 * b + 2] = A::in(half_lo(eq[b].z, hi)); ee[4 * b + 3] = A::in(half_lo(eq[b].w, hi));
+                }
+            }
+          else
+            {
+#pragma unroll
+              for (int x = 0; x < R; ++x)
+                {
+                  hp[x] = A::in(half_lo(colck_at(s, m - 1, g * 16 + l, x), hi));
+                  ee[x] = A::in(half_lo(colck_at(s, m - 1, g * 16 + l, R + x), hi));
+                }
+            }
         }
       {
         u32 w[(R + 3) / 4];

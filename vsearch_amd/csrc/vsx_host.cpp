@@ -663,7 +663,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
           t.tlen[s] = targets->len[ti];
           dmax = std::max(dmax, (targets->len[ti] + 3u) & ~3u);
         }
-      t.steps = dmax + 15;
+      t.steps = dmax + 16;                                // pipeline drain (15) rounded to an even step count: the DP
+                                                          // kernel stores row checkpoints two steps at a time
       const uint64_t total_lanes = (t.qlen + pt.rows - 1) / pt.rows;
       const uint64_t nstrips = (total_lanes + 15) / 16;
       const uint64_t nd = (uint64_t) (pt.rows + 3) / 4;
