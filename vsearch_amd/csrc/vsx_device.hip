@@ -73,6 +73,12 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // hands to the next pipeline position (row checkpoints, 8 B) and every 16 steps its whole column state hprev[R], E[R]
 // (column checkpoints); the traceback kernel recomputes the direction bits only for the <= R x 16 tiles the path
 // crosses.  Same bytes to HBM, ~40 % fewer VALU cycles per cell (the sign-bit funnel is gone).
+// column checkpoint of one (strip, 16-step block): [group of 8 lanes][block of 4 rows: hprev blocks, then E blocks][lane in
+// group][4] dwords -- a store instruction (one block, all lanes) writes 8 complete 128 B lines, and the 2R/4 blocks of a lane
+// (and of its neighbours in the pipeline, which the traceback visits next) sit in consecutive lines
+#define VSX_COLCK_G 64      // lanes per group.  64 = [block][lane][4]: a store instruction writes 1 KB of full lines (DP kernel 32.1 ms, traceback 7.8 ms);
+                            // 4 = one 64 B line per (quad, block): a lane's blocks and its neighbours' share L2 lines (32.8 / 7.0 ms).  Same total.
+#define VSX_COLCK_DW(R_, lane_, block_) ((((size_t) ((lane_) / VSX_COLCK_G) * (size_t) ((2 * (R_)) / 4) + (size_t) (block_)) * VSX_COLCK_G + (size_t) ((lane_) % VSX_COLCK_G)) * 4)
 #define VSX_RB 1            // row checkpoints: [2^RB-step block][lane][step in block] uint2
 template <int R, bool GENERIC, bool TRACK, bool CKPT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 16 ? 4 : 1, 8)))
@@ -391,8 +397,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           if (CKPT && (t & 15) == 15)
             {
               // column checkpoint m = t / 16 of this lane: state after its column t - l (or its border state if it has
-              // not started yet).  Layout [strip][m][block of 4 rows: hprev blocks, then E blocks][lane][4]: every store
-              // instruction of the wave writes 1 KB of full lines (R = 1: [strip][m][lane][2]).
+              // not started yet).  Layout VSX_COLCK_DW (R = 1: [strip][m][lane][2]).
               const size_t rowck_dw = (((size_t) nstrips * steps + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
               const size_t nblk = ((size_t) steps + 15) >> 4;
               u32 * cb = dir + T.dir_off + rowck_dw + ((size_t) s * nblk + (t >> 4)) * 64 * (2 * R);
@@ -401,8 +406,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
 #pragma unroll
                   for (int x = 0; x < R; x += 4)
                     {
-                      *reinterpret_cast<uint4 *>(cb + ((x >> 2) * 64 + lane) * 4) = make_uint4(hout[x], hout[x + 1], hout[x + 2], hout[x + 3]);
-                      *reinterpret_cast<uint4 *>(cb + (((R + x) >> 2) * 64 + lane) * 4) = make_uint4(E[x], E[x + 1], E[x + 2], E[x + 3]);
+                      *reinterpret_cast<uint4 *>(cb + VSX_COLCK_DW(R, lane, x >> 2)) = make_uint4(hout[x], hout[x + 1], hout[x + 2], hout[x + 3]);
+                      *reinterpret_cast<uint4 *>(cb + VSX_COLCK_DW(R, lane, (R + x) >> 2)) = make_uint4(E[x], E[x + 1], E[x + 2], E[x + 3]);
                     }
                 }
               else
@@ -711,7 +716,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   // column checkpoint element x (0 .. 2R-1: hprev[R], E[R]) of pipeline lane `lanepos`, strip sp, 16-step block mb
   auto colck_at = [&](int sp, int mb, int lanepos, int x) -> u32 {
     const u32 * cb = colck + ((size_t) sp * nblk + (size_t) mb) * 64 * (2 * R);
-    return (R % 4 == 0) ? cb[((size_t) (x >> 2) * 64 + (size_t) lanepos) * 4 + (x & 3)] : cb[(size_t) lanepos * (2 * R) + x];
+    return (R % 4 == 0) ? cb[VSX_COLCK_DW(R, lanepos, x >> 2) + (x & 3)] : cb[(size_t) lanepos * (2 * R) + x];
   };
   const int g = (int) (sl >> 1);
   const bool hi = (sl & 1) != 0;
@@ -914,13 +919,13 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         {
           if (R % 4 == 0)
             {
-              const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * 64 * (2 * R) + (size_t) (g * 16 + l) * 4;
+              const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * 64 * (2 * R) + VSX_COLCK_DW(R, g * 16 + l, 0);
               Quad hq[R / 4 ? R / 4 : 1], eq[R / 4 ? R / 4 : 1];
 #pragma unroll
               for (int b = 0; b < R / 4; ++b)
                 {
-                  hq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * 256);
-                  eq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) (R / 4 + b) * 256);
+                  hq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * (4 * VSX_COLCK_G));
+                  eq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) (R / 4 + b) * (4 * VSX_COLCK_G));
                 }
 #pragma unroll
               for (int b = 0; b < R / 4; ++b)
