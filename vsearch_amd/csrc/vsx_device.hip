@@ -73,9 +73,8 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // hands to the next pipeline position (row checkpoints, 8 B) and every 16 steps its whole column state hprev[R], E[R]
 // (column checkpoints); the traceback kernel recomputes the direction bits only for the <= R x 16 tiles the path
 // crosses.  Same bytes to HBM, ~40 % fewer VALU cycles per cell (the sign-bit funnel is gone).
-// column checkpoint of one (strip, 16-step block): [group of 8 lanes][block of 4 rows: hprev blocks, then E blocks][lane in
-// group][4] dwords -- a store instruction (one block, all lanes) writes 8 complete 128 B lines, and the 2R/4 blocks of a lane
-// (and of its neighbours in the pipeline, which the traceback visits next) sit in consecutive lines
+// column checkpoint of one (strip, 16-step block): [group of G lanes][block of 4 rows: hprev blocks, then E blocks][lane in
+// group][4] dwords -- a store instruction (one block, all lanes) writes G x 16 B runs of complete lines
 #define VSX_COLCK_G 64      // lanes per group.  64 = [block][lane][4]: a store instruction writes 1 KB of full lines (DP kernel 32.1 ms, traceback 7.8 ms);
                             // 4 = one 64 B line per (quad, block): a lane's blocks and its neighbours' share L2 lines (32.8 / 7.0 ms).  Same total.
 #define VSX_COLCK_DW(R_, lane_, block_) ((((size_t) ((lane_) / VSX_COLCK_G) * (size_t) ((2 * (R_)) / 4) + (size_t) (block_)) * VSX_COLCK_G + (size_t) ((lane_) % VSX_COLCK_G)) * 4)
