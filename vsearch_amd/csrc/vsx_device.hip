@@ -210,6 +210,13 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       // the column penalties are the interior constants (not pipelined), H - QR is shared by E and F, no score capture.
       u32 pendH = 0, pendF = 0;                    // row checkpoint of the even step, stored together with the odd step's
       bool pend_on = false;
+      // per-lane base addresses of this strip's checkpoint regions (computed once: the step only adds a uniform offset)
+      const size_t ck_rowdw = (((size_t) nstrips * steps + 1) & ~(size_t) 1) * 128;
+      const size_t ck_nblk = ((size_t) steps + 15) >> 4;
+      u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps) >> 1) * 64 + lane) * 4;                    // + (t >> 1) * 256
+      u32 * const cck_base = dir + T.dir_off + ck_rowdw + (size_t) s * ck_nblk * 64 * (2 * R);                    // + (t >> 4) * 128 R
+      u32 * const xck_lane = dir + T.dir_off + ck_rowdw + (size_t) nstrips * ck_nblk * 64 * (2 * R) +
+                             ((size_t) g * steps) * 2 - (size_t) l * 2;                                           // + t * 2
       auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R], auto interior_tag, auto odd_tag) __attribute__((always_inline)) {
           constexpr bool INTERIOR = decltype(interior_tag)::value;
           constexpr bool ODD = decltype(odd_tag)::value;
@@ -361,10 +368,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                     {
                       // last-row checkpoint: lets the traceback follow the (typically long) terminal run in query row
                       // Q-1 with one-row recomputes.  [group][column] uint2, after the column checkpoints.
-                      const size_t rowck_dw = (((size_t) nstrips * steps + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
-                      const size_t nblk = ((size_t) steps + 15) >> 4;
-                      u32 * xp = dir + T.dir_off + rowck_dw + (size_t) nstrips * nblk * 64 * (2 * R) + ((size_t) g * steps + (size_t) j) * 2;
-                      *reinterpret_cast<uint2 *>(xp) = make_uint2(xH, xF);
+                      *reinterpret_cast<uint2 *>(xck_lane + (size_t) t * 2) = make_uint2(xH, xF);
                     }
                 }
               else
@@ -388,18 +392,14 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               if (!ODD) pend_on = active;
               else if (pend_on || active)
                 {
-                  const size_t pair = ((size_t) s * steps + (size_t) t) >> 1;
-                  u32 * rp = dir + T.dir_off + (pair * 64 + lane) * 4;
-                  *reinterpret_cast<uint4 *>(rp) = make_uint4(pendH, pendF, outH, outF);
+                  *reinterpret_cast<uint4 *>(rck_base + (size_t) (t >> 1) * 256) = make_uint4(pendH, pendF, outH, outF);
                 }
             }
           if (CKPT && (t & 15) == 15)
             {
               // column checkpoint m = t / 16 of this lane: state after its column t - l (or its border state if it has
               // not started yet).  Layout VSX_COLCK_DW (R = 1: [strip][m][lane][2]).
-              const size_t rowck_dw = (((size_t) nstrips * steps + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
-              const size_t nblk = ((size_t) steps + 15) >> 4;
-              u32 * cb = dir + T.dir_off + rowck_dw + ((size_t) s * nblk + (t >> 4)) * 64 * (2 * R);
+              u32 * cb = cck_base + (size_t) (t >> 4) * 64 * (2 * R);
               if (R % 4 == 0)
                 {
 #pragma unroll
