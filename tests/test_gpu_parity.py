@@ -219,3 +219,23 @@ def test_device_filter_matches_restatement(gpu_required, flt):
         else:
             assert got.row(k) == plain.row(k)
     assert len(seen) >= 2, seen
+
+
+@pytest.mark.gpu
+def test_long_targets_leave_column_beyond_int16(gpu_required):
+    """targets longer than 32767: the last-row run (right-terminal gap) starts beyond the int16 range of a column index"""
+    from oracle import pyoracle
+    from vsearch_amd import Aligner
+    rng = random.Random(31337)
+    orc = pyoracle.Oracle()
+    qs, ts = [], []
+    for pos in (35000, 60000, 100, 40000):
+        q = common.rnd_seq(rng, 90)
+        t = common.rnd_seq(rng, pos) + common.mutate(rng, q, 0.03) + common.rnd_seq(rng, rng.randint(0, 4000))
+        qs.append(q)
+        ts.append(t[:65000])
+    idx = np.arange(len(qs), dtype=np.uint32)
+    with Aligner() as al:
+        res = al.align_pairs(al.sequences(qs), al.sequences(ts), idx, idx)
+    for k in range(len(qs)):
+        assert res.row(k) == orc.align(qs[k], ts[k]), k

@@ -126,6 +126,10 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   const u32 qrt_i_pk = pack16(P.qrt_i);
   u32 hmin = 0, hmax = 0;      // running min(0, H...) / max(0, H...) of align_simd.cpp:810-811,772-773
   u32 score = 0;
+  // Where the traceback leaves the last query row (backtrack16 :1161-1210 restricted to that row): coming from the right in an
+  // 'I' run it continues through column j iff ext-left(j) or left(j); lv1 = column of the first cell (scanning left) where it
+  // does not, carried along the row: lv1(j) = cont(j) ? lv1(j-1) : j.  At column D-1 (no run yet) only left(j) counts.
+  u32 lv1 = 0xFFFFFFFFu, leave = 0;
 
   for (int s = 0; s < nstrips; ++s)
     {
@@ -215,8 +219,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       const size_t ck_nblk = ((size_t) steps + 15) >> 4;
       u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps) >> 1) * 64 + lane) * 4;                    // + (t >> 1) * 256
       u32 * const cck_base = dir + T.dir_off + ck_rowdw + (size_t) s * ck_nblk * 64 * (2 * R);                    // + (t >> 4) * 128 R
-      u32 * const xck_lane = dir + T.dir_off + ck_rowdw + (size_t) nstrips * ck_nblk * 64 * (2 * R) +
-                             ((size_t) g * steps) * 2 - (size_t) l * 2;                                           // + t * 2
+
       auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R], auto interior_tag, auto odd_tag) __attribute__((always_inline)) {
           constexpr bool INTERIOR = decltype(interior_tag)::value;
           constexpr bool ODD = decltype(odd_tag)::value;
@@ -277,9 +280,9 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               u32 F = inF;
               u32 smn = 0x7FFF7FFFu, smx = 0x80008000u;
               u32 acc = 0, h2 = 0;
-              u32 xH = inH, xF = inF;                           // (H, F) entering row R-1 (R == 1: the lane's own inputs)
               u32 capH = 0, capF = 0, capmn = 0, capmx = 0;    // position 0: state after its last real row
               u32 dw[ND];
+              u32 lastL = 0, lastEL = 0;
               // SHARED: the interior query-row and target-column gap penalties coincide (planner flag P.share_sub) and no
               // lane of the wave is in a last / padded column this step, so H - QR is the same number for E and for F in
               // every row but R-1: 9 instead of 10 instructions per lane-row.
@@ -319,6 +322,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   const u32 hf = (SHARED && r < R - 1) ? he : ssub(h2, qrt);
                   const u32 f = ssub(F, rt);
                   const u32 e = ssub(E[r], rq);
+                  if (CKPT && r == R - 1) { lastL = ssub(h1, E[r]); lastEL = ssub(he, e); }     // the last row's left / ext-left diffs
                   if (!CKPT)
                     {
                       const u32 dU = ssub(h0, F);          // sign <=> F > H      (up)
@@ -330,7 +334,6 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                     }
                   F = pmax(f, hf);
                   E[r] = pmax(e, he);
-                  if (CKPT && r == R - 2) { xH = h2; xF = F; }
                   // position 0 holds only rcnt0 rows: its later rows compute junk that never leaves the lane
                   if (!TOPPAD && __builtin_expect(rc0 == r + 1, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
                 }
@@ -344,6 +347,16 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               outH = hl;
               outF = F;
               diag = inH;
+              if (CKPT)
+                {
+                  const u32 jpk = (u32) j | ((u32) j << 16);
+                  if (!INTERIOR)
+                    {
+                      const u32 atlast = a_pk_ashr15(sym << 7);               // bit 8 (column == D-1)
+                      leave = a_bfi_v(atlast, a_bfi_v(a_pk_ashr15(lastL), lv1, jpk), leave);
+                    }
+                  lv1 = a_bfi_v(a_pk_ashr15(lastL | lastEL), lv1, jpk);
+                }
 
               // per-block h_min/h_max tracking incl. padded columns (:772-773, :1774-1786), gated per half
               if (TRACK)
@@ -364,12 +377,6 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               if (CKPT)
                 {
                   if (!ODD) { pendH = outH; pendF = outF; }             // stored by the odd step below
-                  if (lastpos)
-                    {
-                      // last-row checkpoint: lets the traceback follow the (typically long) terminal run in query row
-                      // Q-1 with one-row recomputes.  [group][column] uint2, after the column checkpoints.
-                      *reinterpret_cast<uint2 *>(xck_lane + (size_t) t * 2) = make_uint2(xH, xF);
-                    }
                 }
               else
                 {
@@ -461,6 +468,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
     }
   const int l_last = (total_lanes - 1) & 15;
   score = (u32) __shfl((int) score, l_last, 16);
+  leave = (u32) __shfl((int) leave, l_last, 16);
   if (l == 0)
     {
       const int mnA = (int16_t) (hmin & 0xffff), mnB = (int16_t) (hmin >> 16);
@@ -468,6 +476,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       VsxSlotOut oA, oB;
       oA.score = (int16_t) (score & 0xffff);
       oB.score = (int16_t) (score >> 16);
+      oA.leave = (uint16_t) (leave & 0xffff); oB.leave = (uint16_t) (leave >> 16); oA.pad = 0; oB.pad = 0;
       oA.overflow = (mnA <= P.smin || mxA >= 32767) ? 1 : 0;     // :1774-1786
       oB.overflow = (mnB <= P.smin || mxB >= 32767) ? 1 : 0;
       slot_out[(size_t) blockIdx.x * VSX_TASK_SLOTS + 2 * g] = oA;
@@ -770,80 +779,18 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   };
   auto push = [&](int newop) { push_n(newop, 1u); };
 
-  // ---- phase A: the run along the LAST query row (right-terminal gap when the target is longer than the query).
-  // One-row recomputes from the last-row checkpoints; a lane leaves the phase at the first cell whose move is not 'I'
-  // (that cell is decided again, identically, by the general loop below).  Keeps the lanes of a wave in phase.
-  if (R > 1)
+  // ---- the run of 'I' moves along the LAST query row (right-terminal gap when the target is longer than the query): the DP
+  // kernel already found where it ends (VsxSlotOut::leave), so it is one CIGAR run here.  Within the run op stays 1, hence
+  // exactly one gap is opened (backtrack16 :1161-1210).  All lanes of a wave enter the tile loop in the same phase.
+  if (live)
     {
-      const u32 * __restrict__ xck = colck + (size_t) nstrips * nblk * 64 * (2 * R) + (size_t) g * steps * 2;
-      const int lastL = total_lanes - 1;
-      const int sA = lastL >> 4, lA = lastL & 15;
-      const u32 qlast = live ? ((u32) q[Q - 1] & 15u) : 0u;
-      const u32 pen_qrq = FAST ? (P.qrq_r_pk & 0xffffu) : P.qrq_r_pk;
-      const u32 pen_rq = FAST ? (P.rq_r_pk & 0xffffu) : P.rq_r_pk;
-      bool inA = live;
-      for (;;)
+      const int lv = (so.leave == 0xFFFFu) ? -1 : (int) so.leave;
+      if (lv < D - 1)
         {
-          if (!__any(inA)) break;
-          const int jj = inA ? j : 0;
-          const int m = (jj + lA) >> 4;
-          int c0 = 16 * m - lA;
-          if (c0 < 0) c0 = 0;
-          const int cmax = __builtin_amdgcn_readfirstlane(wave_max_i32(inA ? jj - c0 : 0));
-          u32 hp1, ee1;
-          if (m == 0)
-            {
-              hp1 = A::in((u32) (uint16_t) P.hleft[Q - 1]);
-              ee1 = A::sub(hp1, pen_qrq);
-            }
-          else
-            {
-              hp1 = A::in(half_lo(colck_at(sA, m - 1, g * 16 + lA, R - 1), hi));
-              ee1 = A::in(half_lo(colck_at(sA, m - 1, g * 16 + lA, 2 * R - 1), hi));
-            }
-          stage_top(xck, 4, (long) c0 - 1, (long) ((steps >> 1) - 1));
-          if (c0 == 0) tbL[64 + tid] = A::in((u32) (uint16_t) P.hleft[Q - 2]);     // corner H(Q-2, -1); its F is never used
-          stage_symbols(c0);
-          u32 diag = tbL[64 + tid] & 0xffffu;
-          u32 nib[2] = {0u, 0u};                                 // 16 columns x 4 bits
-          for (int cc = 0; cc <= cmax; ++cc)
-            {
-              const int c = c0 + cc;
-              const u32 qrt = (c < D - 1) ? qrt_i16 : qrt_r16;
-              const u32 rt = (c < D - 1) ? rt_i16 : rt_r16;
-              const u32 tbv = tbL[(cc + 2) * 64 + tid];
-              const u32 topH = tbv & 0xffffu;
-              u32 F = tbv >> 16;
-              const u32 V = A::score(Ssh[(u32) symL[cc * 64 + tid] * 32u + qlast]);
-              const u32 h0 = A::add(diag, V);
-              const u32 up = A::neg(A::dif(h0, F));
-              const u32 h1 = A::max(h0, F);
-              const u32 left = A::neg(A::dif(h1, ee1));
-              const u32 h2 = A::max(h1, ee1);
-              hp1 = h2;
-              const u32 hf = A::sub(h2, qrt), f = A::sub(F, rt);
-              const u32 eu = A::neg(A::dif(hf, f));
-              const u32 he = A::sub(h2, pen_qrq), e = A::sub(ee1, pen_rq);
-              const u32 el = A::neg(A::dif(he, e));
-              ee1 = A::max(e, he);
-              const u32 n4 = (up | (left << 1) | (eu << 2) | (el << 3)) << (4 * (cc & 7));
-              if (cc < 8) nib[0] |= n4; else nib[1] |= n4;
-              diag = topH;
-            }
-          if (inA)
-            {
-              while (j >= c0)
-                {
-                  const int cw = j - c0;
-                  const u32 bts = ((cw < 8 ? nib[0] : nib[1]) >> (4 * (cw & 7))) & 15u;
-                  const bool goI = (op == 1 && (bts & 8u)) || (!(op == 2 && (bts & 4u)) && (bts & 2u));
-                  if (!goI) { inA = false; break; }
-                  ++al;
-                  if (!(op == 1 && (bts & 8u)) && op != 1) ++ga;
-                  --j; push(1);
-                }
-              if (j < 0) inA = false;
-            }
+          const u32 n = (u32) (D - 1 - lv);
+          al += n; ++ga;
+          push_n(1, n);
+          j = lv;
         }
     }
 
@@ -1292,5 +1239,5 @@ extern "C" uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t r
 {
   const uint64_t rowck = (((nstrips * steps) + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
   const uint64_t nblk = (steps + 15) >> 4;
-  return rowck + nstrips * nblk * 64 * 2 * rows + 4 * steps * 2;
+  return rowck + nstrips * nblk * 64 * 2 * rows;
 }

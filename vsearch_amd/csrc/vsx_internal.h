@@ -57,6 +57,9 @@ struct VsxFilterDev {
 struct VsxSlotOut {
   int16_t  score;
   uint16_t overflow;      // 1 = the reference's 16-bit overflow rule fired -> sentinel
+  uint16_t leave;         // checkpoint kernels: the column where the traceback leaves the last query row (the run of 'I'
+                          // moves from (Q-1, D-1) ends there; 0xFFFF = it runs off the left edge); D-1 = no such run
+  uint16_t pad;
 };
 
 // Per pair output of the traceback kernel.
