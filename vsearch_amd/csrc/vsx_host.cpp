@@ -499,6 +499,8 @@ static bool no_overflow_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
 
 static int pick_rows(int Q)
 {
+  static const int forced = std::getenv("VSX_ROWS") ? std::atoi(std::getenv("VSX_ROWS")) : 0;      // A/B experiments: rows per lane
+  if (forced > 0 && Q >= forced) return forced;
   int cnt = 0;
   const int * rows = vsx_supported_rows(&cnt);
   int idx = cnt - 1;
