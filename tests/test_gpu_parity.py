@@ -239,3 +239,38 @@ def test_long_targets_leave_column_beyond_int16(gpu_required):
         res = al.align_pairs(al.sequences(qs), al.sequences(ts), idx, idx)
     for k in range(len(qs)):
         assert res.row(k) == orc.align(qs[k], ts[k]), k
+
+
+@pytest.mark.gpu
+def test_baseline_shape_vs_the_reference_itself(gpu_required):
+    """2 500 queries x 8 family candidates of the BASELINE shape (250 bp vs ~1 kbp): every field incl. the CIGAR against the
+    reference's own SSE2 search16 (oracle/_ref/libvsref.so, the reference sources compiled in place)"""
+    from oracle import pyoracle
+    if not pyoracle.have_ref():
+        pytest.fail("oracle/_ref/libvsref.so missing: run `make -C oracle ref` in the build container")
+    from vsearch_amd import Aligner
+    rng = random.Random(20260924)
+    db, fam = common.family_db(rng, 40, 12, 1000, div=0.08)
+    qs, src = common.queries_from_db(rng, db, 2500, 250)
+    qi, ti = [], []
+    for k, s in enumerate(src):
+        base = (s // 12) * 12
+        for t in rng.sample(range(base, base + 12), 8):
+            qi.append(k)
+            ti.append(t)
+    qi = np.array(qi, np.uint32)
+    ti = np.array(ti, np.uint32)
+    with Aligner() as al:
+        res = al.align_pairs(al.sequences(qs), al.sequences(db), qi, ti)
+    ref = pyoracle.Reference()
+    try:
+        bad = 0
+        for k in range(len(qs)):
+            rows = ref.search16(qs[k], [db[t] for t in ti[8 * k:8 * k + 8]])
+            for x, r in enumerate(rows):
+                if tuple(r) != res.row(8 * k + x):
+                    bad += 1
+                    assert bad < 3, (k, x, tuple(r), res.row(8 * k + x))
+        assert bad == 0
+    finally:
+        ref.close()
