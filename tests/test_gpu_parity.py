@@ -274,3 +274,33 @@ def test_baseline_shape_vs_the_reference_itself(gpu_required):
         assert bad == 0
     finally:
         ref.close()
+
+
+@pytest.mark.gpu
+def test_chunked_plan_equals_single_chunk(gpu_required, oracle):
+    """a checkpoint budget far below the job's needs cuts the plan into many chunks (one buffer, reused chunk after chunk);
+    several kernel classes (rows per lane, overflow tracking) are present: results must not depend on the chunking"""
+    from vsearch_amd import Aligner
+    rng = random.Random(777)
+    qs, ts = [], []
+    for n, (ql, dl) in enumerate([(60, 200), (250, 900), (400, 400), (700, 1500), (150, 300)] * 30):
+        a = common.rnd_seq(rng, ql)
+        b = common.rnd_seq(rng, rng.randint(0, dl // 2)) + common.mutate(rng, a, 0.06) + common.rnd_seq(rng, rng.randint(0, dl // 2))
+        qs.append(a)
+        ts.append(b)
+    qs.append(common.rnd_seq(rng, 3000))
+    ts.append(common.rnd_seq(rng, 3000) + qs[-1][:500])                 # two strips, overflow-tracked class
+    idx = np.arange(len(qs), dtype=np.uint32)
+    with Aligner() as al:
+        Q, T = al.sequences(qs), al.sequences(ts)
+        whole = al.align_pairs(Q, T, idx, idx)
+        p = al.plan(Q, T, idx, idx, dir_budget_bytes=1 << 20)
+        p.run()
+        parts = p.fetch()
+        p.run()                                                        # a second run of the same plan reuses the buffer again
+        again = p.fetch()
+        p.close()
+    for k in range(len(qs)):
+        assert parts.row(k) == whole.row(k) == again.row(k), k
+    for k in range(0, len(qs), 7):
+        assert whole.row(k) == oracle.align(qs[k], ts[k]), k
