@@ -134,3 +134,21 @@ def test_uchime_ref_through_the_shim(binaries, tmp_path):
                  "--chimeras", os.path.join(out, "chim.fa"), "--nonchimeras", os.path.join(out, "non.fa")],
                 ["uchime.tsv", "alns.txt", "chim.fa", "non.fa"])
     _check(_run_both(str(tmp_path), args))
+
+
+def test_four_reference_threads_share_the_gpu(binaries, tmp_path):
+    """--threads 4: four s16info_s contexts (one per reference worker thread, searchcore.hpp:151) drive the same GPU at once;
+    the hits are the single-threaded CLI's (line order depends on thread timing, so lines are compared sorted)"""
+    db, qs = _inputs(97)
+    _fasta(tmp_path / "db.fa", db, "t")
+    _fasta(tmp_path / "q.fa", qs * 3, "q")
+    out = {}
+    for tag, exe, threads in (("ref", REF_BIN, "1"), ("vsx", VSX_BIN, "4")):
+        uf = str(tmp_path / f"{tag}.tsv")
+        p = subprocess.run([exe, "--usearch_global", str(tmp_path / "q.fa"), "--db", str(tmp_path / "db.fa"), "--qmask", "none",
+                            "--dbmask", "none", "--threads", threads, "--id", "0.8", "--maxaccepts", "2", "--userout", uf,
+                            "--userfields", FIELDS, "--quiet"], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (tag, p.stderr[-2000:])
+        out[tag] = sorted(open(uf).read().splitlines())
+    assert len(out["ref"]) > 100
+    assert out["ref"] == out["vsx"]
