@@ -104,7 +104,9 @@ def main():
     al = Aligner(device=local_rank)
     T = SequenceSet(al, blob=db_ascii.numel(), offsets=db_off, lengths=db_len, device_ptr=db_ascii.data_ptr())
     Q = SequenceSet(al, blob=q_ascii.numel(), offsets=q_off, lengths=q_len, device_ptr=q_ascii.data_ptr())
+    t0 = time.time()
     plan = al.plan(Q, T, qidx, tidx, dir_budget_bytes=int(a.dir_budget_gb * (1 << 30)))
+    t_plan = time.time() - t0             # host: pairs -> wavefront tasks, task upload, checkpoint buffer (one-time hipMalloc)
     n_pairs = len(qidx)
     cells = int((q_len[qidx].astype(np.int64) * db_len[tidx].astype(np.int64)).sum())
     hits = torch.empty(n_pairs * 24, dtype=torch.uint8, device=dev)
@@ -199,6 +201,7 @@ def main():
             "hbm_algorithmic_GBps": round(tm.dir_bytes / max(1, tm.forward_launches) / (fwd_avg_ms * 1e-3) / 1e9, 1),
         },
         "kernel_split_ms_per_step": {"forward": round(fwd_ms / a.steps, 3), "traceback": round(tb_ms / a.steps, 3)},
+        "plan_s": round(t_plan, 3),
         "fetch_s": round(t_fetch, 3),
         "value_incl_fetch": round(cells / (ms_per_step * 1e-3 + t_fetch) / 1e9, 2),
         "gen_s": round(t_gen, 2),
