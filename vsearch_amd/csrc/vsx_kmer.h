@@ -7,7 +7,13 @@
 #include <vector>
 #include "../../include/vsx.h"
 
-struct VsxKmerRec { uint32_t query, target, count, pad; };     // one candidate: count >= the query's minmatches
+// candidates of a counting batch, grouped by query: query q owns rec[off[q] .. off[q] + cnt[q]), each (target, count) packed
+// as target | (uint64_t) count << 32; order inside a query arbitrary
+struct VsxKmerResult {
+  std::vector<uint64_t> rec;
+  std::vector<uint64_t> off;
+  std::vector<uint32_t> cnt;
+};
 struct VsxKmerIndex;
 
 struct VsxKmerStats {
@@ -27,11 +33,11 @@ int vsx_kmer_index_create_empty(vsx_ctx * ctx, const vsx_seqset * db, int w, Vsx
 int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_list);
 void vsx_kmer_index_destroy(VsxKmerIndex * ix);
 // qk_start[nq + 1] / qk[]: each query's unique words; minmatch[q] = threshold, 0xffffffff = skip the query.
-// recs: (query, target, count) with count >= minmatch[query], unordered.
+// out: per query the (target, count) records with count >= minmatch[query] that survive the device selection.
 // keep = size of the reference's heap (tophits): per query the device keeps every record whose count is >= the
 // keep-th largest count (a superset of the heap under any tie-break); the caller applies the total order.
 int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_start, const uint32_t * qk,
-                         const uint32_t * minmatch, uint32_t keep, std::vector<VsxKmerRec> & recs, uint32_t cap_hint = 0);
+                         const uint32_t * minmatch, uint32_t keep, VsxKmerResult & out, uint32_t cap_hint = 0);
 const VsxKmerStats * vsx_kmer_stats(const VsxKmerIndex * ix);
 
 #endif

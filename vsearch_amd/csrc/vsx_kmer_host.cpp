@@ -179,7 +179,7 @@ namespace {
 
 // one counting + selection pass over `nslots` query slots (slot -> query through qlist, or identity); appends to recs
 int count_pass(VsxKmerIndex * ix, uint32_t nslots, const uint32_t * d_qlist, const std::vector<uint32_t> * h_qlist, uint32_t cap,
-               uint32_t keep, std::vector<VsxKmerRec> & recs, std::vector<uint32_t> & overflow, uint32_t & overflow_max, float & ms_total)
+               uint32_t keep, VsxKmerResult & out, std::vector<uint32_t> & overflow, uint32_t & overflow_max, float & ms_total)
 {
   KCHK(ix->d_rec.ensure((size_t) nslots * cap));
   KCHK(ix->d_qcount.ensure(nslots));
@@ -208,33 +208,32 @@ int count_pass(VsxKmerIndex * ix, uint32_t nslots, const uint32_t * d_qlist, con
   KCHK(hipEventElapsedTime(&ms, ix->e0, ix->e1));
   ms_total += ms;
   std::vector<uint64_t> mn(nslots), off(nslots);
-  std::vector<uint64_t> dense(produced);
   KCHK(hipMemcpy(mn.data(), ix->d_sel_mn.p, (size_t) nslots * 8, hipMemcpyDeviceToHost));
   KCHK(hipMemcpy(off.data(), ix->d_sel_off.p, (size_t) nslots * 8, hipMemcpyDeviceToHost));
-  if (produced) KCHK(hipMemcpy(dense.data(), ix->d_dense.p, produced * 8, hipMemcpyDeviceToHost));
-  const size_t before = recs.size();
-  recs.reserve(before + produced);
+  // the dense buffer is already grouped by slot: append it wholesale and record each query's range
+  const size_t before = out.rec.size();
+  out.rec.resize(before + produced);
+  if (produced) KCHK(hipMemcpy(out.rec.data() + before, ix->d_dense.p, produced * 8, hipMemcpyDeviceToHost));
   for (uint32_t s = 0; s < nslots; ++s)
     {
       const uint32_t m = (uint32_t) (mn[s] & 0xffffffffu), n = (uint32_t) (mn[s] >> 32);
       const uint32_t q = h_qlist ? (*h_qlist)[s] : s;
-      if (m == 0xffffffffu) { overflow.push_back(q); overflow_max = std::max(overflow_max, n); continue; }
-      for (uint32_t x = 0; x < m; ++x)
-        {
-          const uint64_t w = dense[off[s] + x];                        // uint2 (target, count), little endian
-          recs.push_back(VsxKmerRec {q, (uint32_t) (w & 0xffffffffu), (uint32_t) (w >> 32), 0});
-        }
+      if (m == 0xffffffffu) { overflow.push_back(q); overflow_max = std::max(overflow_max, n); out.cnt[q] = 0; continue; }
+      out.off[q] = before + off[s];
+      out.cnt[q] = m;
     }
-  ix->stats.records += recs.size() - before;
+  ix->stats.records += produced;
   return VSX_OK;
 }
 
 }  // namespace
 
 int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_start, const uint32_t * qk,
-                         const uint32_t * minmatch, uint32_t keep, std::vector<VsxKmerRec> & recs, uint32_t cap_hint)
+                         const uint32_t * minmatch, uint32_t keep, VsxKmerResult & out, uint32_t cap_hint)
 {
-  recs.clear();
+  out.rec.clear();
+  out.off.assign(nq, 0);
+  out.cnt.assign(nq, 0);
   if (!ix || (nq && (!qk_start || !minmatch))) { vsx_internal_set_error("vsx_kmer_count_batch: null argument"); return VSX_EINVAL; }
   if (nq == 0 || ix->nseq == 0) return VSX_OK;
   if (nq >= (1ull << 22)) { vsx_internal_set_error("vsx_kmer_count_batch: at most 4 M queries per batch"); return VSX_EINVAL; }
@@ -259,7 +258,7 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
   // words (chance runs of shared 11..13-mers), so 8 192 x 8 B = 64 KB per query; HBM is plentiful (100 k queries = 6.5 GB)
   uint32_t cap = cap_hint ? cap_hint : (nq <= (1u << 18) ? 8192 : 2048);
   if (const char * c = std::getenv("VSX_KMER_CAP")) cap = (uint32_t) std::max(1, std::atoi(c));      // tests: force the second pass
-  int rc = count_pass(ix, (uint32_t) nq, nullptr, nullptr, cap, keep, recs, overflow, overflow_max, ms);
+  int rc = count_pass(ix, (uint32_t) nq, nullptr, nullptr, cap, keep, out, overflow, overflow_max, ms);
   if (rc != VSX_OK) return rc;
   if (std::getenv("VSX_KMER_DEBUG")) std::fprintf(stderr, "kmer: %zu of %llu queries overflowed cap %u (max %u records), %.1f ms\n", overflow.size(), (unsigned long long) nq, cap, overflow_max, ms);
   if (!overflow.empty())
@@ -272,7 +271,7 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
       std::vector<uint32_t> again;
       uint32_t again_max = 0;
       const std::vector<uint32_t> list = overflow;
-      rc = count_pass(ix, (uint32_t) list.size(), d_qlist.p, &list, overflow_max, keep, recs, again, again_max, ms);
+      rc = count_pass(ix, (uint32_t) list.size(), d_qlist.p, &list, overflow_max, keep, out, again, again_max, ms);
       if (rc != VSX_OK) return rc;
       if (!again.empty()) { vsx_internal_set_error("vsx_kmer_count_batch: record region overflow in the second pass"); return VSX_EHIP; }
     }

@@ -485,7 +485,7 @@ static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out)
   return VSX_OK;
 }
 
-struct Acct { double t_align = 0; uint64_t pairs = 0, cells = 0, stages = 0, sentinels = 0; };
+struct Acct { double t_align = 0, t_advance = 0, t_replay = 0; uint64_t pairs = 0, cells = 0, stages = 0, sentinels = 0; };
 
 // The staged search of a window: every open query contributes its next align_delayed batch, all batches go to the
 // GPU as one plan, then the reference's bookkeeping (:782-878) is replayed per query.  qseq/qlen/qidx map a window
@@ -502,8 +502,37 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
     {
       pq.clear(); pt.clear();
       std::vector<uint32_t> waiting;
-      for (uint32_t k : open)
-        if (advance(S, st[k], qseq(k), qlen(k), qidx(k), pq, pt)) waiting.push_back(k);
+      const double ta = now_s();
+      {
+        // every open query up to its next align_delayed batch: contiguous slices of `open` on host threads, concatenated
+        // in order (the pair list, and with it every result, is independent of the thread count)
+        const int nth = (int) std::max<size_t>(1, std::min<size_t>((size_t) std::max(1, S.threads), open.size() / 512));
+        struct Part { std::vector<uint32_t> pq, pt, waiting; };
+        std::vector<Part> part((size_t) nth);
+        auto work = [&](int t) {
+          Part & p = part[(size_t) t];
+          const size_t b = open.size() * (size_t) t / (size_t) nth, e = open.size() * (size_t) (t + 1) / (size_t) nth;
+          for (size_t w = b; w < e; ++w)
+            {
+              const uint32_t k = open[w];
+              if (advance(S, st[k], qseq(k), qlen(k), qidx(k), p.pq, p.pt)) p.waiting.push_back(k);     // req_first: slice-relative
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto & th : pool) th.join();
+        for (int t = 0; t < nth; ++t)
+          {
+            Part & p = part[(size_t) t];
+            const uint64_t base = pq.size();
+            for (uint32_t k : p.waiting) st[k].req_first += base;
+            pq.insert(pq.end(), p.pq.begin(), p.pq.end());
+            pt.insert(pt.end(), p.pt.begin(), p.pt.end());
+            waiting.insert(waiting.end(), p.waiting.begin(), p.waiting.end());
+          }
+      }
+      acct.t_advance += now_s() - ta;
       if (waiting.empty()) break;
       ++acct.stages;
       const double t0 = now_s();
@@ -514,37 +543,70 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
       acct.t_align += now_s() - t0;
       if (rc != VSX_OK) return rc;
       acct.pairs += pq.size();
-      for (uint32_t k : waiting)
-        {
-          QState & q = st[k];
-          const int64_t ql = qlen(k);
-          uint64_t i = q.req_first;
-          for (size_t x = (size_t) q.finalized; x < q.hits.size(); ++x)
+      // the reference's bookkeeping per query (:782-878), host threads over the queries of the stage
+      const double tr = now_s();
+      {
+        const int nth = (int) std::max<size_t>(1, std::min<size_t>((size_t) std::max(1, S.threads), waiting.size() / 256));
+        std::vector<Acct> part((size_t) nth);
+        std::vector<int> err((size_t) nth, VSX_OK);
+        std::atomic<size_t> next {0};
+        auto work = [&](int tid) {
+          Acct & a = part[(size_t) tid];
+          for (;;)
             {
-              Hit & h = q.hits[x];
-              const bool live = (q.rejects < S.mr) && (q.accepts < S.ma);
-              if (h.rejected) { if (live) ++q.rejects; continue; }
-              const uint64_t r = i++;
-              acct.cells += (uint64_t) ql * S.len[h.target];
-              if (!live) continue;                                   // ignored hit: stays unaligned (:785, :875-878)
-              const uint8_t verdict = res.verdict ? res.verdict[r] : (uint8_t) VSX_VERDICT_UNDECIDED;
-              if (verdict == VSX_VERDICT_REJECTED)
+              const size_t b = next.fetch_add(64);
+              if (b >= waiting.size()) break;
+              const size_t e = std::min(waiting.size(), b + 64);
+              for (size_t w = b; w < e; ++w)
                 {
-                  // decided on the device (align_trim + search_acceptable_aligned): not reported, no CIGAR fetched
-                  h.aligned = true; h.rejected = true; h.weak = false;
-                  ++q.rejects;
-                  continue;
+                  const uint32_t k = waiting[w];
+                  QState & q = st[k];
+                  const int64_t ql = qlen(k);
+                  uint64_t i = q.req_first;
+                  for (size_t x = (size_t) q.finalized; x < q.hits.size(); ++x)
+                    {
+                      Hit & h = q.hits[x];
+                      const bool live = (q.rejects < S.mr) && (q.accepts < S.ma);
+                      if (h.rejected) { if (live) ++q.rejects; continue; }
+                      const uint64_t r = i++;
+                      a.cells += (uint64_t) ql * S.len[h.target];
+                      if (!live) continue;                                   // ignored hit: stays unaligned (:785, :875-878)
+                      const uint8_t verdict = res.verdict ? res.verdict[r] : (uint8_t) VSX_VERDICT_UNDECIDED;
+                      if (verdict == VSX_VERDICT_REJECTED)
+                        {
+                          // decided on the device (align_trim + search_acceptable_aligned): not reported, no CIGAR fetched
+                          h.aligned = true; h.rejected = true; h.weak = false;
+                          ++q.rejects;
+                          continue;
+                        }
+                      const int frc = fill_hit(S, qseq(k), ql, h, res, r, a.sentinels);
+                      if (frc != VSX_OK) { err[(size_t) tid] = frc; return; }
+                      const bool acc = acceptable_aligned(S, ql, h);
+                      if (verdict != VSX_VERDICT_UNDECIDED && (acc != (verdict == VSX_VERDICT_ACCEPTED) || (!acc && !h.weak)))
+                        { err[(size_t) tid] = VSX_EHIP; return; }
+                      if (acc) ++q.accepts; else ++q.rejects;
+                    }
+                  q.finalized = (int64_t) q.hits.size();
+                  q.delayed = 0;
                 }
-              const int frc = fill_hit(S, qseq(k), ql, h, res, r, acct.sentinels);
-              if (frc != VSX_OK) { vsx_results_free(&res); return sfail(frc, "search: fallback aligner failed"); }
-              const bool acc = acceptable_aligned(S, ql, h);
-              if (verdict != VSX_VERDICT_UNDECIDED && (acc != (verdict == VSX_VERDICT_ACCEPTED) || (!acc && !h.weak)))
-                { vsx_results_free(&res); return sfail(VSX_EHIP, "search: device and host accept filters disagree"); }
-              if (acc) ++q.accepts; else ++q.rejects;
             }
-          q.finalized = (int64_t) q.hits.size();
-          q.delayed = 0;
-        }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto & th : pool) th.join();
+        for (int t = 0; t < nth; ++t)
+          {
+            acct.cells += part[(size_t) t].cells; acct.sentinels += part[(size_t) t].sentinels;
+            if (err[(size_t) t] != VSX_OK)
+              {
+                vsx_results_free(&res);
+                return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "search: device and host accept filters disagree"
+                                                                           : "search: fallback aligner failed");
+              }
+          }
+      }
+      acct.t_replay += now_s() - tr;
       vsx_results_free(&res);
       open.swap(waiting);
     }
@@ -608,25 +670,13 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
   std::vector<uint32_t> qk(qk_start[nq]);
   for (uint64_t k = 0; k < nq; ++k)
     if (minmatch[k] != 0xffffffffu) std::copy(words[k].begin(), words[k].end(), qk.begin() + (int64_t) qk_start[k]);
-  // count on the device
-  std::vector<VsxKmerRec> recs;
-  const int rc = vsx_kmer_count_batch(ix, nq, qk_start.data(), qk.data(), minmatch.data(), keep, recs, cap_hint);
+  // count on the device; the records come back grouped by query
+  VsxKmerResult res;
+  const int rc = vsx_kmer_count_batch(ix, nq, qk_start.data(), qk.data(), minmatch.data(), keep, res, cap_hint);
   if (rc != VSX_OK) return rc;
   acct.kernel_ms += vsx_kmer_stats(ix)->count_ms;
   acct.streamed += vsx_kmer_stats(ix)->increments;
-  // bucket by query, then the heap's total order (count desc, length asc, seqno asc) and size
-  std::vector<uint64_t> first(nq + 1, 0);
-  for (const VsxKmerRec & r : recs) ++first[r.query + 1];
-  for (uint64_t k = 0; k < nq; ++k) first[k + 1] += first[k];
-  std::vector<Cand> flat(recs.size());
-  {
-    std::vector<uint64_t> fill(first.begin(), first.end() - 1);
-    for (const VsxKmerRec & r : recs)
-      {
-        const uint32_t t = map ? (*map)[r.target] : r.target;
-        flat[fill[r.query]++] = Cand {t, r.count, S->len[t]};
-      }
-  }
+  // per query: the heap's total order (count desc, length asc, seqno asc) and size
   const int nth = std::max(1, S->threads);
   std::atomic<uint64_t> next {0};
   auto work = [&]() {
@@ -636,7 +686,13 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
         if (k >= nq) break;
         if (minmatch[k] == 0xffffffffu) continue;
         std::vector<Cand> & out = cands[k];
-        out.assign(flat.begin() + (int64_t) first[k], flat.begin() + (int64_t) first[k + 1]);
+        out.resize(res.cnt[k]);
+        for (uint32_t x = 0; x < res.cnt[k]; ++x)
+          {
+            const uint64_t w = res.rec[res.off[k] + x];
+            const uint32_t t = map ? (*map)[(uint32_t) (w & 0xffffffffu)] : (uint32_t) (w & 0xffffffffu);
+            out[x] = Cand {t, (uint32_t) (w >> 32), S->len[t]};
+          }
         if (rank)
           {
             const size_t kp = std::min<size_t>(out.size(), (size_t) keep);
@@ -840,7 +896,7 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
   const double t_begin = now_s();
   const uint64_t window = S->o.window > 0 ? (uint64_t) S->o.window : 65536;
   std::vector<std::vector<Hit>> kept(nq);
-  double t_kmer = 0, t_align = 0;
+  double t_kmer = 0, t_align = 0, t_adv = 0, t_rep = 0, t_qset = 0, t_join = 0;
   uint64_t pairs = 0, cells = 0, stages = 0, sentinels = 0;
 
   const bool dev_kmer = device_kmer_ok(*S);
@@ -893,15 +949,18 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
 
       // ---- the window's sequences as a device sequence set ----
       vsx_seqset * qset = nullptr;
+      const double tq = now_s();
       {
         int rc2 = vsx_seqset_create(S->ctx, &qset, ns, wblob, (hi - mn) + rc.size(), lo.data(), ln.data());
         if (rc2 != VSX_OK) return rc2;
       }
+      t_qset += now_s() - tq;
 
       {
         Acct acct;
         const int src = run_stages(*S, st, seq_of, [&](uint64_t k) { return (int64_t) ln[k]; },
                                    [&](uint64_t k) { return (uint32_t) k; }, qset, acct);
+        t_adv += acct.t_advance; t_rep += acct.t_replay;
         t_align += acct.t_align; pairs += acct.pairs; cells += acct.cells; stages += acct.stages; sentinels += acct.sentinels;
         if (src != VSX_OK) { vsx_seqset_destroy(qset); return src; }
       }
@@ -909,6 +968,7 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
 
       // ---- search_joinhits (:1028-1052): accepted | weak of the plus strand, then of the minus strand, ordered by
       //      hit_compare_byid ----
+      const double tj = now_s();
       for (uint64_t k = 0; k < wn; ++k)
         {
           std::vector<Hit> & dst = kept[w0 + k];
@@ -917,15 +977,20 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
             for (Hit & h : st[wn + k].hits) if (h.accepted || h.weak) { h.minus = true; dst.push_back(std::move(h)); }
           std::sort(dst.begin(), dst.end(), [](const Hit & a, const Hit & b) { return hit_compare_byid(a, b) < 0; });
         }
+      t_join += now_s() - tj;
     }
 
   // ---- marshal ----
+  const double tm = now_s();
   {
     const int mrc = marshal_hits(kept, out);
     if (mrc != VSX_OK) return mrc;
   }
   out->pairs_aligned = pairs; out->cells_aligned = cells; out->stages = stages; out->sentinel_pairs = sentinels;
   out->seconds_kmer = t_kmer; out->seconds_align = t_align; out->seconds_total = now_s() - t_begin;
+  if (std::getenv("VSX_DEBUG_TIMING"))
+    std::fprintf(stderr, "vsx_search_batch: kmer %.3f qset %.3f advance %.3f align %.3f replay %.3f join %.3f marshal %.3f total %.3f s\n",
+                 t_kmer, t_qset, t_adv, t_align, t_rep, t_join, now_s() - tm, out->seconds_total);
   return VSX_OK;
 }
 
