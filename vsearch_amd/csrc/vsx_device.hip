@@ -28,6 +28,7 @@ typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 #define DEV __device__ __forceinline__
+struct __attribute__((aligned(4))) Pair2 { unsigned int x, y; };   // 8 bytes at dword alignment (ds_read2_b32)
 
 #define SIGN2 0x80008000u
 
@@ -294,14 +295,21 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   u32 V;
                   if (GENERIC)
                     {
-                      if (R % 4 == 0)
+                      if (R % 2 == 0)
                         {
-                          if ((r & 3) == 0)
+                          if ((r & 3) == 0 && r + 3 < R)
                             {
-                              const uint2 va = *reinterpret_cast<const uint2 *>(qpA + r);
-                              const uint2 vb = *reinterpret_cast<const uint2 *>(qpB + r);
+                              // 4 rows = 8 bytes; only dword-aligned when R is not a multiple of 4 (Pair2 -> ds_read2_b32)
+                              typedef typename std::conditional<R % 4 == 0, uint2, Pair2>::type Rows4;
+                              const Rows4 va = *reinterpret_cast<const Rows4 *>(qpA + r);
+                              const Rows4 vb = *reinterpret_cast<const Rows4 *>(qpB + r);
                               pa = va.x; pb = vb.x;
                               ac[r + 1] = va.y; ac[r + 2] = vb.y;             // rows r+2, r+3 (ac[] is free in this variant)
+                            }
+                          else if ((r & 3) == 0)                              // R = 4k + 2: the last two rows
+                            {
+                              pa = *reinterpret_cast<const u32 *>(qpA + r);
+                              pb = *reinterpret_cast<const u32 *>(qpB + r);
                             }
                           else if ((r & 3) == 2) { pa = ac[r - 1]; pb = ac[r]; }
                           V = (r & 1) ? __builtin_amdgcn_perm(pb, pa, 0x07060302u) : __builtin_amdgcn_perm(pb, pa, 0x05040100u);
@@ -407,14 +415,13 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               // column checkpoint m = t / 16 of this lane: state after its column t - l (or its border state if it has
               // not started yet).  Layout VSX_COLCK_DW (R = 1: [strip][m][lane][2]).
               u32 * cb = cck_base + (size_t) (t >> 4) * 64 * (2 * R);
-              if (R % 4 == 0)
+              if (R % 2 == 0)
                 {
+                  // the 2R dwords hprev[0..R), E[0..R) as one flat array, four to a block
+                  auto flat = [&](int z) -> u32 { return z < R ? hout[z] : E[z - R]; };
 #pragma unroll
-                  for (int x = 0; x < R; x += 4)
-                    {
-                      *reinterpret_cast<uint4 *>(cb + VSX_COLCK_DW(R, lane, x >> 2)) = make_uint4(hout[x], hout[x + 1], hout[x + 2], hout[x + 3]);
-                      *reinterpret_cast<uint4 *>(cb + VSX_COLCK_DW(R, lane, (R + x) >> 2)) = make_uint4(E[x], E[x + 1], E[x + 2], E[x + 3]);
-                    }
+                  for (int z = 0; z < 2 * R; z += 4)
+                    *reinterpret_cast<uint4 *>(cb + VSX_COLCK_DW(R, lane, z >> 2)) = make_uint4(flat(z), flat(z + 1), flat(z + 2), flat(z + 3));
                 }
               else
                 {
@@ -724,7 +731,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   // column checkpoint element x (0 .. 2R-1: hprev[R], E[R]) of pipeline lane `lanepos`, strip sp, 16-step block mb
   auto colck_at = [&](int sp, int mb, int lanepos, int x) -> u32 {
     const u32 * cb = colck + ((size_t) sp * nblk + (size_t) mb) * 64 * (2 * R);
-    return (R % 4 == 0) ? cb[VSX_COLCK_DW(R, lanepos, x >> 2) + (x & 3)] : cb[(size_t) lanepos * (2 * R) + x];
+    return (R % 2 == 0) ? cb[VSX_COLCK_DW(R, lanepos, x >> 2) + (x & 3)] : cb[(size_t) lanepos * (2 * R) + x];
   };
   const int g = (int) (sl >> 1);
   const bool hi = (sl & 1) != 0;
@@ -863,24 +870,19 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         }
       else
         {
-          if (R % 4 == 0)
+          if (R % 2 == 0)
             {
               const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * 64 * (2 * R) + VSX_COLCK_DW(R, g * 16 + l, 0);
-              Quad hq[R / 4 ? R / 4 : 1], eq[R / 4 ? R / 4 : 1];
+              constexpr int NBQ = (2 * R) / 4 ? (2 * R) / 4 : 1;        // blocks of the flat hprev[R], E[R] array
+              Quad fq[NBQ];
 #pragma unroll
-              for (int b = 0; b < R / 4; ++b)
-                {
-                  hq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * (4 * VSX_COLCK_G));
-                  eq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) (R / 4 + b) * (4 * VSX_COLCK_G));
-                }
+              for (int b = 0; b < NBQ; ++b) fq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * (4 * VSX_COLCK_G));
+              auto flat = [&](int z) -> u32 {
+                const Quad & qd = fq[z >> 2];
+                return (z & 3) == 0 ? qd.x : (z & 3) == 1 ? qd.y : (z & 3) == 2 ? qd.z : qd.w;
+              };
 #pragma unroll
-              for (int b = 0; b < R / 4; ++b)
-                {
-                  hp[4 * b] = A::in(half_lo(hq[b].x, hi)); hp[4 * b + 1] = A::in(half_lo(hq[b].y, hi));
-                  hp[4 * b + 2] = A::in(half_lo(hq[b].z, hi)); hp[4 * b + 3] = A::in(half_lo(hq[b].w, hi));
-                  ee[4 * b] = A::in(half_lo(eq[b].x, hi)); ee[4 * b + 1] = A::in(half_lo(eq[b].y, hi));
-                  ee[4 * b + 2] = A::in(half_lo(eq[b].z, hi)); ee[4 * b + 3] = A::in(half_lo(eq[b].w, hi));
-                }
+              for (int x = 0; x < R; ++x) { hp[x] = A::in(half_lo(flat(x), hi)); ee[x] = A::in(half_lo(flat(R + x), hi)); }
             }
           else
             {
@@ -1117,7 +1119,7 @@ vsx_purity_kernel(const uint8_t * __restrict__ codes, const uint64_t * __restric
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-static const int kRows[] = {1, 4, 8, 12, 16, 20, 24, 28, 32};
+static const int kRows[] = {1, 4, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 32};
 
 extern "C" const int * vsx_supported_rows(int * count)
 {
@@ -1173,14 +1175,24 @@ extern "C" hipError_t vsx_launch_forward(int rows, int generic, int track, int c
                           : launch_fwd2<4, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
     case 8:  return ckpt ? launch_fwd2<8, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
                           : launch_fwd2<8, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 10: return ckpt ? launch_fwd2<10, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<10, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
     case 12: return ckpt ? launch_fwd2<12, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
                           : launch_fwd2<12, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 14: return ckpt ? launch_fwd2<14, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<14, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
     case 16: return ckpt ? launch_fwd2<16, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
                           : launch_fwd2<16, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 18: return ckpt ? launch_fwd2<18, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<18, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
     case 20: return ckpt ? launch_fwd2<20, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
                           : launch_fwd2<20, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 22: return ckpt ? launch_fwd2<22, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<22, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
     case 24: return ckpt ? launch_fwd2<24, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
                           : launch_fwd2<24, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    case 26: return ckpt ? launch_fwd2<26, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+                          : launch_fwd2<26, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
     case 28: return ckpt ? launch_fwd2<28, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
                           : launch_fwd2<28, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
     case 32: return ckpt ? launch_fwd2<32, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
@@ -1228,7 +1240,7 @@ extern "C" hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams
                                         : launch_tbck<RR, false>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st)
   switch (rows)
     {
-    TBCK(1); TBCK(4); TBCK(8); TBCK(12); TBCK(16); TBCK(20); TBCK(24); TBCK(28); TBCK(32);
+    TBCK(1); TBCK(4); TBCK(8); TBCK(10); TBCK(12); TBCK(14); TBCK(16); TBCK(18); TBCK(20); TBCK(22); TBCK(24); TBCK(26); TBCK(28); TBCK(32);
     default: return hipErrorInvalidValue;
     }
 #undef TBCK
