@@ -24,6 +24,7 @@
 #include "vsx_internal.h"
 
 typedef unsigned int u32;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
@@ -407,7 +408,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               if (!ODD) pend_on = active;
               else if (pend_on || active)
                 {
-                  *reinterpret_cast<uint4 *>(rck_base + (size_t) (t >> 1) * 256) = make_uint4(pendH, pendF, outH, outF);
+                  __builtin_nontemporal_store((u32x4) {pendH, pendF, outH, outF}, reinterpret_cast<u32x4 *>(rck_base + (size_t) (t >> 1) * 256));
                 }
             }
           if (CKPT && (t & 15) == 15)
@@ -421,7 +422,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   auto flat = [&](int z) -> u32 { return z < R ? hout[z] : E[z - R]; };
 #pragma unroll
                   for (int z = 0; z < 2 * R; z += 4)
-                    *reinterpret_cast<uint4 *>(cb + VSX_COLCK_DW(R, lane, z >> 2)) = make_uint4(flat(z), flat(z + 1), flat(z + 2), flat(z + 3));
+                    __builtin_nontemporal_store((u32x4) {flat(z), flat(z + 1), flat(z + 2), flat(z + 3)}, reinterpret_cast<u32x4 *>(cb + VSX_COLCK_DW(R, lane, z >> 2)));
                 }
               else
                 {
