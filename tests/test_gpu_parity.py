@@ -1,5 +1,6 @@
 """-m gpu: the HIP path (through the C-ABI) against the committed golden vectors (generated from the
 reference's own compiled sources) and against the oracle on seeded inputs.  Bit-exact: integer work."""
+import os
 import random
 
 import numpy as np
@@ -304,3 +305,21 @@ def test_chunked_plan_equals_single_chunk(gpu_required, oracle):
         assert parts.row(k) == whole.row(k) == again.row(k), k
     for k in range(0, len(qs), 7):
         assert whole.row(k) == oracle.align(qs[k], ts[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [
+    {"VSX_TRACEBACK": "dirs"}, {"VSX_TB_ARITH": "packed"}, {"VSX_SCORE": "arith"}, {"VSX_NO_SHARE_SUB": "1"}, {"VSX_ROWS": "4"},
+], ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
+def test_alternate_kernel_modes(gpu_required, env):
+    """the A/B switches of DESIGN.md section 8 select other kernel variants (stored direction bits, saturating packed traceback,
+    table-free scores, unshared subtraction, many strips): each must reproduce the golden vectors and the torture slice"""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q",
+                        "-k", "golden or torture or multi_strip or reference_batch"], env=e, capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
