@@ -222,9 +222,12 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps) >> 1) * 64 + lane) * 4;                    // + (t >> 1) * 256
       u32 * const cck_base = dir + T.dir_off + ck_rowdw + (size_t) s * ck_nblk * 64 * (2 * R);                    // + (t >> 4) * 128 R
 
-      auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R], auto interior_tag, auto odd_tag) __attribute__((always_inline)) {
+      // STEADY (the part of phase A after the pipeline has filled, t >= 15): every lane that owns rows is inside its targets, so the
+      // per-lane activity test and its EXEC mask are dropped (lanes beyond the query's positions compute junk nobody reads).
+      auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R], auto interior_tag, auto odd_tag, auto steady_tag) __attribute__((always_inline)) {
           constexpr bool INTERIOR = decltype(interior_tag)::value;
           constexpr bool ODD = decltype(odd_tag)::value;
+          constexpr bool STEADY = decltype(steady_tag)::value;
           if ((t & 15) == 0)
             {
               // build the feed block for columns 16k..16k+15 (lane l describes column 16k+l)
@@ -271,7 +274,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           const u32 inF = dpp_shr1(fF, outF);
 
           const int j = t - l;
-          const bool active = lane_on && j >= 0 && j < Dpg;
+          const bool active = STEADY ? true : (lane_on && j >= 0 && j < Dpg);
           if (active)
             {
               const u32 code = sym & 0x000F000Fu;
@@ -448,15 +451,21 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
         }
       int t = 0;
       qrt = qrt_i_pk; rt = pack16(P.rt_i);
-      for (; t < t_switch; t += 2)
+      for (; t < t_switch && t < 16; t += 2)                 // the pipeline fills
         {
-          step(t, hprev, hnext, std::true_type {}, std::false_type {});
-          step(t + 1, hnext, hprev, std::true_type {}, std::true_type {});
+          step(t, hprev, hnext, std::true_type {}, std::false_type {}, std::false_type {});
+          step(t + 1, hnext, hprev, std::true_type {}, std::true_type {}, std::false_type {});
         }
+      if (Dpg > 0)                                            // (a group without targets never becomes active)
+        for (; t < t_switch; t += 2)
+          {
+            step(t, hprev, hnext, std::true_type {}, std::false_type {}, std::true_type {});
+            step(t + 1, hnext, hprev, std::true_type {}, std::true_type {}, std::true_type {});
+          }
       for (; t < steps; t += 2)
         {
-          step(t, hprev, hnext, std::false_type {}, std::false_type {});
-          step(t + 1, hnext, hprev, std::false_type {}, std::true_type {});
+          step(t, hprev, hnext, std::false_type {}, std::false_type {}, std::false_type {});
+          step(t + 1, hnext, hprev, std::false_type {}, std::true_type {}, std::false_type {});
         }
 
       if (s + 1 < nstrips)
