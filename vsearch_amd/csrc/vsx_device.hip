@@ -451,12 +451,13 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
         }
       int t = 0;
       qrt = qrt_i_pk; rt = pack16(P.rt_i);
-      for (; t < t_switch && t < 16; t += 2)                 // the pipeline fills
+      for (; t < t_switch && (TRACK || t < 16); t += 2)       // the pipeline fills (TRACK: the whole interior phase)
         {
           step(t, hprev, hnext, std::true_type {}, std::false_type {}, std::false_type {});
           step(t + 1, hnext, hprev, std::true_type {}, std::true_type {}, std::false_type {});
         }
-      if (Dpg > 0)                                            // (a group without targets never becomes active)
+      if (!TRACK && Dpg > 0)                                  // (a group without targets never becomes active; with overflow
+                                                              //  tracking the junk of the idle lanes would reach the min/max)
         for (; t < t_switch; t += 2)
           {
             step(t, hprev, hnext, std::true_type {}, std::false_type {}, std::true_type {});
