@@ -1004,17 +1004,40 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
   const uint64_t n = S->len.size();
   if (first > n || count > n - first) return sfail(VSX_EINVAL, "vsx_allpairs_block: query block out of range");
   const double t_begin = now_s();
+  // the pair list: each query of the block against every later sequence that passes the unaligned filters -- per-query
+  // target lists on host threads, concatenated in query order
   std::vector<uint32_t> pq, pt;
   std::vector<uint64_t> qfirst(count + 1, 0);
-  for (uint64_t k = 0; k < count; ++k)
-    {
-      const uint64_t qi = first + k;
-      qfirst[k] = pq.size();
-      for (uint64_t t = qi + 1; t < n; ++t)
-        if (acceptall || acceptable_unaligned(*S, S->blob.data() + S->off[qi], S->len[qi], (uint32_t) t))
-          { pq.push_back((uint32_t) qi); pt.push_back((uint32_t) t); }
-    }
-  qfirst[count] = pq.size();
+  {
+    std::vector<std::vector<uint32_t>> tl(count);
+    const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, S->threads), count / 8));
+    std::atomic<uint64_t> next {0};
+    auto work = [&]() {
+      for (;;)
+        {
+          const uint64_t k = next.fetch_add(1);
+          if (k >= count) break;
+          const uint64_t qi = first + k;
+          std::vector<uint32_t> & v = tl[k];
+          v.reserve(n - qi);
+          for (uint64_t t = qi + 1; t < n; ++t)
+            if (acceptall || acceptable_unaligned(*S, S->blob.data() + S->off[qi], S->len[qi], (uint32_t) t)) v.push_back((uint32_t) t);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nth; ++t) pool.emplace_back(work);
+    work();
+    for (auto & th : pool) th.join();
+    uint64_t total = 0;
+    for (uint64_t k = 0; k < count; ++k) { qfirst[k] = total; total += tl[k].size(); }
+    qfirst[count] = total;
+    pq.resize(total); pt.resize(total);
+    for (uint64_t k = 0; k < count; ++k)
+      {
+        std::fill(pq.begin() + (int64_t) qfirst[k], pq.begin() + (int64_t) qfirst[k + 1], (uint32_t) (first + k));
+        std::copy(tl[k].begin(), tl[k].end(), pt.begin() + (int64_t) qfirst[k]);
+      }
+  }
   vsx_results res;
   double t0 = now_s();
   const vsx_filter flt = make_filter(*S);
@@ -1023,30 +1046,54 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
   if (rc != VSX_OK) return rc;
   std::vector<std::vector<Hit>> kept(count);
   uint64_t cells = 0, sentinels = 0;
-  for (uint64_t k = 0; k < count; ++k)
-    {
-      const uint64_t qi = first + k;
-      const char * q = S->blob.data() + S->off[qi];
-      const int64_t ql = S->len[qi];
-      for (uint64_t r = qfirst[k]; r < qfirst[k + 1]; ++r)
+  {
+    // per query: complete the accepted hits (derived fields, fallback on the sentinel) and order them -- host threads
+    const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, S->threads), count / 8));
+    std::vector<uint64_t> pcells((size_t) nth, 0), psent((size_t) nth, 0);
+    std::vector<int> err((size_t) nth, VSX_OK);
+    std::atomic<uint64_t> next {0};
+    auto work = [&](int tid) {
+      for (;;)
         {
-          Hit h;
-          h.target = pt[r];
-          cells += (uint64_t) ql * S->len[h.target];
-          const uint8_t verdict = res.verdict ? res.verdict[r] : (uint8_t) VSX_VERDICT_UNDECIDED;
-          if (verdict == VSX_VERDICT_REJECTED || verdict == VSX_VERDICT_WEAK) continue;      // only accepted hits are kept (:509-527)
-          rc = fill_hit(*S, q, ql, h, res, r, sentinels);
-          if (rc != VSX_OK) { vsx_results_free(&res); return sfail(rc, "vsx_allpairs_block: fallback aligner failed"); }
-          const bool acc = acceptall || acceptable_aligned(*S, ql, h);
-          if (verdict == VSX_VERDICT_ACCEPTED && !acc)
-            { vsx_results_free(&res); return sfail(VSX_EHIP, "vsx_allpairs_block: device and host accept filters disagree"); }
-          if (acc) kept[k].push_back(std::move(h));
+          const uint64_t k = next.fetch_add(1);
+          if (k >= count) break;
+          const uint64_t qi = first + k;
+          const char * q = S->blob.data() + S->off[qi];
+          const int64_t ql = S->len[qi];
+          for (uint64_t r = qfirst[k]; r < qfirst[k + 1]; ++r)
+            {
+              Hit h;
+              h.target = pt[r];
+              pcells[(size_t) tid] += (uint64_t) ql * S->len[h.target];
+              const uint8_t verdict = res.verdict ? res.verdict[r] : (uint8_t) VSX_VERDICT_UNDECIDED;
+              if (verdict == VSX_VERDICT_REJECTED || verdict == VSX_VERDICT_WEAK) continue;      // only accepted hits are kept (:509-527)
+              const int frc = fill_hit(*S, q, ql, h, res, r, psent[(size_t) tid]);
+              if (frc != VSX_OK) { err[(size_t) tid] = frc; return; }
+              const bool acc = acceptall || acceptable_aligned(*S, ql, h);
+              if (verdict == VSX_VERDICT_ACCEPTED && !acc) { err[(size_t) tid] = VSX_EHIP; return; }
+              if (acc) kept[k].push_back(std::move(h));
+            }
+          std::sort(kept[k].begin(), kept[k].end(), [](const Hit & a, const Hit & b) {
+            if (a.id != b.id) return a.id > b.id;
+            return a.target < b.target;
+          });
         }
-      std::sort(kept[k].begin(), kept[k].end(), [](const Hit & a, const Hit & b) {
-        if (a.id != b.id) return a.id > b.id;
-        return a.target < b.target;
-      });
-    }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto & th : pool) th.join();
+    for (int t = 0; t < nth; ++t)
+      {
+        cells += pcells[(size_t) t]; sentinels += psent[(size_t) t];
+        if (err[(size_t) t] != VSX_OK)
+          {
+            vsx_results_free(&res);
+            return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "vsx_allpairs_block: device and host accept filters disagree"
+                                                                       : "vsx_allpairs_block: fallback aligner failed");
+          }
+      }
+  }
   vsx_results_free(&res);
   rc = marshal_hits(kept, out);
   if (rc != VSX_OK) return rc;
