@@ -157,6 +157,17 @@ typedef struct vsx_msa_out {
 int vsx_msa(uint32_t n, const char * const * seqs, const uint32_t * lens, const char * const * cigars,
             const uint64_t * abundances /* NULL = all 1 */, vsx_msa_out * out);
 void vsx_msa_out_free(vsx_msa_out * o);
+/* The same on the device (vsx_msa.hip), for one cluster or for many in one pass: cluster c owns entries
+   cluster_start[c] .. cluster_start[c+1]-1 of seqs/lens/cigars/abundances (first entry = its centroid, whose cigar is
+   ignored); outs[c] receives what vsx_msa would return for it (byte-identical; free each with vsx_msa_out_free).
+   The CIGAR text is parsed and max-insertions/column offsets are computed on the host (O(runs)); the O(rows x alnlen)
+   work -- row fill, profile, consensus row -- runs in three kernels.  Fails (VSX_EINVAL) on what vsx_msa rejects and on
+   two adjacent 'D' runs; no CPU fallback. */
+int vsx_msa_device(vsx_ctx * ctx, uint32_t n, const char * const * seqs, const uint32_t * lens, const char * const * cigars,
+                   const uint64_t * abundances /* NULL = all 1 */, vsx_msa_out * out);
+int vsx_msa_device_batch(vsx_ctx * ctx, uint32_t n_clusters, const uint64_t * cluster_start /* n_clusters + 1 */,
+                         const char * const * seqs, const uint32_t * lens, const char * const * cigars,
+                         const uint64_t * abundances /* NULL = all 1 */, vsx_msa_out * outs /* n_clusters */);
 
 /* The scalar fallback the callers run on the SHRT_MAX sentinel: LinearMemoryAligner::align + alignstats
    (core/linmemalign.cpp:694-808; call sites core/searchcore.cpp:806-832, commands/allpairs_global.cpp:447-473).

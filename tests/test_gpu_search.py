@@ -195,12 +195,14 @@ def _wrap(seq, width=80):
     return [seq[i:i + width] for i in range(0, len(seq), width)] or [""]
 
 
-def test_cluster_msa_consensus_profile_match_reference_cli(gpu_required, tmp_path):
+@pytest.mark.parametrize("device_msa", [False, True])
+def test_cluster_msa_consensus_profile_match_reference_cli(gpu_required, tmp_path, device_msa):
     """--cluster_fast --msaout --consout --profile: the CIGARs we store per member must drive the reference's star MSA,
-    consensus and profile to byte-identical files (the consumer of the CIGAR contract)."""
+    consensus and profile to byte-identical files (the consumer of the CIGAR contract) -- with the MSA
+    itself on the host (vsx_msa) and on the device (vsx_msa_device_batch, all clusters in one pass)."""
     if not os.path.exists(REF_BIN):
         pytest.fail("oracle/_ref/vsearch_ref missing")
-    from vsearch_amd import Aligner, SearchSession, msa
+    from vsearch_amd import Aligner, SearchSession, msa_batch
     rng = random.Random(17)
     seqs = []
     for f in range(8):
@@ -223,14 +225,16 @@ def test_cluster_msa_consensus_profile_match_reference_cli(gpu_required, tmp_pat
     with Aligner() as al:
         ss = SearchSession(al, sseqs, id=0.85, maxrejects=8)
         cno, per, ncl = ss.cluster_fast(round=16)
-    members = [[] for _ in range(ncl)]
-    for s, c in enumerate(cno):
-        members[c].append(s)                       # ascending seqno: the centroid comes first
+        members = [[] for _ in range(ncl)]
+        for s, c in enumerate(cno):
+            members[c].append(s)                       # ascending seqno: the centroid comes first
+        assert all(per[m[0]] is None for m in members)
+        results = msa_batch([[sseqs[s] for s in m] for m in members],
+                            [[None] + [per[s]["cigar"] for s in m[1:]] for m in members], None, al if device_msa else None)
     msa_lines, cons_lines, prof_lines = [], [], []
     for c in range(ncl):
         m = members[c]
-        assert per[m[0]] is None
-        res = msa([sseqs[s] for s in m], [None] + [per[s]["cigar"] for s in m[1:]])
+        res = results[c]
         msa_lines.append("")
         for k, s in enumerate(m):
             msa_lines.append(">" + ("*" if k == 0 else "") + snames[s])
@@ -368,3 +372,73 @@ def test_strand_both_matches_reference_cli(gpu_required, tmp_path):
         got = ss.userout(qs, fields=flds)
     assert sum(1 for l in exp if l.endswith("-")) > 10 and sum(1 for l in exp if l.endswith("+")) > 10
     assert got == exp, _first_diff(got, exp)
+
+
+def _random_cluster(rng, n, clen, alphabet="ACGT", pins=0.03, pdel=0.03, long_ins=False):
+    """a centroid and n-1 members with CIGARs drawn directly (member = query, centroid = target: 'D' = symbols only the member has)"""
+    cen = "".join(rng.choice(alphabet) for _ in range(clen))
+    seqs, cigars = [cen], [None]
+    for _ in range(n - 1):
+        ops, mem = [], []
+        if rng.random() < 0.2:
+            k = rng.randint(1, 30 if long_ins else 4); ops.append(("D", k)); mem += [rng.choice(alphabet) for _ in range(k)]
+        p = 0
+        while p < clen:
+            r = rng.random()
+            if r < pdel:
+                k = min(clen - p, rng.randint(1, 5)); ops.append(("I", k)); p += k
+            elif r < pdel + pins and ops and ops[-1][0] != "D":
+                k = rng.randint(1, 30 if long_ins else 3); ops.append(("D", k)); mem += [rng.choice(alphabet) for _ in range(k)]
+            else:
+                k = min(clen - p, rng.randint(1, 40)); ops.append(("M", k))
+                mem += [cen[p + j] if rng.random() < 0.9 else rng.choice(alphabet) for j in range(k)]; p += k
+        if rng.random() < 0.2 and ops[-1][0] != "D":
+            k = rng.randint(1, 6); ops.append(("D", k)); mem += [rng.choice(alphabet) for _ in range(k)]
+        merged = []
+        for op, k in ops:
+            if merged and merged[-1][0] == op:
+                merged[-1][1] += k
+            else:
+                merged.append([op, k])
+        cigars.append("".join((str(k) if k > 1 else "") + op for op, k in merged))
+        seqs.append("".join(mem))
+    return seqs, cigars
+
+
+def test_msa_device_equals_host(gpu_required):
+    """vsx_msa_device_batch == vsx_msa (the host restatement of core/msa.cpp that the reference-CLI test pins), byte for byte:
+    rows, consensus row with its '+' censoring, consensus sequence, 64-bit profile -- over IUPAC / lower-case / uncounted symbols,
+    abundances (large and zero), terminal insertions, a 9000-member cluster (several row tiles), singletons and empty members."""
+    from vsearch_amd import Aligner, msa_batch
+    rng = random.Random(5)
+    cl_s, cl_c, cl_a = [], [], []
+    for k in range(40):
+        n = rng.choice([1, 1, 2, 3, 8, 30, 200])
+        alpha = rng.choice(["ACGT", "ACGTacgtNRYn", "ACGTUX*-"])
+        s, c = _random_cluster(rng, n, rng.choice([1, 7, 64, 65, 255, 256, 257, 400]), alpha, long_ins=(k % 5 == 0))
+        cl_s.append(s); cl_c.append(c)
+        cl_a.append([rng.choice([0, 1, 1, 3, 2 ** 40 + 7]) for _ in s])
+    s, c = _random_cluster(rng, 9000, 300, "ACGT")
+    cl_s.append(s); cl_c.append(c); cl_a.append([rng.randint(0, 5) for _ in s])
+    cl_s.append(["ACGT", "", "ACGT"]); cl_c.append([None, "4I", "4M"]); cl_a.append([0, 0, 0])      # empty member, all-zero columns
+    host = msa_batch(cl_s, cl_c, cl_a, None)
+    with Aligner() as al:
+        dev = msa_batch(cl_s, cl_c, cl_a, al)
+        dev1 = msa_batch(cl_s[:3], cl_c[:3], None, al)
+    assert len(dev) == len(host)
+    for k, (d, h) in enumerate(zip(dev, host)):
+        assert d["rows"] == h["rows"], k
+        assert d["consensus"] == h["consensus"], k
+        assert d["profile"] == h["profile"], k
+    assert dev1 == msa_batch(cl_s[:3], cl_c[:3], None, None)
+    assert host[-1]["consensus"] == "----"              # the reference appends the '-' of an all-zero column (msa.cpp:474-483)
+
+
+def test_msa_device_rejects_bad_cigars(gpu_required):
+    from vsearch_amd import Aligner, msa
+    from vsearch_amd._lib import VsxError
+    with Aligner() as al:
+        for seqs, cig in [(["ACGT", "ACG"], [None, "4M"]), (["ACGT", "ACGT"], [None, "3M"]), (["ACGT", "ACGTA"], [None, "5M"]),
+                          (["ACGT", "ACGTAA"], [None, "4MDD"])]:
+            with pytest.raises(VsxError):
+                msa(seqs, cig, aligner=al)

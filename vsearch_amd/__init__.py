@@ -4,7 +4,7 @@ The package is a thin host-side mirror of the reference's aligner interface over
 (include/vsx.h); all arithmetic runs in hand-written HIP kernels (vsearch_amd/csrc).
 """
 from .aligner import Aligner, SequenceSet, Plan, AlignmentResults, DEFAULT_SCORING, scoring_from_tuple  # noqa: F401
-from .search import SearchSession, msa  # noqa: F401
+from .search import SearchSession, msa, msa_batch  # noqa: F401
 from ._lib import SENTINEL, VsxError, load as load_library  # noqa: F401
 
 __all__ = ["Aligner", "SequenceSet", "Plan", "AlignmentResults", "DEFAULT_SCORING", "scoring_from_tuple",

@@ -22,7 +22,8 @@ SYMBOLS = [
 ]
 # include/vsx_search.h
 SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
-                  "vsx_hits_free", "vsx_search_candidates", "vsx_search_candidates_batch", "vsx_candidates_free", "vsx_lma_align", "vsx_allpairs_block", "vsx_cluster_fast", "vsx_cluster_out_free", "vsx_msa", "vsx_msa_out_free"]
+                  "vsx_hits_free", "vsx_search_candidates", "vsx_search_candidates_batch", "vsx_candidates_free", "vsx_lma_align", "vsx_allpairs_block", "vsx_cluster_fast", "vsx_cluster_out_free", "vsx_msa", "vsx_msa_out_free",
+                  "vsx_msa_device", "vsx_msa_device_batch"]
 
 
 class Candidates(C.Structure):
@@ -159,6 +160,8 @@ def load():
     lib.vsx_cluster_out_free.argtypes = [C.POINTER(ClusterOut)]
     lib.vsx_cluster_out_free.restype = None
     lib.vsx_msa.argtypes = [C.c_uint32, vp, vp, vp, vp, C.POINTER(MsaOut)]
+    lib.vsx_msa_device.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.POINTER(MsaOut)]
+    lib.vsx_msa_device_batch.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, C.POINTER(MsaOut)]
     lib.vsx_msa_out_free.argtypes = [C.POINTER(MsaOut)]
     lib.vsx_msa_out_free.restype = None
     lib.vsx_lma_align.argtypes = [C.POINTER(Scoring), C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64] + \

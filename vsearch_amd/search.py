@@ -197,23 +197,56 @@ class SearchSession:
         return lines
 
 
-def msa(seqs, cigars):
+def _msa_unpack(lib, out):
+    L = int(out.alnlen)
+    raw = C.string_at(out.rows, int(out.n_rows) * (L + 1))
+    rows = [raw[k * (L + 1):k * (L + 1) + L].decode("latin-1") for k in range(int(out.n_rows))]
+    prof = np.ctypeslib.as_array(out.profile, shape=(max(L, 1), 6))[:L].tolist()
+    return dict(rows=rows, consensus=C.string_at(out.consensus, int(out.conslen)).decode("latin-1"), profile=prof)
+
+
+def msa(seqs, cigars, abundances=None, aligner=None):
     """star MSA / profile / consensus of one cluster (core/msa.cpp): seqs[0] = centroid, cigars[i] = member i vs centroid.
-    -> dict(rows=[centroid, members..., consensus row], consensus=str, profile=[[A,C,G,T,N,gap] per column])"""
+    -> dict(rows=[centroid, members..., consensus row], consensus=str, profile=[[A,C,G,T,N,gap] per column]).
+    With `aligner` (an Aligner = a device context) the rows, profile and consensus are computed on the GPU (vsx_msa_device);
+    without, by the host form (vsx_msa).  Both return the same bytes."""
+    return msa_batch([seqs], [cigars], [abundances] if abundances is not None else None, aligner)[0]
+
+
+def msa_batch(clusters_seqs, clusters_cigars, clusters_abundances=None, aligner=None):
+    """many clusters; with `aligner` they go to the device in ONE pass (vsx_msa_device_batch)."""
     lib = _lib.load()
-    n = len(seqs)
-    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
-    cs = [(c.encode() if isinstance(c, str) else c) if c is not None else b"" for c in cigars]
-    sp = (C.c_char_p * n)(*bs)
-    cp = (C.c_char_p * n)(*cs)
-    lens = (C.c_uint32 * n)(*[len(b) for b in bs])
-    out = _lib.MsaOut()
-    check(lib.vsx_msa(n, sp, lens, cp, None, C.byref(out)), "vsx_msa")
-    try:
-        L = int(out.alnlen)
-        raw = C.string_at(out.rows, int(out.n_rows) * (L + 1))
-        rows = [raw[k * (L + 1):k * (L + 1) + L].decode() for k in range(int(out.n_rows))]
-        prof = [[int(out.profile[i * 6 + k]) for k in range(6)] for i in range(L)]
-        return dict(rows=rows, consensus=C.string_at(out.consensus, int(out.conslen)).decode(), profile=prof)
-    finally:
-        lib.vsx_msa_out_free(C.byref(out))
+    bs, cs, ab, start = [], [], [], [0]
+    for k, (seqs, cigars) in enumerate(zip(clusters_seqs, clusters_cigars)):
+        bs += [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        cs += [(c.encode() if isinstance(c, str) else c) if c is not None else b"" for c in cigars]
+        if clusters_abundances is not None:
+            ab += [int(x) for x in clusters_abundances[k]]
+        start.append(len(bs))
+    n = len(bs)
+    nc = len(start) - 1
+    sp = (C.c_char_p * max(n, 1))(*bs)
+    cp = (C.c_char_p * max(n, 1))(*cs)
+    lens = (C.c_uint32 * max(n, 1))(*[len(b) for b in bs])
+    abp = (C.c_uint64 * max(n, 1))(*ab) if clusters_abundances is not None else None
+    outs = (_lib.MsaOut * max(nc, 1))()
+    res = []
+    if aligner is not None:
+        st = (C.c_uint64 * (nc + 1))(*start)
+        check(lib.vsx_msa_device_batch(aligner.h, nc, st, sp, lens, cp, abp, outs), "vsx_msa_device_batch")
+        try:
+            res = [_msa_unpack(lib, outs[k]) for k in range(nc)]
+        finally:
+            for k in range(nc):
+                lib.vsx_msa_out_free(C.byref(outs[k]))
+        return res
+    for k in range(nc):
+        a, b = start[k], start[k + 1]
+        off = lambda arr, ty: C.cast(C.byref(arr, a * C.sizeof(ty)), C.c_void_p)
+        check(lib.vsx_msa(b - a, off(sp, C.c_char_p), off(lens, C.c_uint32), off(cp, C.c_char_p),
+                          off(abp, C.c_uint64) if abp is not None else None, C.byref(outs[k])), "vsx_msa")
+        try:
+            res.append(_msa_unpack(lib, outs[k]))
+        finally:
+            lib.vsx_msa_out_free(C.byref(outs[k]))
+    return res
