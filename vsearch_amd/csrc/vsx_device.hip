@@ -81,7 +81,17 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
                             // 4 = one 64 B line per (quad, block): a lane's blocks and its neighbours' share L2 lines (32.8 / 7.0 ms).  Same total.
 #define VSX_COLCK_DW(R_, lane_, block_) ((((size_t) ((lane_) / VSX_COLCK_G) * (size_t) ((2 * (R_)) / 4) + (size_t) (block_)) * VSX_COLCK_G + (size_t) ((lane_) % VSX_COLCK_G)) * 4)
 #define VSX_RB 1            // row checkpoints: [2^RB-step block][lane][step in block] uint2
-template <int R, bool GENERIC, bool TRACK, bool CKPT>
+// TILT = true (a sub-class of TOPPAD: checkpoints, LDS profile, no tracking): the kernel runs in TILTED coordinates,
+//   X*(i, j) = X(i, j) + (i + j) g   for X in {H, E, F},   g = the interior gap extension (both sides equal),
+// in which the recurrence is the same max-plus recurrence with score' = score + 2g, every QR' = QR - g, every R' = R - g:
+//   H*(i,j) = max(H*(i-1,j-1) + S + 2g, F*(i,j), E*(i,j)),  F*(i+1,j) = max(F*(i,j) - (Rt_j - g), H*(i,j) - (QRt_j - g)),  E* alike.
+// Both sides of every comparison sit on the same cell, so every maximum picks the same operand and every direction bit is
+// unchanged; the planner proves the shifted range (vsx_host.cpp tilt_possible()).  The host hands over the primed constants
+// and tables (VsxDevParams with tilt = g); what this kernel adds is that in the interior R' = 0, so F - R and E - R are not
+// computed at all: 7 instead of 9 packed instructions per lane-row.  Borders: Htop*(j) = Htop(j) + (j-1)g, Hleft* alike,
+// H*(-1,-1) = -2g; the score is un-tilted in the epilogue; checkpoints hold tilted values (the traceback recomputes with the
+// same primed constants).
+template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 16 ? 4 : 1, 8)))
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
@@ -96,6 +106,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   // QR_q(interior) >= ge (the planner checks both, vsx_host.cpp no_overflow_possible()).  The traceback of this class
   // (vsx_traceback_ck_kernel<R, true>) uses the same slot layout.
   constexpr bool TOPPAD = CKPT && GENERIC && !TRACK;
+  static_assert(!TILT || TOPPAD, "tilted coordinates exist for the TOPPAD class only");
+  const int tl = TILT ? P.tilt : 0;                // g of the tilt (P then holds the primed constants)
   // GENERIC: query profile in LDS, QP[target code][row of the strip] = S[code][query symbol of the row] (int16).
   // Any IUPAC / unknown symbol on either side is handled by construction; one v_perm_b32 per row packs the two targets.
   __shared__ __attribute__((aligned(16))) int16_t QP[GENERIC ? 16 * 16 * R : 8];
@@ -149,7 +161,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               const int code = idx / (16 * R), row = idx % (16 * R);
               const int Lr = 16 * s + row / R, rr = row % R;
               int v = 0;
-              if (TOPPAD && Lr == 0 && rr < pad) v = -P.top_step;
+              if (TOPPAD && Lr == 0 && rr < pad) v = -P.top_step + 2 * tl;
               else if (Lr < total_lanes && (TOPPAD || !(Lr == 0 && rr >= rcnt0)))
                 {
                   const int gi = (Lr == 0) ? rr - pad : rcnt0 + (Lr - 1) * R + rr;
@@ -178,14 +190,15 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           u32 e0 = ssub(hl, (i < Q - 1) ? P.qrq_i_pk : P.qrq_r_pk);
           if (dummy)
             {
-              hl = (r == pad - 1) ? 0u : pack16(-P.top_open);                       // Htop(-1) = 0 for the first real row's diagonal
-              e0 = ssub(pack16(-P.top_open - P.top_step), P.qrq_i_pk);               // <= Htop(0), stays below the chain
+              const int sh = (r - pad - 1) * tl;                                     // tilt of (i, -1), i = r - pad
+              hl = pack16(((r == pad - 1) ? 0 : -P.top_open) + sh);                  // Htop(-1) = 0 for the first real row's diagonal
+              e0 = ssub(pack16(-P.top_open - P.top_step + sh), P.qrq_i_pk);          // <= Htop(0), stays below the chain
             }
           hprev[r] = hl;
           hnext[r] = hl;     // a lane that has not started yet must find its border state in either array
           E[r] = e0;
         }
-      u32 diag = first ? ((TOPPAD && pad > 0) ? pack16(-P.top_open) : 0u) : pack16(P.hleft[i0 - 1]);   // H(i0-1, -1); Htop(-1) = 0 (:1895)
+      u32 diag = first ? pack16(((TOPPAD && pad > 0) ? -P.top_open : 0) - (pad + 2) * tl) : pack16(P.hleft[i0 - 1]);   // H(i0-1, -1); Htop(-1) = 0 (:1895)
       // query-gap penalties of row R-1: only the globally last row uses the right-end pair (:836-897)
       const bool lastpos = (L == total_lanes - 1);
       const u32 qrq_last = lastpos ? P.qrq_r_pk : P.qrq_i_pk;
@@ -250,7 +263,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               f_rt = rA | (rB << 16);
               if (s == 0)
                 {
-                  f_H = pack16(rawH);                  // H(-1, j) = Htop(j)
+                  f_H = pack16(rawH - pad * tl);       // H(-1, j) = Htop(j) (tilted: it enters at row -pad - 1)
                   f_F = ssub(f_H, f_qrt);              // f = v_sub(f, QR_t) at block entry (:830-833)
                 }
               else
@@ -332,8 +345,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   const u32 rq = (r == R - 1) ? rq_last : P.rq_i_pk;
                   const u32 he = ssub(h2, qrq);
                   const u32 hf = (SHARED && r < R - 1) ? he : ssub(h2, qrt);
-                  const u32 f = ssub(F, rt);
-                  const u32 e = ssub(E[r], rq);
+                  const u32 f = (TILT && INTERIOR) ? F : ssub(F, rt);                      // tilted interior: R' = 0
+                  const u32 e = (TILT && INTERIOR && r < R - 1) ? E[r] : ssub(E[r], rq);   // (row R-1 may be the query's last row)
                   if (CKPT && r == R - 1) { lastL = ssub(h1, E[r]); lastEL = ssub(he, e); }     // the last row's left / ext-left diffs
                   if (!CKPT)
                     {
@@ -492,8 +505,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       const int mnA = (int16_t) (hmin & 0xffff), mnB = (int16_t) (hmin >> 16);
       const int mxA = (int16_t) (hmax & 0xffff), mxB = (int16_t) (hmax >> 16);
       VsxSlotOut oA, oB;
-      oA.score = (int16_t) (score & 0xffff);
-      oB.score = (int16_t) (score >> 16);
+      oA.score = (int16_t) ((int) (int16_t) (score & 0xffff) - (DA > 0 ? (Q + DA - 2) * tl : 0));     // H = H* - (i + j) g
+      oB.score = (int16_t) ((int) (int16_t) (score >> 16) - (DB > 0 ? (Q + DB - 2) * tl : 0));
       oA.leave = (uint16_t) (leave & 0xffff); oB.leave = (uint16_t) (leave >> 16); oA.pad = 0; oB.pad = 0;
       oA.overflow = (mnA <= P.smin || mxA >= 32767) ? 1 : 0;     // :1774-1786
       oB.overflow = (mnB <= P.smin || mxB >= 32767) ? 1 : 0;
@@ -714,7 +727,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   __shared__ uint8_t symL[16 * 64];                // target symbols of the tile's columns
   const int tid = (int) threadIdx.x;
   for (int x = tid; x < 512; x += 64)
-    Ssh[x] = ((x & 31) < 16) ? P.matrix[(x >> 5) * 16 + (x & 15)] : (int16_t) -P.top_step;
+    Ssh[x] = ((x & 31) < 16) ? P.matrix[(x >> 5) * 16 + (x & 15)] : (int16_t) (-P.top_step + 2 * P.tilt);
   __syncthreads();
 
   // every lane of the wave stays in the tile loop until all are done (wave-uniform bounds, shuffles)
@@ -748,8 +761,12 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   const bool hi = (sl & 1) != 0;
   const u32 half_sel = hi ? 0x07060302u : 0x05040100u;           // v_perm_b32(F, H, sel) = this pair's H | F << 16
   const u32 bias2 = FAST ? 0x80008000u : 0u;
-  const u32 qrt_i16 = (u32) (uint16_t) P.qrt_i, qrt_r16 = (u32) (uint16_t) P.qrt_r;     // column penalties (target-side gaps)
-  const u32 rt_i16 = (u32) (uint16_t) P.rt_i, rt_r16 = (u32) (uint16_t) P.rt_r;
+  // penalties: FAST subtracts them in 32 bits, so they are sign-extended there (tilted penalties can be negative)
+  auto pen = [](int v) -> u32 { return FAST ? (u32) v : (u32) (uint16_t) v; };
+  auto pen_pk = [](u32 pk) -> u32 { return FAST ? (u32) (int) (int16_t) (pk & 0xffffu) : pk; };
+  const int tl = FAST ? P.tilt : 0;                // tilted coordinates, see vsx_forward_kernel
+  const u32 qrt_i16 = pen(P.qrt_i), qrt_r16 = pen(P.qrt_r);     // column penalties (target-side gaps)
+  const u32 rt_i16 = pen(P.rt_i), rt_r16 = pen(P.rt_r);
   const uint8_t * __restrict__ q = qc + T.qoff;
   const uint8_t * __restrict__ d = tc + T.toff[sl];
   u32 * __restrict__ my = slab + slab_off[valid ? k : 0];
@@ -839,8 +856,8 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
             {
               int c = c0 - 1 + cc;
               if (c > jj) c = jj;
-              const u32 corner = (TOPPAD && pad > 0) ? (u32) (uint16_t) (-P.top_open) : 0u;       // see the DP kernel's diag seed
-              tbL[(cc + 1) * 64 + tid] = (c < 0) ? A::in(corner) : A::in((u32) (uint16_t) P.htop[c]);   // F is derived from H below
+              const u32 corner = (u32) (uint16_t) (((TOPPAD && pad > 0) ? -P.top_open : 0) - (pad + 2) * tl);   // see the DP kernel's diag seed
+              tbL[(cc + 1) * 64 + tid] = (c < 0) ? A::in(corner) : A::in((u32) (uint16_t) (P.htop[c] - pad * tl));   // F is derived from H below
             }
         }
       else
@@ -855,10 +872,10 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
 
       // left boundary (state after column c0 - 1)
       u32 hp[R], ee[R], qa[R];
-      const u32 qrq_i = FAST ? (P.qrq_i_pk & 0xffffu) : P.qrq_i_pk;
-      const u32 rq_i = FAST ? (P.rq_i_pk & 0xffffu) : P.rq_i_pk;
-      const u32 qrq_last = lastpos ? (FAST ? (P.qrq_r_pk & 0xffffu) : P.qrq_r_pk) : qrq_i;
-      const u32 rq_last = lastpos ? (FAST ? (P.rq_r_pk & 0xffffu) : P.rq_r_pk) : rq_i;
+      const u32 qrq_i = pen_pk(P.qrq_i_pk);
+      const u32 rq_i = pen_pk(P.rq_i_pk);
+      const u32 qrq_last = lastpos ? pen_pk(P.qrq_r_pk) : qrq_i;
+      const u32 rq_last = lastpos ? pen_pk(P.rq_r_pk) : rq_i;
       if (m == 0)
         {
 #pragma unroll
@@ -868,15 +885,18 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
               if (ii < 0) ii = 0;
               const u32 hl = A::in((u32) (uint16_t) P.hleft[ii]);
               hp[x] = hl;
-              ee[x] = A::sub(hl, (ii < Q - 1) ? qrq_i : (FAST ? (P.qrq_r_pk & 0xffffu) : P.qrq_r_pk));
+              ee[x] = A::sub(hl, (ii < Q - 1) ? qrq_i : pen_pk(P.qrq_r_pk));
             }
           if (TOPPAD && L == 0 && pad > 0)                       // border state of the dummy rows, as seeded by the DP kernel
             {
-              const u32 hd = A::in((u32) (uint16_t) (-P.top_open));
-              const u32 ed = A::sub(A::in((u32) (uint16_t) (-P.top_open - P.top_step)), qrq_i);
 #pragma unroll
               for (int x = 0; x < R - 1; ++x)
-                if (x < pad) { hp[x] = (x == pad - 1) ? A::in(0u) : hd; ee[x] = ed; }
+                if (x < pad)
+                  {
+                    const int sh = (x - pad - 1) * tl;                  // tilt of (i, -1), i = x - pad
+                    hp[x] = A::in((u32) (uint16_t) (((x == pad - 1) ? 0 : -P.top_open) + sh));
+                    ee[x] = A::sub(A::in((u32) (uint16_t) (-P.top_open - P.top_step + sh)), qrq_i);
+                  }
             }
         }
       else
@@ -1162,7 +1182,13 @@ static hipError_t launch_fwd2(int generic, int track, const VsxDevParams & P, co
                               const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
                               VsxSlotOut * slot, hipStream_t st)
 {
-  if (generic && track)
+  if (P.tilt != 0)
+    {
+      if (!(CK && generic && !track)) return hipErrorInvalidValue;
+      if constexpr (CK)
+        hipLaunchKernelGGL((vsx_forward_kernel<R, true, false, true, true>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+    }
+  else if (generic && track)
     hipLaunchKernelGGL((vsx_forward_kernel<R, true, true, CK>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
   else if (generic)
     hipLaunchKernelGGL((vsx_forward_kernel<R, true, false, CK>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);

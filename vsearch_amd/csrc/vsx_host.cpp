@@ -165,6 +165,8 @@ struct vsx_ctx {
   int pen[12] {};                   // clamped CELL penalties: go_q_l, go_t_l, go_q_i, go_t_i, go_q_r, go_t_r, ge_*
   VsxDevParams P {};
   DevBuf<int16_t> d_htop, d_hleft, d_matrix;
+  VsxDevParams Pt {};               // the same scoring in TILTED coordinates (VsxDevParams::tilt, vsx_forward_kernel TILT); Pt.tilt == 0: unavailable
+  DevBuf<int16_t> d_htop_t, d_hleft_t, d_matrix_t;
   ScratchPool pool;
 };
 
@@ -185,7 +187,7 @@ struct vsx_seqset {
 
 namespace {
 
-struct Launch { int rows; int generic; int track; uint32_t first, count; uint32_t pair_first, pair_count; };
+struct Launch { int rows; int generic; int track; int tilt; uint32_t first, count; uint32_t pair_first, pair_count; };
 
 struct Chunk {
   uint32_t task_first = 0, task_count = 0;
@@ -379,6 +381,40 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   P.htop = c->d_htop.p;
   P.hleft = c->d_hleft.p;
   P.matrix = c->d_matrix.p;
+  P.tilt = 0;
+
+  // Tilted coordinates X* = X + (i + j) g, g = the interior extension (VsxDevParams::tilt): available when both interior
+  // extensions are g > 0 and the interior QR coincide (the DP kernel's shared H - QR); per task the planner still has to
+  // prove the shifted range (tilt_possible()).  VSX_TILT=0 switches the class off (A/B measurements, tests).
+  if (geqi == geti && geti > 0 && P.share_sub && c->ckpt && !c->tb_packed && !c->force_fallback &&
+      !(std::getenv("VSX_TILT") && std::strcmp(std::getenv("VSX_TILT"), "0") == 0))
+    {
+      const int g = geti;
+      VsxDevParams & T = c->Pt;
+      T = P;
+      T.tilt = g;
+      T.qrq_i_pk = pk(goqi + geqi - g); T.rq_i_pk = pk(geqi - g);
+      T.qrq_r_pk = pk(goqr + geqr - g); T.rq_r_pk = pk(geqr - g);
+      T.qrt_i = goti + geti - g; T.rt_i = geti - g;
+      T.qrt_r = gotr + getr - g; T.rt_r = getr - g;
+      std::vector<int16_t> htop_t(VSX_TABLE_LEN), hleft_t(VSX_TABLE_LEN), matrix_t(256);
+      for (int j = 0; j < VSX_TABLE_LEN; ++j)              // entries beyond the range tilt_possible() admits are never read
+        {
+          htop_t[j] = (int16_t) sat16((int) htop[j] + (j - 1) * g);
+          hleft_t[j] = (int16_t) sat16((int) hleft[j] + (j - 1) * g);
+        }
+      for (int x = 0; x < 256; ++x) matrix_t[x] = (int16_t) sat16(matrix[x] + 2 * g);
+      if ((e = c->d_htop_t.alloc(VSX_TABLE_LEN)) != hipSuccess || (e = c->d_hleft_t.alloc(VSX_TABLE_LEN)) != hipSuccess ||
+          (e = c->d_matrix_t.alloc(256)) != hipSuccess ||
+          (e = hipMemcpy(c->d_htop_t.p, htop_t.data(), VSX_TABLE_LEN * 2, hipMemcpyHostToDevice)) != hipSuccess ||
+          (e = hipMemcpy(c->d_hleft_t.p, hleft_t.data(), VSX_TABLE_LEN * 2, hipMemcpyHostToDevice)) != hipSuccess ||
+          (e = hipMemcpy(c->d_matrix_t.p, matrix_t.data(), 512, hipMemcpyHostToDevice)) != hipSuccess)
+        {
+          cleanup();
+          return fail(VSX_EHIP, "vsx_create: %s", hipGetErrorString(e));
+        }
+      T.htop = c->d_htop_t.p; T.hleft = c->d_hleft_t.p; T.matrix = c->d_matrix_t.p;
+    }
   *out = c;
   return VSX_OK;
 }
@@ -497,6 +533,19 @@ static bool no_overflow_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
   return 4 * G + (Q + Dp + 16) * B < 32000;
 }
 
+// The TILT class (vsx_forward_kernel): every value is shifted by (i + j) g with -R - 2 <= i < Q, -1 <= j < Dp + 16 and g <= B,
+// scores grow by 2g: the interval of no_overflow_possible() widened by that shift must still fit.
+static bool tilt_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
+{
+  if (ctx->Pt.tilt == 0) return false;
+  int64_t B = std::max<int64_t>(std::llabs(ctx->P.match), std::llabs(ctx->P.mismatch));
+  int64_t G = 0;
+  for (int k = 0; k < 12; ++k)
+    if (k < 6) G = std::max<int64_t>(G, ctx->pen[k]); else B = std::max<int64_t>(B, ctx->pen[k]);
+  const int64_t Dp = (D + 3) & ~3ll;
+  return 4 * G + 2 * (Q + Dp + 64) * B < 32000;
+}
+
 static int pick_rows(int Q)
 {
   static const int forced = std::getenv("VSX_ROWS") ? std::atoi(std::getenv("VSX_ROWS")) : 0;      // A/B experiments: rows per lane
@@ -564,7 +613,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   // ---- group by query -> tasks of <= 8 targets, similar lengths together (host threads over query groups) ----
   auto by_query = [&](uint32_t a, uint32_t b) { return qidx[a] < qidx[b]; };
   if (!std::is_sorted(gpu_pairs.begin(), gpu_pairs.end(), by_query)) std::stable_sort(gpu_pairs.begin(), gpu_pairs.end(), by_query);
-  struct ProtoTask { uint32_t q; int rows; int generic; int track; uint32_t n; uint32_t pair[8]; };
+  struct ProtoTask { uint32_t q; int rows; int generic; int track; int tilt; uint32_t n; uint32_t pair[8]; };
   std::vector<size_t> group_begin;                       // start of every query's run in gpu_pairs, plus the end
   for (size_t b = 0; b < gpu_pairs.size();)
     {
@@ -607,6 +656,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
                 dmax = std::max(dmax, targets->len[tidx[pt.pair[sidx]]]);
               }
             pt.track = (!ctx->tb_packed && no_overflow_possible(ctx, queries->len[q], dmax)) ? 0 : 1;
+            pt.tilt = (pt.track == 0 && generic && ctx->ckpt && tilt_possible(ctx, queries->len[q], dmax)) ? 1 : 0;
             outp.push_back(pt);
           }
       }
@@ -628,7 +678,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   auto by_class = [](const ProtoTask & a, const ProtoTask & b) {
     if (a.rows != b.rows) return a.rows < b.rows;
     if (a.generic != b.generic) return a.generic < b.generic;
-    return a.track < b.track;
+    if (a.track != b.track) return a.track < b.track;
+    return a.tilt < b.tilt;
   };
   if (!std::is_sorted(protos.begin(), protos.end(), by_class)) std::stable_sort(protos.begin(), protos.end(), by_class);
 
@@ -681,8 +732,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       pl->dir_bytes_total += dwords * 4;
       const uint32_t task_index = (uint32_t) pl->tasks.size();
       if (cur.launches.empty() || cur.launches.back().rows != pt.rows || cur.launches.back().generic != pt.generic ||
-          cur.launches.back().track != pt.track)
-        cur.launches.push_back(Launch {pt.rows, pt.generic, pt.track, task_index, 0, cur.pair_first + cur.pair_count, 0});
+          cur.launches.back().track != pt.track || cur.launches.back().tilt != pt.tilt)
+        cur.launches.push_back(Launch {pt.rows, pt.generic, pt.track, pt.tilt, task_index, 0, cur.pair_first + cur.pair_count, 0});
       cur.launches.back().count++;
       cur.launches.back().pair_count += pt.n;
       for (uint32_t s = 0; s < pt.n; ++s)
@@ -775,7 +826,7 @@ int vsx_plan_run(vsx_plan * pl)
       if (k >= 1) HIPCHK(hipStreamWaitEvent(st, pl->chunks[k - 1].e2, 0));      // buffer reuse: the previous traceback is done
       HIPCHK(hipEventRecord(c.e0, st));
       for (const Launch & L : c.launches)
-        HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, ctx->P, pl->d_tasks.p + L.first, L.count,
+        HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, L.tilt ? ctx->Pt : ctx->P, pl->d_tasks.p + L.first, L.count,
                                   pl->Q->codes(), pl->T->codes(), dir, pl->d_strip.p,
                                   pl->d_slot.p + (size_t) L.first * VSX_TASK_SLOTS, st));
       HIPCHK(hipEventRecord(c.e1, st));
@@ -784,7 +835,7 @@ int vsx_plan_run(vsx_plan * pl)
       if (ctx->ckpt)
         {
           for (const Launch & L : c.launches)      // the recompute traceback is specialised on R like the DP kernel
-            HIPCHK(vsx_launch_traceback_ck(L.rows, (L.track == 0 && L.generic != 0) ? 1 : 0, ctx->P, pl->filter, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
+            HIPCHK(vsx_launch_traceback_ck(L.rows, (L.track == 0 && L.generic != 0) ? 1 : 0, L.tilt ? ctx->Pt : ctx->P, pl->filter, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
                                            pl->d_pair_ids.p + L.pair_first, L.pair_count, pl->Q->codes(), pl->T->codes(),
                                            dir, pl->d_slot.p, pl->d_slab.p, pl->d_slab_off.p + L.pair_first,
                                            pl->d_runs.p, pl->runs_capacity, pl->d_cursor.p, pl->d_out.p, st2));

@@ -26,6 +26,9 @@ struct VsxDevParams {
   int32_t  n_mismatch;
   int32_t  share_sub;             // 1: QR_q(interior) == QR_t(interior): the DP kernel shares one H - QR per row (see `rows`)
   int32_t  top_open, top_step;    // go / ge of a query-left terminal gap: Htop(j) = -(go + (j + 1) ge); the dummy rows of TOPPAD
+  int32_t  tilt;                  // g > 0: TILTED coordinates X* = X + (i + j) g (vsx_forward_kernel TILT): every penalty above is
+                                  // the original minus g, matrix = original + 2g, htop[j] / hleft[i] = original + (j - 1) g / (i - 1) g;
+                                  // top_open / top_step stay the originals.  0: plain coordinates
   const int16_t * htop;           // H(-1, j), j >= 0: top border chain (:1895-1910, :2043-2051)
   const int16_t * hleft;          // H(i, -1), i >= 0: left border chain (:844-859, :881-887)
   const int16_t * matrix;         // 16x16 score matrix S[target code][query code] (:1319-1342)
