@@ -32,13 +32,31 @@ import torch  # noqa: E402
 #  vsearch_amd/csrc/ubench_valu.hip: 69-73 T int16-ops/s, profiles/r01_ubench_valu.txt)
 PEAK_INT16_TOPS = 256 * 4 * 16 * 2 * 2.4e9 / 1e12
 # ops per DP cell.  SURVEY.md 8(d) prescribes 15 = the reference's onestep (align_simd.cpp:765-780: add + 4 sub + 4 max + min +
-# max + 4 direction compares).  The checkpointing DP kernel does NOT execute 15: its row body is score pack + add + 2 max +
-# 4 sub + 2 max = 10 int16 ops per cell (9 while all columns in flight are interior); the 4 direction compares run only on
-# the tiles the traceback crosses, the min/max only for tasks that can overflow.  Pricing the kernel with 15 therefore
-# exceeds the hardware peak (frac > 1 since r01g).  `roofline.frac` uses the 10 ops the kernel's general row body issues --
-# the honest "how close to the VALU peak" number -- and `roofline.survey_accounting` carries the 15-op figure.
+# max + 4 direction compares).  The checkpointing DP kernel does NOT execute 15: its general row body is score pack + add +
+# 2 max + 4 sub + 2 max = 10 packed-int16 instructions per cell pair; the 4 direction compares run only on the tiles the
+# traceback crosses, the min/max only for tasks that can overflow.  Since r01k the bench workload runs in TILTED coordinates
+# (DESIGN.md 4.2): the interior row body is perm + add + 2 max + sub + 2 max = 7 instructions, two of them (add, sub) 32-bit
+# ops at twice the VOP3P rate = 6.0 VOP3P issue slots; row R-1 of a lane needs 9.5.  `roofline.frac` prices the kernel with
+# the issue slots its own row body needs (the honest "how much of the VALU is doing recurrence work" number); the 10-op and the
+# SURVEY 15-op accountings are carried next to it (both exceed or approach 1 by construction: that work is no longer executed).
 SURVEY_OPS_PER_CELL = 15
-OPS_PER_CELL = 10
+GENERAL_OPS_PER_CELL = 10
+
+
+def tilt_active(qlen, dlen):
+    """mirrors vsx_host.cpp tilt_possible() for the default scoring (match 2, mismatch -4, open 20/2, extend 2/1)"""
+    if os.environ.get("VSX_TILT") == "0" or os.environ.get("VSX_TRACEBACK") == "dirs" or os.environ.get("VSX_TB_ARITH") == "packed" \
+            or os.environ.get("VSX_NO_SHARE_SUB"):
+        return False
+    G, B = 20, 4
+    return 4 * G + 2 * (qlen + ((dlen + 3) & ~3) + 64) * B < 32000
+
+
+def ops_per_cell(qlen, dlen):
+    rows = next((r for r in (1, 4, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 32) if 16 * r >= qlen), 32)   # vsx_host.cpp pick_rows()
+    if not tilt_active(qlen, dlen):
+        return float(GENERAL_OPS_PER_CELL)
+    return ((rows - 1) * 6.0 + 9.5) / rows
 
 
 def traffic_from_profile(a, world):
@@ -162,6 +180,7 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     fwd_avg_ms = fwd_ms / max(1, fwd_launches)
     cells_per_launch = cells * a.steps / max(1, fwd_launches)
+    OPS_PER_CELL = ops_per_cell(a.qlen, a.dlen)
     achieved = cells_per_launch * OPS_PER_CELL / (fwd_avg_ms * 1e-3) / 1e12
     out = {
         "metric": "GCUPS (useful DP cells/s of the search16 global-alignment path: DP + traceback + CIGAR)",
@@ -181,13 +200,16 @@ def main():
             "cells_per_step_per_gpu": cells,
         },
         "roofline": {
-            "kernel": "vsx_forward_kernel<16,true,false,true>",
+            "kernel": "vsx_forward_kernel<16,true,false,true,true>" if tilt_active(a.qlen, a.dlen) else "vsx_forward_kernel<16,true,false,true>",
             "bound": "valu-int16",
             "achieved": round(achieved, 3),
             "peak": round(PEAK_INT16_TOPS, 2),
             "unit": "Tops/s",
             "frac": round(achieved / PEAK_INT16_TOPS, 4),
-            "ops_per_cell": OPS_PER_CELL,
+            "ops_per_cell": round(OPS_PER_CELL, 3),
+            "coordinates": "tilted" if tilt_active(a.qlen, a.dlen) else "plain",
+            "general_row_body_accounting": {"ops_per_cell": GENERAL_OPS_PER_CELL,
+                                            "frac": round(achieved * GENERAL_OPS_PER_CELL / OPS_PER_CELL / PEAK_INT16_TOPS, 4)},
             "survey_accounting": {"ops_per_cell": SURVEY_OPS_PER_CELL,
                                   "achieved": round(achieved * SURVEY_OPS_PER_CELL / OPS_PER_CELL, 3),
                                   "frac": round(achieved * SURVEY_OPS_PER_CELL / OPS_PER_CELL / PEAK_INT16_TOPS, 4),

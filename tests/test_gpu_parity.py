@@ -310,10 +310,11 @@ def test_chunked_plan_equals_single_chunk(gpu_required, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [
     {"VSX_TRACEBACK": "dirs"}, {"VSX_TB_ARITH": "packed"}, {"VSX_SCORE": "arith"}, {"VSX_NO_SHARE_SUB": "1"}, {"VSX_ROWS": "4"},
+    {"VSX_TILT": "0"}, {"VSX_TILT": "0", "VSX_ROWS": "4"},
 ], ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_kernel_modes(gpu_required, env):
     """the A/B switches of DESIGN.md section 8 select other kernel variants (stored direction bits, saturating packed traceback,
-    table-free scores, unshared subtraction, many strips): each must reproduce the golden vectors and the torture slice"""
+    table-free scores, unshared subtraction, many strips, plain instead of tilted coordinates): each must reproduce the golden vectors and the torture slice"""
     import subprocess
     import sys
     e = dict(os.environ)

@@ -43,6 +43,8 @@ DEV u32 ssub(u32 a, u32 b) { return UI(__builtin_elementwise_sub_sat(S2(a), S2(b
 DEV u32 pmax(u32 a, u32 b) { return UI(__builtin_elementwise_max(S2(a), S2(b))); }       // v_pk_max_i16
 DEV u32 pmin(u32 a, u32 b) { return UI(__builtin_elementwise_min(S2(a), S2(b))); }       // v_pk_min_i16
 DEV u32 pminu(u32 a, u32 b) { return UI(__builtin_elementwise_min(U2(a), U2(b))); }      // v_pk_min_u16
+DEV u32 pmaxu(u32 a, u32 b) { return UI(__builtin_elementwise_max(U2(a), U2(b))); }      // v_pk_max_u16
+DEV u32 psubw(u32 a, u32 b) { return UI((us2) (U2(a) - U2(b))); }                        // v_pk_sub_u16 (wraps per half)
 DEV u32 pmad(u32 a, u32 b, u32 c) { return UI((us2) (U2(a) * U2(b) + U2(c))); }          // v_pk_mad_u16
 DEV u32 pashr15(u32 a) { return UI((s2) (S2(a) >> (s2){15, 15})); }                      // v_pk_ashrrev_i16
 DEV u32 bfi(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }                 // v_bfi_b32
@@ -92,7 +94,7 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // H*(-1,-1) = -2g; the score is un-tilted in the epilogue; checkpoints hold tilted values (the traceback recomputes with the
 // same primed constants).
 template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 16 ? 4 : 1, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 16 ? 4 : (R > 24 ? 2 : 1), 8)))
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
                    u32 * __restrict__ dir, uint2 * strip, VsxSlotOut * __restrict__ slot_out)
@@ -108,6 +110,15 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   constexpr bool TOPPAD = CKPT && GENERIC && !TRACK;
   static_assert(!TILT || TOPPAD, "tilted coordinates exist for the TOPPAD class only");
   const int tl = TILT ? P.tilt : 0;                // g of the tilt (P then holds the primed constants)
+  // TILT values are additionally BIASED into unsigned 16 bits (x + 0x8000 per half; the planner's range proof keeps every
+  // intermediate inside (0, 65535)): the primed scores and the interior QR' = go are non-negative, so H + S' and H - go are
+  // ONE 32-bit v_add_u32 / v_sub_u32 for both halves (2 cycles instead of the 4 of v_pk_add/sub_i16: no carry or borrow can
+  // cross the halves); maxima are v_pk_max_u16, the remaining (possibly negative) penalties subtract with v_pk_sub_u16.
+  constexpr u32 BIAS = TILT ? 0x80008000u : 0u;
+  auto vadd = [](u32 a, u32 b) -> u32 { return TILT ? a + b : sadd(a, b); };       // b >= 0 per half
+  auto vsubk = [](u32 a, u32 b) -> u32 { return TILT ? a - b : ssub(a, b); };      // b >= 0 per half, a >= b per half
+  auto vsub = [](u32 a, u32 b) -> u32 { return TILT ? psubw(a, b) : ssub(a, b); };
+  auto vmax = [](u32 a, u32 b) -> u32 { return TILT ? pmaxu(a, b) : pmax(a, b); };
   // GENERIC: query profile in LDS, QP[target code][row of the strip] = S[code][query symbol of the row] (int16).
   // Any IUPAC / unknown symbol on either side is handled by construction; one v_perm_b32 per row packs the two targets.
   __shared__ __attribute__((aligned(16))) int16_t QP[GENERIC ? 16 * 16 * R : 8];
@@ -186,19 +197,19 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           if (i < 0) i = 0;
           const u32 a = qq[i];
           ac[r] = a | (a << 16);
-          u32 hl = pack16(P.hleft[i]);
-          u32 e0 = ssub(hl, (i < Q - 1) ? P.qrq_i_pk : P.qrq_r_pk);
+          u32 hl = pack16(P.hleft[i]) ^ BIAS;
+          u32 e0 = vsub(hl, (i < Q - 1) ? P.qrq_i_pk : P.qrq_r_pk);
           if (dummy)
             {
               const int sh = (r - pad - 1) * tl;                                     // tilt of (i, -1), i = r - pad
-              hl = pack16(((r == pad - 1) ? 0 : -P.top_open) + sh);                  // Htop(-1) = 0 for the first real row's diagonal
-              e0 = ssub(pack16(-P.top_open - P.top_step + sh), P.qrq_i_pk);          // <= Htop(0), stays below the chain
+              hl = pack16(((r == pad - 1) ? 0 : -P.top_open) + sh) ^ BIAS;           // Htop(-1) = 0 for the first real row's diagonal
+              e0 = vsub(pack16(-P.top_open - P.top_step + sh) ^ BIAS, P.qrq_i_pk);   // <= Htop(0), stays below the chain
             }
           hprev[r] = hl;
           hnext[r] = hl;     // a lane that has not started yet must find its border state in either array
           E[r] = e0;
         }
-      u32 diag = first ? pack16(((TOPPAD && pad > 0) ? -P.top_open : 0) - (pad + 2) * tl) : pack16(P.hleft[i0 - 1]);   // H(i0-1, -1); Htop(-1) = 0 (:1895)
+      u32 diag = (first ? pack16(((TOPPAD && pad > 0) ? -P.top_open : 0) - (pad + 2) * tl) : pack16(P.hleft[i0 - 1])) ^ BIAS;   // H(i0-1, -1); Htop(-1) = 0 (:1895)
       // query-gap penalties of row R-1: only the globally last row uses the right-end pair (:836-897)
       const bool lastpos = (L == total_lanes - 1);
       const u32 qrq_last = lastpos ? P.qrq_r_pk : P.qrq_i_pk;
@@ -263,8 +274,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               f_rt = rA | (rB << 16);
               if (s == 0)
                 {
-                  f_H = pack16(rawH - pad * tl);       // H(-1, j) = Htop(j) (tilted: it enters at row -pad - 1)
-                  f_F = ssub(f_H, f_qrt);              // f = v_sub(f, QR_t) at block entry (:830-833)
+                  f_H = pack16(rawH - pad * tl) ^ BIAS;     // H(-1, j) = Htop(j) (tilted: it enters at row -pad - 1)
+                  f_F = vsub(f_H, f_qrt);              // f = v_sub(f, QR_t) at block entry (:830-833)
                 }
               else
                 {
@@ -335,19 +346,19 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                     }
                   else V = a_pk_mad(a_pk_minu(ac[r] ^ code, 0x00010001u), nd, P.match_pk);
                   // onestep (:765-780)
-                  const u32 h0 = sadd(Hd, V);
-                  const u32 h1 = pmax(h0, F);
-                  h2 = pmax(h1, E[r]);
+                  const u32 h0 = vadd(Hd, V);
+                  const u32 h1 = vmax(h0, F);
+                  h2 = vmax(h1, E[r]);
                   if (TRACK) { smn = pmin(smn, h2); smx = pmax(smx, h2); }
                   Hd = hin[r];
                   hout[r] = h2;
                   const u32 qrq = (r == R - 1) ? qrq_last : P.qrq_i_pk;
                   const u32 rq = (r == R - 1) ? rq_last : P.rq_i_pk;
-                  const u32 he = ssub(h2, qrq);
-                  const u32 hf = (SHARED && r < R - 1) ? he : ssub(h2, qrt);
-                  const u32 f = (TILT && INTERIOR) ? F : ssub(F, rt);                      // tilted interior: R' = 0
-                  const u32 e = (TILT && INTERIOR && r < R - 1) ? E[r] : ssub(E[r], rq);   // (row R-1 may be the query's last row)
-                  if (CKPT && r == R - 1) { lastL = ssub(h1, E[r]); lastEL = ssub(he, e); }     // the last row's left / ext-left diffs
+                  const u32 he = (r < R - 1) ? vsubk(h2, qrq) : vsub(h2, qrq);             // QR'(interior rows) = go >= 0
+                  const u32 hf = (SHARED && r < R - 1) ? he : vsub(h2, qrt);
+                  const u32 f = (TILT && INTERIOR) ? F : vsub(F, rt);                      // tilted interior: R' = 0
+                  const u32 e = (TILT && INTERIOR && r < R - 1) ? E[r] : vsub(E[r], rq);   // (row R-1 may be the query's last row)
+                  if (CKPT && r == R - 1) { lastL = vsub(h1, E[r]); lastEL = vsub(he, e); }     // the last row's left / ext-left diffs
                   if (!CKPT)
                     {
                       const u32 dU = ssub(h0, F);          // sign <=> F > H      (up)
@@ -357,8 +368,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                       acc = funnel(funnel(funnel(funnel(acc, dU), dL), dEU), dEL);
                       if ((r & 3) == 3 || r == R - 1) dw[r >> 2] = acc;
                     }
-                  F = pmax(f, hf);
-                  E[r] = pmax(e, he);
+                  F = vmax(f, hf);
+                  E[r] = vmax(e, he);
                   // position 0 holds only rcnt0 rows: its later rows compute junk that never leaves the lane
                   if (!TOPPAD && __builtin_expect(rc0 == r + 1, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
                 }
@@ -505,6 +516,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       const int mnA = (int16_t) (hmin & 0xffff), mnB = (int16_t) (hmin >> 16);
       const int mxA = (int16_t) (hmax & 0xffff), mxB = (int16_t) (hmax >> 16);
       VsxSlotOut oA, oB;
+      score ^= BIAS;
       oA.score = (int16_t) ((int) (int16_t) (score & 0xffff) - (DA > 0 ? (Q + DA - 2) * tl : 0));     // H = H* - (i + j) g
       oB.score = (int16_t) ((int) (int16_t) (score >> 16) - (DB > 0 ? (Q + DB - 2) * tl : 0));
       oA.leave = (uint16_t) (leave & 0xffff); oB.leave = (uint16_t) (leave >> 16); oA.pad = 0; oB.pad = 0;
@@ -708,7 +720,7 @@ DEV u32 accept_verdict(const VsxFilterDev & F, int Q, int D, int al, int ma, int
 }
 
 template <int R, bool FAST>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 16 ? 3 : (R >= 28 ? 2 : 1), 8)))      // R = 16: <= 168 VGPRs, R >= 28: <= 256
 vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTask * __restrict__ tasks,
                         const u32 * __restrict__ pair_slot, const u32 * __restrict__ pair_ids, u32 npairs,
                         const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
@@ -760,7 +772,8 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   const int g = (int) (sl >> 1);
   const bool hi = (sl & 1) != 0;
   const u32 half_sel = hi ? 0x07060302u : 0x05040100u;           // v_perm_b32(F, H, sel) = this pair's H | F << 16
-  const u32 bias2 = FAST ? 0x80008000u : 0u;
+  const u32 bias2 = (FAST && P.tilt == 0) ? 0x80008000u : 0u;      // checkpoints of the TILT class are stored biased
+  const u32 ckb = (FAST && P.tilt == 0) ? 0x8000u : 0u;
   // penalties: FAST subtracts them in 32 bits, so they are sign-extended there (tilted penalties can be negative)
   auto pen = [](int v) -> u32 { return FAST ? (u32) v : (u32) (uint16_t) v; };
   auto pen_pk = [](u32 pk) -> u32 { return FAST ? (u32) (int) (int16_t) (pk & 0xffffu) : pk; };
@@ -792,6 +805,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         dst[(2 * e + 1) * 64] = __builtin_amdgcn_perm(v[e].w, v[e].z, half_sel) ^ bias2;
       }
   };
+  auto inck = [&](u32 lo16) -> u32 { return FAST ? ((lo16 & 0xffffu) ^ ckb) : lo16; };     // a checkpoint value -> A's domain
   auto stage_symbols = [&](int c0) {
     u32 w[4];
 #pragma unroll
@@ -913,15 +927,15 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
                 return (z & 3) == 0 ? qd.x : (z & 3) == 1 ? qd.y : (z & 3) == 2 ? qd.z : qd.w;
               };
 #pragma unroll
-              for (int x = 0; x < R; ++x) { hp[x] = A::in(half_lo(flat(x), hi)); ee[x] = A::in(half_lo(flat(R + x), hi)); }
+              for (int x = 0; x < R; ++x) { hp[x] = inck(half_lo(flat(x), hi)); ee[x] = inck(half_lo(flat(R + x), hi)); }
             }
           else
             {
 #pragma unroll
               for (int x = 0; x < R; ++x)
                 {
-                  hp[x] = A::in(half_lo(colck_at(s, m - 1, g * 16 + l, x), hi));
-                  ee[x] = A::in(half_lo(colck_at(s, m - 1, g * 16 + l, R + x), hi));
+                  hp[x] = inck(half_lo(colck_at(s, m - 1, g * 16 + l, x), hi));
+                  ee[x] = inck(half_lo(colck_at(s, m - 1, g * 16 + l, R + x), hi));
                 }
             }
         }

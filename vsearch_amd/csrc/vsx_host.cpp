@@ -386,7 +386,10 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   // Tilted coordinates X* = X + (i + j) g, g = the interior extension (VsxDevParams::tilt): available when both interior
   // extensions are g > 0 and the interior QR coincide (the DP kernel's shared H - QR); per task the planner still has to
   // prove the shifted range (tilt_possible()).  VSX_TILT=0 switches the class off (A/B measurements, tests).
+  // The tilted kernel adds the primed scores with a 32-bit add over both int16 halves: they must be non-negative
+  // (mismatch + 2g >= 0, the dummy rows' -ge(query left) + 2g >= 0).
   if (geqi == geti && geti > 0 && P.share_sub && c->ckpt && !c->tb_packed && !c->force_fallback &&
+      std::min(match, mism) + 2 * geti >= 0 && 2 * geti - geql >= 0 &&
       !(std::getenv("VSX_TILT") && std::strcmp(std::getenv("VSX_TILT"), "0") == 0))
     {
       const int g = geti;
