@@ -11,14 +11,18 @@
 //     j = t - l (systolic skew), so H/F cross lanes through one v_mov_b32_dpp row_shr:1 per step
 //     and E / the left-neighbour H never leave VGPRs;
 //   * the column descriptor (target symbol pair, column penalties, score delta) travels down the
-//     same DPP pipeline; lane 0 is fed from a 16-column block that rotates with row_ror:15;
-//   * the 4 direction bits per cell are the SIGN bits of four saturating subtractions
-//     (a > b  <=>  ssub(b, a) < 0, exact under saturation), funnelled into 16-bit fields with
-//     v_lshrrev_b32 + v_bfi_b32; each lane stores R/4 dwords per step, laid out [4-step block][lane][step];
-//   * no MFMA: this is a max-plus recurrence on int16, bound by VALU issue (see DESIGN.md).
-//
-// A second kernel walks the stored direction bits (one lane per pair) and emits the alignment
-// statistics and run-length CIGAR exactly as backtrack16 does.
+//     same DPP pipeline; lane 0 is fed from a 16-column block parked in LDS once per 16 steps;
+//   * default (CKPT): no direction bits are stored.  Every step each lane stores the (H, F) pair it hands to the next pipeline
+//     position (row checkpoints) and every 16 steps its column state hprev[R], E[R] (column checkpoints); the traceback kernel
+//     (vsx_traceback_ck_kernel, one lane per pair) recomputes the direction bits only for the <= R x 16 tiles the path crosses
+//     and walks them with backtrack16's rules, emitting statistics and the run-length CIGAR;
+//   * default arithmetic (TILT, tasks whose score range the planner can bound): tilted coordinates X* = X + (i + j) g remove
+//     F - R and E - R from the interior (7 instructions per lane-row); values biased into unsigned halves so that the add and
+//     the subtraction are 32-bit ops over both halves.  Exact: every maximum compares two values of the same cell;
+//   * VSX_TRACEBACK=dirs keeps the first design: the 4 direction bits per cell are the SIGN bits of four saturating
+//     subtractions (a > b  <=>  ssub(b, a) < 0, exact under saturation), funnelled into 16-bit fields with v_lshrrev_b32 +
+//     v_bfi_b32, R/4 dwords per lane and step, walked by vsx_traceback_kernel;
+//   * no MFMA: this is a max-plus recurrence on int16, bound by VALU issue (see DESIGN.md 4.1).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "vsx_internal.h"
