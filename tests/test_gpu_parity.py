@@ -324,3 +324,47 @@ def test_alternate_kernel_modes(gpu_required, env):
                         "-k", "golden or torture or multi_strip or reference_batch"], env=e, capture_output=True, text=True,
                        timeout=600, cwd=root)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+
+
+_PIPE_SNIPPET = r"""
+import hashlib, random, sys
+import numpy as np
+sys.path.insert(0, %r)
+from tests import common
+from vsearch_amd import Aligner
+rng = random.Random(21)
+fam = [common.rnd_seq(rng, rng.randint(40, 160)) for _ in range(40)]
+seqs = [common.mutate(rng, rng.choice(fam), rng.choice([0.03, 0.1, 0.3])) for _ in range(400)] + ["", "A"]
+qi = np.array([rng.randrange(len(seqs)) for _ in range(9000)], np.uint32)
+qi.sort()
+ti = np.array([rng.randrange(len(seqs)) for _ in range(9000)], np.uint32)
+h = hashlib.sha256()
+with Aligner() as al:
+    ss = al.sequences(seqs)
+    for flt in (None, dict(id=0.8, weak_id=0.7)):
+        res = al.align_pairs_oneshot(ss, ss, qi, ti, filter=flt)
+        for arr in (res.score, res.aligned, res.matches, res.mismatches, res.gaps):
+            h.update(np.ascontiguousarray(arr).tobytes())
+        if flt:
+            h.update(np.ascontiguousarray(res.verdict).tobytes())
+        h.update("\n".join(res.cigar).encode())
+    ss.close()
+print("HASH", h.hexdigest())
+"""
+
+
+@pytest.mark.gpu
+def test_pipelined_slices_equal_one_plan(gpu_required):
+    """vsx_align_pairs pipelines large pair lists as several plans (planner thread + GPU + fetch): with the slice size forced
+    down to 700 pairs a 9 000-pair call (unfiltered and filtered, incl. closed-form pairs) must return the same bytes as one plan"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({"VSX_PIPELINE": "0"}, {"VSX_PIPELINE_SLICE": "700"}):
+        e = dict(os.environ)
+        e.update(env)
+        p = subprocess.run([sys.executable, "-c", _PIPE_SNIPPET % root], env=e, capture_output=True, text=True, timeout=600, cwd=root)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        outs.append([ln for ln in p.stdout.splitlines() if ln.startswith("HASH")])
+    assert outs[0] and outs[0] == outs[1]

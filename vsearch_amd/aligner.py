@@ -117,6 +117,18 @@ class SequenceSet:
         return self.n
 
 
+def make_filter(**kw):
+    """a vsx_filter with defaults that accept everything, overridden by the keyword arguments"""
+    f = _lib.Filter()
+    f.iddef, f.id, f.weak_id, f.maxid = 2, 0.0, 0.0, 1.0
+    f.maxsubs = f.maxgaps = f.maxdiffs = 2 ** 31 - 1
+    for k, v in kw.items():
+        if not hasattr(f, k):
+            raise TypeError(f"unknown filter field {k}")
+        setattr(f, k, v)
+    return f
+
+
 class Plan:
     """A batch of (query, target) pairs bound to device buffers (vsx_plan)."""
 
@@ -135,14 +147,7 @@ class Plan:
     def set_filter(self, **kw):
         """device-side accept filter (vsx_filter): iddef, id, weak_id, maxid, mid, query_cov, target_cov, maxsubs, maxgaps,
         mincols, maxdiffs, leftjust, rightjust; call before run().  No arguments = defaults that accept everything."""
-        f = _lib.Filter()
-        f.iddef, f.id, f.weak_id, f.maxid = 2, 0.0, 0.0, 1.0
-        f.maxsubs = f.maxgaps = f.maxdiffs = 2 ** 31 - 1
-        for k, v in kw.items():
-            if not hasattr(f, k):
-                raise TypeError(f"unknown filter field {k}")
-            setattr(f, k, v)
-        check(_lib.load().vsx_plan_set_filter(self.h, C.byref(f)), "vsx_plan_set_filter")
+        check(_lib.load().vsx_plan_set_filter(self.h, C.byref(make_filter(**kw))), "vsx_plan_set_filter")
 
     def run(self):
         check(_lib.load().vsx_plan_run(self.h), "vsx_plan_run")
@@ -249,6 +254,22 @@ class Aligner:
             return p.fetch()
         finally:
             p.close()
+
+    def align_pairs_oneshot(self, queries, targets, qidx, tidx, filter=None):
+        """vsx_align_pairs / vsx_align_pairs_filtered: plan + run + fetch in one C call (large lists are pipelined as several
+        plans inside the library); `filter` = dict of vsx_filter fields or None"""
+        lib = _lib.load()
+        qidx = np.ascontiguousarray(qidx, np.uint32)
+        tidx = np.ascontiguousarray(tidx, np.uint32)
+        res = Results()
+        f = make_filter(**filter) if filter is not None else None
+        check(lib.vsx_align_pairs_filtered(self.h, queries.h, targets.h, qidx.size, qidx.ctypes.data_as(C.c_void_p),
+                                           tidx.ctypes.data_as(C.c_void_p), C.byref(f) if f is not None else None, C.byref(res)),
+              "vsx_align_pairs_filtered")
+        try:
+            return AlignmentResults(res)
+        finally:
+            lib.vsx_results_free(C.byref(res))
 
     def align(self, q, t):
         """one pair -> (score, aligned, matches, mismatches, gaps, cigar)"""

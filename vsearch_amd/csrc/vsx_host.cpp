@@ -20,6 +20,8 @@
 #include <cstring>
 #include <sched.h>
 #include <thread>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <chrono>
 #include <memory>
@@ -109,7 +111,7 @@ struct ScratchPool {
     if (!enabled) { (void) hipFree(p); return; }
     std::lock_guard<std::mutex> lk(mu);
     free_blocks.push_back(PoolBlock {p, bytes});
-    while (free_blocks.size() > 12)                       // bound the number of idle blocks: drop the smallest
+    while (free_blocks.size() > 64)                       // bound the number of idle blocks: drop the smallest
       {
         size_t m = 0;
         for (size_t k = 1; k < free_blocks.size(); ++k) if (free_blocks[k].bytes < free_blocks[m].bytes) m = k;
@@ -152,12 +154,53 @@ struct PoolBuf {
   }
 };
 
+// Stream-ordered scratch shared by the plans of one context: checkpoints and the traceback slab are dead once a plan's
+// kernels have finished, and the plans of a context execute in order on its streams, so they can all use ONE block (the
+// next plan's kernels are queued behind the previous plan's traceback).  A plan holds a reference; a larger request
+// replaces the context's current block, the old one goes back to the pool when its last plan dies.
+struct SharedBlock {
+  void * p = nullptr;
+  size_t bytes = 0;
+  ScratchPool * pool = nullptr;
+  ~SharedBlock() { if (p) { if (pool) pool->put(p, bytes); else (void) hipFree(p); } }
+};
+struct SharedSlot {
+  std::mutex mu;
+  std::shared_ptr<SharedBlock> cur;
+  hipError_t acquire(ScratchPool * pool, size_t bytes, std::shared_ptr<SharedBlock> & out)
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (cur && cur->bytes >= bytes) { out = cur; return hipSuccess; }
+    auto b = std::make_shared<SharedBlock>();
+    hipError_t e = pool->get(bytes, &b->p, &b->bytes);
+    if (e != hipSuccess) { b->p = nullptr; return e; }
+    b->pool = pool;
+    cur = b;
+    out = b;
+    return hipSuccess;
+  }
+  void reset() { std::lock_guard<std::mutex> lk(mu); cur.reset(); }
+  size_t bytes() { std::lock_guard<std::mutex> lk(mu); return cur ? cur->bytes : 0; }
+};
+template <typename T>
+struct SharedBuf {
+  std::shared_ptr<SharedBlock> blk;
+  T * p = nullptr;
+  hipError_t alloc(SharedSlot & slot, ScratchPool * pool, size_t count)
+  {
+    hipError_t e = slot.acquire(pool, std::max<size_t>(count, 1) * sizeof(T), blk);
+    p = (e == hipSuccess) ? static_cast<T *>(blk->p) : nullptr;
+    return e;
+  }
+};
+
 }  // namespace
 
 struct vsx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // DP kernels, copies
   hipStream_t stream2 = nullptr;     // traceback kernels (overlap with the next chunk's DP)
+  hipStream_t stream_up = nullptr;   // plan uploads (a plan may be created while another one runs: vsx_align_pairs pipeline)
   vsx_scoring sc {};
   bool force_fallback = false;      // a score/penalty left the 16-bit range: every pair -> sentinel
   bool tb_packed = false;           // VSX_TB_ARITH=packed: plan every task into the TRACK = 1 class (saturating packed ops, capture layout)
@@ -168,6 +211,7 @@ struct vsx_ctx {
   VsxDevParams Pt {};               // the same scoring in TILTED coordinates (VsxDevParams::tilt, vsx_forward_kernel TILT); Pt.tilt == 0: unavailable
   DevBuf<int16_t> d_htop_t, d_hleft_t, d_matrix_t;
   ScratchPool pool;
+  SharedSlot shared_dir, shared_slab;   // declared after the pool: released first
 };
 
 struct vsx_seqset {
@@ -216,14 +260,16 @@ struct vsx_plan {
   std::vector<Chunk> chunks;
   uint64_t cells = 0, dir_bytes_total = 0;
 
-  DevBuf<VsxTask> d_tasks;
-  DevBuf<uint32_t> d_pair_slot, d_pair_ids;
-  PoolBuf<uint32_t> d_dir[2], d_slab, d_runs;   // two direction buffers: chunk k uses k & 1; pooled per context
-  DevBuf<uint64_t> d_slab_off;
-  DevBuf<uint2> d_strip;
-  DevBuf<VsxSlotOut> d_slot;
-  DevBuf<VsxPairOut> d_out;
-  DevBuf<unsigned long long> d_cursor;
+  // every device buffer comes from the context's pool (hipFree synchronises the device: it would stall a pipeline of plans)
+  PoolBuf<VsxTask> d_tasks;
+  PoolBuf<uint32_t> d_pair_slot, d_pair_ids;
+  SharedBuf<uint32_t> d_dir[1], d_slab;         // stream-ordered scratch shared by the context's plans
+  PoolBuf<uint32_t> d_runs;
+  PoolBuf<uint64_t> d_slab_off;
+  PoolBuf<uint2> d_strip;
+  PoolBuf<VsxSlotOut> d_slot;
+  PoolBuf<VsxPairOut> d_out;
+  PoolBuf<unsigned long long> d_cursor;
   uint64_t runs_capacity = 0;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   bool ran = false;
@@ -364,11 +410,13 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   auto cleanup = [&]() {
     if (c->stream) (void) hipStreamDestroy(c->stream);
     if (c->stream2) (void) hipStreamDestroy(c->stream2);
+    if (c->stream_up) (void) hipStreamDestroy(c->stream_up);
     delete c;
   };
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking)) != hipSuccess ||
       (e = c->d_htop.alloc(VSX_TABLE_LEN)) != hipSuccess || (e = c->d_hleft.alloc(VSX_TABLE_LEN)) != hipSuccess ||
       (e = c->d_matrix.alloc(256)) != hipSuccess ||
       (e = hipMemcpy(c->d_htop.p, htop.data(), VSX_TABLE_LEN * 2, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -428,6 +476,9 @@ void vsx_destroy(vsx_ctx * c)
   (void) hipSetDevice(c->device);
   if (c->stream) { (void) hipStreamSynchronize(c->stream); (void) hipStreamDestroy(c->stream); }
   if (c->stream2) { (void) hipStreamSynchronize(c->stream2); (void) hipStreamDestroy(c->stream2); }
+  if (c->stream_up) { (void) hipStreamSynchronize(c->stream_up); (void) hipStreamDestroy(c->stream_up); }
+  c->shared_dir.reset();
+  c->shared_slab.reset();
   c->pool.trim();
   delete c;
 }
@@ -571,9 +622,25 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   *out = nullptr;
   if (queries->ctx != ctx || targets->ctx != ctx) return fail(VSX_EINVAL, "vsx_plan_create: seqset belongs to another context");
   if (n_pairs > 0xffffffffull / 8) return fail(VSX_EINVAL, "vsx_plan_create: too many pairs for one plan");
-  for (uint64_t k = 0; k < n_pairs; ++k)
-    if (qidx[k] >= queries->n || tidx[k] >= targets->n)
-      return fail(VSX_EINVAL, "vsx_plan_create: pair %" PRIu64 " references a sequence out of range", k);
+  static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tc0 = now();
+  const int nthc = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) vsx_internal_usable_cpus(), n_pairs / 262144));
+  {
+    std::vector<uint64_t> bad((size_t) nthc, UINT64_MAX);
+    auto check = [&](int t) {
+      const uint64_t lo = n_pairs * (uint64_t) t / (uint64_t) nthc, hi = n_pairs * (uint64_t) (t + 1) / (uint64_t) nthc;
+      for (uint64_t k = lo; k < hi; ++k)
+        if (qidx[k] >= queries->n || tidx[k] >= targets->n) { bad[(size_t) t] = k; return; }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthc; ++t) pool.emplace_back(check, t);
+    check(0);
+    for (auto & th : pool) th.join();
+    for (int t = 0; t < nthc; ++t)
+      if (bad[(size_t) t] != UINT64_MAX)
+        return fail(VSX_EINVAL, "vsx_plan_create: pair %" PRIu64 " references a sequence out of range", bad[(size_t) t]);
+  }
   HIPCHK(hipSetDevice(ctx->device));
   int rc = ensure_impure(const_cast<vsx_seqset *>(queries));
   if (rc != VSX_OK) return rc;
@@ -584,34 +651,71 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   pl->is_gpu.assign(n_pairs, 0);
 
   // ---- the reference's closed-form / sentinel cases (no DP) ----
+  // host threads classify contiguous slices: the common case (a pair for the GPU) is handled in place, the rare closed-form
+  // pairs are collected per slice and answered serially below (they append to shared CIGAR lists, in pair order)
   std::vector<uint32_t> gpu_pairs;
-  gpu_pairs.reserve(n_pairs);
-  for (uint64_t k = 0; k < n_pairs; ++k)
-    {
-      const int64_t Q = queries->len[qidx[k]], D = targets->len[tidx[k]];
-      VsxPairOut & o = pl->host_out[k];
-      auto sentinel = [&]() { o = VsxPairOut {}; o.score = 32767; };
-      if (ctx->force_fallback) { sentinel(); continue; }              // align_simd.cpp:1463-1479
-      if (Q == 0)                                                      // :1481-1539
+  {
+    std::vector<std::vector<uint32_t>> gp((size_t) nthc), special((size_t) nthc);
+    std::vector<uint64_t> pcells((size_t) nthc, 0);
+    auto classify = [&](int t) {
+      const uint64_t lo = n_pairs * (uint64_t) t / (uint64_t) nthc, hi = n_pairs * (uint64_t) (t + 1) / (uint64_t) nthc;
+      gp[(size_t) t].reserve(hi - lo);
+      uint64_t cells = 0;
+      for (uint64_t k = lo; k < hi; ++k)
         {
-          if (!fits(0, D)) { sentinel(); continue; }
-          o = VsxPairOut {};
-          o.aligned = (uint16_t) D; o.gaps = (uint16_t) D;
-          if (D > 0)
-            {
-              const int64_t a = -(int64_t) ctx->pen[1] - D * (int64_t) ctx->pen[7];
-              const int64_t b = -(int64_t) ctx->pen[5] - D * (int64_t) ctx->pen[11];
-              o.score = (int16_t) (uint16_t) (std::max(a, b) & 0xffff);   // plain narrowing cast :1515
-              pl->host_cigar.push_back(std::to_string(D) + "I");
-              pl->host_cigar_pair.push_back((uint32_t) k);
-            }
-          continue;
+          const int64_t Q = queries->len[qidx[k]], D = targets->len[tidx[k]];
+          if (ctx->force_fallback || Q == 0 || D == 0 || !fits(Q, D)) { special[(size_t) t].push_back((uint32_t) k); continue; }
+          pl->is_gpu[k] = 1;
+          gp[(size_t) t].push_back((uint32_t) k);
+          cells += (uint64_t) Q * (uint64_t) D;
         }
-      if (D == 0 || !fits(Q, D)) { sentinel(); continue; }            // :1867-1882
-      pl->is_gpu[k] = 1;
-      gpu_pairs.push_back((uint32_t) k);
-      pl->cells += (uint64_t) Q * (uint64_t) D;
+      pcells[(size_t) t] = cells;
+    };
+    {
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nthc; ++t) pool.emplace_back(classify, t);
+      classify(0);
+      for (auto & th : pool) th.join();
     }
+    size_t total = 0;
+    for (auto & v : gp) total += v.size();
+    gpu_pairs.resize(total);
+    {
+      std::vector<size_t> base((size_t) nthc);
+      size_t acc = 0;
+      for (int t = 0; t < nthc; ++t) { base[(size_t) t] = acc; acc += gp[(size_t) t].size(); pl->cells += pcells[(size_t) t]; }
+      auto place = [&](int t) { if (!gp[(size_t) t].empty()) std::memcpy(gpu_pairs.data() + base[(size_t) t], gp[(size_t) t].data(), gp[(size_t) t].size() * 4); };
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nthc; ++t) pool.emplace_back(place, t);
+      place(0);
+      for (auto & th : pool) th.join();
+    }
+    for (int t = 0; t < nthc; ++t)
+      for (uint32_t k : special[(size_t) t])
+        {
+          const int64_t Q = queries->len[qidx[k]], D = targets->len[tidx[k]];
+          VsxPairOut & o = pl->host_out[k];
+          auto sentinel = [&]() { o = VsxPairOut {}; o.score = 32767; };
+          if (ctx->force_fallback) { sentinel(); continue; }              // align_simd.cpp:1463-1479
+          if (Q == 0)                                                      // :1481-1539
+            {
+              if (!fits(0, D)) { sentinel(); continue; }
+              o = VsxPairOut {};
+              o.aligned = (uint16_t) D; o.gaps = (uint16_t) D;
+              if (D > 0)
+                {
+                  const int64_t a = -(int64_t) ctx->pen[1] - D * (int64_t) ctx->pen[7];
+                  const int64_t b = -(int64_t) ctx->pen[5] - D * (int64_t) ctx->pen[11];
+                  o.score = (int16_t) (uint16_t) (std::max(a, b) & 0xffff);   // plain narrowing cast :1515
+                  pl->host_cigar.push_back(std::to_string(D) + "I");
+                  pl->host_cigar_pair.push_back(k);
+                }
+              continue;
+            }
+          sentinel();                                                      // D == 0 or the size guard (:1867-1882)
+        }
+  }
+  const double tc1 = now();
 
   // ---- group by query -> tasks of <= 8 targets, similar lengths together (host threads over query groups) ----
   auto by_query = [&](uint32_t a, uint32_t b) { return qidx[a] < qidx[b]; };
@@ -691,12 +795,21 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
     {
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
-      free_b += ctx->pool.idle_bytes();                     // blocks this context can hand straight back
+      free_b += ctx->pool.idle_bytes() + ctx->shared_dir.bytes();   // blocks this context can hand straight back / already holds
       dir_budget_bytes = std::min<uint64_t>((uint64_t) (free_b * 0.4), 128ull << 30);
+      // stay inside the context's current checkpoint block unless it is less than half of what could be had: a slightly
+      // larger request would cost another multi-second hipMalloc
+      const uint64_t have = ctx->shared_dir.bytes();
+      if (have >= dir_budget_bytes / 2) dir_budget_bytes = have;
     }
   const uint64_t budget_dwords = std::max<uint64_t>(dir_budget_bytes / 4, 1);
 
+  const double tc2 = now();
   pl->tasks.reserve(protos.size());
+  pl->pair_slot.resize(gpu_pairs.size());
+  pl->pair_ids.resize(gpu_pairs.size());
+  pl->slab_off.resize(gpu_pairs.size());
+  size_t np_out = 0;
   Chunk cur;
   auto close_chunk = [&]() {
     if (cur.task_count) pl->chunks.push_back(cur);
@@ -741,9 +854,10 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       cur.launches.back().pair_count += pt.n;
       for (uint32_t s = 0; s < pt.n; ++s)
         {
-          pl->pair_slot.push_back(task_index * VSX_TASK_SLOTS + s);
-          pl->pair_ids.push_back(pt.pair[s]);
-          pl->slab_off.push_back(cur.slab_words);
+          pl->pair_slot[np_out] = task_index * VSX_TASK_SLOTS + s;
+          pl->pair_ids[np_out] = pt.pair[s];
+          pl->slab_off[np_out] = cur.slab_words;
+          ++np_out;
           cur.slab_words += (uint64_t) t.qlen + t.tlen[s] + 1;
           cur.pair_count++;
         }
@@ -751,6 +865,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       pl->tasks.push_back(t);
     }
   close_chunk();
+  const double tc3 = now();
 
   // ---- device buffers ----
   uint64_t max_dir = 1, max_strip = 1, max_slab = 1, worst_runs = 0;
@@ -763,26 +878,26 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
     }
   const size_t ngp = pl->pair_ids.size();
   pl->runs_capacity = std::min<uint64_t>(worst_runs, std::max<uint64_t>(16ull << 20, 48ull * ngp)) + 1;
-  HIPCHK(pl->d_tasks.alloc(pl->tasks.size()));
-  HIPCHK(pl->d_pair_slot.alloc(ngp));
-  HIPCHK(pl->d_pair_ids.alloc(ngp));
-  HIPCHK(pl->d_slab_off.alloc(ngp));
-  HIPCHK(pl->d_slot.alloc(pl->tasks.size() * VSX_TASK_SLOTS));
-  HIPCHK(pl->d_out.alloc(n_pairs));
-  HIPCHK(pl->d_cursor.alloc(1));
+  HIPCHK(pl->d_tasks.alloc(&ctx->pool, pl->tasks.size()));
+  HIPCHK(pl->d_pair_slot.alloc(&ctx->pool, ngp));
+  HIPCHK(pl->d_pair_ids.alloc(&ctx->pool, ngp));
+  HIPCHK(pl->d_slab_off.alloc(&ctx->pool, ngp));
+  HIPCHK(pl->d_slot.alloc(&ctx->pool, pl->tasks.size() * VSX_TASK_SLOTS));
+  HIPCHK(pl->d_out.alloc(&ctx->pool, n_pairs));
+  HIPCHK(pl->d_cursor.alloc(&ctx->pool, 1));
   // one checkpoint buffer, reused chunk after chunk: overlapping chunk k's traceback with chunk k+1's DP bought nothing
   // (both are issue-bound), while a second buffer doubled a multi-second hipMalloc
-  HIPCHK(pl->d_dir[0].alloc(&ctx->pool, max_dir));
-  HIPCHK(pl->d_strip.alloc(max_strip));
-  HIPCHK(pl->d_slab.alloc(&ctx->pool, max_slab));
+  HIPCHK(pl->d_dir[0].alloc(ctx->shared_dir, &ctx->pool, max_dir));
+  HIPCHK(pl->d_strip.alloc(&ctx->pool, max_strip));
+  HIPCHK(pl->d_slab.alloc(ctx->shared_slab, &ctx->pool, max_slab));
   HIPCHK(pl->d_runs.alloc(&ctx->pool, pl->runs_capacity));
   if (!pl->tasks.empty())
-    HIPCHK(hipMemcpyAsync(pl->d_tasks.p, pl->tasks.data(), pl->tasks.size() * sizeof(VsxTask), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(pl->d_tasks.p, pl->tasks.data(), pl->tasks.size() * sizeof(VsxTask), hipMemcpyHostToDevice, ctx->stream_up));
   if (ngp)
     {
-      HIPCHK(hipMemcpyAsync(pl->d_pair_slot.p, pl->pair_slot.data(), ngp * 4, hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(hipMemcpyAsync(pl->d_pair_ids.p, pl->pair_ids.data(), ngp * 4, hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(hipMemcpyAsync(pl->d_slab_off.p, pl->slab_off.data(), ngp * 8, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(pl->d_pair_slot.p, pl->pair_slot.data(), ngp * 4, hipMemcpyHostToDevice, ctx->stream_up));
+      HIPCHK(hipMemcpyAsync(pl->d_pair_ids.p, pl->pair_ids.data(), ngp * 4, hipMemcpyHostToDevice, ctx->stream_up));
+      HIPCHK(hipMemcpyAsync(pl->d_slab_off.p, pl->slab_off.data(), ngp * 8, hipMemcpyHostToDevice, ctx->stream_up));
     }
   HIPCHK(hipEventCreate(&pl->ev_begin));
   HIPCHK(hipEventCreate(&pl->ev_end));
@@ -793,7 +908,10 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       HIPCHK(hipEventCreate(&c.e1b));
       HIPCHK(hipEventCreate(&c.e2));
     }
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream_up));
+  if (timing)
+    std::fprintf(stderr, "vsx_plan_create: %llu pairs, %zu tasks: classify %.3f s, group %.3f s, tasks %.3f s, device buffers + upload %.3f s\n",
+                 (unsigned long long) n_pairs, pl->tasks.size(), tc1 - tc0, tc2 - tc1, tc3 - tc2, now() - tc3);
   *out = pl.release();
   return VSX_OK;
 }
@@ -1023,8 +1141,9 @@ int vsx_align_pairs(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset 
   return vsx_align_pairs_filtered(ctx, queries, targets, n_pairs, qidx, tidx, nullptr, out);
 }
 
-int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
-                             const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, vsx_results * out)
+// one plan: create, run, fetch, destroy
+static int align_pairs_single(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
+                              const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, vsx_results * out)
 {
   static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1043,6 +1162,158 @@ int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vs
     std::fprintf(stderr, "vsx_align_pairs: %llu pairs: plan %.3f s, run+sync %.3f s, fetch %.3f s, destroy %.3f s\n",
                  (unsigned long long) n_pairs, t1 - t0, t2 - t1, t3 - t2, now() - t3);
   return rc;
+}
+
+// Large pair lists run as a PIPELINE of plans over contiguous slices (cut at query boundaries): a helper thread plans slice
+// i+1 (host grouping, task upload) while the GPU runs slice i and the caller's thread fetches slice i-1 (download, CIGAR
+// text); the slices' results are concatenated.  Same results as one plan -- a pair's alignment does not depend on its
+// batch.  VSX_PIPELINE=0 switches it off.
+int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
+                             const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, vsx_results * out)
+{
+  static const bool pipeline_off = std::getenv("VSX_PIPELINE") && std::strcmp(std::getenv("VSX_PIPELINE"), "0") == 0;
+  static const uint64_t slice_pairs = std::getenv("VSX_PIPELINE_SLICE") ? std::strtoull(std::getenv("VSX_PIPELINE_SLICE"), nullptr, 10) : (2ull << 20);
+  if (pipeline_off || !ctx || !out || !queries || !targets || !qidx || !tidx || n_pairs < 2 * slice_pairs)
+    return align_pairs_single(ctx, queries, targets, n_pairs, qidx, tidx, filter, out);
+  static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
+  std::memset(out, 0, sizeof *out);
+  {
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(VSX_EHIP, "vsx_align_pairs: hipSetDevice failed");
+    const int irc = ensure_impure(const_cast<vsx_seqset *>(queries));      // lazily computed per seqset: not from the planner thread
+    if (irc != VSX_OK) return irc;
+  }
+
+  // slices of about slice_pairs pairs, cut where the query changes (a query's pairs then share tasks as in one plan)
+  std::vector<uint64_t> cut {0};
+  while (cut.back() < n_pairs)
+    {
+      uint64_t e = std::min<uint64_t>(n_pairs, cut.back() + slice_pairs);
+      const uint64_t limit = std::min<uint64_t>(n_pairs, e + slice_pairs / 2);
+      while (e < limit && qidx[e] == qidx[e - 1]) ++e;
+      if (n_pairs - e < slice_pairs / 4) e = n_pairs;
+      cut.push_back(e);
+    }
+  const size_t S = cut.size() - 1;
+  const uint64_t slice_budget = 0;       // the context's shared checkpoint block (the plans execute in stream order)
+  std::vector<vsx_plan *> plans(S, nullptr);
+  std::vector<int> plan_rc(S, VSX_OK);
+  std::vector<std::string> plan_msg(S);
+  std::vector<vsx_results> res(S);
+  for (auto & r : res) std::memset(&r, 0, sizeof r);
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t ready = 0, consumed = 0;
+  bool stop = false;
+  std::thread planner([&]() {
+    (void) hipSetDevice(ctx->device);
+    for (size_t i = 0; i < S; ++i)
+      {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return stop || i < consumed + 3; });      // at most three plans alive beyond the fetched ones
+          if (stop) return;
+        }
+        vsx_plan * pl = nullptr;
+        int rc = vsx_plan_create(ctx, &pl, queries, targets, cut[i + 1] - cut[i], qidx + cut[i], tidx + cut[i], slice_budget);
+        if (rc == VSX_OK && filter && ctx->ckpt) rc = vsx_plan_set_filter(pl, filter);
+        if (rc != VSX_OK) { plan_msg[i] = vsx_last_error(); if (pl) vsx_plan_destroy(pl); pl = nullptr; }
+        std::lock_guard<std::mutex> lk(mu);
+        plans[i] = pl; plan_rc[i] = rc; ready = i + 1;
+        cv.notify_all();
+        if (rc != VSX_OK) return;
+      }
+  });
+  int rc = VSX_OK;
+  std::string msg;
+  size_t launched = 0;
+  auto finish = [&](size_t i) {           // fetch and release slice i
+    int frc = vsx_plan_fetch(plans[i], &res[i]);
+    vsx_plan_destroy(plans[i]);
+    plans[i] = nullptr;
+    { std::lock_guard<std::mutex> lk(mu); consumed = i + 1; }
+    cv.notify_all();
+    return frc;
+  };
+  for (size_t i = 0; i < S && rc == VSX_OK; ++i)
+    {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return ready > i; });
+      }
+      if (plan_rc[i] != VSX_OK) { rc = plan_rc[i]; msg = plan_msg[i]; break; }
+      rc = vsx_plan_run(plans[i]);                       // asynchronous: queued behind slice i-1 on the context's streams
+      if (rc != VSX_OK) { msg = vsx_last_error(); break; }
+      launched = i + 1;
+      if (i > 0) { rc = finish(i - 1); if (rc != VSX_OK) msg = vsx_last_error(); }
+    }
+  if (rc == VSX_OK && launched == S) { rc = finish(S - 1); if (rc != VSX_OK) msg = vsx_last_error(); }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    stop = true;
+  }
+  cv.notify_all();
+  planner.join();
+  for (size_t i = 0; i < S; ++i)
+    if (plans[i]) { vsx_plan_destroy(plans[i]); plans[i] = nullptr; }
+  if (rc != VSX_OK)
+    {
+      for (auto & r : res) vsx_results_free(&r);
+      vsx_internal_set_error(msg.c_str());
+      return rc;
+    }
+
+  // concatenate
+  const uint64_t n = n_pairs;
+  uint64_t blob = 0;
+  std::vector<uint64_t> blob_base(S);
+  for (size_t i = 0; i < S; ++i) { blob_base[i] = blob; blob += res[i].cigar_bytes; }
+  out->n_pairs = n;
+  out->score = (int16_t *) std::malloc(n * 2);
+  out->aligned = (uint16_t *) std::malloc(n * 2);
+  out->matches = (uint16_t *) std::malloc(n * 2);
+  out->mismatches = (uint16_t *) std::malloc(n * 2);
+  out->gaps = (uint16_t *) std::malloc(n * 2);
+  out->cigar_off = (uint64_t *) std::malloc(n * 8);
+  out->verdict = res[0].verdict ? (uint8_t *) std::malloc(n) : nullptr;
+  out->cigar_bytes = blob;
+  out->cigar_blob = (char *) std::malloc(std::max<uint64_t>(blob, 1));
+  if (!out->score || !out->aligned || !out->matches || !out->mismatches || !out->gaps || !out->cigar_off || !out->cigar_blob ||
+      (res[0].verdict && !out->verdict))
+    {
+      for (auto & r : res) vsx_results_free(&r);
+      vsx_results_free(out);
+      return fail(VSX_ENOMEM, "vsx_align_pairs: host allocation failed");
+    }
+  {
+    std::atomic<size_t> next {0};
+    auto place = [&]() {
+      for (;;)
+        {
+          const size_t i = next.fetch_add(1);
+          if (i >= S) break;
+          const uint64_t lo = cut[i], m = cut[i + 1] - cut[i];
+          std::memcpy(out->score + lo, res[i].score, m * 2);
+          std::memcpy(out->aligned + lo, res[i].aligned, m * 2);
+          std::memcpy(out->matches + lo, res[i].matches, m * 2);
+          std::memcpy(out->mismatches + lo, res[i].mismatches, m * 2);
+          std::memcpy(out->gaps + lo, res[i].gaps, m * 2);
+          if (out->verdict) std::memcpy(out->verdict + lo, res[i].verdict, m);
+          for (uint64_t k = 0; k < m; ++k) out->cigar_off[lo + k] = res[i].cigar_off[k] + blob_base[i];
+          std::memcpy(out->cigar_blob + blob_base[i], res[i].cigar_blob, res[i].cigar_bytes);
+          vsx_results_free(&res[i]);
+        }
+    };
+    const int nth = (int) std::min<size_t>(S, (size_t) std::max(1, vsx_internal_usable_cpus()));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nth; ++t) pool.emplace_back(place);
+    place();
+    for (auto & th : pool) th.join();
+  }
+  if (timing)
+    std::fprintf(stderr, "vsx_align_pairs: %llu pairs in %zu pipelined slices: %.3f s\n", (unsigned long long) n_pairs, S, now() - t_begin);
+  return VSX_OK;
 }
 
 void vsx_results_free(vsx_results * r)
