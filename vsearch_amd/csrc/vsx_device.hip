@@ -29,6 +29,7 @@
 
 typedef unsigned int u32;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef short s2 __attribute__((ext_vector_type(2)));
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
@@ -87,6 +88,14 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
                             // 4 = one 64 B line per (quad, block): a lane's blocks and its neighbours' share L2 lines (32.8 / 7.0 ms).  Same total.
 #define VSX_COLCK_DW(R_, lane_, block_) ((((size_t) ((lane_) / VSX_COLCK_G) * (size_t) ((2 * (R_)) / 4) + (size_t) (block_)) * VSX_COLCK_G + (size_t) ((lane_) % VSX_COLCK_G)) * 4)
 #define VSX_RB 1            // row checkpoints: [2^RB-step block][lane][step in block] uint2
+// TILT class: COMPRESSED checkpoints.  In tilted coordinates the value a lane hands on differs from its H by a bounded amount:
+// F(i+1,j) = max(F - R', H - QR') with H >= F gives d = H - F(i+1,j) in [min(R', QR'), QR'], likewise H - E(i,j+1) (the planner
+// admits the class only if that interval fits a signed byte).  Row checkpoints of a two-step pair: 3 dwords {H_t, H_t+1,
+// bytes d_t(lo) d_t(hi) d_t+1(lo) d_t+1(hi)} instead of 4; column checkpoints: hprev[R] followed by R/2 dwords of the bytes
+// d_r(lo) d_r(hi) d_r+1(lo) d_r+1(hi), padded to blocks of 4 dwords: 12 instead of 16 bytes per lane-step.
+#define VSX_ROWCK_PAIR_DW(TILT_) ((TILT_) ? 192 : 256)                       // dwords of one two-step pair of a wave
+#define VSX_COLCK_NB(R_, TILT_) ((TILT_) ? ((R_) + ((R_) + 1) / 2 + 3) / 4 : (2 * (R_)) / 4)   // 4-dword blocks per lane and column checkpoint
+#define VSX_COLCK_CDW(lane_, block_) (((size_t) (block_) * 64 + (size_t) (lane_)) * 4)       // compressed layout: [block][lane][4]
 // TILT = true (a sub-class of TOPPAD: checkpoints, LDS profile, no tracking): the kernel runs in TILTED coordinates,
 //   X*(i, j) = X(i, j) + (i + j) g   for X in {H, E, F},   g = the interior gap extension (both sides equal),
 // in which the recurrence is the same max-plus recurrence with score' = score + 2g, every QR' = QR - g, every R' = R - g:
@@ -245,10 +254,12 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       u32 pendH = 0, pendF = 0;                    // row checkpoint of the even step, stored together with the odd step's
       bool pend_on = false;
       // per-lane base addresses of this strip's checkpoint regions (computed once: the step only adds a uniform offset)
-      const size_t ck_rowdw = (((size_t) nstrips * steps + 1) & ~(size_t) 1) * 128;
+      const size_t ck_rowdw = ((((size_t) nstrips * steps + 1) & ~(size_t) 1) >> 1) * VSX_ROWCK_PAIR_DW(TILT);
       const size_t ck_nblk = ((size_t) steps + 15) >> 4;
-      u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps) >> 1) * 64 + lane) * 4;                    // + (t >> 1) * 256
-      u32 * const cck_base = dir + T.dir_off + ck_rowdw + (size_t) s * ck_nblk * 64 * (2 * R);                    // + (t >> 4) * 128 R
+      constexpr int CK_LANE_DW = TILT ? 3 : 4;                                                                     // row checkpoint dwords per lane and pair
+      constexpr size_t CK_COL_DW = TILT ? (size_t) 64 * 4 * VSX_COLCK_NB(R, true) : (size_t) 64 * (2 * R);           // column checkpoint dwords per wave
+      u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps) >> 1) * 64 + lane) * CK_LANE_DW;             // + (t >> 1) * VSX_ROWCK_PAIR_DW
+      u32 * const cck_base = dir + T.dir_off + ck_rowdw + (size_t) s * ck_nblk * CK_COL_DW;                        // + (t >> 4) * CK_COL_DW
 
       // STEADY (the part of phase A after the pipeline has filled, t >= 15): every lane that owns rows is inside its targets, so the
       // per-lane activity test and its EXEC mask are dropped (lanes beyond the query's positions compute junk nobody reads).
@@ -439,15 +450,39 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               if (!ODD) pend_on = active;
               else if (pend_on || active)
                 {
-                  __builtin_nontemporal_store((u32x4) {pendH, pendF, outH, outF}, reinterpret_cast<u32x4 *>(rck_base + (size_t) (t >> 1) * 256));
+                  if (TILT)
+                    {
+                      // bytes 0 / 2 of the two wrapped differences = the signed 8-bit H - F of the lo / hi target, steps t-1 and t
+                      const u32 dpk = __builtin_amdgcn_perm(psubw(outH, outF), psubw(pendH, pendF), 0x06040200u);
+                      __builtin_nontemporal_store((u32x3) {pendH, outH, dpk}, reinterpret_cast<u32x3 *>(rck_base + (size_t) (t >> 1) * 192));
+                    }
+                  else
+                    __builtin_nontemporal_store((u32x4) {pendH, pendF, outH, outF}, reinterpret_cast<u32x4 *>(rck_base + (size_t) (t >> 1) * 256));
                 }
             }
           if (CKPT && (t & 15) == 15)
             {
               // column checkpoint m = t / 16 of this lane: state after its column t - l (or its border state if it has
               // not started yet).  Layout VSX_COLCK_DW (R = 1: [strip][m][lane][2]).
-              u32 * cb = cck_base + (size_t) (t >> 4) * 64 * (2 * R);
-              if (R % 2 == 0)
+              u32 * cb = cck_base + (size_t) (t >> 4) * CK_COL_DW;
+              if (TILT)
+                {
+                  // hprev[0..R), then the byte differences of two rows per dword; zero-padded to whole blocks
+                  constexpr int NF = R + (R + 1) / 2;
+                  auto flatc = [&](int z) -> u32 {
+                    if (z < R) return hout[z];
+                    if (z < NF)
+                      {
+                        const int r0 = 2 * (z - R), r1 = r0 + 1 < R ? r0 + 1 : r0;
+                        return __builtin_amdgcn_perm(psubw(hout[r1], E[r1]), psubw(hout[r0], E[r0]), 0x06040200u);
+                      }
+                    return 0u;
+                  };
+#pragma unroll
+                  for (int z = 0; z < 4 * VSX_COLCK_NB(R, true); z += 4)
+                    __builtin_nontemporal_store((u32x4) {flatc(z), flatc(z + 1), flatc(z + 2), flatc(z + 3)}, reinterpret_cast<u32x4 *>(cb + VSX_COLCK_CDW(lane, z >> 2)));
+                }
+              else if (R % 2 == 0)
                 {
                   // the 2R dwords hprev[0..R), E[0..R) as one flat array, four to a block
                   auto flat = [&](int z) -> u32 { return z < R ? hout[z] : E[z - R]; };
@@ -690,6 +725,7 @@ template <> struct TbOps<true>
 typedef u32 u32_unaligned __attribute__((aligned(1)));
 typedef unsigned long long u64_unaligned __attribute__((aligned(1)));
 struct __attribute__((aligned(4))) Quad { u32 x, y, z, w; };
+struct __attribute__((aligned(4))) Trio { u32 x, y, z; };
 
 // align_trim (core/searchcore.cpp:343-464) + search_acceptable_aligned (:664-737) on the finished alignment, with the
 // reference's double expressions (no contraction: every product feeds a comparison or a quotient, never a sum).
@@ -723,7 +759,8 @@ DEV u32 accept_verdict(const VsxFilterDev & F, int Q, int D, int al, int ma, int
   return (id >= 100.0 * F.id) ? 1u : 2u;
 }
 
-template <int R, bool FAST>
+// CK8 = the compressed checkpoint layout of the TILT class (VSX_ROWCK_PAIR_DW / VSX_COLCK_NB): FAST arithmetic, tilted constants
+template <int R, bool FAST, bool CK8 = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 16 ? 3 : (R >= 28 ? 2 : 1), 8)))      // R = 16: <= 168 VGPRs, R >= 28: <= 256
 vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTask * __restrict__ tasks,
                         const u32 * __restrict__ pair_slot, const u32 * __restrict__ pair_ids, u32 npairs,
@@ -735,6 +772,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
 {
   typedef TbOps<FAST> A;
   static_assert(VSX_RB == 1, "the tile staging below reads row checkpoints as two-step (16-byte) pairs");
+  static_assert(!CK8 || FAST, "compressed checkpoints belong to the TILT class");
   constexpr int ND = (R + 3) / 4;
   constexpr bool TOPPAD = FAST;                    // slot layout of position 0, see vsx_forward_kernel
   __shared__ int16_t Ssh[512];                     // S[target code][query code], row stride 32; query "code" 16 = a dummy row
@@ -765,12 +803,13 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   const size_t steps = T.steps;
   const size_t nblk = (steps + 15) >> 4;
   const size_t rowsteps = ((size_t) nstrips * steps + 1) & ~(size_t) 1;
-  const size_t rowck_dw = rowsteps * 128;
+  const size_t rowck_dw = (rowsteps >> 1) * VSX_ROWCK_PAIR_DW(CK8);
+  constexpr size_t COL_DW = CK8 ? (size_t) 64 * 4 * VSX_COLCK_NB(R, true) : (size_t) 64 * (2 * R);     // column checkpoint dwords per wave
   const u32 * __restrict__ rowck = ck + T.dir_off;
   const u32 * __restrict__ colck = ck + T.dir_off + rowck_dw;
   // column checkpoint element x (0 .. 2R-1: hprev[R], E[R]) of pipeline lane `lanepos`, strip sp, 16-step block mb
   auto colck_at = [&](int sp, int mb, int lanepos, int x) -> u32 {
-    const u32 * cb = colck + ((size_t) sp * nblk + (size_t) mb) * 64 * (2 * R);
+    const u32 * cb = colck + ((size_t) sp * nblk + (size_t) mb) * COL_DW;
     return (R % 2 == 0) ? cb[VSX_COLCK_DW(R, lanepos, x >> 2) + (x & 3)] : cb[(size_t) lanepos * (2 * R) + x];
   };
   const int g = (int) (sl >> 1);
@@ -793,6 +832,29 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   auto stage_top = [&](const u32 * base, size_t stride, long gstart, long maxpair) {
     const long p0 = gstart >> 1;                               // floor, also for gstart = -1
     const int par = (int) (gstart - 2 * p0);
+    if (CK8)
+      {
+        // {H_t, H_t+1, bytes d_t(lo) d_t(hi) d_t+1(lo) d_t+1(hi)}: F = H - d
+        Trio v3[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+          {
+            long p = p0 + e;
+            p = p < 0 ? 0 : (p > maxpair ? maxpair : p);
+            v3[e] = *reinterpret_cast<const Trio *>(base + (size_t) p * stride);
+          }
+        u32 * dst = tbL + (1 - par) * 64 + tid;
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+          {
+            const u32 h0 = half_lo(v3[e].x, hi) & 0xffffu, h1 = half_lo(v3[e].y, hi) & 0xffffu;
+            const u32 dd = hi ? (v3[e].z >> 8) : v3[e].z;
+            const int d0 = (int) (int8_t) (dd & 0xffu), d1 = (int) (int8_t) ((dd >> 16) & 0xffu);
+            dst[(2 * e) * 64] = h0 | ((h0 - (u32) d0) << 16);
+            dst[(2 * e + 1) * 64] = h1 | ((h1 - (u32) d1) << 16);
+          }
+        return;
+      }
     Quad v[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e)
@@ -882,7 +944,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         {
           const int Lp = L - 1;
           const int sp = Lp >> 4, lp = Lp & 15;
-          stage_top(rowck + (size_t) (g * 16 + lp) * 4, 256, (long) ((size_t) sp * steps) + (long) (c0 - 1 + lp),
+          stage_top(rowck + (size_t) (g * 16 + lp) * (CK8 ? 3 : 4), VSX_ROWCK_PAIR_DW(CK8), (long) ((size_t) sp * steps) + (long) (c0 - 1 + lp),
                     (long) (rowsteps >> 1) - 1);
           if (c0 == 0) tbL[64 + tid] = A::in((u32) (uint16_t) P.hleft[i0 - 1]);     // corner H(i0-1, -1)
         }
@@ -919,9 +981,29 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         }
       else
         {
-          if (R % 2 == 0)
+          if (CK8)
             {
-              const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * 64 * (2 * R) + VSX_COLCK_DW(R, g * 16 + l, 0);
+              const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * COL_DW + VSX_COLCK_CDW(g * 16 + l, 0);
+              constexpr int NBQ = VSX_COLCK_NB(R, true);
+              Quad fq[NBQ];
+#pragma unroll
+              for (int b = 0; b < NBQ; ++b) fq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * (4 * 64));
+              auto flat = [&](int z) -> u32 {
+                const Quad & qd = fq[z >> 2];
+                return (z & 3) == 0 ? qd.x : (z & 3) == 1 ? qd.y : (z & 3) == 2 ? qd.z : qd.w;
+              };
+#pragma unroll
+              for (int x = 0; x < R; ++x)
+                {
+                  const u32 h = half_lo(flat(x), hi) & 0xffffu;                       // stored biased: already in A's domain
+                  const u32 dd = flat(R + (x >> 1)) >> (8 * ((x & 1) * 2 + (hi ? 1 : 0)));
+                  hp[x] = h;
+                  ee[x] = h - (u32) (int) (int8_t) (dd & 0xffu);
+                }
+            }
+          else if (R % 2 == 0)
+            {
+              const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * COL_DW + VSX_COLCK_DW(R, g * 16 + l, 0);
               constexpr int NBQ = (2 * R) / 4 ? (2 * R) / 4 : 1;        // blocks of the flat hprev[R], E[R] array
               Quad fq[NBQ];
 #pragma unroll
@@ -1271,13 +1353,13 @@ extern "C" hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tas
   return hipGetLastError();
 }
 
-template <int R, bool FAST>
+template <int R, bool FAST, bool CK8 = false>
 static hipError_t launch_tbck(const VsxDevParams & P, const VsxFilterDev & F, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
                               const uint32_t * d_pair_ids, uint32_t npairs, const uint8_t * q, const uint8_t * t,
                               const uint32_t * ck, const VsxSlotOut * slot, uint32_t * slab, const uint64_t * slab_off,
                               uint32_t * runs, uint64_t cap, unsigned long long * cursor, VsxPairOut * out, hipStream_t st)
 {
-  hipLaunchKernelGGL((vsx_traceback_ck_kernel<R, FAST>), dim3((npairs + 63) / 64), dim3(64), 0, st,
+  hipLaunchKernelGGL((vsx_traceback_ck_kernel<R, FAST, CK8>), dim3((npairs + 63) / 64), dim3(64), 0, st,
                      P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, cap, cursor, out);
   return hipGetLastError();
 }
@@ -1291,7 +1373,8 @@ extern "C" hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams
                                               VsxPairOut * out, hipStream_t st)
 {
   if (npairs == 0) return hipSuccess;
-#define TBCK(RR) case RR: return fast16 ? launch_tbck<RR, true>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
+#define TBCK(RR) case RR: return (fast16 && P.tilt != 0) ? launch_tbck<RR, true, true>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
+                                 : fast16 ? launch_tbck<RR, true>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
                                         : launch_tbck<RR, false>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st)
   switch (rows)
     {
@@ -1302,9 +1385,9 @@ extern "C" hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams
 }
 
 // dwords of checkpoint storage one task needs (row + column checkpoints)
-extern "C" uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t rows)
+extern "C" uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t rows, int tilt)
 {
-  const uint64_t rowck = (((nstrips * steps) + (1u << VSX_RB) - 1) >> VSX_RB << VSX_RB) * 128;
+  const uint64_t rowck = (((nstrips * steps) + 1) >> 1) * VSX_ROWCK_PAIR_DW(tilt != 0);
   const uint64_t nblk = (steps + 15) >> 4;
-  return rowck + nstrips * nblk * 64 * 2 * rows;
+  return rowck + nstrips * nblk * (tilt ? 64 * 4 * (uint64_t) VSX_COLCK_NB(rows, true) : 64 * 2 * rows);
 }

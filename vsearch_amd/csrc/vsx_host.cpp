@@ -438,6 +438,9 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   // (mismatch + 2g >= 0, the dummy rows' -ge(query left) + 2g >= 0).
   if (geqi == geti && geti > 0 && P.share_sub && c->ckpt && !c->tb_packed && !c->force_fallback &&
       std::min(match, mism) + 2 * geti >= 0 && 2 * geti - geql >= 0 &&
+      // compressed checkpoints: H - F(next row) and H - E(next column) lie in [-g, max QR'] (plus the dummy rows' seed
+      // go_ql + ge_ql + QR'): they must fit a signed byte
+      geti <= 127 && std::max({goqi, goti, goqr + geqr - geti, gotr + getr - geti, goql + geql + goqi}) <= 127 &&
       !(std::getenv("VSX_TILT") && std::strcmp(std::getenv("VSX_TILT"), "0") == 0))
     {
       const int g = geti;
@@ -837,7 +840,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       const uint64_t total_lanes = (t.qlen + pt.rows - 1) / pt.rows;
       const uint64_t nstrips = (total_lanes + 15) / 16;
       const uint64_t nd = (uint64_t) (pt.rows + 3) / 4;
-      const uint64_t dwords = ctx->ckpt ? vsx_ckpt_dwords(nstrips, t.steps, (uint64_t) pt.rows)
+      const uint64_t dwords = ctx->ckpt ? vsx_ckpt_dwords(nstrips, t.steps, (uint64_t) pt.rows, pt.tilt)
                                         : ((nstrips * t.steps + 3) & ~3ull) * 64 * nd;     // [4-step block][lane][4][nd]
       const uint64_t strip = nstrips > 1 ? 2ull * 4 * t.steps : 0;
       if (cur.task_count && cur.dir_dwords + dwords > budget_dwords) close_chunk();

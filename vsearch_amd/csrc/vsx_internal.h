@@ -102,7 +102,7 @@ hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams P, VsxFilt
                                    uint32_t * d_slab, const uint64_t * d_slab_off,
                                    uint32_t * d_runs, uint64_t runs_capacity, unsigned long long * d_cursor,
                                    VsxPairOut * d_out, hipStream_t st);
-uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t rows);
+uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t rows, int tilt /* compressed layout of the TILT class */);
 const int * vsx_supported_rows(int * count);
 
 // launchers implemented in vsx_kmer.hip (k-mer candidate counting)
