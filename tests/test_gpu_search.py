@@ -442,3 +442,16 @@ def test_msa_device_rejects_bad_cigars(gpu_required):
                           (["ACGT", "ACGTAA"], [None, "4MDD"])]:
             with pytest.raises(VsxError):
                 msa(seqs, cig, aligner=al)
+
+
+def test_search_window_pipeline_equals_single_thread(gpu_required):
+    """vsx_search_batch runs the k-mer stage of window i+1 on a producer thread while window i is aligned; with the window
+    forced down to 5 queries the reference-CLI comparisons (userout byte-identical, both strands, '*' penalties) must still hold"""
+    import sys
+    e = dict(os.environ)
+    e["VSX_SEARCH_WINDOW"] = "5"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_search.py"), "-x", "-q",
+                        "-k", "usearch_global or strand_both or infinite_gap or candidate_order or sentinel_pairs"], env=e, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout

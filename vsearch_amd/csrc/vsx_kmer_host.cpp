@@ -62,10 +62,19 @@ struct VsxKmerIndex {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   VsxKmerStats stats;
   std::vector<uint64_t> word_total;   // postings per word over all tiles
+  bool own_stream = false;
   ~VsxKmerIndex()
   {
     if (e0) (void) hipEventDestroy(e0);
     if (e1) (void) hipEventDestroy(e1);
+    if (own_stream && st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
+  }
+  // the index works on a stream of its own: its kernels read the (already complete) sequence codes only, and a search
+  // counts the candidates of window i+1 while the aligner's streams run window i (vsx_search_batch)
+  void make_stream()
+  {
+    hipStream_t s2 = nullptr;
+    if (hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess) { st = s2; own_stream = true; }
   }
 };
 
@@ -78,6 +87,7 @@ int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIn
   if (w < 3 || w > 8) { vsx_internal_set_error("vsx_kmer_index_create: device index supports word lengths 3..8"); return VSX_EINVAL; }
   std::unique_ptr<VsxKmerIndex> ix(new VsxKmerIndex);
   ix->ctx = ctx; ix->db = db; ix->device = vsx_internal_device(ctx); ix->st = vsx_internal_stream(ctx); ix->w = w;
+  ix->make_stream();
   KCHK(hipSetDevice(ix->device));
   KCHK(hipEventCreate(&ix->e0));
   KCHK(hipEventCreate(&ix->e1));
@@ -95,6 +105,7 @@ int vsx_kmer_index_create_empty(vsx_ctx * ctx, const vsx_seqset * db, int w, Vsx
   if (w < 3 || w > 8) { vsx_internal_set_error("vsx_kmer_index_create_empty: device index supports word lengths 3..8"); return VSX_EINVAL; }
   std::unique_ptr<VsxKmerIndex> ix(new VsxKmerIndex);
   ix->ctx = ctx; ix->db = db; ix->device = vsx_internal_device(ctx); ix->st = vsx_internal_stream(ctx); ix->w = w;
+  ix->make_stream();
   KCHK(hipSetDevice(ix->device));
   KCHK(hipEventCreate(&ix->e0));
   KCHK(hipEventCreate(&ix->e1));

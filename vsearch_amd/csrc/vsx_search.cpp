@@ -25,6 +25,8 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 
 #include <sched.h>
@@ -894,80 +896,98 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
   for (uint64_t i = 0; i < nq; ++i)
     if (qoff[i] + qlen[i] > qbytes) return sfail(VSX_EINVAL, "vsx_search_batch: query exceeds the blob");
   const double t_begin = now_s();
-  const uint64_t window = S->o.window > 0 ? (uint64_t) S->o.window : 65536;
+  // Windows of queries; the k-mer stage of window i+1 (host word extraction, device counting, host ranking) runs on a
+  // producer thread while this thread aligns window i (a query's hits do not depend on its window).  Large batches use
+  // smaller windows so that the two stages overlap; VSX_SEARCH_PIPELINE=0 = one thread, as before.
+  static const bool pipe_off = std::getenv("VSX_SEARCH_PIPELINE") && std::strcmp(std::getenv("VSX_SEARCH_PIPELINE"), "0") == 0;
+  static const uint64_t env_window = std::getenv("VSX_SEARCH_WINDOW") ? std::strtoull(std::getenv("VSX_SEARCH_WINDOW"), nullptr, 10) : 0;   // tests
+  const bool piped = !pipe_off && (env_window ? nq > env_window : (S->o.window <= 0 && nq > 32768));
+  const uint64_t window = env_window ? env_window : (S->o.window > 0 ? (uint64_t) S->o.window : (piped ? 16384 : 65536));
   std::vector<std::vector<Hit>> kept(nq);
   double t_kmer = 0, t_align = 0, t_adv = 0, t_rep = 0, t_qset = 0, t_join = 0;
   uint64_t pairs = 0, cells = 0, stages = 0, sentinels = 0;
 
   const bool dev_kmer = device_kmer_ok(*S);
   KmerAcct kacct;
-
   const bool both = S->o.strand_both != 0;
-  for (uint64_t w0 = 0; w0 < nq; w0 += window)
-    {
-      const uint64_t wn = std::min<uint64_t>(window, nq - w0);
-      // --strand both: state k < wn searches query w0 + k, state wn + k its reverse complement (search.cpp:200-214)
-      const uint64_t ns = both ? 2 * wn : wn;
-      std::vector<QState> st(ns);
 
-      // ---- the window's sequences in one blob: the queries, then (both strands) their reverse complements ----
+  struct Window {
+    uint64_t w0 = 0, wn = 0, ns = 0, mn = 0, hi = 0;
+    std::vector<QState> st;
+    std::vector<uint64_t> lo;
+    std::vector<uint32_t> ln;
+    std::string rc, joined;
+    const char * wblob = nullptr;
+    int krc = VSX_OK;
+    std::string err;
+    double t_kmer = 0;
+  };
+  // stage 1: the window's sequences and their candidate lists
+  auto prepare = [&](uint64_t w0) -> std::unique_ptr<Window> {
+      std::unique_ptr<Window> W(new Window);
+      W->w0 = w0;
+      const uint64_t wn = W->wn = std::min<uint64_t>(window, nq - w0);
+      // --strand both: state k < wn searches query w0 + k, state wn + k its reverse complement (search.cpp:200-214)
+      const uint64_t ns = W->ns = both ? 2 * wn : wn;
+      W->st.resize(ns);
+      // the window's sequences in one blob: the queries, then (both strands) their reverse complements
       uint64_t mn = qoff[w0], hi = qoff[w0];
       for (uint64_t k = 0; k < wn; ++k) { mn = std::min(mn, qoff[w0 + k]); hi = std::max(hi, qoff[w0 + k] + qlen[w0 + k]); }
-      std::vector<uint64_t> lo(ns);
-      std::vector<uint32_t> ln(ns);
-      std::string rc;
-      for (uint64_t k = 0; k < wn; ++k) { lo[k] = qoff[w0 + k] - mn; ln[k] = qlen[w0 + k]; }
+      W->mn = mn; W->hi = hi;
+      W->lo.resize(ns); W->ln.resize(ns);
+      for (uint64_t k = 0; k < wn; ++k) { W->lo[k] = qoff[w0 + k] - mn; W->ln[k] = qlen[w0 + k]; }
       if (both)
         {
           uint64_t tot = 0;
           for (uint64_t k = 0; k < wn; ++k) tot += qlen[w0 + k];
-          rc.resize(tot);
+          W->rc.resize(tot);
           uint64_t p = 0;
           for (uint64_t k = 0; k < wn; ++k)
             {
               const char * q = qblob + qoff[w0 + k];
               const uint32_t L = qlen[w0 + k];
-              lo[wn + k] = (hi - mn) + p; ln[wn + k] = L;
-              for (uint32_t x = 0; x < L; ++x) rc[p + x] = complement((unsigned char) q[L - 1 - x]);
+              W->lo[wn + k] = (hi - mn) + p; W->ln[wn + k] = L;
+              for (uint32_t x = 0; x < L; ++x) W->rc[p + x] = complement((unsigned char) q[L - 1 - x]);
               p += L;
             }
         }
-      std::string joined;
-      const char * wblob = qblob + mn;
-      if (both) { joined.assign(qblob + mn, hi - mn); joined += rc; wblob = joined.data(); }
-      auto seq_of = [&](uint64_t k) { return wblob + lo[k]; };
-
-      // ---- k-mer heuristic for the whole window: device counters (vsx_kmer.hip) or host threads ----
-      double t0 = now_s();
-      {
-        std::vector<std::vector<Cand>> cands;
-        const int krc = batch_candidates(S, dev_kmer, ns, seq_of, [&](uint64_t k) { return (int64_t) ln[k]; }, cands, kacct);
-        if (krc != VSX_OK) return krc;
-        for (uint64_t k = 0; k < ns; ++k) st[k].cands = std::move(cands[k]);
-      }
-      t_kmer += now_s() - t0;
-
-      // ---- the window's sequences as a device sequence set ----
+      W->wblob = qblob + mn;
+      if (both) { W->joined.assign(qblob + mn, hi - mn); W->joined += W->rc; W->wblob = W->joined.data(); }
+      Window * w = W.get();
+      // k-mer heuristic for the whole window: device counters (vsx_kmer.hip) or host threads
+      const double t0 = now_s();
+      std::vector<std::vector<Cand>> cands;
+      w->krc = batch_candidates(S, dev_kmer, ns, [w](uint64_t k) { return w->wblob + w->lo[k]; },
+                                [w](uint64_t k) { return (int64_t) w->ln[k]; }, cands, kacct);
+      if (w->krc != VSX_OK) w->err = vsx_last_error();
+      else
+        for (uint64_t k = 0; k < ns; ++k) w->st[k].cands = std::move(cands[k]);
+      w->t_kmer = now_s() - t0;
+      return W;
+  };
+  // stage 2: align, replay the accept counters, join the hits
+  auto consume = [&](Window & W) -> int {
+      const uint64_t w0 = W.w0, wn = W.wn, ns = W.ns;
+      auto seq_of = [&](uint64_t k) { return W.wblob + W.lo[k]; };
+      std::vector<QState> & st = W.st;
+      // the window's sequences as a device sequence set
       vsx_seqset * qset = nullptr;
       const double tq = now_s();
       {
-        int rc2 = vsx_seqset_create(S->ctx, &qset, ns, wblob, (hi - mn) + rc.size(), lo.data(), ln.data());
+        int rc2 = vsx_seqset_create(S->ctx, &qset, ns, W.wblob, (W.hi - W.mn) + W.rc.size(), W.lo.data(), W.ln.data());
         if (rc2 != VSX_OK) return rc2;
       }
       t_qset += now_s() - tq;
-
       {
         Acct acct;
-        const int src = run_stages(*S, st, seq_of, [&](uint64_t k) { return (int64_t) ln[k]; },
+        const int src = run_stages(*S, st, seq_of, [&](uint64_t k) { return (int64_t) W.ln[k]; },
                                    [&](uint64_t k) { return (uint32_t) k; }, qset, acct);
         t_adv += acct.t_advance; t_rep += acct.t_replay;
         t_align += acct.t_align; pairs += acct.pairs; cells += acct.cells; stages += acct.stages; sentinels += acct.sentinels;
         if (src != VSX_OK) { vsx_seqset_destroy(qset); return src; }
       }
       vsx_seqset_destroy(qset);
-
-      // ---- search_joinhits (:1028-1052): accepted | weak of the plus strand, then of the minus strand, ordered by
-      //      hit_compare_byid ----
+      // search_joinhits (:1028-1052): accepted | weak of the plus strand, then of the minus strand, ordered by hit_compare_byid
       const double tj = now_s();
       for (uint64_t k = 0; k < wn; ++k)
         {
@@ -978,6 +998,66 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
           std::sort(dst.begin(), dst.end(), [](const Hit & a, const Hit & b) { return hit_compare_byid(a, b) < 0; });
         }
       t_join += now_s() - tj;
+      return VSX_OK;
+  };
+
+  if (!piped)
+    {
+      for (uint64_t w0 = 0; w0 < nq; w0 += window)
+        {
+          std::unique_ptr<Window> W = prepare(w0);
+          t_kmer += W->t_kmer;
+          if (W->krc != VSX_OK) { vsx_internal_set_error(W->err.c_str()); return W->krc; }
+          const int crc = consume(*W);
+          if (crc != VSX_OK) return crc;
+        }
+    }
+  else
+    {
+      std::mutex mu;
+      std::condition_variable cv;
+      std::unique_ptr<Window> slot;            // one window ahead
+      bool done = false, stop = false;
+      std::thread producer([&]() {
+        for (uint64_t w0 = 0; w0 < nq; w0 += window)
+          {
+            std::unique_ptr<Window> W = prepare(w0);
+            const bool failed = W->krc != VSX_OK;
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return stop || !slot; });
+            if (stop) return;
+            slot = std::move(W);
+            cv.notify_all();
+            if (failed) break;
+          }
+        std::lock_guard<std::mutex> lk(mu);
+        done = true;
+        cv.notify_all();
+      });
+      int rc = VSX_OK;
+      std::string msg;
+      for (;;)
+        {
+          std::unique_ptr<Window> W;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return slot || done; });
+            if (!slot) break;
+            W = std::move(slot);
+            cv.notify_all();
+          }
+          t_kmer += W->t_kmer;
+          if (W->krc != VSX_OK) { rc = W->krc; msg = W->err; break; }
+          rc = consume(*W);
+          if (rc != VSX_OK) { msg = vsx_last_error(); break; }
+        }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+      }
+      cv.notify_all();
+      producer.join();
+      if (rc != VSX_OK) { vsx_internal_set_error(msg.c_str()); return rc; }
     }
 
   // ---- marshal ----
