@@ -711,6 +711,63 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
   return VSX_OK;
 }
 
+// device path of search_topscores, stage 1: unique words per query (host threads; unique_count, core/unique.cpp:155-352)
+template <typename FSeq, typename FLen>
+static void kmer_words(const vsx_searcher * S, uint64_t nq, FSeq qseq, FLen qlen, std::vector<std::vector<uint32_t>> & words)
+{
+  const int nth = std::max(1, S->threads);
+  const uint64_t nwords = 1ull << (2 * S->w);
+  words.assign(nq, {});
+  std::vector<std::vector<uint64_t>> seen((size_t) nth, std::vector<uint64_t>((nwords + 63) / 64, 0));
+  std::atomic<uint64_t> next {0};
+  auto work = [&](int tid) {
+    for (;;)
+      {
+        const uint64_t k = next.fetch_add(1);
+        if (k >= nq) break;
+        unique_kmers(qseq(k), qlen(k), S->w, false, words[k], seen[(size_t) tid]);
+      }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto & th : pool) th.join();
+}
+
+// stage 2: count on the device index (built on first use), threshold, rank; queries the 16-bit counters cannot serve go
+// through the host restatement
+template <typename FSeq, typename FLen>
+static int kmer_rank(vsx_searcher * S, uint64_t nq, FSeq qseq, FLen qlen, const std::vector<std::vector<uint32_t>> & words,
+                     std::vector<std::vector<Cand>> & cands, KmerAcct & acct)
+{
+  static const bool kdebug = std::getenv("VSX_KMER_DEBUG") != nullptr;
+  cands.assign(nq, {});
+  if (!S->kidx)
+    {
+      const int rc = vsx_kmer_index_create(S->ctx, S->dbset, S->w, &S->kidx);
+      if (rc != VSX_OK) return rc;
+      acct.build_ms = vsx_kmer_stats(S->kidx)->build_ms;
+    }
+  acct.postings = vsx_kmer_stats(S->kidx)->postings;
+  std::vector<uint64_t> fallback;
+  const double tw1 = now_s();
+  {
+    const int rc = device_rank(S, S->kidx, nullptr, nq, words, (uint32_t) std::max<int64_t>(S->tophits, 1), 0, true, cands, fallback, acct);
+    if (rc != VSX_OK) return rc;
+  }
+  if (kdebug) std::fprintf(stderr, "kmer_rank: %llu queries: %.3f s\n", (unsigned long long) nq, now_s() - tw1);
+  if (!fallback.empty())
+    {
+      const uint64_t nwords = 1ull << (2 * S->w);
+      build_index(S);
+      std::vector<uint16_t> counts(S->len.size(), 0);
+      std::vector<uint32_t> touched, km;
+      std::vector<uint64_t> seen(S->w < 10 ? (nwords + 63) / 64 : 1, 0);
+      for (uint64_t k : fallback) candidates_for(*S, qseq(k), qlen(k), counts, touched, km, seen, cands[k]);
+    }
+  return VSX_OK;
+}
+
 // search_topscores for a batch: cands[k] = candidate list of query k, best first, <= tophits entries.
 template <typename FSeq, typename FLen>
 static int batch_candidates(vsx_searcher * S, bool device, uint64_t nq, FSeq qseq, FLen qlen,
@@ -745,34 +802,9 @@ static int batch_candidates(vsx_searcher * S, bool device, uint64_t nq, FSeq qse
       return VSX_OK;
     }
 
-  if (!S->kidx)
-    {
-      const int rc = vsx_kmer_index_create(S->ctx, S->dbset, S->w, &S->kidx);
-      if (rc != VSX_OK) return rc;
-      acct.build_ms = vsx_kmer_stats(S->kidx)->build_ms;
-    }
-  acct.postings = vsx_kmer_stats(S->kidx)->postings;
-
-  // 1. unique words per query (host threads; unique_count, core/unique.cpp:155-352)
-  std::vector<std::vector<uint32_t>> words(nq);
-  {
-    std::vector<std::vector<uint64_t>> seen((size_t) nth, std::vector<uint64_t>((nwords + 63) / 64, 0));
-    parallel([&](int tid, uint64_t k) { unique_kmers(qseq(k), qlen(k), S->w, false, words[k], seen[(size_t) tid]); });
-  }
-  std::vector<uint64_t> fallback;
-  {
-    const int rc = device_rank(S, S->kidx, nullptr, nq, words, (uint32_t) std::max<int64_t>(S->tophits, 1), 0, true, cands, fallback, acct);
-    if (rc != VSX_OK) return rc;
-  }
-  if (!fallback.empty())
-    {
-      build_index(S);
-      std::vector<uint16_t> counts(S->len.size(), 0);
-      std::vector<uint32_t> touched, km;
-      std::vector<uint64_t> seen(S->w < 10 ? (nwords + 63) / 64 : 1, 0);
-      for (uint64_t k : fallback) candidates_for(*S, qseq(k), qlen(k), counts, touched, km, seen, cands[k]);
-    }
-  return VSX_OK;
+  std::vector<std::vector<uint32_t>> words;
+  kmer_words(S, nq, qseq, qlen, words);
+  return kmer_rank(S, nq, qseq, qlen, words, cands, acct);
 }
 
 extern "C" {
@@ -918,12 +950,13 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
     std::vector<uint32_t> ln;
     std::string rc, joined;
     const char * wblob = nullptr;
+    std::vector<std::vector<uint32_t>> words;      // device k-mer path: unique words per state
     int krc = VSX_OK;
     std::string err;
     double t_kmer = 0;
   };
-  // stage 1: the window's sequences and their candidate lists
-  auto prepare = [&](uint64_t w0) -> std::unique_ptr<Window> {
+  // stage 1a: the window's sequences (and, on the device k-mer path, their unique words)
+  auto prepare_words = [&](uint64_t w0) -> std::unique_ptr<Window> {
       std::unique_ptr<Window> W(new Window);
       W->w0 = w0;
       const uint64_t wn = W->wn = std::min<uint64_t>(window, nq - w0);
@@ -954,15 +987,29 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
       W->wblob = qblob + mn;
       if (both) { W->joined.assign(qblob + mn, hi - mn); W->joined += W->rc; W->wblob = W->joined.data(); }
       Window * w = W.get();
-      // k-mer heuristic for the whole window: device counters (vsx_kmer.hip) or host threads
+      const double t0 = now_s();
+      if (dev_kmer)
+        kmer_words(S, ns, [w](uint64_t k) { return w->wblob + w->lo[k]; }, [w](uint64_t k) { return (int64_t) w->ln[k]; }, w->words);
+      w->t_kmer = now_s() - t0;
+      return W;
+  };
+  // stage 1b: k-mer heuristic for the whole window: device counters (vsx_kmer.hip) or host threads
+  auto prepare_rank = [&](Window & Wr) {
+      Window * w = &Wr;
       const double t0 = now_s();
       std::vector<std::vector<Cand>> cands;
-      w->krc = batch_candidates(S, dev_kmer, ns, [w](uint64_t k) { return w->wblob + w->lo[k]; },
-                                [w](uint64_t k) { return (int64_t) w->ln[k]; }, cands, kacct);
+      auto seqf = [w](uint64_t k) { return w->wblob + w->lo[k]; };
+      auto lenf = [w](uint64_t k) { return (int64_t) w->ln[k]; };
+      w->krc = dev_kmer ? kmer_rank(S, w->ns, seqf, lenf, w->words, cands, kacct) : batch_candidates(S, false, w->ns, seqf, lenf, cands, kacct);
       if (w->krc != VSX_OK) w->err = vsx_last_error();
       else
-        for (uint64_t k = 0; k < ns; ++k) w->st[k].cands = std::move(cands[k]);
-      w->t_kmer = now_s() - t0;
+        for (uint64_t k = 0; k < w->ns; ++k) w->st[k].cands = std::move(cands[k]);
+      std::vector<std::vector<uint32_t>>().swap(w->words);
+      w->t_kmer += now_s() - t0;
+  };
+  auto prepare = [&](uint64_t w0) -> std::unique_ptr<Window> {
+      std::unique_ptr<Window> W = prepare_words(w0);
+      prepare_rank(*W);
       return W;
   };
   // stage 2: align, replay the accept counters, join the hits
@@ -1014,49 +1061,66 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
     }
   else
     {
-      std::mutex mu;
-      std::condition_variable cv;
-      std::unique_ptr<Window> slot;            // one window ahead
-      bool done = false, stop = false;
-      std::thread producer([&]() {
+      // three stages, one window in flight between each pair: words (host threads) -> count + rank (device, host threads)
+      // -> align (this thread)
+      struct Slot {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::unique_ptr<Window> w;
+        bool done = false, stop = false;
+        bool put(std::unique_ptr<Window> x)       // false: the consumer has given up
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return stop || !w; });
+          if (stop) return false;
+          w = std::move(x);
+          cv.notify_all();
+          return true;
+        }
+        std::unique_ptr<Window> get()             // null: the producer has finished
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return w || done; });
+          std::unique_ptr<Window> x = std::move(w);
+          cv.notify_all();
+          return x;
+        }
+        void finish() { std::lock_guard<std::mutex> lk(mu); done = true; cv.notify_all(); }
+        void abort() { std::lock_guard<std::mutex> lk(mu); stop = true; cv.notify_all(); }
+      };
+      Slot s1, s2;
+      std::thread stage_words([&]() {
         for (uint64_t w0 = 0; w0 < nq; w0 += window)
+          if (!s1.put(prepare_words(w0))) break;
+        s1.finish();
+      });
+      std::thread stage_rank([&]() {
+        for (;;)
           {
-            std::unique_ptr<Window> W = prepare(w0);
+            std::unique_ptr<Window> W = s1.get();
+            if (!W) break;
+            prepare_rank(*W);
             const bool failed = W->krc != VSX_OK;
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return stop || !slot; });
-            if (stop) return;
-            slot = std::move(W);
-            cv.notify_all();
-            if (failed) break;
+            if (!s2.put(std::move(W)) || failed) break;
           }
-        std::lock_guard<std::mutex> lk(mu);
-        done = true;
-        cv.notify_all();
+        s1.abort();
+        s2.finish();
       });
       int rc = VSX_OK;
       std::string msg;
       for (;;)
         {
-          std::unique_ptr<Window> W;
-          {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return slot || done; });
-            if (!slot) break;
-            W = std::move(slot);
-            cv.notify_all();
-          }
+          std::unique_ptr<Window> W = s2.get();
+          if (!W) break;
           t_kmer += W->t_kmer;
           if (W->krc != VSX_OK) { rc = W->krc; msg = W->err; break; }
           rc = consume(*W);
           if (rc != VSX_OK) { msg = vsx_last_error(); break; }
         }
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        stop = true;
-      }
-      cv.notify_all();
-      producer.join();
+      s2.abort();
+      s1.abort();
+      stage_words.join();
+      stage_rank.join();
       if (rc != VSX_OK) { vsx_internal_set_error(msg.c_str()); return rc; }
     }
 
