@@ -43,18 +43,10 @@ SURVEY_OPS_PER_CELL = 15
 GENERAL_OPS_PER_CELL = 10
 
 
-def tilt_active(qlen, dlen):
-    """mirrors vsx_host.cpp tilt_possible() for the default scoring (match 2, mismatch -4, open 20/2, extend 2/1)"""
-    if os.environ.get("VSX_TILT") == "0" or os.environ.get("VSX_TRACEBACK") == "dirs" or os.environ.get("VSX_TB_ARITH") == "packed" \
-            or os.environ.get("VSX_NO_SHARE_SUB"):
-        return False
-    G, B = 20, 4
-    return 4 * G + 2 * (qlen + ((dlen + 3) & ~3) + 64) * B < 32000
-
-
-def ops_per_cell(qlen, dlen):
-    rows = next((r for r in (1, 4, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 32) if 16 * r >= qlen), 32)   # vsx_host.cpp pick_rows()
-    if not tilt_active(qlen, dlen):
+def ops_per_cell(info):
+    """VOP3P issue slots per DP cell of the dominant launch's row body (see the comment above); info = Plan.describe()"""
+    rows = max(1, info["rows_dominant"])
+    if 2 * info["tasks_tilted"] < info["tasks"]:
         return float(GENERAL_OPS_PER_CELL)
     return ((rows - 1) * 6.0 + 9.5) / rows
 
@@ -180,7 +172,9 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     fwd_avg_ms = fwd_ms / max(1, fwd_launches)
     cells_per_launch = cells * a.steps / max(1, fwd_launches)
-    OPS_PER_CELL = ops_per_cell(a.qlen, a.dlen)
+    info = plan.describe()
+    tilted = 2 * info["tasks_tilted"] >= info["tasks"]
+    OPS_PER_CELL = ops_per_cell(info)
     achieved = cells_per_launch * OPS_PER_CELL / (fwd_avg_ms * 1e-3) / 1e12
     out = {
         "metric": "GCUPS (useful DP cells/s of the search16 global-alignment path: DP + traceback + CIGAR)",
@@ -200,14 +194,15 @@ def main():
             "cells_per_step_per_gpu": cells,
         },
         "roofline": {
-            "kernel": "vsx_forward_kernel<16,true,false,true,true>" if tilt_active(a.qlen, a.dlen) else "vsx_forward_kernel<16,true,false,true>",
+            "kernel": f"vsx_forward_kernel<{info['rows_dominant']},true,false,true,true>" if tilted else f"vsx_forward_kernel<{info['rows_dominant']},true,...>",
             "bound": "valu-int16",
             "achieved": round(achieved, 3),
             "peak": round(PEAK_INT16_TOPS, 2),
             "unit": "Tops/s",
             "frac": round(achieved / PEAK_INT16_TOPS, 4),
             "ops_per_cell": round(OPS_PER_CELL, 3),
-            "coordinates": "tilted" if tilt_active(a.qlen, a.dlen) else "plain",
+            "coordinates": "tilted" if tilted else "plain",
+            "plan": info,
             "general_row_body_accounting": {"ops_per_cell": GENERAL_OPS_PER_CELL,
                                             "frac": round(achieved * GENERAL_OPS_PER_CELL / OPS_PER_CELL / PEAK_INT16_TOPS, 4)},
             "survey_accounting": {"ops_per_cell": SURVEY_OPS_PER_CELL,

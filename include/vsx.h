@@ -106,6 +106,15 @@ typedef struct vsx_timing {
   uint64_t dir_bytes;       /* direction bytes written by the DP kernel */
 } vsx_timing;
 
+/* How a plan was mapped onto kernel classes (for measurement code: which row body does the dominant launch issue?). */
+typedef struct vsx_plan_info {
+  uint64_t tasks;           /* wavefront tasks (one query x <= 8 targets)                                  */
+  uint64_t tasks_tilted;    /* ... in the TILT class (tilted coordinates, compressed checkpoints)           */
+  uint64_t tasks_tracked;   /* ... in the TRACK class (overflow rule evaluated, saturating arithmetic)      */
+  uint32_t rows_dominant;   /* query rows per lane (R) of the launch with the most tasks                   */
+  uint32_t chunks;          /* checkpoint-buffer chunks the plan runs in                                    */
+} vsx_plan_info;
+
 const char * vsx_version_string(void);
 int vsx_device_count(void);                       /* usable gfx950 devices, 0 if none */
 const char * vsx_last_error(void);                /* thread-local message of the last failure */
@@ -145,6 +154,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out,
 int vsx_plan_run(vsx_plan * plan);
 int vsx_plan_sync(vsx_plan * plan, vsx_timing * timing /* may be NULL */);
 int vsx_plan_fetch(vsx_plan * plan, vsx_results * out);
+int vsx_plan_describe(const vsx_plan * plan, vsx_plan_info * info);
 /* Device-side hit records of the last run, for a multi-GPU gather without a host round trip:
    copies n_pairs records of VSX_HIT_RECORD_BYTES each {int16 score; uint16 aligned, matches,
    mismatches, gaps, pad; uint32 n_cigar_runs; uint64 cigar_run_offset} into device memory `d_dst`

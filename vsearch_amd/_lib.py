@@ -18,7 +18,7 @@ SYMBOLS = [
     "vsx_version_string", "vsx_device_count", "vsx_last_error", "vsx_create", "vsx_destroy",
     "vsx_seqset_create", "vsx_seqset_create_from_device", "vsx_seqset_destroy", "vsx_seqset_count",
     "vsx_plan_create", "vsx_plan_run", "vsx_plan_sync", "vsx_plan_fetch", "vsx_plan_export_hits", "vsx_plan_destroy",
-    "vsx_align_pairs", "vsx_align_pairs_filtered", "vsx_plan_set_filter", "vsx_results_free",
+    "vsx_align_pairs", "vsx_align_pairs_filtered", "vsx_plan_set_filter", "vsx_results_free", "vsx_plan_describe",
 ]
 # include/vsx_search.h
 SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
@@ -89,6 +89,12 @@ class Filter(C.Structure):
                 ("maxsubs", C.c_int64), ("maxgaps", C.c_int64), ("mincols", C.c_int64), ("maxdiffs", C.c_int64)]
 
 
+class PlanInfo(C.Structure):
+    """vsx_plan_info (include/vsx.h)"""
+    _fields_ = [("tasks", C.c_uint64), ("tasks_tilted", C.c_uint64), ("tasks_tracked", C.c_uint64),
+                ("rows_dominant", C.c_uint32), ("chunks", C.c_uint32)]
+
+
 class Timing(C.Structure):
     _fields_ = [("forward_ms", C.c_float), ("traceback_ms", C.c_float), ("total_ms", C.c_float),
                 ("forward_launches", C.c_uint32), ("traceback_launches", C.c_uint32),
@@ -137,6 +143,7 @@ def load():
     lib.vsx_plan_export_hits.argtypes = [vp, vp, C.c_uint64]
     lib.vsx_plan_destroy.argtypes = [vp]
     lib.vsx_plan_destroy.restype = None
+    lib.vsx_plan_describe.argtypes = [vp, C.POINTER(PlanInfo)]
     lib.vsx_align_pairs.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.POINTER(Results)]
     lib.vsx_align_pairs_filtered.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.POINTER(Filter), C.POINTER(Results)]
     lib.vsx_plan_set_filter.argtypes = [vp, C.POINTER(Filter)]

@@ -157,6 +157,12 @@ class Plan:
         check(_lib.load().vsx_plan_sync(self.h, C.byref(t)), "vsx_plan_sync")
         return t
 
+    def describe(self):
+        """vsx_plan_describe: dict(tasks, tasks_tilted, tasks_tracked, rows_dominant, chunks)"""
+        info = _lib.PlanInfo()
+        check(_lib.load().vsx_plan_describe(self.h, C.byref(info)), "vsx_plan_describe")
+        return {k: int(getattr(info, k)) for k, _ in info._fields_}
+
     def fetch(self):
         res = Results()
         lib = _lib.load()

@@ -1003,6 +1003,23 @@ int vsx_plan_sync(vsx_plan * pl, vsx_timing * tm)
   return VSX_OK;
 }
 
+int vsx_plan_describe(const vsx_plan * pl, vsx_plan_info * info)
+{
+  if (!pl || !info) return fail(VSX_EINVAL, "vsx_plan_describe: null argument");
+  *info = vsx_plan_info {};
+  info->tasks = pl->tasks.size();
+  info->chunks = (uint32_t) pl->chunks.size();
+  uint64_t best = 0;
+  for (const Chunk & c : pl->chunks)
+    for (const Launch & L : c.launches)
+      {
+        if (L.tilt) info->tasks_tilted += L.count;
+        if (L.track) info->tasks_tracked += L.count;
+        if (L.count > best) { best = L.count; info->rows_dominant = (uint32_t) L.rows; }
+      }
+  return VSX_OK;
+}
+
 static void append_cigar(std::string & s, const uint32_t * runs, uint32_t n)
 {
   // runs are in traceback order (last column first); the text runs left to right,
