@@ -1192,7 +1192,8 @@ int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vs
                              const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, vsx_results * out)
 {
   static const bool pipeline_off = std::getenv("VSX_PIPELINE") && std::strcmp(std::getenv("VSX_PIPELINE"), "0") == 0;
-  static const uint64_t slice_pairs = std::getenv("VSX_PIPELINE_SLICE") ? std::strtoull(std::getenv("VSX_PIPELINE_SLICE"), nullptr, 10) : (2ull << 20);
+  static const uint64_t slice_pairs = std::max<uint64_t>(64, std::getenv("VSX_PIPELINE_SLICE") ? std::strtoull(std::getenv("VSX_PIPELINE_SLICE"), nullptr, 10)
+                                                                                              : (2ull << 20));
   if (pipeline_off || !ctx || !out || !queries || !targets || !qidx || !tidx || n_pairs < 2 * slice_pairs)
     return align_pairs_single(ctx, queries, targets, n_pairs, qidx, tidx, filter, out);
   static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
