@@ -154,13 +154,24 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   uint64_t acc = 0;
   // a bucket holds 16-bit tile-local indices, two per dword: start[] counts DWORDS, odd buckets end in a 0xFFFF sentinel
   uint64_t entries = 0;
-  for (uint64_t b = 0; b < ix->nbuckets; ++b)
-    {
-      start[b] = acc;
-      acc += (cnt[b] + 1u) / 2u;
-      entries += cnt[b];
-      ix->word_total[b / ix->ntiles] += cnt[b];
-    }
+  {
+    // buckets are word-major: b = word * ntiles + tile (nested loops: no division per bucket -- clustering rebuilds the index
+    // once per round)
+    const uint64_t nwords = 1ull << (2 * w), nt = ix->ntiles;
+    uint64_t b = 0;
+    for (uint64_t word = 0; word < nwords; ++word)
+      {
+        uint64_t tot = 0;
+        for (uint64_t t = 0; t < nt; ++t, ++b)
+          {
+            start[b] = acc;
+            acc += (cnt[b] + 1u) / 2u;
+            tot += cnt[b];
+          }
+        ix->word_total[word] = tot;
+        entries += tot;
+      }
+  }
   start[ix->nbuckets] = acc;
   KCHK(ix->d_post.ensure(acc));
   if (acc) KCHK(hipMemsetAsync(ix->d_post.p, 0xff, acc * 4, ix->st));
