@@ -95,7 +95,10 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // d_r(lo) d_r(hi) d_r+1(lo) d_r+1(hi), padded to blocks of 4 dwords: 12 instead of 16 bytes per lane-step.
 #define VSX_ROWCK_PAIR_DW(TILT_) ((TILT_) ? 192 : 256)                       // dwords of one two-step pair of a wave
 #define VSX_COLCK_NB(R_, TILT_) ((TILT_) ? ((R_) + ((R_) + 1) / 2 + 3) / 4 : (2 * (R_)) / 4)   // 4-dword blocks per lane and column checkpoint
-#define VSX_COLCK_CDW(lane_, block_) (((size_t) (block_) * 64 + (size_t) (lane_)) * 4)       // compressed layout: [block][lane][4]
+#ifndef VSX_COLCK_CG
+#define VSX_COLCK_CG 64     // lanes per group of the compressed layout: [group][block][lane in group][4] dwords
+#endif
+#define VSX_COLCK_CDW(NB_, lane_, block_) ((((size_t) ((lane_) / VSX_COLCK_CG) * (size_t) (NB_) + (size_t) (block_)) * VSX_COLCK_CG + (size_t) ((lane_) % VSX_COLCK_CG)) * 4)
 // TILT = true (a sub-class of TOPPAD: checkpoints, LDS profile, no tracking): the kernel runs in TILTED coordinates,
 //   X*(i, j) = X(i, j) + (i + j) g   for X in {H, E, F},   g = the interior gap extension (both sides equal),
 // in which the recurrence is the same max-plus recurrence with score' = score + 2g, every QR' = QR - g, every R' = R - g:
@@ -480,7 +483,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   };
 #pragma unroll
                   for (int z = 0; z < 4 * VSX_COLCK_NB(R, true); z += 4)
-                    __builtin_nontemporal_store((u32x4) {flatc(z), flatc(z + 1), flatc(z + 2), flatc(z + 3)}, reinterpret_cast<u32x4 *>(cb + VSX_COLCK_CDW(lane, z >> 2)));
+                    __builtin_nontemporal_store((u32x4) {flatc(z), flatc(z + 1), flatc(z + 2), flatc(z + 3)}, reinterpret_cast<u32x4 *>(cb + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), lane, z >> 2)));
                 }
               else if (R % 2 == 0)
                 {
@@ -983,11 +986,11 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         {
           if (CK8)
             {
-              const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * COL_DW + VSX_COLCK_CDW(g * 16 + l, 0);
+              const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * COL_DW + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), g * 16 + l, 0);
               constexpr int NBQ = VSX_COLCK_NB(R, true);
               Quad fq[NBQ];
 #pragma unroll
-              for (int b = 0; b < NBQ; ++b) fq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * (4 * 64));
+              for (int b = 0; b < NBQ; ++b) fq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * (4 * VSX_COLCK_CG));
               auto flat = [&](int z) -> u32 {
                 const Quad & qd = fq[z >> 2];
                 return (z & 3) == 0 ? qd.x : (z & 3) == 1 ? qd.y : (z & 3) == 2 ? qd.z : qd.w;
