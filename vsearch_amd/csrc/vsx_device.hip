@@ -95,6 +95,13 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // d_r(lo) d_r(hi) d_r+1(lo) d_r+1(hi), padded to blocks of 4 dwords: 12 instead of 16 bytes per lane-step.
 #define VSX_ROWCK_PAIR_DW(TILT_) ((TILT_) ? 192 : 256)                       // dwords of one two-step pair of a wave
 #define VSX_COLCK_NB(R_, TILT_) ((TILT_) ? ((R_) + ((R_) + 1) / 2 + 3) / 4 : (2 * (R_)) / 4)   // 4-dword blocks per lane and column checkpoint
+// Slot of pipeline lane (g, l) inside a wave's checkpoint chunk (TILT class).  1: l * 4 + g -- the four lane groups of a task
+// (= its 8 targets, whose tracebacks move through the same tiles most of the time) sit next to each other, so the lanes of
+// a traceback wave that work on one task read the same lines; 0: g * 16 + l (lane order).
+#ifndef VSX_CK_TASKMAJOR
+#define VSX_CK_TASKMAJOR 1
+#endif
+#define VSX_CK_SLOT(TILT_, g_, l_) (((TILT_) && VSX_CK_TASKMAJOR) ? ((l_) * 4 + (g_)) : ((g_) * 16 + (l_)))
 #ifndef VSX_COLCK_CG
 #define VSX_COLCK_CG 64     // lanes per group of the compressed layout: [group][block][lane in group][4] dwords
 #endif
@@ -261,7 +268,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       const size_t ck_nblk = ((size_t) steps + 15) >> 4;
       constexpr int CK_LANE_DW = TILT ? 3 : 4;                                                                     // row checkpoint dwords per lane and pair
       constexpr size_t CK_COL_DW = TILT ? (size_t) 64 * 4 * VSX_COLCK_NB(R, true) : (size_t) 64 * (2 * R);           // column checkpoint dwords per wave
-      u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps) >> 1) * 64 + lane) * CK_LANE_DW;             // + (t >> 1) * VSX_ROWCK_PAIR_DW
+      const int ck_slot = VSX_CK_SLOT(TILT, g, l);
+      u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps) >> 1) * 64 + ck_slot) * CK_LANE_DW;         // + (t >> 1) * VSX_ROWCK_PAIR_DW
       u32 * const cck_base = dir + T.dir_off + ck_rowdw + (size_t) s * ck_nblk * CK_COL_DW;                        // + (t >> 4) * CK_COL_DW
 
       // STEADY (the part of phase A after the pipeline has filled, t >= 15): every lane that owns rows is inside its targets, so the
@@ -483,7 +491,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   };
 #pragma unroll
                   for (int z = 0; z < 4 * VSX_COLCK_NB(R, true); z += 4)
-                    __builtin_nontemporal_store((u32x4) {flatc(z), flatc(z + 1), flatc(z + 2), flatc(z + 3)}, reinterpret_cast<u32x4 *>(cb + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), lane, z >> 2)));
+                    __builtin_nontemporal_store((u32x4) {flatc(z), flatc(z + 1), flatc(z + 2), flatc(z + 3)}, reinterpret_cast<u32x4 *>(cb + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), ck_slot, z >> 2)));
                 }
               else if (R % 2 == 0)
                 {
@@ -947,7 +955,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         {
           const int Lp = L - 1;
           const int sp = Lp >> 4, lp = Lp & 15;
-          stage_top(rowck + (size_t) (g * 16 + lp) * (CK8 ? 3 : 4), VSX_ROWCK_PAIR_DW(CK8), (long) ((size_t) sp * steps) + (long) (c0 - 1 + lp),
+          stage_top(rowck + (size_t) VSX_CK_SLOT(CK8, g, lp) * (CK8 ? 3 : 4), VSX_ROWCK_PAIR_DW(CK8), (long) ((size_t) sp * steps) + (long) (c0 - 1 + lp),
                     (long) (rowsteps >> 1) - 1);
           if (c0 == 0) tbL[64 + tid] = A::in((u32) (uint16_t) P.hleft[i0 - 1]);     // corner H(i0-1, -1)
         }
@@ -986,7 +994,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         {
           if (CK8)
             {
-              const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * COL_DW + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), g * 16 + l, 0);
+              const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * COL_DW + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), VSX_CK_SLOT(true, g, l), 0);
               constexpr int NBQ = VSX_COLCK_NB(R, true);
               Quad fq[NBQ];
 #pragma unroll
