@@ -7,16 +7,28 @@ aligned pairs/s on the 250 bp x 1 M-seq DB shape at --id 0.9).
 
 A "step" = one pass of the hot path over one batch: every (query, candidate) pair of 100 k x 250 bp
 queries against their 8 candidates in a device-resident 1 M x 1 kbp family-structured DB
-(BASELINE config[1]) -> packed-int16 DP kernel (scores + direction bits) + traceback kernel
-(statistics + CIGAR run lists).  Inputs (DB, queries, pair/task list) are resident in HBM before the
-timed region; results stay in HBM (the PCIe fetch is timed separately and reported, never in `value`).
+(BASELINE config[1]) -> packed-int16 DP kernel (scores + checkpoints) + traceback kernel (statistics +
+CIGAR run lists) + text kernel (CIGAR strings, output arrays).  Inputs (DB, queries, pair/task list) are
+resident in HBM before the timed region; results stay in HBM -- that is `value`.  Next to it, never in it:
+  end_to_end        vsx_align_pairs on the same pair list, host arrays in / host arrays + CIGAR text out
+                    (planning, kernels, PCIe, pipelined slices; pools warm), steady state
+  search_end_to_end vsx_search_batch (= --usearch_global --id 0.9) for the same queries against the same DB:
+                    k-mer candidate stage + dispatch + alignments + hit lists, next to the reference CLI
+                    (oracle/_ref/vsearch_ref, all usable cores) on a sample of the same queries
+With --gpus N every rank plays one block of a query-sharded job (vsearch_amd/sharding.py): own queries, DB
+replica, no data-path collective, one gather of hit records + CIGAR run words at the end of every step.
 
 Rank 0 prints ONE JSON line (see DESIGN.md for `roofline` / `cpu_baseline`).
 """
 import argparse
+import ctypes as C
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -51,19 +63,34 @@ def ops_per_cell(info):
     return ((rows - 1) * 6.0 + 9.5) / rows
 
 
-def traffic_from_profile(a, world):
-    """HBM bytes per DP-kernel launch from the committed PMC passes (profiles/r01_traffic.json, written by
-    profiles/summarize.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of THIS command); counters cannot be
-    collected from inside the timed run, so the figure is only reported for the workload it was measured on."""
+KERNEL_SOURCES = ("vsearch_amd/csrc/vsx_device.hip", "vsearch_amd/csrc/vsx_internal.h", "vsearch_amd/csrc/vsx_tbtext.hip")
+
+
+def kernel_source_sha():
+    """identity of the kernels a PMC file was measured on: sha256 over the kernel sources (first 16 hex digits)"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def counters_from_profile(a, world):
+    """PMC results of THIS command on THESE kernels (profiles/pmc_current.json, written by profiles/run_profile.sh ->
+    summarize.py from separate rocprofv3 --pmc passes; counters cannot be collected from inside the timed run).  The file
+    carries the sha of the kernel sources it was measured on: a stale file (kernels changed since) or another workload is
+    refused and `traffic` is null."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
             t = json.load(f)
-        w = t["workload"]
-        if world == 1 and all(getattr(a, k) == w[k] for k in ("queries", "qlen", "db", "dlen", "cands")):
-            return t["hbm_bytes_per_launch"]
     except Exception:
-        pass
-    return None
+        return None, "no profiles/pmc_current.json"
+    if t.get("kernel_source_sha") != kernel_source_sha():
+        return None, f"profiles/pmc_current.json was measured on kernel sources {t.get('kernel_source_sha')}, HEAD has {kernel_source_sha()}: refused"
+    w = t.get("workload", {})
+    if world != 1 or any(getattr(a, k) != w.get(k) for k in ("queries", "qlen", "db", "dlen", "cands")):
+        return None, "profiles/pmc_current.json was measured on another workload"
+    return t, None
 
 
 def parse():
@@ -78,7 +105,12 @@ def parse():
     ap.add_argument("--cands", type=int, default=8)
     ap.add_argument("--cpu-pairs", type=int, default=400_000, help="pairs in the bounded CPU-baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all online cores")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip every CPU leg (cpu_baseline and the reference CLI)")
+    ap.add_argument("--kernels-only", action="store_true", help="only the timed kernel steps (profiling passes)")
+    ap.add_argument("--e2e-calls", type=int, default=5, help="timed vsx_align_pairs calls of the end-to-end figure")
+    ap.add_argument("--no-search", action="store_true", help="skip the vsx_search_batch end-to-end figure")
+    ap.add_argument("--ref-search-queries", type=int, default=512,
+                    help="queries the reference CLI searches against the full DB (0 = skip; its index build takes ~1 min)")
     ap.add_argument("--dir-budget-gb", type=float, default=0.0)
     return ap.parse_args()
 
@@ -100,12 +132,14 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)     # RCCL
 
-    from vsearch_amd import Aligner, SequenceSet, workload
+    from vsearch_amd import Aligner, SequenceSet, sharding, workload
 
-    # ---- synthetic inputs, generated in HBM (weak scaling: every rank holds a DB replica and its own queries)
+    # ---- synthetic inputs, generated in HBM.  Weak scaling: the job has world x a.queries queries, rank r owns the
+    # contiguous block sharding.shard_queries() gives it (generated here from its own seed) and a replica of the DB
     t0 = time.time()
+    q_lo, q_hi = sharding.shard_queries(world * a.queries, world, rank)
     db_ascii, db_off, db_len, fam = workload.make_family_db(a.db, a.dlen, seed=17, device=dev)
-    q_ascii, q_off, q_len, src = workload.make_queries(db_ascii, db_off, db_len, a.queries, a.qlen,
+    q_ascii, q_off, q_len, src = workload.make_queries(db_ascii, db_off, db_len, q_hi - q_lo, a.qlen,
                                                        seed=11 + 1000 * rank, device=dev)
     qidx, tidx = workload.family_candidates(src, fam, per_query=a.cands, seed=5 + rank)
     torch.cuda.synchronize()
@@ -119,16 +153,22 @@ def main():
     t_plan = time.time() - t0             # host: pairs -> wavefront tasks, task upload, checkpoint buffer (one-time hipMalloc)
     n_pairs = len(qidx)
     cells = int((q_len[qidx].astype(np.int64) * db_len[tidx].astype(np.int64)).sum())
-    hits = torch.empty(n_pairs * 24, dtype=torch.uint8, device=dev)
-    gathered = torch.empty(world * n_pairs * 24, dtype=torch.uint8, device=dev) if world > 1 else None
+    hits = torch.empty((n_pairs, sharding.HIT_RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
+    runs_buf = None
+    gathered = None
 
     def step():
+        nonlocal runs_buf, gathered
         plan.run()
         tm = plan.sync()
         if world > 1:
-            # the only collective on the path: final gather of the fixed-size hit records over RCCL/xGMI
+            # the only collective on the path: final gather of the hit records and the CIGAR run words over RCCL/xGMI
             plan.export_hits(hits.data_ptr(), hits.numel())
-            dist.all_gather_into_tensor(gathered, hits)
+            n_runs = plan.export_runs()
+            if runs_buf is None or runs_buf.numel() < n_runs:
+                runs_buf = torch.empty(n_runs + n_runs // 8 + 1024, dtype=torch.int32, device=dev)
+            plan.export_runs(runs_buf.data_ptr(), runs_buf.numel() * 4)
+            gathered = sharding.gather_results(hits, runs_buf[:n_runs], dist)
         return tm
 
     def barrier():
@@ -141,13 +181,14 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    fwd_ms = tb_ms = 0.0
+    fwd_ms = tb_ms = tot_ms = 0.0
     fwd_launches = 0
     tm = None
     for _ in range(a.steps):
         tm = step()
         fwd_ms += tm.forward_ms
         tb_ms += tm.traceback_ms
+        tot_ms += tm.total_ms
         fwd_launches += tm.forward_launches
     barrier()
     elapsed = time.perf_counter() - t0
@@ -162,7 +203,20 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- PCIe-inclusive rate (results + CIGAR text on the host), informational ----
+    gather_check = None
+    if world > 1:
+        # rank 0 holds every rank's pairs: its own block must come back unchanged, offsets of the others rebased past it
+        rec_all, runs_all, counts = gathered
+        mine = sharding.decode_records(rec_all[:n_pairs])
+        own = sharding.decode_records(hits)
+        other = sharding.decode_records(rec_all[n_pairs:2 * n_pairs])
+        n_runs0 = int(own["nruns"].sum())
+        gather_check = bool(counts == [n_pairs] * world and np.array_equal(mine["score"], own["score"])
+                            and np.array_equal(mine["run_off"], own["run_off"])
+                            and int(other["run_off"][other["nruns"] > 0].min()) >= n_runs0
+                            and int(runs_all.numel()) >= n_runs0 + int(other["nruns"].sum()))
+
+    # ---- results on the host (PCIe + malloc'd arrays + CIGAR text), one plan, informational ----
     t0 = time.perf_counter()
     res = plan.fetch()
     t_fetch = time.perf_counter() - t0
@@ -176,6 +230,7 @@ def main():
     tilted = 2 * info["tasks_tilted"] >= info["tasks"]
     OPS_PER_CELL = ops_per_cell(info)
     achieved = cells_per_launch * OPS_PER_CELL / (fwd_avg_ms * 1e-3) / 1e12
+    pmc, pmc_note = counters_from_profile(a, world)
     out = {
         "metric": "GCUPS (useful DP cells/s of the search16 global-alignment path: DP + traceback + CIGAR)",
         "value": round(value, 2),
@@ -189,8 +244,10 @@ def main():
             "workload": f"usearch_global candidate batch: {a.queries} x {a.qlen} bp queries vs {a.db} x {a.dlen} bp "
                         f"family-structured DB (device-resident), {a.cands} candidates/query = {n_pairs} pairs/GPU/step, "
                         "--id 0.9 shape, default scoring (BASELINE config[1])",
-            "candidates": "synthetic: source member + 7 same-family members (k-mer heuristic is host-side, outside the path)",
-            "parallelism": f"query-sharded x{world}, DB replicated" if world > 1 else "single GPU",
+            "candidates": "synthetic for `value`: source member + 7 same-family members (what the k-mer stage yields on this DB); "
+                          "search_end_to_end runs the real device k-mer stage (vsx_kmer.hip) in front of the aligner",
+            "parallelism": f"query-sharded x{world} (sharding.shard_queries), DB replicated, one gather of records + CIGAR runs per step"
+                           if world > 1 else "single GPU",
             "cells_per_step_per_gpu": cells,
         },
         "roofline": {
@@ -209,32 +266,198 @@ def main():
                                   "achieved": round(achieved * SURVEY_OPS_PER_CELL / OPS_PER_CELL, 3),
                                   "frac": round(achieved * SURVEY_OPS_PER_CELL / OPS_PER_CELL / PEAK_INT16_TOPS, 4),
                                   "note": "SURVEY 8(d) counts the reference's onestep incl. 4 direction compares + min/max; the kernel "
-                                          "does not execute those per cell, so this exceeds 1 by construction"},
+                                          "does not execute those per cell (DESIGN 4.1), so 15 ops/cell is not a lower bound here"},
             "kernel_ms_avg": round(fwd_avg_ms, 3),
             "kernel_launches": fwd_launches,
             "kernel_gcups": round(cells_per_launch / (fwd_avg_ms * 1e-3) / 1e9, 1),
-            "traffic": traffic_from_profile(a, world),
+            "traffic": pmc["forward"]["hbm_bytes_per_launch"] if pmc else None,
             "hbm_algorithmic_bytes_per_launch": int(tm.dir_bytes / max(1, tm.forward_launches)),
             "hbm_algorithmic_GBps": round(tm.dir_bytes / max(1, tm.forward_launches) / (fwd_avg_ms * 1e-3) / 1e9, 1),
         },
-        "kernel_split_ms_per_step": {"forward": round(fwd_ms / a.steps, 3), "traceback": round(tb_ms / a.steps, 3)},
+        "kernel_split_ms_per_step": {"forward": round(fwd_ms / a.steps, 3), "traceback": round(tb_ms / a.steps, 3),
+                                     "cigar_text_and_rest": round((tot_ms - fwd_ms - tb_ms) / a.steps, 3)},
         "plan_s": round(t_plan, 3),
         "fetch_s": round(t_fetch, 3),
         "value_incl_fetch": round(cells / (ms_per_step * 1e-3 + t_fetch) / 1e9, 2),
         "gen_s": round(t_gen, 2),
     }
+    if pmc:
+        out["roofline"]["pmc"] = {k: pmc[k] for k in ("kernel_source_sha", "forward", "traceback", "valu_issue") if k in pmc}
+    else:
+        out["roofline"]["traffic_note"] = pmc_note
+    if gather_check is not None:
+        out["gather_check"] = gather_check
+
+    if not a.kernels_only and world == 1:
+        # ---- end to end through the one-call entry (host index arrays in, host result arrays + CIGAR text out) ----
+        try:
+            out["end_to_end"] = end_to_end(a, al, Q, T, qidx, tidx, cells, res)
+            out["value_end_to_end"] = out["end_to_end"]["value"]
+        except Exception as e:
+            out["end_to_end"] = {"error": repr(e)}
 
     # ---- CPU baseline: the reference's own SSE2 search16 (oracle/_ref, built from /root/reference) on a
     #      bounded sample of the SAME workload; falls back to the scalar port if _ref was not shipped ----
-    if not a.no_cpu:
+    if not a.no_cpu and not a.kernels_only:
         try:
             out["cpu_baseline"] = cpu_baseline(a, db_ascii, db_off, db_len, q_ascii, q_off, q_len, qidx, tidx, res)
+            if "value_end_to_end" in out and out["cpu_baseline"].get("value"):
+                out["end_to_end"]["vs_cpu_baseline"] = round(out["value_end_to_end"] / out["cpu_baseline"]["value"], 1)
         except Exception as e:  # the baseline is a side measurement: never lose the bench line over it
             out["cpu_baseline"] = {"error": repr(e)}
+
+    if not a.kernels_only and not a.no_search and world == 1:
+        plan.close()
+        try:
+            out["search_end_to_end"] = search_end_to_end(a, al, db_ascii, db_off, db_len, q_ascii, q_off, q_len)
+        except Exception as e:
+            out["search_end_to_end"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def end_to_end(a, al, Q, T, qidx, tidx, cells, res):
+    """vsx_align_pairs (plan + kernels + fetch, pipelined slices inside the library) on the step's pair list, steady state:
+    one untimed call (pools, pinned staging), then a.e2e_calls timed calls back to back."""
+    r = al.align_pairs_raw(Q, T, qidx, tidx)
+    n = len(r)
+    same = bool(np.array_equal(r.score, res.score) and np.array_equal(r.aligned, res.aligned) and np.array_equal(r.matches, res.matches)
+                and np.array_equal(r.gaps, res.gaps) and all(r.cigar(k) == res.cigar[k] for k in range(0, n, max(1, n // 5000))))
+    text_bytes = r.cigar_bytes
+    r.close()
+    calls = max(1, a.e2e_calls)
+    times = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        r = al.align_pairs_raw(Q, T, qidx, tidx)
+        times.append(time.perf_counter() - t0)
+        r.close()
+    avg = sum(times) / calls
+    return {"value": round(cells / avg / 1e9, 2), "unit": "GCUPS", "pairs_per_s": round(n / avg, 1),
+            "ms_per_call": round(avg * 1e3, 2), "ms_per_call_min": round(min(times) * 1e3, 2), "calls": calls,
+            "what": "vsx_align_pairs: host pair list -> planning, DP + traceback + CIGAR-text kernels, PCIe, malloc'd result arrays and "
+                    "CIGAR strings on the host; slices of the list pipelined inside the library; pools warm",
+            "cigar_text_bytes": int(text_bytes), "equals_plan_results": same}
+
+
+def _write_fasta(path, blob, off, ln, prefix):
+    with open(path, "wb") as f:
+        parts = []
+        for i in range(len(ln)):
+            o = int(off[i])
+            parts.append(b">%s%d\n%s\n" % (prefix, i, blob[o:o + int(ln[i])]))
+            if len(parts) >= 65536:
+                f.write(b"".join(parts))
+                parts = []
+        f.write(b"".join(parts))
+
+
+def search_end_to_end(a, al, db_ascii, db_off, db_len, q_ascii, q_off, q_len):
+    """vsx_search_batch = --usearch_global --id 0.9 (defaults: maxaccepts 1, maxrejects 32, wordlength 8) for ALL queries of the
+    step against the DB: device k-mer counting + candidate ranking + the reference's accept/reject loop + alignments + hits.
+    The reference CLI (oracle/_ref/vsearch_ref, same options, --qmask/--dbmask none, all usable cores) searches the first
+    --ref-search-queries of the same queries against the same DB file; its search phase is timed from its own progress
+    output (the 'Searching' prompt appears when the phase starts), index construction excluded."""
+    from vsearch_amd import _lib
+    from vsearch_amd._lib import check
+    lib = _lib.load()
+    db_blob = db_ascii.cpu().numpy().tobytes()
+    q_blob = q_ascii.cpu().numpy().tobytes()
+
+    def vp(arr):
+        return arr.ctypes.data_as(C.c_void_p)
+
+    o = _lib.SearchOpts()
+    lib.vsx_search_opts_default(C.byref(o))
+    o.id = 0.9
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    check(lib.vsx_searcher_create(al.h, C.byref(h), C.byref(o), len(db_len), C.cast(C.c_char_p(db_blob), C.c_void_p),
+                                  len(db_blob), vp(db_off), vp(db_len)), "vsx_searcher_create")
+    t_create = time.perf_counter() - t0
+    nq = len(q_len)
+    out = {}
+    try:
+        secs = []
+        hits = None
+        for rep in range(3):                      # the first call pays the one-time index build and scratch-pool hipMalloc
+            if hits is not None:
+                lib.vsx_hits_free(C.byref(hits))
+            hits = _lib.Hits()
+            t0 = time.perf_counter()
+            check(lib.vsx_search_batch(h, nq, C.cast(C.c_char_p(q_blob), C.c_void_p), len(q_blob), vp(q_off), vp(q_len),
+                                       C.byref(hits)), "vsx_search_batch")
+            secs.append(time.perf_counter() - t0)
+        best = min(secs[1:])
+        first = np.ctypeslib.as_array(hits.first, shape=(nq + 1,)).copy()
+        out = {"queries": nq, "seconds": round(best, 3), "seconds_first_call": round(secs[0], 3), "queries_per_s": round(nq / best, 1),
+               "pairs_aligned": int(hits.pairs_aligned), "cells_aligned": int(hits.cells_aligned),
+               "value": round(int(hits.cells_aligned) / best / 1e9, 2), "unit": "GCUPS (cells the reference's dispatch aligns / wall)",
+               "hits": int(hits.n_hits), "queries_with_hit": int((first[1:] > first[:-1]).sum()),
+               "seconds_kmer": round(hits.seconds_kmer, 3), "seconds_align": round(hits.seconds_align, 3),
+               "searcher_create_s": round(t_create, 2)}
+        nref = min(a.ref_search_queries, nq)
+        ref_bin = os.path.join(ROOT, "oracle", "_ref", "vsearch_ref")
+        if nref > 0 and not a.no_cpu and os.path.exists(ref_bin):
+            harr = np.ctypeslib.as_array(hits.hit, shape=(max(1, int(hits.n_hits)),))[:int(hits.n_hits)]
+            keep = (harr["query"] < nref) & (harr["accepted"] != 0)
+            ours = set(zip(harr["query"][keep].tolist(), harr["target"][keep].tolist()))
+            out["reference_cli"] = reference_search(ref_bin, db_blob, db_off, db_len, q_blob, q_off, q_len, nref, ours)
+            rq = out["reference_cli"].get("queries_per_s")
+            if rq:
+                out["vs_reference_cli"] = round(out["queries_per_s"] / rq, 1)
+    finally:
+        if hits is not None:
+            lib.vsx_hits_free(C.byref(hits))
+        lib.vsx_searcher_destroy(h)
+    return out
+
+
+def reference_search(ref_bin, db_blob, db_off, db_len, q_blob, q_off, q_len, nref, ours):
+    threads = usable_cpus()
+    with tempfile.TemporaryDirectory(prefix="vsxbench_") as tmp:
+        dbf, qf, uo = (os.path.join(tmp, x) for x in ("db.fa", "q.fa", "u.txt"))
+        _write_fasta(dbf, db_blob, db_off, db_len, b"t")
+        _write_fasta(qf, q_blob, q_off[:nref], q_len[:nref], b"q")
+        cmd = [ref_bin, "--usearch_global", qf, "--db", dbf, "--id", "0.9", "--threads", str(threads), "--qmask", "none",
+               "--dbmask", "none", "--userout", uo, "--userfields", "query+target"]
+        t_start = time.perf_counter()
+        p = subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
+        stamp = {}
+
+        def watch():
+            buf = b""
+            while True:
+                c = p.stderr.read(1)
+                if not c:
+                    break
+                buf += c
+                if "search_begin" not in stamp:
+                    if buf.endswith(b"Searching"):
+                        stamp["search_begin"] = time.perf_counter()
+                        buf = b""
+                elif "search_end" not in stamp and buf.endswith(b"100%"):
+                    stamp["search_end"] = time.perf_counter()
+        th = threading.Thread(target=watch)
+        th.start()
+        rc = p.wait()
+        t_end = time.perf_counter()
+        th.join()
+        if rc != 0 or "search_begin" not in stamp:
+            return {"error": f"vsearch_ref rc {rc}"}
+        secs = stamp.get("search_end", t_end) - stamp["search_begin"]
+        theirs = set()
+        with open(uo) as f:
+            for line in f:
+                qn, tn = line.split()
+                theirs.add((int(qn[1:]), int(tn[1:])))
+        return {"queries": nref, "threads": threads, "search_seconds": round(secs, 3), "queries_per_s": round(nref / secs, 1),
+                "load_and_index_seconds": round(stamp["search_begin"] - t_start, 1),
+                "what": "vsearch_ref --usearch_global --id 0.9 --qmask none --dbmask none, search phase only (from its 'Searching' prompt "
+                        "to the '100%' that ends it), full DB",
+                "hits": len(theirs), "same_hits_as_vsx": bool(theirs == ours)}
 
 
 def usable_cpus():

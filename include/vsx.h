@@ -145,8 +145,10 @@ uint64_t vsx_seqset_count(const vsx_seqset * s);
    vsx_plan_create groups pairs by query into wavefront tasks (<= 8 targets each),
    uploads the task list and sizes the device buffers; vsx_plan_run launches the
    DP + traceback kernels (asynchronously, in chunks that fit `dir_budget_bytes`
-   of direction storage; 0 = default); vsx_plan_fetch waits, copies the results
-   back and formats the CIGAR strings. */
+   of direction storage; 0 = default) and, behind them, the kernel that formats the
+   CIGAR text and the output arrays in HBM (pushop/finishop, align_simd.cpp:1013-1049);
+   vsx_plan_fetch waits and copies them to the host (pinned staging -> malloc'd arrays;
+   strings are 4-byte aligned inside cigar_blob, in no particular order). */
 int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out,
                     const vsx_seqset * queries, const vsx_seqset * targets,
                     uint64_t n_pairs, const uint32_t * qidx, const uint32_t * tidx,
@@ -162,6 +164,15 @@ int vsx_plan_describe(const vsx_plan * plan, vsx_plan_info * info);
    (sentinels / empty query) are filled from the host copy. */
 #define VSX_HIT_RECORD_BYTES 24
 int vsx_plan_export_hits(vsx_plan * plan, void * d_dst, uint64_t dst_bytes);
+/* The dense run buffer those records point into (cigar_run_offset, n_cigar_runs): n_runs words of (length << 2) | op,
+   op 0 = M, 1 = I, 2 = D, each pair's runs in traceback order (last alignment column first).  d_dst == NULL only reports
+   *n_runs.  Together with vsx_plan_export_hits this is what a rank contributes to the multi-GPU gather (SURVEY 8e:
+   "{query, target, score, 4 stats, cigar_off} + CIGAR bytes to rank 0"); the receiver rebases cigar_run_offset by the
+   run counts of the lower ranks and formats text with vsx_cigar_from_runs. */
+int vsx_plan_export_runs(vsx_plan * plan, void * d_dst, uint64_t dst_bytes, uint64_t * n_runs);
+/* pushop / finishop (align_simd.cpp:1013-1049) on the host: run words -> NUL-terminated CIGAR text (count omitted when 1).
+   Returns the bytes needed including the NUL; writes only if cap suffices.  No device needed. */
+int64_t vsx_cigar_from_runs(const uint32_t * runs, uint32_t n, char * dst, uint64_t cap);
 void vsx_plan_destroy(vsx_plan * plan);
 
 /* Convenience: create + run + fetch + destroy. */

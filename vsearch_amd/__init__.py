@@ -3,9 +3,10 @@
 The package is a thin host-side mirror of the reference's aligner interface over libvsx's C-ABI
 (include/vsx.h); all arithmetic runs in hand-written HIP kernels (vsearch_amd/csrc).
 """
-from .aligner import Aligner, SequenceSet, Plan, AlignmentResults, DEFAULT_SCORING, scoring_from_tuple  # noqa: F401
+from .aligner import (Aligner, SequenceSet, Plan, AlignmentResults, RawResults, DEFAULT_SCORING,  # noqa: F401
+                      scoring_from_tuple, cigar_from_runs)
 from .search import SearchSession, msa, msa_batch  # noqa: F401
 from ._lib import SENTINEL, VsxError, load as load_library  # noqa: F401
 
-__all__ = ["Aligner", "SequenceSet", "Plan", "AlignmentResults", "DEFAULT_SCORING", "scoring_from_tuple",
+__all__ = ["Aligner", "SequenceSet", "Plan", "AlignmentResults", "RawResults", "cigar_from_runs", "DEFAULT_SCORING", "scoring_from_tuple",
            "SearchSession", "SENTINEL", "VsxError", "load_library"]

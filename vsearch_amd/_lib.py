@@ -17,7 +17,8 @@ SENTINEL = 32767
 SYMBOLS = [
     "vsx_version_string", "vsx_device_count", "vsx_last_error", "vsx_create", "vsx_destroy",
     "vsx_seqset_create", "vsx_seqset_create_from_device", "vsx_seqset_destroy", "vsx_seqset_count",
-    "vsx_plan_create", "vsx_plan_run", "vsx_plan_sync", "vsx_plan_fetch", "vsx_plan_export_hits", "vsx_plan_destroy",
+    "vsx_plan_create", "vsx_plan_run", "vsx_plan_sync", "vsx_plan_fetch", "vsx_plan_export_hits", "vsx_plan_export_runs",
+    "vsx_cigar_from_runs", "vsx_plan_destroy",
     "vsx_align_pairs", "vsx_align_pairs_filtered", "vsx_plan_set_filter", "vsx_results_free", "vsx_plan_describe",
 ]
 # include/vsx_search.h
@@ -141,6 +142,9 @@ def load():
     lib.vsx_plan_sync.argtypes = [vp, C.POINTER(Timing)]
     lib.vsx_plan_fetch.argtypes = [vp, C.POINTER(Results)]
     lib.vsx_plan_export_hits.argtypes = [vp, vp, C.c_uint64]
+    lib.vsx_plan_export_runs.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.vsx_cigar_from_runs.argtypes = [vp, C.c_uint32, vp, C.c_uint64]
+    lib.vsx_cigar_from_runs.restype = C.c_int64
     lib.vsx_plan_destroy.argtypes = [vp]
     lib.vsx_plan_destroy.restype = None
     lib.vsx_plan_describe.argtypes = [vp, C.POINTER(PlanInfo)]

@@ -69,6 +69,48 @@ class AlignmentResults:
                 int(self.gaps[k]), self.cigar[k])
 
 
+class RawResults:
+    """vsx_results as handed out by the library (malloc'd arrays, freed on close): zero-copy numpy views and CIGARs on
+    demand -- for callers that consume a few fields of many pairs (bench.py's end-to-end loop, the sharded gather)."""
+
+    def __init__(self, res):
+        self._res = res
+        n = self.n = int(res.n_pairs)
+        view = lambda p: np.ctypeslib.as_array(p, shape=(n,)) if n else np.zeros(0, np.uint16)
+        self.score, self.aligned, self.matches = view(res.score), view(res.aligned), view(res.matches)
+        self.mismatches, self.gaps, self.cigar_off = view(res.mismatches), view(res.gaps), view(res.cigar_off)
+        self.verdict = np.ctypeslib.as_array(res.verdict, shape=(n,)) if (n and bool(res.verdict)) else None
+        self.cigar_bytes = int(res.cigar_bytes)
+
+    def cigar(self, k):
+        return C.string_at(C.addressof(self._res.cigar_blob.contents) + int(self.cigar_off[k])).decode()
+
+    def row(self, k):
+        return (int(self.score[k]), int(self.aligned[k]), int(self.matches[k]), int(self.mismatches[k]),
+                int(self.gaps[k]), self.cigar(k))
+
+    def __len__(self):
+        return self.n
+
+    def close(self):
+        if self._res is not None:
+            self.score = self.aligned = self.matches = self.mismatches = self.gaps = self.cigar_off = self.verdict = None
+            _lib.load().vsx_results_free(C.byref(self._res))
+            self._res = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class SequenceSet:
     """Device-resident sequences (mirror of Database: core/db.hpp getsequence/getsequencelen)."""
 
@@ -115,6 +157,14 @@ class SequenceSet:
 
     def __len__(self):
         return self.n
+
+
+def cigar_from_runs(runs):
+    """vsx_cigar_from_runs: run words ((length << 2) | op, traceback order) -> CIGAR text; host only"""
+    r = np.ascontiguousarray(runs, np.uint32)
+    buf = C.create_string_buffer(7 * r.size + 1)
+    _lib.load().vsx_cigar_from_runs(_ptr(r), r.size, buf, len(buf))
+    return buf.value.decode()
 
 
 def make_filter(**kw):
@@ -175,6 +225,13 @@ class Plan:
     def export_hits(self, device_ptr, nbytes):
         """copy the 24-byte hit records of the last run into device memory (e.g. a torch tensor)"""
         check(_lib.load().vsx_plan_export_hits(self.h, C.c_void_p(device_ptr), int(nbytes)), "vsx_plan_export_hits")
+
+    def export_runs(self, device_ptr=None, nbytes=0):
+        """vsx_plan_export_runs: number of run words of the last run; with a destination, also copies them there (device memory)"""
+        n = C.c_uint64(0)
+        check(_lib.load().vsx_plan_export_runs(self.h, C.c_void_p(device_ptr) if device_ptr else None, int(nbytes), C.byref(n)),
+              "vsx_plan_export_runs")
+        return int(n.value)
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -276,6 +333,18 @@ class Aligner:
             return AlignmentResults(res)
         finally:
             lib.vsx_results_free(C.byref(res))
+
+    def align_pairs_raw(self, queries, targets, qidx, tidx, filter=None):
+        """vsx_align_pairs[_filtered] without the Python-side copies: returns RawResults (close() it)"""
+        lib = _lib.load()
+        qidx = np.ascontiguousarray(qidx, np.uint32)
+        tidx = np.ascontiguousarray(tidx, np.uint32)
+        res = Results()
+        f = make_filter(**filter) if filter is not None else None
+        check(lib.vsx_align_pairs_filtered(self.h, queries.h, targets.h, qidx.size, qidx.ctypes.data_as(C.c_void_p),
+                                           tidx.ctypes.data_as(C.c_void_p), C.byref(f) if f is not None else None, C.byref(res)),
+              "vsx_align_pairs_filtered")
+        return RawResults(res)
 
     def align(self, q, t):
         """one pair -> (score, aligned, matches, mismatches, gaps, cigar)"""

@@ -79,7 +79,8 @@ struct DevBuf {
 
 // Scratch pool: hipMalloc/hipFree of the multi-GB checkpoint, slab and run buffers cost seconds per plan (page-table
 // set-up), far more than the kernels of a 500 k-pair stage.  A context keeps the blocks its finished plans give back and
-// hands them to the next plan (best fit).  VSX_POOL=0 disables it; vsx_destroy frees everything.
+// hands them to the next plan (best fit, but never a block more than 4x + 1 MB larger than the request: a retired multi-GB
+// checkpoint block must not end up pinned under an 8-byte cursor).  VSX_POOL=0 disables it; vsx_destroy frees everything.
 struct PoolBlock { void * p; size_t bytes; };
 struct ScratchPool {
   std::vector<PoolBlock> free_blocks;
@@ -91,8 +92,10 @@ struct ScratchPool {
     {
       std::lock_guard<std::mutex> lk(mu);
       size_t best = SIZE_MAX;
+      const size_t limit = bytes > (SIZE_MAX >> 3) ? SIZE_MAX : 4 * bytes + (1u << 20);
       for (size_t k = 0; k < free_blocks.size(); ++k)
-        if (free_blocks[k].bytes >= bytes && (best == SIZE_MAX || free_blocks[k].bytes < free_blocks[best].bytes)) best = k;
+        if (free_blocks[k].bytes >= bytes && free_blocks[k].bytes <= limit &&
+            (best == SIZE_MAX || free_blocks[k].bytes < free_blocks[best].bytes)) best = k;
       if (best != SIZE_MAX)
         {
           *out = free_blocks[best].p; *got = free_blocks[best].bytes;
@@ -201,6 +204,7 @@ struct vsx_ctx {
   hipStream_t stream = nullptr;      // DP kernels, copies
   hipStream_t stream2 = nullptr;     // traceback kernels (overlap with the next chunk's DP)
   hipStream_t stream_up = nullptr;   // plan uploads (a plan may be created while another one runs: vsx_align_pairs pipeline)
+  hipStream_t stream_dn = nullptr;   // result downloads (vsx_plan_fetch of slice i-1 while slice i's kernels occupy `stream`)
   vsx_scoring sc {};
   bool force_fallback = false;      // a score/penalty left the 16-bit range: every pair -> sentinel
   bool tb_packed = false;           // VSX_TB_ARITH=packed: plan every task into the TRACK = 1 class (saturating packed ops, capture layout)
@@ -212,6 +216,16 @@ struct vsx_ctx {
   DevBuf<int16_t> d_htop_t, d_hleft_t, d_matrix_t;
   ScratchPool pool;
   SharedSlot shared_dir, shared_slab;   // declared after the pool: released first
+  // pinned host memory: results cross PCIe into it (vsx_plan_fetch), one fetch at a time; grow-only
+  std::mutex stage_mu;
+  uint8_t * stage = nullptr;
+  size_t stage_bytes = 0;
+  std::vector<unsigned long long *> cursor_slots;   // idle pinned {run cursor, text cursor} pairs of finished plans
+  ~vsx_ctx()
+  {
+    if (stage) (void) hipHostFree(stage);
+    for (auto * c : cursor_slots) (void) hipHostFree(c);
+  }
 };
 
 struct vsx_seqset {
@@ -225,8 +239,10 @@ struct vsx_seqset {
   uint8_t * codes() const { return d_codes.p + VSX_CODE_SLACK; }
   DevBuf<uint64_t> d_off;
   DevBuf<uint32_t> d_len;
-  std::vector<uint8_t> impure;      // lazily computed on the device (vsx_purity_kernel)
-  bool have_impure = false;
+  // VSX_SCORE=arith only: per-sequence "contains a non-ACGT symbol", computed on first use (vsx_purity_kernel) under the lock
+  mutable std::mutex impure_mu;
+  mutable std::vector<uint8_t> impure;
+  mutable bool have_impure = false;
 };
 
 namespace {
@@ -242,6 +258,22 @@ struct Chunk {
 };
 
 }  // namespace
+
+extern "C" int vsx_internal_usable_cpus(void);
+// threads for a memory-bound host pass over `bytes` bytes
+static int copy_threads(uint64_t bytes)
+{
+  return (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) vsx_internal_usable_cpus(), bytes >> 21));
+}
+
+template <typename F>
+static void run_threads(int nth, F && f)
+{
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nth; ++t) pool.emplace_back(f, t);
+  f(0);
+  for (auto & th : pool) th.join();
+}
 
 struct vsx_plan {
   vsx_ctx * ctx = nullptr;
@@ -269,7 +301,13 @@ struct vsx_plan {
   PoolBuf<uint2> d_strip;
   PoolBuf<VsxSlotOut> d_slot;
   PoolBuf<VsxPairOut> d_out;
-  PoolBuf<unsigned long long> d_cursor;
+  PoolBuf<unsigned long long> d_cursor;  // [0] run words used, [1] text bytes used
+  PoolBuf<uint8_t> d_text, d_soa;        // CIGAR text and the output arrays, written by vsx_cigar_text_kernel (vsx_tbtext.hip)
+  VsxSoaOut soa {};
+  uint64_t soa_bytes = 0, soa_off[7] {};
+  uint64_t text_capacity = 0;
+  unsigned long long * h_cursor = nullptr;   // pinned copy of d_cursor, filled at the end of a run
+  std::vector<uint32_t> host_pairs;      // pairs answered without DP (sentinels, empty query), ascending
   uint64_t runs_capacity = 0;
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
   bool ran = false;
@@ -286,6 +324,7 @@ struct vsx_plan {
       }
     if (ev_begin) (void) hipEventDestroy(ev_begin);
     if (ev_end) (void) hipEventDestroy(ev_end);
+    if (h_cursor) { std::lock_guard<std::mutex> lk(ctx->stage_mu); ctx->cursor_slots.push_back(h_cursor); }
   }
 };
 
@@ -411,12 +450,14 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
     if (c->stream) (void) hipStreamDestroy(c->stream);
     if (c->stream2) (void) hipStreamDestroy(c->stream2);
     if (c->stream_up) (void) hipStreamDestroy(c->stream_up);
+    if (c->stream_dn) (void) hipStreamDestroy(c->stream_dn);
     delete c;
   };
   hipError_t e;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&c->stream_dn, hipStreamNonBlocking)) != hipSuccess ||
       (e = c->d_htop.alloc(VSX_TABLE_LEN)) != hipSuccess || (e = c->d_hleft.alloc(VSX_TABLE_LEN)) != hipSuccess ||
       (e = c->d_matrix.alloc(256)) != hipSuccess ||
       (e = hipMemcpy(c->d_htop.p, htop.data(), VSX_TABLE_LEN * 2, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -480,6 +521,7 @@ void vsx_destroy(vsx_ctx * c)
   if (c->stream) { (void) hipStreamSynchronize(c->stream); (void) hipStreamDestroy(c->stream); }
   if (c->stream2) { (void) hipStreamSynchronize(c->stream2); (void) hipStreamDestroy(c->stream2); }
   if (c->stream_up) { (void) hipStreamSynchronize(c->stream_up); (void) hipStreamDestroy(c->stream_up); }
+  if (c->stream_dn) { (void) hipStreamSynchronize(c->stream_dn); (void) hipStreamDestroy(c->stream_dn); }
   c->shared_dir.reset();
   c->shared_slab.reset();
   c->pool.trim();
@@ -554,8 +596,9 @@ void vsx_seqset_destroy(vsx_seqset * s)
 
 uint64_t vsx_seqset_count(const vsx_seqset * s) { return s ? s->n : 0; }
 
-static int ensure_impure(vsx_seqset * s)
+static int ensure_impure(const vsx_seqset * s)
 {
+  std::lock_guard<std::mutex> lk(s->impure_mu);
   if (s->have_impure) return VSX_OK;
   vsx_ctx * ctx = s->ctx;
   HIPCHK(hipSetDevice(ctx->device));
@@ -645,8 +688,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
         return fail(VSX_EINVAL, "vsx_plan_create: pair %" PRIu64 " references a sequence out of range", bad[(size_t) t]);
   }
   HIPCHK(hipSetDevice(ctx->device));
-  int rc = ensure_impure(const_cast<vsx_seqset *>(queries));
-  if (rc != VSX_OK) return rc;
+  static const bool arith = std::getenv("VSX_SCORE") && std::strcmp(std::getenv("VSX_SCORE"), "arith") == 0;
+  if (arith) { const int rc = ensure_impure(queries); if (rc != VSX_OK) return rc; }
 
   std::unique_ptr<vsx_plan> pl(new vsx_plan);
   pl->ctx = ctx; pl->Q = queries; pl->T = targets; pl->n_pairs = n_pairs;
@@ -697,6 +740,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       for (uint32_t k : special[(size_t) t])
         {
           const int64_t Q = queries->len[qidx[k]], D = targets->len[tidx[k]];
+          pl->host_pairs.push_back(k);
           VsxPairOut & o = pl->host_out[k];
           auto sentinel = [&]() { o = VsxPairOut {}; o.score = 32767; };
           if (ctx->force_fallback) { sentinel(); continue; }              // align_simd.cpp:1463-1479
@@ -736,7 +780,6 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   group_begin.push_back(gpu_pairs.size());
   // substitution scores: LDS query profile by default (handles every symbol); VSX_SCORE=arith selects the XOR/min/mad
   // variant for queries made of A/C/G/T(U) only (kept for A/B measurements)
-  static const bool arith = std::getenv("VSX_SCORE") && std::strcmp(std::getenv("VSX_SCORE"), "arith") == 0;
   const size_t ngroups = group_begin.size() - 1;
   const int nth = (int) std::max<size_t>(1, std::min<size_t>((size_t) vsx_internal_usable_cpus(), gpu_pairs.size() / 65536));
   std::vector<std::vector<ProtoTask>> part((size_t) nth);
@@ -753,7 +796,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
         std::stable_sort(gpu_pairs.begin() + (long) b, gpu_pairs.begin() + (long) e,
                          [&](uint32_t x, uint32_t y) { return targets->len[tidx[x]] > targets->len[tidx[y]]; });
         const int rows = pick_rows((int) queries->len[q]);
-        const int generic = (queries->impure[q] || !arith) ? 1 : 0;
+        const int generic = (!arith || queries->impure[q]) ? 1 : 0;
         for (size_t x = b; x < e; x += VSX_TASK_SLOTS)
           {
             ProtoTask pt {};
@@ -887,13 +930,38 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   HIPCHK(pl->d_slab_off.alloc(&ctx->pool, ngp));
   HIPCHK(pl->d_slot.alloc(&ctx->pool, pl->tasks.size() * VSX_TASK_SLOTS));
   HIPCHK(pl->d_out.alloc(&ctx->pool, n_pairs));
-  HIPCHK(pl->d_cursor.alloc(&ctx->pool, 1));
+  HIPCHK(pl->d_cursor.alloc(&ctx->pool, 2));
+  {
+    // output arrays, 16-byte aligned sections of one block: score, aligned, matches, mismatches, gaps (2 B), verdict (1 B), text offset (8 B)
+    const uint64_t np = std::max<uint64_t>(n_pairs, 1);
+    const uint64_t width[7] = {2, 2, 2, 2, 2, 1, 8};
+    uint64_t at = 0;
+    for (int x = 0; x < 7; ++x) { pl->soa_off[x] = at; at += (np * width[x] + 15) & ~15ull; }
+    pl->soa_bytes = at;
+    HIPCHK(pl->d_soa.alloc(&ctx->pool, at));
+    uint8_t * b = pl->d_soa.p;
+    pl->soa.score = reinterpret_cast<int16_t *>(b + pl->soa_off[0]);
+    pl->soa.aligned = reinterpret_cast<uint16_t *>(b + pl->soa_off[1]);
+    pl->soa.matches = reinterpret_cast<uint16_t *>(b + pl->soa_off[2]);
+    pl->soa.mismatches = reinterpret_cast<uint16_t *>(b + pl->soa_off[3]);
+    pl->soa.gaps = reinterpret_cast<uint16_t *>(b + pl->soa_off[4]);
+    pl->soa.verdict = b + pl->soa_off[5];
+    pl->soa.text_off = reinterpret_cast<uint64_t *>(b + pl->soa_off[6]);
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->stage_mu);
+    if (!ctx->cursor_slots.empty()) { pl->h_cursor = ctx->cursor_slots.back(); ctx->cursor_slots.pop_back(); }
+  }
+  if (!pl->h_cursor) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&pl->h_cursor), 64, hipHostMallocDefault));
   // one checkpoint buffer, reused chunk after chunk: overlapping chunk k's traceback with chunk k+1's DP bought nothing
   // (both are issue-bound), while a second buffer doubled a multi-second hipMalloc
   HIPCHK(pl->d_dir[0].alloc(ctx->shared_dir, &ctx->pool, max_dir));
   HIPCHK(pl->d_strip.alloc(&ctx->pool, max_strip));
   HIPCHK(pl->d_slab.alloc(ctx->shared_slab, &ctx->pool, max_slab));
   HIPCHK(pl->d_runs.alloc(&ctx->pool, pl->runs_capacity));
+  // text: <= 6 bytes per run (5 digits + op) + NUL + padding per pair in the worst case; typical alignments need ~2 per run
+  pl->text_capacity = std::min<uint64_t>(6 * worst_runs + 8 * (uint64_t) ngp, std::max<uint64_t>(32ull << 20, 128ull * ngp)) + 16;
+  HIPCHK(pl->d_text.alloc(&ctx->pool, pl->text_capacity));
   if (!pl->tasks.empty())
     HIPCHK(hipMemcpyAsync(pl->d_tasks.p, pl->tasks.data(), pl->tasks.size() * sizeof(VsxTask), hipMemcpyHostToDevice, ctx->stream_up));
   if (ngp)
@@ -940,7 +1008,7 @@ int vsx_plan_run(vsx_plan * pl)
   vsx_ctx * ctx = pl->ctx;
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream, st2 = ctx->stream2;
-  HIPCHK(hipMemsetAsync(pl->d_cursor.p, 0, sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(pl->d_cursor.p, 0, 2 * sizeof(unsigned long long), st));
   HIPCHK(hipEventRecord(pl->ev_begin, st));
   // per chunk: DP kernels on `st`, then its traceback on `st2`; the next chunk's DP waits for it (one checkpoint buffer)
   for (size_t k = 0; k < pl->chunks.size(); ++k)
@@ -972,6 +1040,10 @@ int vsx_plan_run(vsx_plan * pl)
       HIPCHK(hipEventRecord(c.e2, st2));
     }
   if (!pl->chunks.empty()) HIPCHK(hipStreamWaitEvent(st, pl->chunks.back().e2, 0));   // st2 is in order
+  // run lists -> CIGAR text, records -> output arrays (pushop / finishop are part of the reference's timed path)
+  HIPCHK(vsx_launch_cigar_text(pl->d_out.p, pl->d_pair_ids.p, (uint32_t) pl->pair_ids.size(), pl->d_runs.p, pl->runs_capacity,
+                               pl->d_text.p, pl->text_capacity, pl->d_cursor.p + 1, pl->soa, st));
+  HIPCHK(hipMemcpyAsync(pl->h_cursor, pl->d_cursor.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(pl->ev_end, st));
   pl->ran = true;
   return VSX_OK;
@@ -1043,9 +1115,9 @@ int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
   int rc = vsx_plan_sync(pl, nullptr);
   if (rc != VSX_OK) return rc;
   HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
 
-  unsigned long long used = 0;
-  HIPCHK(hipMemcpy(&used, pl->d_cursor.p, sizeof used, hipMemcpyDeviceToHost));
+  unsigned long long used = pl->h_cursor[0], text_used = pl->h_cursor[1];
   if (used > pl->runs_capacity)
     {
       // the dense run buffer was sized for typical alignments; size it exactly and run again
@@ -1053,75 +1125,99 @@ int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
       HIPCHK(pl->d_runs.alloc(&pl->ctx->pool, pl->runs_capacity));
       if ((rc = vsx_plan_run(pl)) != VSX_OK) return rc;
       if ((rc = vsx_plan_sync(pl, nullptr)) != VSX_OK) return rc;
-      HIPCHK(hipMemcpy(&used, pl->d_cursor.p, sizeof used, hipMemcpyDeviceToHost));
+      used = pl->h_cursor[0]; text_used = pl->h_cursor[1];
       if (used > pl->runs_capacity) return fail(VSX_EHIP, "vsx_plan_fetch: run buffer overflow after resize");
+    }
+  if (text_used > pl->text_capacity)
+    {
+      // same for the text: only the formatting kernel runs again
+      pl->text_capacity = text_used + 16;
+      HIPCHK(pl->d_text.alloc(&pl->ctx->pool, pl->text_capacity));
+      HIPCHK(hipMemsetAsync(pl->d_cursor.p + 1, 0, sizeof(unsigned long long), st));
+      HIPCHK(vsx_launch_cigar_text(pl->d_out.p, pl->d_pair_ids.p, (uint32_t) pl->pair_ids.size(), pl->d_runs.p, pl->runs_capacity,
+                                   pl->d_text.p, pl->text_capacity, pl->d_cursor.p + 1, pl->soa, st));
+      HIPCHK(hipMemcpyAsync(pl->h_cursor, pl->d_cursor.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      text_used = pl->h_cursor[1];
+      if (text_used > pl->text_capacity) return fail(VSX_EHIP, "vsx_plan_fetch: text buffer overflow after resize");
     }
 
   const uint64_t n = pl->n_pairs;
-  std::vector<VsxPairOut> dev(n);
-  std::vector<uint32_t> runs(used);
-  if (n) HIPCHK(hipMemcpy(dev.data(), pl->d_out.p, n * sizeof(VsxPairOut), hipMemcpyDeviceToHost));
-  if (used) HIPCHK(hipMemcpy(runs.data(), pl->d_runs.p, used * 4, hipMemcpyDeviceToHost));
-
+  const uint64_t n1 = std::max<uint64_t>(n, 1);
+  // the rare pairs answered on the host get their strings behind the device text
+  uint64_t tail = 0;
+  for (size_t h = 0, hc = 0; h < pl->host_pairs.size(); ++h)
+    {
+      ++tail;
+      if (hc < pl->host_cigar_pair.size() && pl->host_cigar_pair[hc] == pl->host_pairs[h]) tail += pl->host_cigar[hc++].size();
+    }
   out->n_pairs = n;
-  out->score = (int16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
-  out->aligned = (uint16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
-  out->matches = (uint16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
-  out->mismatches = (uint16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
-  out->gaps = (uint16_t *) std::malloc(std::max<uint64_t>(n, 1) * 2);
-  out->cigar_off = (uint64_t *) std::malloc(std::max<uint64_t>(n, 1) * 8);
-  out->verdict = pl->filter.enabled ? (uint8_t *) std::malloc(std::max<uint64_t>(n, 1)) : nullptr;
-  if (!out->score || !out->aligned || !out->matches || !out->mismatches || !out->gaps || !out->cigar_off || (pl->filter.enabled && !out->verdict))
+  out->score = (int16_t *) std::malloc(n1 * 2);
+  out->aligned = (uint16_t *) std::malloc(n1 * 2);
+  out->matches = (uint16_t *) std::malloc(n1 * 2);
+  out->mismatches = (uint16_t *) std::malloc(n1 * 2);
+  out->gaps = (uint16_t *) std::malloc(n1 * 2);
+  out->cigar_off = (uint64_t *) std::malloc(n1 * 8);
+  out->verdict = pl->filter.enabled ? (uint8_t *) std::malloc(n1) : nullptr;
+  out->cigar_bytes = text_used + tail;
+  out->cigar_blob = (char *) std::malloc(std::max<uint64_t>(out->cigar_bytes, 1));
+  if (!out->score || !out->aligned || !out->matches || !out->mismatches || !out->gaps || !out->cigar_off || !out->cigar_blob ||
+      (pl->filter.enabled && !out->verdict))
     { vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: host allocation failed"); }
 
-  // statistics + CIGAR text: contiguous slices of the pair list are formatted by host threads, then concatenated
-  const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) vsx_internal_usable_cpus(), n / 4096));
-  std::vector<std::string> part((size_t) nth);
-  std::vector<uint64_t> lo((size_t) nth + 1);
-  for (int t = 0; t <= nth; ++t) lo[(size_t) t] = n * (uint64_t) t / (uint64_t) nth;
-  // pairs answered on the host with a CIGAR (Q == 0 closed form) are rare: index them once
-  auto work = [&](int t) {
-    std::string & b = part[(size_t) t];
-    b.reserve((size_t) ((used * 3 + n) / (uint64_t) nth + 64));
-    size_t hc = (size_t) (std::lower_bound(pl->host_cigar_pair.begin(), pl->host_cigar_pair.end(), (uint32_t) lo[(size_t) t]) -
-                          pl->host_cigar_pair.begin());
-    for (uint64_t k = lo[(size_t) t]; k < lo[(size_t) t + 1]; ++k)
+  {
+    // one PCIe crossing into pinned memory (arrays + text), then host threads spread it over the result arrays
+    std::lock_guard<std::mutex> lk(ctx->stage_mu);
+    const uint64_t need = pl->soa_bytes + ((text_used + 15) & ~15ull);
+    if (need > ctx->stage_bytes)
       {
-        const VsxPairOut & o = pl->is_gpu[k] ? dev[k] : pl->host_out[k];
-        out->score[k] = o.score;
-        out->aligned[k] = o.aligned;
-        out->matches[k] = o.matches;
-        out->mismatches[k] = o.mismatches;
-        out->gaps[k] = o.gaps;
-        if (out->verdict) out->verdict[k] = pl->is_gpu[k] ? (uint8_t) o.pad : (uint8_t) VSX_VERDICT_UNDECIDED;
-        out->cigar_off[k] = b.size();                              // slice-relative, rebased below
-        if (pl->is_gpu[k]) { if (o.nruns) append_cigar(b, runs.data() + o.run_off, o.nruns); }
-        else if (hc < pl->host_cigar_pair.size() && pl->host_cigar_pair[hc] == k) b += pl->host_cigar[hc++];
-        b.push_back('\0');
+        if (ctx->stage) { (void) hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+        const uint64_t want = need + need / 4 + (1u << 20);
+        if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), want, hipHostMallocDefault) != hipSuccess)
+          { (void) hipGetLastError(); vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: pinned staging allocation failed"); }
+        ctx->stage_bytes = want;
       }
-  };
-  {
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto & th : pool) th.join();
+    hipError_t e = hipSuccess;
+    // (the plan's kernels are done -- vsx_plan_sync above -- so the copies need no ordering against `stream`, where the next
+    //  slice of a pipeline may already be running)
+    if (n) e = hipMemcpyAsync(ctx->stage, pl->d_soa.p, pl->soa_bytes, hipMemcpyDeviceToHost, ctx->stream_dn);
+    if (e == hipSuccess && text_used) e = hipMemcpyAsync(ctx->stage + pl->soa_bytes, pl->d_text.p, text_used, hipMemcpyDeviceToHost, ctx->stream_dn);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_dn);
+    if (e != hipSuccess) { vsx_results_free(out); return fail(VSX_EHIP, "vsx_plan_fetch: %s", hipGetErrorString(e)); }
+    const uint8_t * sg = ctx->stage;
+    const int nth = copy_threads(n * 19 + text_used);
+    run_threads(nth, [&](int t) {
+      const uint64_t lo = n * (uint64_t) t / (uint64_t) nth, hi = n * (uint64_t) (t + 1) / (uint64_t) nth;
+      if (hi > lo)
+        {
+          std::memcpy(out->score + lo, sg + pl->soa_off[0] + 2 * lo, 2 * (hi - lo));
+          std::memcpy(out->aligned + lo, sg + pl->soa_off[1] + 2 * lo, 2 * (hi - lo));
+          std::memcpy(out->matches + lo, sg + pl->soa_off[2] + 2 * lo, 2 * (hi - lo));
+          std::memcpy(out->mismatches + lo, sg + pl->soa_off[3] + 2 * lo, 2 * (hi - lo));
+          std::memcpy(out->gaps + lo, sg + pl->soa_off[4] + 2 * lo, 2 * (hi - lo));
+          if (out->verdict) std::memcpy(out->verdict + lo, sg + pl->soa_off[5] + lo, hi - lo);
+          std::memcpy(out->cigar_off + lo, sg + pl->soa_off[6] + 8 * lo, 8 * (hi - lo));
+        }
+      const uint64_t blo = text_used * (uint64_t) t / (uint64_t) nth, bhi = text_used * (uint64_t) (t + 1) / (uint64_t) nth;
+      if (bhi > blo) std::memcpy(out->cigar_blob + blo, sg + pl->soa_bytes + blo, bhi - blo);
+    });
   }
-  size_t total = 0;
-  std::vector<size_t> base((size_t) nth);
-  for (int t = 0; t < nth; ++t) { base[(size_t) t] = total; total += part[(size_t) t].size(); }
-  out->cigar_bytes = total;
-  out->cigar_blob = (char *) std::malloc(std::max<size_t>(total, 1));
-  if (!out->cigar_blob) { vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: host allocation failed"); }
-  {
-    auto place = [&](int t) {
-      std::memcpy(out->cigar_blob + base[(size_t) t], part[(size_t) t].data(), part[(size_t) t].size());
-      for (uint64_t k = lo[(size_t) t]; k < lo[(size_t) t + 1]; ++k) out->cigar_off[k] += base[(size_t) t];
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nth; ++t) pool.emplace_back(place, t);
-    place(0);
-    for (auto & th : pool) th.join();
-  }
+  uint64_t at = text_used;
+  for (size_t h = 0, hc = 0; h < pl->host_pairs.size(); ++h)
+    {
+      const uint32_t k = pl->host_pairs[h];
+      const VsxPairOut & o = pl->host_out[k];
+      out->score[k] = o.score; out->aligned[k] = o.aligned; out->matches[k] = o.matches;
+      out->mismatches[k] = o.mismatches; out->gaps[k] = o.gaps;
+      if (out->verdict) out->verdict[k] = (uint8_t) VSX_VERDICT_UNDECIDED;
+      out->cigar_off[k] = at;
+      if (hc < pl->host_cigar_pair.size() && pl->host_cigar_pair[hc] == k)
+        {
+          std::memcpy(out->cigar_blob + at, pl->host_cigar[hc].data(), pl->host_cigar[hc].size());
+          at += pl->host_cigar[hc++].size();
+        }
+      out->cigar_blob[at++] = '\0';
+    }
   return VSX_OK;
 }
 
@@ -1146,12 +1242,41 @@ int vsx_plan_export_hits(vsx_plan * pl, void * d_dst, uint64_t dst_bytes)
   return VSX_OK;
 }
 
+int vsx_plan_export_runs(vsx_plan * pl, void * d_dst, uint64_t dst_bytes, uint64_t * n_runs)
+{
+  if (!pl || !n_runs) return fail(VSX_EINVAL, "vsx_plan_export_runs: null argument");
+  if (!pl->ran) return fail(VSX_EINVAL, "vsx_plan_export_runs: plan has not been run");
+  HIPCHK(hipSetDevice(pl->ctx->device));
+  HIPCHK(hipEventSynchronize(pl->ev_end));
+  const uint64_t used = pl->h_cursor[0];
+  if (used > pl->runs_capacity) return fail(VSX_EINVAL, "vsx_plan_export_runs: the run buffer overflowed; call vsx_plan_fetch first (it resizes and re-runs)");
+  *n_runs = used;
+  if (!d_dst) return VSX_OK;                     // size query
+  if (dst_bytes < used * 4) return fail(VSX_EINVAL, "vsx_plan_export_runs: destination too small");
+  if (used)
+    {
+      HIPCHK(hipMemcpyAsync(d_dst, pl->d_runs.p, used * 4, hipMemcpyDeviceToDevice, pl->ctx->stream));
+      HIPCHK(hipStreamSynchronize(pl->ctx->stream));
+    }
+  return VSX_OK;
+}
+
+int64_t vsx_cigar_from_runs(const uint32_t * runs, uint32_t n, char * dst, uint64_t cap)
+{
+  if (n && !runs) { (void) fail(VSX_EINVAL, "vsx_cigar_from_runs: null argument"); return VSX_EINVAL; }
+  std::string s;
+  append_cigar(s, runs, n);
+  if (dst && cap > s.size()) std::memcpy(dst, s.c_str(), s.size() + 1);
+  return (int64_t) s.size() + 1;
+}
+
 void vsx_plan_destroy(vsx_plan * pl)
 {
   if (!pl) return;
   (void) hipSetDevice(pl->ctx->device);
-  (void) hipStreamSynchronize(pl->ctx->stream);
-  (void) hipStreamSynchronize(pl->ctx->stream2);
+  // all of a plan's device work precedes its ev_end (uploads were synchronised at creation): waiting for the context's
+  // streams instead would also wait for the NEXT plan of a pipeline and leave the GPU idle between slices
+  if (pl->ran) (void) hipEventSynchronize(pl->ev_end);
   delete pl;
 }
 
@@ -1192,19 +1317,17 @@ int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vs
                              const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, vsx_results * out)
 {
   static const bool pipeline_off = std::getenv("VSX_PIPELINE") && std::strcmp(std::getenv("VSX_PIPELINE"), "0") == 0;
-  static const uint64_t slice_pairs = std::max<uint64_t>(64, std::getenv("VSX_PIPELINE_SLICE") ? std::strtoull(std::getenv("VSX_PIPELINE_SLICE"), nullptr, 10)
-                                                                                              : (2ull << 20));
+  // slice size: VSX_PIPELINE_SLICE, else a quarter of the list within [128 k, 2 M] pairs -- mid-sized lists (one search
+  // stage of 100 k queries = 800 k pairs) overlap planning, kernels and the fetch as well; below 256 k pairs one plan
+  static const uint64_t forced_slice = std::getenv("VSX_PIPELINE_SLICE") ? std::max<uint64_t>(64, std::strtoull(std::getenv("VSX_PIPELINE_SLICE"), nullptr, 10)) : 0;
+  const uint64_t slice_pairs = forced_slice ? forced_slice : std::min<uint64_t>(2ull << 20, std::max<uint64_t>(128ull << 10, n_pairs / 4));
   if (pipeline_off || !ctx || !out || !queries || !targets || !qidx || !tidx || n_pairs < 2 * slice_pairs)
     return align_pairs_single(ctx, queries, targets, n_pairs, qidx, tidx, filter, out);
   static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = now();
   std::memset(out, 0, sizeof *out);
-  {
-    if (hipSetDevice(ctx->device) != hipSuccess) return fail(VSX_EHIP, "vsx_align_pairs: hipSetDevice failed");
-    const int irc = ensure_impure(const_cast<vsx_seqset *>(queries));      // lazily computed per seqset: not from the planner thread
-    if (irc != VSX_OK) return irc;
-  }
+  if (hipSetDevice(ctx->device) != hipSuccess) return fail(VSX_EHIP, "vsx_align_pairs: hipSetDevice failed");
 
   // slices of about slice_pairs pairs, cut where the query changes (a query's pairs then share tasks as in one plan)
   std::vector<uint64_t> cut {0};

@@ -74,9 +74,24 @@ struct VsxPairOut {
   uint64_t run_off;       // offset into the dense run buffer (unordered allocation)
 };
 
+// The reference's five output arrays (align_simd.hpp:99-108) + verdict + text offset, indexed by pair id, in HBM:
+// written by vsx_cigar_text_kernel, copied to the host as they are.
+struct VsxSoaOut {
+  int16_t  * score;
+  uint16_t * aligned, * matches, * mismatches, * gaps;
+  uint8_t  * verdict;
+  uint64_t * text_off;
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+// vsx_tbtext.hip: run lists -> CIGAR text (pushop / finishop, align_simd.cpp:1013-1049) + records -> output arrays
+hipError_t vsx_launch_cigar_text(const VsxPairOut * d_out, const uint32_t * d_pair_ids, uint32_t npairs,
+                                 const uint32_t * d_runs, uint64_t runs_capacity,
+                                 uint8_t * d_text, uint64_t text_capacity, unsigned long long * d_text_cursor,
+                                 VsxSoaOut soa, hipStream_t st);
 
 // launchers implemented in vsx_device.hip (host code compiled by hipcc)
 hipError_t vsx_launch_encode(const uint8_t * d_ascii, uint8_t * d_codes, uint64_t nbytes, hipStream_t st);

@@ -1,8 +1,13 @@
-"""Multi-GPU layout of the path: every (query, target) pair is independent, so ranks
-take contiguous blocks of QUERIES (the DB is replicated in each GPU's HBM), align their own pairs with
-no data-path collective, and gather the fixed-size hit records once at the end (RCCL on GPUs; the same
-code runs over gloo on CPU tensors in the tests)."""
+"""Multi-GPU layout of the path: every (query, target) pair is independent, so ranks take
+contiguous blocks of QUERIES (usearch_global; the DB is replicated in each GPU's HBM) or interleaved ROWS of
+the triangular pair space (allpairs_global), align their own pairs with no data-path collective, and gather
+the results once at the end: the fixed-size hit records AND the CIGAR run words they point into (RCCL over
+xGMI on GPUs; the same code runs over gloo on CPU tensors in the tests).  bench.py --gpus N, the world-2
+tests and SearchSession.search_batch_sharded all go through the functions below."""
 import numpy as np
+
+HIT_RECORD_BYTES = 24      # include/vsx.h VSX_HIT_RECORD_BYTES: {i16 score; u16 aligned, matches, mismatches, gaps, pad;
+                           #                                    u32 n_cigar_runs; u64 cigar_run_offset}
 
 
 def shard_queries(n_queries, world, rank):
@@ -14,7 +19,7 @@ def shard_queries(n_queries, world, rank):
 
 
 def shard_pairs(qidx, tidx, n_queries, world, rank):
-    """pairs whose query falls into this rank's block; returns (local_qidx, tidx, global_pair_index)"""
+    """pairs whose query falls into this rank's block; returns (local_qidx, tidx, global_pair_index, (lo, hi))"""
     qidx = np.asarray(qidx)
     tidx = np.asarray(tidx)
     lo, hi = shard_queries(n_queries, world, rank)
@@ -22,33 +27,103 @@ def shard_pairs(qidx, tidx, n_queries, world, rank):
     return (qidx[sel] - lo).astype(np.uint32), tidx[sel].astype(np.uint32), sel.astype(np.int64), (lo, hi)
 
 
-def gather_hits(local_records, global_index, n_total, dist=None, device=None):
-    """All-gather variable-length blocks of 24-byte hit records and scatter them into global pair order.
+def shard_allpairs_rows(n, world, rank):
+    """allpairs_global (commands/allpairs_global.cpp:407-422: query i is aligned with every LATER sequence, N-1-i pairs):
+    rows are dealt out in a boustrophedon over the ranks (0,1,..,w-1,w-1,..,1,0,0,1,..), so every rank gets rows from the
+    whole range and the cell counts balance to within one row pair.  Returns the ascending row indices of `rank`;
+    every pair (i, j > i) belongs to exactly one rank -- the owner of row i."""
+    i = np.arange(int(n), dtype=np.int64)
+    period = 2 * int(world)
+    pos = i % period
+    owner = np.where(pos < world, pos, period - 1 - pos)
+    return i[owner == rank]
 
-    local_records: uint8 tensor (n_local, 24); global_index: int64 tensor (n_local,).  With dist=None the
-    call is the single-rank identity.  Returns a (n_total, 24) uint8 tensor on every rank."""
+
+def allpairs_row_cost(n, rows, length=None):
+    """pairs (and, with per-sequence lengths, DP cells) a set of rows stands for"""
+    rows = np.asarray(rows, dtype=np.int64)
+    if length is None:
+        return int((int(n) - 1 - rows).sum())
+    length = np.asarray(length, dtype=np.int64)
+    suffix = np.concatenate([np.cumsum(length[::-1])[::-1][1:], [0]])      # sum of the lengths behind row i
+    return int((length[rows] * suffix[rows]).sum())
+
+
+def _all_gather_var(t, dist):
+    """all-gather of 1-D/2-D tensors whose first dimension differs per rank -> (list of per-rank tensors, counts)"""
     import torch
-    if dist is None or dist.get_world_size() == 1:
-        out = torch.zeros((n_total, 24), dtype=torch.uint8, device=local_records.device)
-        out[global_index] = local_records
-        return out
     world = dist.get_world_size()
-    dev = local_records.device
-    n_local = torch.tensor([local_records.shape[0]], dtype=torch.int64, device=dev)
+    dev = t.device
+    n_local = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, n_local)
     counts = [int(c.item()) for c in counts]
     cap = max(counts + [1])
-    pad_r = torch.zeros((cap, 24), dtype=torch.uint8, device=dev)
-    pad_i = torch.full((cap,), -1, dtype=torch.int64, device=dev)
-    pad_r[:local_records.shape[0]] = local_records
-    pad_i[:local_records.shape[0]] = global_index
-    all_r = [torch.zeros_like(pad_r) for _ in range(world)]
-    all_i = [torch.zeros_like(pad_i) for _ in range(world)]
-    dist.all_gather(all_r, pad_r)
-    dist.all_gather(all_i, pad_i)
-    out = torch.zeros((n_total, 24), dtype=torch.uint8, device=dev)
-    for r in range(world):
-        n = counts[r]
-        out[all_i[r][:n]] = all_r[r][:n]
+    pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+    pad[:t.shape[0]] = t
+    parts = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return [parts[r][:counts[r]] for r in range(world)], counts
+
+
+def gather_results(records, runs, dist=None):
+    """The final gather of SURVEY 8e: every rank contributes its hit records (n_local, 24) uint8 -- in its local pair
+    order -- and its dense run buffer (r_local,) int32 (vsx_plan_export_hits / vsx_plan_export_runs); every rank receives
+    (records_all, runs_all, record_counts): the records of rank 0, 1, ... back to back with cigar_run_offset REBASED into
+    runs_all (= the ranks' run buffers back to back).  With contiguous query blocks that is the global pair order.
+    Two collectives of counts, two of payload; no data-path collective before this point."""
+    import torch
+    if records.dtype != torch.uint8 or records.dim() != 2 or records.shape[1] != HIT_RECORD_BYTES:
+        raise ValueError("records must be a (n, 24) uint8 tensor")
+    runs = runs.view(torch.int32) if runs.dtype != torch.int32 else runs
+    if dist is None or dist.get_world_size() == 1:
+        return records.clone(), runs.clone(), [int(records.shape[0])]
+    rec_parts, rec_counts = _all_gather_var(records.contiguous(), dist)
+    run_parts, run_counts = _all_gather_var(runs.contiguous(), dist)
+    base = 0
+    out = []
+    for r, part in enumerate(rec_parts):
+        part = part.clone()
+        if part.shape[0]:
+            w = part.view(torch.int64).view(-1, 3)          # 24 bytes = 3 little-endian qwords; [2] = cigar_run_offset
+            w[:, 2] += base
+        out.append(part)
+        base += run_counts[r]
+    return torch.cat(out), torch.cat(run_parts), rec_counts
+
+
+def gather_hits(local_records, global_index, n_total, dist=None, device=None):
+    """Scatter form of the record gather (arbitrary pair subsets per rank): all-gathers the 24-byte records with their
+    global pair indices and returns a (n_total, 24) uint8 tensor in global pair order on every rank.  The run offsets stay
+    rank-local here -- use gather_results when the CIGARs are needed."""
+    import torch
+    if dist is None or dist.get_world_size() == 1:
+        out = torch.zeros((n_total, HIT_RECORD_BYTES), dtype=torch.uint8, device=local_records.device)
+        out[global_index] = local_records
+        return out
+    rec_parts, counts = _all_gather_var(local_records.contiguous(), dist)
+    idx_parts, _ = _all_gather_var(global_index.contiguous(), dist)
+    out = torch.zeros((n_total, HIT_RECORD_BYTES), dtype=torch.uint8, device=local_records.device)
+    for r in range(len(counts)):
+        out[idx_parts[r]] = rec_parts[r]
     return out
+
+
+def decode_records(records):
+    """(n, 24) uint8 tensor / array -> dict of numpy arrays (score, aligned, matches, mismatches, gaps, verdict, nruns, run_off)"""
+    a = records.cpu().numpy() if hasattr(records, "cpu") else np.asarray(records)
+    a = np.ascontiguousarray(a).reshape(-1, HIT_RECORD_BYTES)
+    h = a[:, :12].copy().view(np.uint16).reshape(-1, 6)
+    return {"score": h[:, 0].view(np.int16).copy(), "aligned": h[:, 1].copy(), "matches": h[:, 2].copy(),
+            "mismatches": h[:, 3].copy(), "gaps": h[:, 4].copy(), "verdict": h[:, 5].copy(),
+            "nruns": a[:, 12:16].copy().view(np.uint32).reshape(-1), "run_off": a[:, 16:24].copy().view(np.uint64).reshape(-1)}
+
+
+def cigars_from_gather(records, runs, which=None):
+    """CIGAR strings of gathered pairs (all, or the indices in `which`) from rebased records + runs_all: pushop/finishop on
+    the host (vsx_cigar_from_runs)."""
+    from .aligner import cigar_from_runs
+    d = decode_records(records)
+    r = runs.cpu().numpy().view(np.uint32) if hasattr(runs, "cpu") else np.asarray(runs).view(np.uint32)
+    ks = range(len(d["nruns"])) if which is None else which
+    return [cigar_from_runs(r[int(d["run_off"][k]):int(d["run_off"][k]) + int(d["nruns"][k])]) for k in ks]
