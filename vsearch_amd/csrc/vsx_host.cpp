@@ -281,8 +281,7 @@ struct vsx_plan {
   const vsx_seqset * T = nullptr;
   uint64_t n_pairs = 0;
   VsxFilterDev filter {};                // accept filter evaluated by the traceback kernel (enabled == 0: none)
-  std::vector<VsxPairOut> host_out;      // closed-form / sentinel pairs pre-filled; GPU pairs overwritten on fetch
-  std::vector<uint8_t> is_gpu;
+  std::vector<VsxPairOut> host_out;      // answers of the closed-form / sentinel pairs, parallel to host_pairs
   std::vector<std::string> host_cigar;   // only for the Q == 0 closed form
   std::vector<uint32_t> host_cigar_pair;
 
@@ -671,7 +670,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tc0 = now();
-  const int nthc = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) vsx_internal_usable_cpus(), n_pairs / 262144));
+  const int nthc = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) vsx_internal_usable_cpus(), n_pairs / 32768));
   {
     std::vector<uint64_t> bad((size_t) nthc, UINT64_MAX);
     auto check = [&](int t) {
@@ -693,8 +692,6 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
 
   std::unique_ptr<vsx_plan> pl(new vsx_plan);
   pl->ctx = ctx; pl->Q = queries; pl->T = targets; pl->n_pairs = n_pairs;
-  pl->host_out.assign(n_pairs, VsxPairOut {});
-  pl->is_gpu.assign(n_pairs, 0);
 
   // ---- the reference's closed-form / sentinel cases (no DP) ----
   // host threads classify contiguous slices: the common case (a pair for the GPU) is handled in place, the rare closed-form
@@ -711,7 +708,6 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
         {
           const int64_t Q = queries->len[qidx[k]], D = targets->len[tidx[k]];
           if (ctx->force_fallback || Q == 0 || D == 0 || !fits(Q, D)) { special[(size_t) t].push_back((uint32_t) k); continue; }
-          pl->is_gpu[k] = 1;
           gp[(size_t) t].push_back((uint32_t) k);
           cells += (uint64_t) Q * (uint64_t) D;
         }
@@ -741,7 +737,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
         {
           const int64_t Q = queries->len[qidx[k]], D = targets->len[tidx[k]];
           pl->host_pairs.push_back(k);
-          VsxPairOut & o = pl->host_out[k];
+          pl->host_out.emplace_back();
+          VsxPairOut & o = pl->host_out.back();
           auto sentinel = [&]() { o = VsxPairOut {}; o.score = 32767; };
           if (ctx->force_fallback) { sentinel(); continue; }              // align_simd.cpp:1463-1479
           if (Q == 0)                                                      // :1481-1539
@@ -781,7 +778,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   // substitution scores: LDS query profile by default (handles every symbol); VSX_SCORE=arith selects the XOR/min/mad
   // variant for queries made of A/C/G/T(U) only (kept for A/B measurements)
   const size_t ngroups = group_begin.size() - 1;
-  const int nth = (int) std::max<size_t>(1, std::min<size_t>((size_t) vsx_internal_usable_cpus(), gpu_pairs.size() / 65536));
+  const int nth = (int) std::max<size_t>(1, std::min<size_t>((size_t) vsx_internal_usable_cpus(), gpu_pairs.size() / 16384));
   std::vector<std::vector<ProtoTask>> part((size_t) nth);
   auto work = [&](int t) {
     // contiguous ranges of groups with about the same number of pairs
@@ -851,10 +848,47 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   const uint64_t budget_dwords = std::max<uint64_t>(dir_budget_bytes / 4, 1);
 
   const double tc2 = now();
-  pl->tasks.reserve(protos.size());
+  // tasks: (1) host threads fill the descriptors and sizes, (2) a serial scan assigns checkpoint / strip / slab offsets and cuts
+  // chunks and launches, (3) host threads write the per-pair tables.  (1) and (3) are bound by random reads of the sequence
+  // tables; the scan touches 3 numbers per task.
+  const size_t NT = protos.size();
+  pl->tasks.resize(NT);
   pl->pair_slot.resize(gpu_pairs.size());
   pl->pair_ids.resize(gpu_pairs.size());
   pl->slab_off.resize(gpu_pairs.size());
+  std::vector<uint64_t> t_dwords(NT), t_slab(NT), t_pair0(NT);
+  const int ntt = (int) std::max<size_t>(1, std::min<size_t>((size_t) vsx_internal_usable_cpus(), NT / 4096));
+  run_threads(ntt, [&](int th) {
+    const size_t lo = NT * (size_t) th / (size_t) ntt, hi = NT * (size_t) (th + 1) / (size_t) ntt;
+    for (size_t x = lo; x < hi; ++x)
+      {
+        const ProtoTask & pt = protos[x];
+        VsxTask t {};
+        t.qoff = queries->off[pt.q];
+        t.qlen = queries->len[pt.q];
+        t.rows = (uint32_t) pt.rows;
+        uint32_t dmax = 0;
+        uint64_t slab = 0;
+        for (uint32_t sl = 0; sl < pt.n; ++sl)
+          {
+            const uint32_t ti = tidx[pt.pair[sl]];
+            t.toff[sl] = targets->off[ti];
+            t.tlen[sl] = targets->len[ti];
+            dmax = std::max(dmax, (targets->len[ti] + 3u) & ~3u);
+            slab += (uint64_t) t.qlen + t.tlen[sl] + 1;
+          }
+        t.steps = dmax + 16;                                // pipeline drain (15) rounded to an even step count: the DP
+                                                            // kernel stores row checkpoints two steps at a time
+        const uint64_t total_lanes = (t.qlen + pt.rows - 1) / pt.rows;
+        const uint64_t nstrips = (total_lanes + 15) / 16;
+        const uint64_t nd = (uint64_t) (pt.rows + 3) / 4;
+        t_dwords[x] = ctx->ckpt ? vsx_ckpt_dwords(nstrips, t.steps, (uint64_t) pt.rows, pt.tilt)
+                                : ((nstrips * t.steps + 3) & ~3ull) * 64 * nd;     // [4-step block][lane][4][nd]
+        t.strip_off = nstrips > 1 ? 2ull * 4 * t.steps : 0;                          // size for now, offset after the scan
+        t_slab[x] = slab;
+        pl->tasks[x] = t;
+      }
+  });
   size_t np_out = 0;
   Chunk cur;
   auto close_chunk = [&]() {
@@ -864,52 +898,47 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
     nc.pair_first = cur.pair_first + cur.pair_count;
     cur = nc;
   };
-  for (const ProtoTask & pt : protos)
+  for (size_t x = 0; x < NT; ++x)
     {
-      VsxTask t {};
-      t.qoff = queries->off[pt.q];
-      t.qlen = queries->len[pt.q];
-      t.rows = (uint32_t) pt.rows;
-      uint32_t dmax = 0;
-      for (uint32_t s = 0; s < pt.n; ++s)
-        {
-          const uint32_t ti = tidx[pt.pair[s]];
-          t.toff[s] = targets->off[ti];
-          t.tlen[s] = targets->len[ti];
-          dmax = std::max(dmax, (targets->len[ti] + 3u) & ~3u);
-        }
-      t.steps = dmax + 16;                                // pipeline drain (15) rounded to an even step count: the DP
-                                                          // kernel stores row checkpoints two steps at a time
-      const uint64_t total_lanes = (t.qlen + pt.rows - 1) / pt.rows;
-      const uint64_t nstrips = (total_lanes + 15) / 16;
-      const uint64_t nd = (uint64_t) (pt.rows + 3) / 4;
-      const uint64_t dwords = ctx->ckpt ? vsx_ckpt_dwords(nstrips, t.steps, (uint64_t) pt.rows, pt.tilt)
-                                        : ((nstrips * t.steps + 3) & ~3ull) * 64 * nd;     // [4-step block][lane][4][nd]
-      const uint64_t strip = nstrips > 1 ? 2ull * 4 * t.steps : 0;
+      const ProtoTask & pt = protos[x];
+      VsxTask & t = pl->tasks[x];
+      const uint64_t dwords = t_dwords[x], strip = t.strip_off;
       if (cur.task_count && cur.dir_dwords + dwords > budget_dwords) close_chunk();
       t.dir_off = cur.dir_dwords;
       t.strip_off = cur.strip_elems;
       cur.dir_dwords += dwords;
       cur.strip_elems += strip;
       pl->dir_bytes_total += dwords * 4;
-      const uint32_t task_index = (uint32_t) pl->tasks.size();
       if (cur.launches.empty() || cur.launches.back().rows != pt.rows || cur.launches.back().generic != pt.generic ||
           cur.launches.back().track != pt.track || cur.launches.back().tilt != pt.tilt)
-        cur.launches.push_back(Launch {pt.rows, pt.generic, pt.track, pt.tilt, task_index, 0, cur.pair_first + cur.pair_count, 0});
+        cur.launches.push_back(Launch {pt.rows, pt.generic, pt.track, pt.tilt, (uint32_t) x, 0, cur.pair_first + cur.pair_count, 0});
       cur.launches.back().count++;
       cur.launches.back().pair_count += pt.n;
-      for (uint32_t s = 0; s < pt.n; ++s)
-        {
-          pl->pair_slot[np_out] = task_index * VSX_TASK_SLOTS + s;
-          pl->pair_ids[np_out] = pt.pair[s];
-          pl->slab_off[np_out] = cur.slab_words;
-          ++np_out;
-          cur.slab_words += (uint64_t) t.qlen + t.tlen[s] + 1;
-          cur.pair_count++;
-        }
+      t_pair0[x] = np_out;
+      np_out += pt.n;
+      const uint64_t slab = t_slab[x];
+      t_slab[x] = cur.slab_words;                         // from here on: the task's first slab word (chunk-relative)
+      cur.slab_words += slab;
+      cur.pair_count += pt.n;
       cur.task_count++;
-      pl->tasks.push_back(t);
     }
+  run_threads(ntt, [&](int th) {
+    const size_t lo = NT * (size_t) th / (size_t) ntt, hi = NT * (size_t) (th + 1) / (size_t) ntt;
+    for (size_t x = lo; x < hi; ++x)
+      {
+        const ProtoTask & pt = protos[x];
+        const VsxTask & t = pl->tasks[x];
+        uint64_t slab = t_slab[x];
+        for (uint32_t sl = 0; sl < pt.n; ++sl)
+          {
+            const size_t o = (size_t) t_pair0[x] + sl;
+            pl->pair_slot[o] = (uint32_t) x * VSX_TASK_SLOTS + sl;
+            pl->pair_ids[o] = pt.pair[sl];
+            pl->slab_off[o] = slab;
+            slab += (uint64_t) t.qlen + t.tlen[sl] + 1;
+          }
+      }
+  });
   close_chunk();
   const double tc3 = now();
 
@@ -1106,10 +1135,14 @@ static void append_cigar(std::string & s, const uint32_t * runs, uint32_t n)
     }
 }
 
-int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
+// Where a plan's results go: arrays of the caller (already offset to the plan's first pair), a growing text blob.
+struct FetchDest {
+  int16_t * score; uint16_t * aligned, * matches, * mismatches, * gaps; uint64_t * cigar_off; uint8_t * verdict;
+  char ** blob; uint64_t * blob_used;      // text is appended at *blob_used (the blob is realloc'ed); offsets are rebased by it
+};
+
+static int fetch_core(vsx_plan * pl, const FetchDest & D)
 {
-  if (!pl || !out) return fail(VSX_EINVAL, "vsx_plan_fetch: null argument");
-  std::memset(out, 0, sizeof *out);
   vsx_ctx * ctx = pl->ctx;
   if (!pl->ran) { int rc = vsx_plan_run(pl); if (rc != VSX_OK) return rc; }
   int rc = vsx_plan_sync(pl, nullptr);
@@ -1143,7 +1176,6 @@ int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
     }
 
   const uint64_t n = pl->n_pairs;
-  const uint64_t n1 = std::max<uint64_t>(n, 1);
   // the rare pairs answered on the host get their strings behind the device text
   uint64_t tail = 0;
   for (size_t h = 0, hc = 0; h < pl->host_pairs.size(); ++h)
@@ -1151,19 +1183,13 @@ int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
       ++tail;
       if (hc < pl->host_cigar_pair.size() && pl->host_cigar_pair[hc] == pl->host_pairs[h]) tail += pl->host_cigar[hc++].size();
     }
-  out->n_pairs = n;
-  out->score = (int16_t *) std::malloc(n1 * 2);
-  out->aligned = (uint16_t *) std::malloc(n1 * 2);
-  out->matches = (uint16_t *) std::malloc(n1 * 2);
-  out->mismatches = (uint16_t *) std::malloc(n1 * 2);
-  out->gaps = (uint16_t *) std::malloc(n1 * 2);
-  out->cigar_off = (uint64_t *) std::malloc(n1 * 8);
-  out->verdict = pl->filter.enabled ? (uint8_t *) std::malloc(n1) : nullptr;
-  out->cigar_bytes = text_used + tail;
-  out->cigar_blob = (char *) std::malloc(std::max<uint64_t>(out->cigar_bytes, 1));
-  if (!out->score || !out->aligned || !out->matches || !out->mismatches || !out->gaps || !out->cigar_off || !out->cigar_blob ||
-      (pl->filter.enabled && !out->verdict))
-    { vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: host allocation failed"); }
+  const uint64_t base = *D.blob_used;
+  {
+    char * nb = (char *) std::realloc(*D.blob, std::max<uint64_t>(base + text_used + tail, 1));
+    if (!nb) return fail(VSX_ENOMEM, "vsx_plan_fetch: host allocation failed");
+    *D.blob = nb;
+  }
+  char * const blob = *D.blob;
 
   {
     // one PCIe crossing into pinned memory (arrays + text), then host threads spread it over the result arrays
@@ -1174,7 +1200,7 @@ int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
         if (ctx->stage) { (void) hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
         const uint64_t want = need + need / 4 + (1u << 20);
         if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), want, hipHostMallocDefault) != hipSuccess)
-          { (void) hipGetLastError(); vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: pinned staging allocation failed"); }
+          { (void) hipGetLastError(); return fail(VSX_ENOMEM, "vsx_plan_fetch: pinned staging allocation failed"); }
         ctx->stage_bytes = want;
       }
     hipError_t e = hipSuccess;
@@ -1183,42 +1209,80 @@ int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
     if (n) e = hipMemcpyAsync(ctx->stage, pl->d_soa.p, pl->soa_bytes, hipMemcpyDeviceToHost, ctx->stream_dn);
     if (e == hipSuccess && text_used) e = hipMemcpyAsync(ctx->stage + pl->soa_bytes, pl->d_text.p, text_used, hipMemcpyDeviceToHost, ctx->stream_dn);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream_dn);
-    if (e != hipSuccess) { vsx_results_free(out); return fail(VSX_EHIP, "vsx_plan_fetch: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) return fail(VSX_EHIP, "vsx_plan_fetch: %s", hipGetErrorString(e));
     const uint8_t * sg = ctx->stage;
     const int nth = copy_threads(n * 19 + text_used);
     run_threads(nth, [&](int t) {
       const uint64_t lo = n * (uint64_t) t / (uint64_t) nth, hi = n * (uint64_t) (t + 1) / (uint64_t) nth;
       if (hi > lo)
         {
-          std::memcpy(out->score + lo, sg + pl->soa_off[0] + 2 * lo, 2 * (hi - lo));
-          std::memcpy(out->aligned + lo, sg + pl->soa_off[1] + 2 * lo, 2 * (hi - lo));
-          std::memcpy(out->matches + lo, sg + pl->soa_off[2] + 2 * lo, 2 * (hi - lo));
-          std::memcpy(out->mismatches + lo, sg + pl->soa_off[3] + 2 * lo, 2 * (hi - lo));
-          std::memcpy(out->gaps + lo, sg + pl->soa_off[4] + 2 * lo, 2 * (hi - lo));
-          if (out->verdict) std::memcpy(out->verdict + lo, sg + pl->soa_off[5] + lo, hi - lo);
-          std::memcpy(out->cigar_off + lo, sg + pl->soa_off[6] + 8 * lo, 8 * (hi - lo));
+          std::memcpy(D.score + lo, sg + pl->soa_off[0] + 2 * lo, 2 * (hi - lo));
+          std::memcpy(D.aligned + lo, sg + pl->soa_off[1] + 2 * lo, 2 * (hi - lo));
+          std::memcpy(D.matches + lo, sg + pl->soa_off[2] + 2 * lo, 2 * (hi - lo));
+          std::memcpy(D.mismatches + lo, sg + pl->soa_off[3] + 2 * lo, 2 * (hi - lo));
+          std::memcpy(D.gaps + lo, sg + pl->soa_off[4] + 2 * lo, 2 * (hi - lo));
+          if (D.verdict) std::memcpy(D.verdict + lo, sg + pl->soa_off[5] + lo, hi - lo);
+          const uint64_t * so = reinterpret_cast<const uint64_t *>(sg + pl->soa_off[6]);
+          for (uint64_t k = lo; k < hi; ++k) D.cigar_off[k] = so[k] + base;
         }
       const uint64_t blo = text_used * (uint64_t) t / (uint64_t) nth, bhi = text_used * (uint64_t) (t + 1) / (uint64_t) nth;
-      if (bhi > blo) std::memcpy(out->cigar_blob + blo, sg + pl->soa_bytes + blo, bhi - blo);
+      if (bhi > blo) std::memcpy(blob + base + blo, sg + pl->soa_bytes + blo, bhi - blo);
     });
   }
-  uint64_t at = text_used;
+  uint64_t at = base + text_used;
   for (size_t h = 0, hc = 0; h < pl->host_pairs.size(); ++h)
     {
       const uint32_t k = pl->host_pairs[h];
-      const VsxPairOut & o = pl->host_out[k];
-      out->score[k] = o.score; out->aligned[k] = o.aligned; out->matches[k] = o.matches;
-      out->mismatches[k] = o.mismatches; out->gaps[k] = o.gaps;
-      if (out->verdict) out->verdict[k] = (uint8_t) VSX_VERDICT_UNDECIDED;
-      out->cigar_off[k] = at;
+      const VsxPairOut & o = pl->host_out[h];
+      D.score[k] = o.score; D.aligned[k] = o.aligned; D.matches[k] = o.matches;
+      D.mismatches[k] = o.mismatches; D.gaps[k] = o.gaps;
+      if (D.verdict) D.verdict[k] = (uint8_t) VSX_VERDICT_UNDECIDED;
+      D.cigar_off[k] = at;
       if (hc < pl->host_cigar_pair.size() && pl->host_cigar_pair[hc] == k)
         {
-          std::memcpy(out->cigar_blob + at, pl->host_cigar[hc].data(), pl->host_cigar[hc].size());
+          std::memcpy(blob + at, pl->host_cigar[hc].data(), pl->host_cigar[hc].size());
           at += pl->host_cigar[hc++].size();
         }
-      out->cigar_blob[at++] = '\0';
+      blob[at++] = '\0';
     }
+  *D.blob_used = at;
   return VSX_OK;
+}
+
+// result arrays for n pairs (the blob starts empty and grows with every fetched plan)
+static int results_alloc(vsx_results * out, uint64_t n, bool with_verdict)
+{
+  std::memset(out, 0, sizeof *out);
+  const uint64_t n1 = std::max<uint64_t>(n, 1);
+  out->n_pairs = n;
+  out->score = (int16_t *) std::malloc(n1 * 2);
+  out->aligned = (uint16_t *) std::malloc(n1 * 2);
+  out->matches = (uint16_t *) std::malloc(n1 * 2);
+  out->mismatches = (uint16_t *) std::malloc(n1 * 2);
+  out->gaps = (uint16_t *) std::malloc(n1 * 2);
+  out->cigar_off = (uint64_t *) std::malloc(n1 * 8);
+  out->verdict = with_verdict ? (uint8_t *) std::malloc(n1) : nullptr;
+  out->cigar_blob = (char *) std::malloc(1);
+  if (!out->score || !out->aligned || !out->matches || !out->mismatches || !out->gaps || !out->cigar_off || !out->cigar_blob ||
+      (with_verdict && !out->verdict))
+    { vsx_results_free(out); return fail(VSX_ENOMEM, "vsx_plan_fetch: host allocation failed"); }
+  return VSX_OK;
+}
+
+static FetchDest dest_at(vsx_results * out, uint64_t first)
+{
+  return FetchDest {out->score + first, out->aligned + first, out->matches + first, out->mismatches + first, out->gaps + first,
+                    out->cigar_off + first, out->verdict ? out->verdict + first : nullptr, &out->cigar_blob, &out->cigar_bytes};
+}
+
+int vsx_plan_fetch(vsx_plan * pl, vsx_results * out)
+{
+  if (!pl || !out) return fail(VSX_EINVAL, "vsx_plan_fetch: null argument");
+  int rc = results_alloc(out, pl->n_pairs, pl->filter.enabled != 0);
+  if (rc != VSX_OK) return rc;
+  rc = fetch_core(pl, dest_at(out, 0));
+  if (rc != VSX_OK) { const std::string keep = g_err; vsx_results_free(out); g_err = keep; }
+  return rc;
 }
 
 int vsx_plan_export_hits(vsx_plan * pl, void * d_dst, uint64_t dst_bytes)
@@ -1232,9 +1296,8 @@ int vsx_plan_export_hits(vsx_plan * pl, void * d_dst, uint64_t dst_bytes)
   if (!pl->host_patched)
     {
       // pairs answered without DP live on the host: patch them into the device array once
-      for (uint64_t k = 0; k < pl->n_pairs; ++k)
-        if (!pl->is_gpu[k])
-          HIPCHK(hipMemcpyAsync(pl->d_out.p + k, &pl->host_out[k], sizeof(VsxPairOut), hipMemcpyHostToDevice, st));
+      for (size_t h = 0; h < pl->host_pairs.size(); ++h)
+        HIPCHK(hipMemcpyAsync(pl->d_out.p + pl->host_pairs[h], &pl->host_out[h], sizeof(VsxPairOut), hipMemcpyHostToDevice, st));
       pl->host_patched = true;
     }
   HIPCHK(hipMemcpyAsync(d_dst, pl->d_out.p, pl->n_pairs * sizeof(VsxPairOut), hipMemcpyDeviceToDevice, st));
@@ -1330,13 +1393,20 @@ int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vs
   if (hipSetDevice(ctx->device) != hipSuccess) return fail(VSX_EHIP, "vsx_align_pairs: hipSetDevice failed");
 
   // slices of about slice_pairs pairs, cut where the query changes (a query's pairs then share tasks as in one plan)
+  // (the first and the last slice are half-size: the GPU starts after planning the first one, and the last one's fetch is
+  //  the only one nothing overlaps)
   std::vector<uint64_t> cut {0};
   while (cut.back() < n_pairs)
     {
-      uint64_t e = std::min<uint64_t>(n_pairs, cut.back() + slice_pairs);
-      const uint64_t limit = std::min<uint64_t>(n_pairs, e + slice_pairs / 2);
+      const uint64_t left = n_pairs - cut.back();
+      uint64_t want = slice_pairs;
+      if (cut.size() == 1) want = slice_pairs / 2;
+      else if (left <= slice_pairs / 2 + slice_pairs / 8) want = left;
+      else if (left <= slice_pairs + slice_pairs / 2) want = left - slice_pairs / 2;
+      uint64_t e = std::min<uint64_t>(n_pairs, cut.back() + want);
+      const uint64_t limit = std::min<uint64_t>(n_pairs, e + want / 2);
       while (e < limit && qidx[e] == qidx[e - 1]) ++e;
-      if (n_pairs - e < slice_pairs / 4) e = n_pairs;
+      if (n_pairs - e < slice_pairs / 8) e = n_pairs;
       cut.push_back(e);
     }
   const size_t S = cut.size() - 1;
@@ -1344,8 +1414,10 @@ int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vs
   std::vector<vsx_plan *> plans(S, nullptr);
   std::vector<int> plan_rc(S, VSX_OK);
   std::vector<std::string> plan_msg(S);
-  std::vector<vsx_results> res(S);
-  for (auto & r : res) std::memset(&r, 0, sizeof r);
+  {
+    const int arc = results_alloc(out, n_pairs, filter && ctx->ckpt);
+    if (arc != VSX_OK) return arc;
+  }
   std::mutex mu;
   std::condition_variable cv;
   size_t ready = 0, consumed = 0;
@@ -1372,8 +1444,8 @@ int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vs
   int rc = VSX_OK;
   std::string msg;
   size_t launched = 0;
-  auto finish = [&](size_t i) {           // fetch and release slice i
-    int frc = vsx_plan_fetch(plans[i], &res[i]);
+  auto finish = [&](size_t i) {           // fetch slice i straight into its part of the result arrays, release it
+    int frc = fetch_core(plans[i], dest_at(out, cut[i]));
     vsx_plan_destroy(plans[i]);
     plans[i] = nullptr;
     { std::lock_guard<std::mutex> lk(mu); consumed = i + 1; }
@@ -1403,58 +1475,10 @@ int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vs
     if (plans[i]) { vsx_plan_destroy(plans[i]); plans[i] = nullptr; }
   if (rc != VSX_OK)
     {
-      for (auto & r : res) vsx_results_free(&r);
+      vsx_results_free(out);
       vsx_internal_set_error(msg.c_str());
       return rc;
     }
-
-  // concatenate
-  const uint64_t n = n_pairs;
-  uint64_t blob = 0;
-  std::vector<uint64_t> blob_base(S);
-  for (size_t i = 0; i < S; ++i) { blob_base[i] = blob; blob += res[i].cigar_bytes; }
-  out->n_pairs = n;
-  out->score = (int16_t *) std::malloc(n * 2);
-  out->aligned = (uint16_t *) std::malloc(n * 2);
-  out->matches = (uint16_t *) std::malloc(n * 2);
-  out->mismatches = (uint16_t *) std::malloc(n * 2);
-  out->gaps = (uint16_t *) std::malloc(n * 2);
-  out->cigar_off = (uint64_t *) std::malloc(n * 8);
-  out->verdict = res[0].verdict ? (uint8_t *) std::malloc(n) : nullptr;
-  out->cigar_bytes = blob;
-  out->cigar_blob = (char *) std::malloc(std::max<uint64_t>(blob, 1));
-  if (!out->score || !out->aligned || !out->matches || !out->mismatches || !out->gaps || !out->cigar_off || !out->cigar_blob ||
-      (res[0].verdict && !out->verdict))
-    {
-      for (auto & r : res) vsx_results_free(&r);
-      vsx_results_free(out);
-      return fail(VSX_ENOMEM, "vsx_align_pairs: host allocation failed");
-    }
-  {
-    std::atomic<size_t> next {0};
-    auto place = [&]() {
-      for (;;)
-        {
-          const size_t i = next.fetch_add(1);
-          if (i >= S) break;
-          const uint64_t lo = cut[i], m = cut[i + 1] - cut[i];
-          std::memcpy(out->score + lo, res[i].score, m * 2);
-          std::memcpy(out->aligned + lo, res[i].aligned, m * 2);
-          std::memcpy(out->matches + lo, res[i].matches, m * 2);
-          std::memcpy(out->mismatches + lo, res[i].mismatches, m * 2);
-          std::memcpy(out->gaps + lo, res[i].gaps, m * 2);
-          if (out->verdict) std::memcpy(out->verdict + lo, res[i].verdict, m);
-          for (uint64_t k = 0; k < m; ++k) out->cigar_off[lo + k] = res[i].cigar_off[k] + blob_base[i];
-          std::memcpy(out->cigar_blob + blob_base[i], res[i].cigar_blob, res[i].cigar_bytes);
-          vsx_results_free(&res[i]);
-        }
-    };
-    const int nth = (int) std::min<size_t>(S, (size_t) std::max(1, vsx_internal_usable_cpus()));
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nth; ++t) pool.emplace_back(place);
-    place();
-    for (auto & th : pool) th.join();
-  }
   if (timing)
     std::fprintf(stderr, "vsx_align_pairs: %llu pairs in %zu pipelined slices: %.3f s\n", (unsigned long long) n_pairs, S, now() - t_begin);
   return VSX_OK;
