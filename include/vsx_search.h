@@ -8,7 +8,7 @@
     search_acceptable_unaligned / _aligned   :541-609 / :664-737
     align_trim             core/searchcore.cpp:343-464   terminal-gap trimming, id0..id4
     search_joinhits / hit_compare_byid       :1028-1052 / :133-179
-    search_topscores + unique_count + Dbindex + minheap order   (host side in this phase)
+    search_topscores + unique_count + Dbindex + minheap order   (device: vsx_kmer.hip; host restatement kept as checker)
                            core/searchcore.cpp:260-340, core/unique.cpp:155-352, core/dbindex.cpp:163-255,
                            core/minheap.cpp:82-146
   and mirrors the reference's library entry points search_session_* / search_batch
@@ -55,6 +55,19 @@ typedef struct vsx_search_opts {
                                an alignment using a forbidden gap class is rejected (searchcore.cpp:621-660) */
   uint32_t strand_both;     /* 0: --strand plus (default); 1: --strand both -- the reverse complement of every query is
                                searched as well (search.cpp:200-214), hits of both strands are joined (searchcore.cpp:1028-1052) */
+  /* abundance-aware part of search_acceptable_unaligned (searchcore.cpp:541-609); abundances arrive through
+     struct vsx_seq_meta; the caller resolves --sizein (the ';size=' annotation, or 1) */
+  int64_t maxqsize;         /* --maxqsize, default INT64_MAX: query abundance above it -> every target rejected           */
+  int64_t mintsize;         /* --mintsize, default 0                                                                    */
+  double  minsizeratio;     /* --minsizeratio, default 0: query size >= ratio * target size (abundance_ratio_cmp :480)  */
+  double  maxsizeratio;     /* --maxsizeratio, default DBL_MAX                                                          */
+  int32_t self;             /* --self: a target whose label equals the query's label is rejected (needs labels)         */
+  int32_t sizeorder;        /* --sizeorder (cluster_*): the member joins the most ABUNDANT accepted centroid
+                               (hit_compare_bysize / search_findbest2_bysize, searchcore.cpp:182-243, :994-1025)        */
+  int32_t cluster_unoise;   /* --cluster_unoise: UNOISE skew rule instead of the --id threshold in
+                               search_acceptable_aligned (searchcore.cpp:701-718); weak_id is forced to 0.90 (cli.cc:4153) */
+  int32_t pad2;
+  double  unoise_alpha;     /* --unoise_alpha, default 2.0                                                              */
 } vsx_search_opts;
 
 void vsx_search_opts_default(vsx_search_opts * o);
@@ -93,9 +106,21 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
                         const uint64_t * offsets, const uint32_t * lengths);
 void vsx_searcher_destroy(vsx_searcher * s);
 
+/* Per-sequence annotations the filters above read: Database::getabundance / getheader (core/db.hpp).  Either member may
+   be NULL (abundances all 1, no labels).  The arrays are copied. */
+typedef struct vsx_seq_meta {
+  const uint64_t * abundance;       /* n values                                   */
+  const char * const * label;       /* n NUL-terminated headers                   */
+} vsx_seq_meta;
+/* annotations of the searcher's database sequences (targets; in allpairs / clustering also the queries) */
+int vsx_searcher_set_meta(vsx_searcher * s, const vsx_seq_meta * meta);
+
 /* search_batch (core/search.hpp:131-145), plus strand only. */
 int vsx_search_batch(vsx_searcher * s, uint64_t n_queries, const char * qblob, uint64_t qblob_bytes,
                      const uint64_t * qoffsets, const uint32_t * qlengths, vsx_hits * out);
+/* the same with the queries' annotations (si->qsize, si->query_head: core/search.cpp:88-94); qmeta may be NULL */
+int vsx_search_batch_meta(vsx_searcher * s, uint64_t n_queries, const char * qblob, uint64_t qblob_bytes,
+                          const uint64_t * qoffsets, const uint32_t * qlengths, const vsx_seq_meta * qmeta, vsx_hits * out);
 void vsx_hits_free(vsx_hits * h);
 
 /* allpairs_global (commands/allpairs_global.cpp:394-527): database sequences [first, first+count) as

@@ -23,6 +23,7 @@ SYMBOLS = [
 ]
 # include/vsx_search.h
 SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
+                  "vsx_search_batch_meta", "vsx_searcher_set_meta",
                   "vsx_hits_free", "vsx_search_candidates", "vsx_search_candidates_batch", "vsx_candidates_free", "vsx_lma_align", "vsx_allpairs_block", "vsx_cluster_fast", "vsx_cluster_out_free", "vsx_msa", "vsx_msa_out_free",
                   "vsx_msa_device", "vsx_msa_device_batch"]
 
@@ -43,7 +44,15 @@ class SearchOpts(C.Structure):
                 ("leftjust", C.c_int32), ("rightjust", C.c_int32),
                 ("minqt", C.c_double), ("maxqt", C.c_double), ("minsl", C.c_double), ("maxsl", C.c_double),
                 ("idprefix", C.c_int64), ("idsuffix", C.c_int64), ("selfid", C.c_int32), ("threads", C.c_int32),
-                ("window", C.c_int64), ("gap_infinite", C.c_uint32), ("strand_both", C.c_uint32)]
+                ("window", C.c_int64), ("gap_infinite", C.c_uint32), ("strand_both", C.c_uint32),
+                ("maxqsize", C.c_int64), ("mintsize", C.c_int64), ("minsizeratio", C.c_double), ("maxsizeratio", C.c_double),
+                ("self", C.c_int32), ("sizeorder", C.c_int32), ("cluster_unoise", C.c_int32), ("pad2", C.c_int32),
+                ("unoise_alpha", C.c_double)]
+
+
+class SeqMeta(C.Structure):
+    """vsx_seq_meta (include/vsx_search.h): abundances / labels of a set of sequences"""
+    _fields_ = [("abundance", C.POINTER(C.c_uint64)), ("label", C.POINTER(C.c_char_p))]
 
 
 class Hit(C.Structure):
@@ -159,6 +168,8 @@ def load():
     lib.vsx_searcher_destroy.argtypes = [vp]
     lib.vsx_searcher_destroy.restype = None
     lib.vsx_search_batch.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, vp, C.POINTER(Hits)]
+    lib.vsx_search_batch_meta.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, vp, C.POINTER(SeqMeta), C.POINTER(Hits)]
+    lib.vsx_searcher_set_meta.argtypes = [vp, C.POINTER(SeqMeta)]
     lib.vsx_hits_free.argtypes = [C.POINTER(Hits)]
     lib.vsx_hits_free.restype = None
     lib.vsx_search_candidates.argtypes = [vp, C.c_char_p, C.c_uint32, vp, vp, C.c_uint64]

@@ -247,6 +247,9 @@ struct QState {
 
 }  // namespace
 
+// the query side of one searchinfo_s (core/searchcore.hpp:131-176) beyond the sequence: abundance, label
+struct QMeta { int64_t qsize = 1; const char * label = nullptr; };
+
 struct vsx_searcher {
   vsx_ctx * ctx = nullptr;
   vsx_scoring scoring {};           // unclamped values, for the linear-memory fallback
@@ -264,7 +267,13 @@ struct vsx_searcher {
   VsxKmerIndex * kidx = nullptr;     // device index (vsx_kmer.hip), built on first use by the batch search
   std::vector<uint64_t> word_total;  // postings per word (statistics of the device index)
   std::vector<uint8_t> is_centroid;  // clustering: which sequences are in the growing index
+  std::vector<uint64_t> tsize;       // Database::getabundance of the targets (empty: all 1)
+  std::vector<std::string> tlabel;   // Database::getheader (empty: no labels, --self never fires)
+  int64_t abundance(uint64_t seqno) const { return tsize.empty() ? 1 : (int64_t) tsize[seqno]; }
+  // a database sequence in the query role (allpairs, clustering: si->qsize = db.getabundance, allpairs_global.cpp:398, cluster.cpp:176)
+  QMeta meta_of(uint64_t seqno) const { return QMeta {abundance(seqno), tlabel.empty() ? nullptr : tlabel[seqno].c_str()}; }
 };
+
 
 namespace {
 
@@ -309,19 +318,45 @@ void candidates_for(const vsx_searcher & S, const char * q, int64_t qlen, std::v
   out.resize(keep);
 }
 
-// search_acceptable_unaligned, core/searchcore.cpp:541-609 (abundance filters need sizes: all 1 here)
-bool acceptable_unaligned(const vsx_searcher & S, const char * q, int64_t qlen, uint32_t target)
+// abundance_ratio_cmp, core/searchcore.cpp:480-537: sign of value - ratio * reference, exact beyond 2^53
+int abundance_ratio_cmp(int64_t value, double ratio, int64_t reference)
+{
+  if (reference <= 0 || ratio <= 0.0) return value > 0 ? 1 : 0;
+  if (!std::isfinite(ratio)) return -1;
+  constexpr int64_t exact_double_limit = int64_t {1} << 53;
+  if (value < exact_double_limit && reference < exact_double_limit)
+    {
+      const double product = ratio * (double) reference, v = (double) value;
+      return v < product ? -1 : (v > product ? 1 : 0);
+    }
+  typedef unsigned __int128 u128;
+  int exponent = 0;
+  const int64_t mantissa = (int64_t) std::ldexp(std::frexp(ratio, &exponent), 53);
+  exponent -= 53;
+  u128 lhs = (u128) (uint64_t) value, rhs = (u128) (uint64_t) mantissa * (u128) (uint64_t) reference;
+  for (int sh = exponent; sh > 0; --sh) { if ((rhs >> 126) != 0) return -1; rhs <<= 1; }
+  for (int sh = exponent; sh < 0; ++sh) { if ((lhs >> 126) != 0) return 1; lhs <<= 1; }
+  return lhs < rhs ? -1 : (lhs > rhs ? 1 : 0);
+}
+
+// search_acceptable_unaligned, core/searchcore.cpp:541-609
+bool acceptable_unaligned(const vsx_searcher & S, const char * q, int64_t qlen, uint32_t target, const QMeta & qm = QMeta {})
 {
   const vsx_search_opts & o = S.o;
   const char * d = S.blob.data() + S.off[target];
   const int64_t dlen = S.len[target];
   const double dl = (double) dlen;
-  return (qlen >= o.minqt * dl) && (qlen <= o.maxqt * dl) &&
+  const int64_t tsize = S.abundance(target);
+  return (qm.qsize <= o.maxqsize) && (tsize >= o.mintsize) &&
+         (abundance_ratio_cmp(qm.qsize, o.minsizeratio, tsize) >= 0) &&
+         (abundance_ratio_cmp(qm.qsize, o.maxsizeratio, tsize) <= 0) &&
+         (qlen >= o.minqt * dl) && (qlen <= o.maxqt * dl) &&
          (qlen < dlen ? qlen >= o.minsl * dl : dl >= o.minsl * qlen) &&
          (qlen < dlen ? qlen <= o.maxsl * dl : dl <= o.maxsl * qlen) &&
          ((qlen >= o.idprefix) && (dlen >= o.idprefix) && (seqcmp(q, d, o.idprefix) == 0)) &&
          ((qlen >= o.idsuffix) && (dlen >= o.idsuffix) &&
           (seqcmp(q + qlen - o.idsuffix, d + dlen - o.idsuffix, o.idsuffix) == 0)) &&
+         ((o.self == 0) || !qm.label || S.tlabel.empty() || (std::strcmp(qm.label, S.tlabel[target].c_str()) != 0)) &&
          ((o.selfid == 0) || (qlen != dlen) || (seqcmp(q, d, qlen) != 0));
 }
 
@@ -351,8 +386,8 @@ bool uses_forbidden_gap(const std::string & cigar, uint32_t mask)
   return false;
 }
 
-// search_acceptable_aligned, core/searchcore.cpp:664-737 (no unoise)
-bool acceptable_aligned(const vsx_searcher & S, int64_t qlen, Hit & h)
+// search_acceptable_aligned, core/searchcore.cpp:664-737
+bool acceptable_aligned(const vsx_searcher & S, int64_t qlen, Hit & h, int64_t qsize = 1)
 {
   const vsx_search_opts & o = S.o;
   if ((h.id >= 100.0 * o.weak_id) && (h.mismatches <= o.maxsubs) && (h.internal_gaps <= o.maxgaps) &&
@@ -366,6 +401,13 @@ bool acceptable_aligned(const vsx_searcher & S, int64_t qlen, Hit & h)
       (100.0 * h.matches / (h.matches + h.mismatches) >= o.mid) &&
       (h.mismatches + h.internal_indels <= o.maxdiffs))
     {
+      if (o.cluster_unoise)                                             // UNOISE skew rule (:701-718)
+        {
+          const double skew = 1.0 * (double) qsize / (double) S.abundance(h.target);
+          const double beta = 1.0 / std::pow(2, (1.0 * o.unoise_alpha * h.mismatches) + 1);
+          if (skew <= beta || h.mismatches == 0) { h.accepted = true; h.weak = false; return true; }
+          h.rejected = true; h.weak = true; return false;
+        }
       if (h.id >= 100.0 * o.id) { h.accepted = true; h.weak = false; return true; }
       h.rejected = true; h.weak = true; return false;
     }
@@ -373,9 +415,28 @@ bool acceptable_aligned(const vsx_searcher & S, int64_t qlen, Hit & h)
   return false;
 }
 
+// hit_compare_bysize_typed, core/searchcore.cpp:182-243 (negative = lhs first)
+int hit_compare_bysize(const vsx_searcher & S, const Hit & l, const Hit & r)
+{
+  if (l.rejected < r.rejected) return -1;
+  if (l.rejected > r.rejected) return +1;
+  if (l.rejected) return 0;
+  if (l.aligned > r.aligned) return -1;
+  if (l.aligned < r.aligned) return +1;
+  if (!l.aligned) return 0;
+  const int64_t la = S.abundance(l.target), ra = S.abundance(r.target);
+  if (la > ra) return -1;
+  if (la < ra) return +1;
+  if (l.id > r.id) return -1;
+  if (l.id < r.id) return +1;
+  if (l.target < r.target) return -1;
+  if (l.target > r.target) return +1;
+  return 0;
+}
+
 // The while loop of search_onequery (:915-950) up to the point where align_delayed would be called.
 // Returns true if a batch of targets must be aligned now (appended to tq/tt), false if the query is finished.
-bool advance(const vsx_searcher & S, QState & st, const char * q, int64_t qlen, uint32_t qlocal,
+bool advance(const vsx_searcher & S, QState & st, const char * q, int64_t qlen, uint32_t qlocal, const QMeta & qm,
              std::vector<uint32_t> & pq, std::vector<uint32_t> & pt)
 {
   while ((st.finalized + st.delayed < S.ma + S.mr - 1) && (st.rejects < S.mr) && (st.accepts < S.ma) &&
@@ -384,7 +445,7 @@ bool advance(const vsx_searcher & S, QState & st, const char * q, int64_t qlen, 
       const Cand & c = st.cands[st.next++];            // minheap_poplast: best remaining
       Hit h;
       h.target = c.target; h.count = c.count;
-      if (acceptable_unaligned(S, q, qlen, c.target)) ++st.delayed; else h.rejected = true;
+      if (acceptable_unaligned(S, q, qlen, c.target, qm)) ++st.delayed; else h.rejected = true;
       st.hits.push_back(std::move(h));
       if (st.delayed == 8) break;                      // MAXDELAYED
     }
@@ -492,8 +553,8 @@ struct Acct { double t_align = 0, t_advance = 0, t_replay = 0; uint64_t pairs = 
 // The staged search of a window: every open query contributes its next align_delayed batch, all batches go to the
 // GPU as one plan, then the reference's bookkeeping (:782-878) is replayed per query.  qseq/qlen/qidx map a window
 // slot to its sequence, length and index inside `qset`.
-template <typename FSeq, typename FLen, typename FIdx>
-static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qseq, FLen qlen, FIdx qidx,
+template <typename FSeq, typename FLen, typename FIdx, typename FMeta>
+static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qseq, FLen qlen, FIdx qidx, FMeta qmeta,
                       const vsx_seqset * qset, Acct & acct)
 {
   const uint64_t wn = st.size();
@@ -517,7 +578,7 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
           for (size_t w = b; w < e; ++w)
             {
               const uint32_t k = open[w];
-              if (advance(S, st[k], qseq(k), qlen(k), qidx(k), p.pq, p.pt)) p.waiting.push_back(k);     // req_first: slice-relative
+              if (advance(S, st[k], qseq(k), qlen(k), qidx(k), qmeta(k), p.pq, p.pt)) p.waiting.push_back(k);     // req_first: slice-relative
             }
         };
         std::vector<std::thread> pool;
@@ -540,8 +601,10 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
       const double t0 = now_s();
       vsx_results res;
       const vsx_filter flt = make_filter(S);
-      // with '*' penalties every pair takes the linear-memory fallback and the forbidden-gap test: nothing for the device to decide
-      int rc = vsx_align_pairs_filtered(S.ctx, qset, S.dbset, pq.size(), pq.data(), pt.data(), S.o.gap_infinite ? nullptr : &flt, &res);
+      // with '*' penalties every pair takes the linear-memory fallback and the forbidden-gap test, and the UNOISE rule needs the
+      // abundances: nothing for the device to decide
+      int rc = vsx_align_pairs_filtered(S.ctx, qset, S.dbset, pq.size(), pq.data(), pt.data(),
+                                        (S.o.gap_infinite || S.o.cluster_unoise) ? nullptr : &flt, &res);
       acct.t_align += now_s() - t0;
       if (rc != VSX_OK) return rc;
       acct.pairs += pq.size();
@@ -583,7 +646,7 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
                         }
                       const int frc = fill_hit(S, qseq(k), ql, h, res, r, a.sentinels);
                       if (frc != VSX_OK) { err[(size_t) tid] = frc; return; }
-                      const bool acc = acceptable_aligned(S, ql, h);
+                      const bool acc = acceptable_aligned(S, ql, h, qmeta(k).qsize);
                       if (verdict != VSX_VERDICT_UNDECIDED && (acc != (verdict == VSX_VERDICT_ACCEPTED) || (!acc && !h.weak)))
                         { err[(size_t) tid] = VSX_EHIP; return; }
                       if (acc) ++q.accepts; else ++q.rejects;
@@ -818,6 +881,8 @@ void vsx_search_opts_default(vsx_search_opts * o)
   o->query_cov = 0; o->target_cov = 0; o->maxid = 1.0; o->mid = 0;
   o->minqt = 0; o->maxqt = DBL_MAX; o->minsl = 0; o->maxsl = DBL_MAX;
   o->threads = 0; o->window = 0;
+  o->maxqsize = INT64_MAX; o->mintsize = 0; o->minsizeratio = 0.0; o->maxsizeratio = DBL_MAX;
+  o->self = 0; o->sizeorder = 0; o->cluster_unoise = 0; o->unoise_alpha = 2.0;
 }
 
 int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opts * opts, uint64_t n,
@@ -832,7 +897,8 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
   S->ctx = ctx;
   S->scoring = *vsx_internal_scoring(ctx);
   S->o = *opts;
-  if (S->o.weak_id > S->o.id) S->o.weak_id = S->o.id;                       // vsearch.cc:206-209
+  if (S->o.cluster_unoise) S->o.weak_id = 0.90;                             // cli.cc:4153-4160
+  else if (S->o.weak_id > S->o.id) S->o.weak_id = S->o.id;
   S->w = (int) opts->wordlength;
   static const int defaults[16] = {-1, -1, -1, 18, 17, 16, 15, 14, 12, 11, 10, 9, 8, 7, 5, 3};   // searchcore.hpp:75-76
   S->minwordmatches = opts->minwordmatches < 0 ? defaults[S->w] : opts->minwordmatches;
@@ -852,6 +918,22 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
   int rc = vsx_seqset_create(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths);
   if (rc != VSX_OK) return rc;
   *out = S.release();
+  return VSX_OK;
+}
+
+int vsx_searcher_set_meta(vsx_searcher * S, const vsx_seq_meta * meta)
+{
+  if (!S) return sfail(VSX_EINVAL, "vsx_searcher_set_meta: null searcher");
+  S->tsize.clear();
+  S->tlabel.clear();
+  if (!meta) return VSX_OK;
+  const uint64_t n = S->len.size();
+  if (meta->abundance) S->tsize.assign(meta->abundance, meta->abundance + n);
+  if (meta->label)
+    {
+      S->tlabel.resize(n);
+      for (uint64_t i = 0; i < n; ++i) S->tlabel[i] = meta->label[i] ? meta->label[i] : "";
+    }
   return VSX_OK;
 }
 
@@ -922,6 +1004,12 @@ void vsx_candidates_free(vsx_candidates * c)
 
 int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t qbytes, const uint64_t * qoff,
                      const uint32_t * qlen, vsx_hits * out)
+{
+  return vsx_search_batch_meta(S, nq, qblob, qbytes, qoff, qlen, nullptr, out);
+}
+
+int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t qbytes, const uint64_t * qoff,
+                          const uint32_t * qlen, const vsx_seq_meta * qmeta, vsx_hits * out)
 {
   if (!S || !out || (nq && (!qblob || !qoff || !qlen))) return sfail(VSX_EINVAL, "vsx_search_batch: null argument");
   std::memset(out, 0, sizeof *out);
@@ -1027,8 +1115,12 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
       t_qset += now_s() - tq;
       {
         Acct acct;
+        auto meta_of = [&](uint64_t k) {                       // both strands of a query share its abundance and label
+          const uint64_t qi = w0 + (k < wn ? k : k - wn);
+          return QMeta {(qmeta && qmeta->abundance) ? (int64_t) qmeta->abundance[qi] : 1, (qmeta && qmeta->label) ? qmeta->label[qi] : nullptr};
+        };
         const int src = run_stages(*S, st, seq_of, [&](uint64_t k) { return (int64_t) W.ln[k]; },
-                                   [&](uint64_t k) { return (uint32_t) k; }, qset, acct);
+                                   [&](uint64_t k) { return (uint32_t) k; }, meta_of, qset, acct);
         t_adv += acct.t_advance; t_rep += acct.t_replay;
         t_align += acct.t_align; pairs += acct.pairs; cells += acct.cells; stages += acct.stages; sentinels += acct.sentinels;
         if (src != VSX_OK) { vsx_seqset_destroy(qset); return src; }
@@ -1165,7 +1257,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
           std::vector<uint32_t> & v = tl[k];
           v.reserve(n - qi);
           for (uint64_t t = qi + 1; t < n; ++t)
-            if (acceptall || acceptable_unaligned(*S, S->blob.data() + S->off[qi], S->len[qi], (uint32_t) t)) v.push_back((uint32_t) t);
+            if (acceptall || acceptable_unaligned(*S, S->blob.data() + S->off[qi], S->len[qi], (uint32_t) t, S->meta_of(qi))) v.push_back((uint32_t) t);
         }
     };
     std::vector<std::thread> pool;
@@ -1185,7 +1277,8 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
   vsx_results res;
   double t0 = now_s();
   const vsx_filter flt = make_filter(*S);
-  int rc = vsx_align_pairs_filtered(S->ctx, S->dbset, S->dbset, pq.size(), pq.data(), pt.data(), (acceptall || S->o.gap_infinite) ? nullptr : &flt, &res);
+  int rc = vsx_align_pairs_filtered(S->ctx, S->dbset, S->dbset, pq.size(), pq.data(), pt.data(),
+                                    (acceptall || S->o.gap_infinite || S->o.cluster_unoise) ? nullptr : &flt, &res);
   const double t_align = now_s() - t0;
   if (rc != VSX_OK) return rc;
   std::vector<std::vector<Hit>> kept(count);
@@ -1213,7 +1306,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
               if (verdict == VSX_VERDICT_REJECTED || verdict == VSX_VERDICT_WEAK) continue;      // only accepted hits are kept (:509-527)
               const int frc = fill_hit(*S, q, ql, h, res, r, psent[(size_t) tid]);
               if (frc != VSX_OK) { err[(size_t) tid] = frc; return; }
-              const bool acc = acceptall || acceptable_aligned(*S, ql, h);
+              const bool acc = acceptall || acceptable_aligned(*S, ql, h, S->abundance(qi));
               if (verdict == VSX_VERDICT_ACCEPTED && !acc) { err[(size_t) tid] = VSX_EHIP; return; }
               if (acc) kept[k].push_back(std::move(h));
             }
@@ -1372,7 +1465,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
 
       // ---- phase 1b: staged GPU search (queries and targets both live in the database sequence set) ----
       int rc = run_stages(*S, st, [&](uint64_t k) { return seq_of(s0 + k); }, [&](uint64_t k) { return (int64_t) S->len[s0 + k]; },
-                          [&](uint64_t k) { return (uint32_t) (s0 + k); }, S->dbset, acct);
+                          [&](uint64_t k) { return (uint32_t) (s0 + k); }, [&](uint64_t k) { return S->meta_of(s0 + k); }, S->dbset, acct);
       if (rc != VSX_OK) return rc;
 
       // ---- phase 1c: intra-round shared k-mer counts (unique_count_shared, core/unique.cpp:356-395) and the
@@ -1398,7 +1491,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
                 const uint32_t k = (uint32_t) (c.target - s0);
                 if (k >= i) break;                                    // only earlier members can have become centroids
                 Near nr {k, c.count, -1};
-                if (acceptable_unaligned(*S, seq_of(s0 + i), S->len[s0 + i], (uint32_t) (s0 + k)))
+                if (acceptable_unaligned(*S, seq_of(s0 + i), S->len[s0 + i], (uint32_t) (s0 + k), S->meta_of(s0 + i)))
                   {
                     nr.res = (int64_t) sq.size();
                     sq.push_back((uint32_t) (s0 + i));
@@ -1423,7 +1516,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
                 Near nr {k, cnt[k], -1};
                 cnt[k] = 0;
                 if (enough_kmers(*S, nr.shared, (uint32_t) kmers[i].size()) &&
-                    acceptable_unaligned(*S, seq_of(s0 + i), S->len[s0 + i], (uint32_t) (s0 + k)))
+                    acceptable_unaligned(*S, seq_of(s0 + i), S->len[s0 + i], (uint32_t) (s0 + k), S->meta_of(s0 + i)))
                   {
                     nr.res = (int64_t) sq.size();
                     sq.push_back((uint32_t) (s0 + i));
@@ -1489,7 +1582,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
                   Hit & h = hits[t];
                   if (!h.aligned)
                     {
-                      if (acceptable_unaligned(*S, seq_of(seqno), ql, h.target))
+                      if (acceptable_unaligned(*S, seq_of(seqno), ql, h.target, S->meta_of(seqno)))
                         {
                           // single-target alignment (:743): taken from the speculative batch when it is there
                           int64_t ri = -1;
@@ -1515,7 +1608,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
                     }
                   if (!h.rejected)
                     {
-                      if (acceptable_aligned(*S, ql, h)) ++q.accepts; else ++q.rejects;
+                      if (acceptable_aligned(*S, ql, h, S->abundance(seqno))) ++q.accepts; else ++q.rejects;
                     }
                 }
               // delete all undetermined hits from the first one on (:841-854)
@@ -1525,9 +1618,11 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
               hits.resize(cut);
             }
 
-          // search_findbest2_byid (searchcore.cpp:960-991): first minimum under hit_compare_byid, must be accepted
+          // search_findbest2_byid / _bysize (searchcore.cpp:960-1025, chosen by --sizeorder, cluster.cpp:1072-1079): first minimum
+          // under the comparison, must be accepted
           const Hit * best = nullptr;
-          for (const Hit & h : hits) if (!best || hit_compare_byid(h, *best) < 0) best = &h;
+          if (S->o.sizeorder) { for (const Hit & h : hits) if (!best || hit_compare_bysize(*S, h, *best) < 0) best = &h; }
+          else for (const Hit & h : hits) if (!best || hit_compare_byid(h, *best) < 0) best = &h;
           if (best && !best->accepted) best = nullptr;
           if (best)
             {

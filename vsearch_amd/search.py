@@ -25,14 +25,34 @@ def _blob(seqs):
 HIT_FIELDS = [n for n, _ in _lib.Hit._fields_ if n not in ("pad", "cigar_off")]
 
 
+def _meta(sizes, labels, n):
+    """vsx_seq_meta + the buffers it points into (keep them alive for the call)"""
+    m = _lib.SeqMeta()
+    keep = []
+    if sizes is not None:
+        a = np.ascontiguousarray(sizes, np.uint64)
+        if a.size != n:
+            raise ValueError("sizes: one abundance per sequence")
+        m.abundance = a.ctypes.data_as(C.POINTER(C.c_uint64))
+        keep.append(a)
+    if labels is not None:
+        if len(labels) != n:
+            raise ValueError("labels: one header per sequence")
+        arr = (C.c_char_p * max(n, 1))(*[l.encode() if isinstance(l, str) else bytes(l) for l in labels])
+        m.label = arr
+        keep.append(arr)
+    return m, keep
+
+
 class SearchSession:
-    def __init__(self, aligner, db, **opts):
+    def __init__(self, aligner, db, sizes=None, labels=None, **opts):
         lib = _lib.load()
         self.aligner = aligner
         aligner._children.add(self)
         o = SearchOpts()
         lib.vsx_search_opts_default(C.byref(o))
         for k, v in opts.items():
+            k = "self" if k == "self_" else k             # --self (a Python keyword-ish name: pass self_=1)
             if not hasattr(o, k):
                 raise TypeError(f"unknown search option {k}")
             setattr(o, k, v)
@@ -45,6 +65,10 @@ class SearchSession:
                                       C.cast(C.c_char_p(blob), C.c_void_p), len(blob),
                                       off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p)),
               "vsx_searcher_create")
+        if sizes is not None or labels is not None:
+            # Database::getabundance / getheader of the targets (--sizein, --self; core/db.hpp)
+            m, keep = _meta(sizes, labels, len(lens))
+            check(lib.vsx_searcher_set_meta(self.h, C.byref(m)), "vsx_searcher_set_meta")
         self.stats = {}
 
     def close(self):
@@ -142,13 +166,16 @@ class SearchSession:
             lines.append(f"C\t{c}\t{size[c]}\t*\t*\t*\t*\t*\t{names[centroid[c]]}\t*")
         return lines
 
-    def search_batch(self, queries):
+    def search_batch(self, queries, sizes=None, labels=None):
+        """search_batch (core/search.hpp:131-145); sizes / labels = the queries' abundances and headers (--sizein, --self)"""
         lib = _lib.load()
         blob, off, lens = _blob(queries)
         res = Hits()
-        check(lib.vsx_search_batch(self.h, len(lens), C.cast(C.c_char_p(blob), C.c_void_p), len(blob),
-                                   off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), C.byref(res)),
-              "vsx_search_batch")
+        m, keep = _meta(sizes, labels, len(lens))
+        check(lib.vsx_search_batch_meta(self.h, len(lens), C.cast(C.c_char_p(blob), C.c_void_p), len(blob),
+                                        off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                                        C.byref(m) if keep else None, C.byref(res)),
+              "vsx_search_batch_meta")
         return self._unpack(res)
 
     def _unpack(self, res):
