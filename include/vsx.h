@@ -135,6 +135,12 @@ int vsx_seqset_create(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n,
 int vsx_seqset_create_from_device(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n,
                                   const void * d_blob, uint64_t blob_bytes,
                                   const uint64_t * offsets, const uint32_t * lengths);
+/* Both strands of n sequences (--strand both: core/search.cpp:200-214 searches every query and its reverse complement,
+   utils/reverse_complement.cpp:70-82): a set of 2n sequences, k < n as given, n + k = the reverse complement of k,
+   computed ON THE DEVICE from the 4-bit codes -- only the plus strands cross PCIe. */
+int vsx_seqset_create_both_strands(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n,
+                                   const char * blob, uint64_t blob_bytes,
+                                   const uint64_t * offsets, const uint32_t * lengths);
 void vsx_seqset_destroy(vsx_seqset * s);
 uint64_t vsx_seqset_count(const vsx_seqset * s);
 

@@ -220,3 +220,37 @@ def test_device_filter_matches_reference_cli(gpu_required, tmp_path, flt, extra)
         else:
             assert got.cigar[k] == passing[key], key
     assert len(seen) >= 2, seen
+
+
+def test_device_reverse_complement_matches_reference_cli(gpu_required, tmp_path):
+    """vsx_seqset_create_both_strands (reverse complement in the 4-bit code domain on the device) against the reference's own
+    --fastx_revcomp (utils/reverse_complement.cpp + chrmap_complement): aligning the device-made minus strand of q with t must
+    equal aligning the reference's reverse-complemented text of q with t -- IUPAC, lower case and U included."""
+    _need_ref()
+    from vsearch_amd import Aligner
+    rng = random.Random(12)
+    qs = [common.rnd_seq(rng, rng.randint(1, 300), "ACGT") for _ in range(20)]
+    qs += [common.rnd_seq(rng, rng.randint(20, 200), "ACGTURYSWKMBDHVNacgtunryk") for _ in range(30)]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    ts = []
+    for q in qs:                                     # targets related to the MINUS strand, so that the alignments are not trivial
+        core = "".join(comp.get(c.upper(), "N") for c in reversed(q))
+        ts.append(common.mutate(rng, core, 0.05, "ACGTN") + common.rnd_seq(rng, rng.randint(0, 30)))
+    tmp = str(tmp_path)
+    _write(tmp + "/q.fa", [f"q{i}" for i in range(len(qs))], qs)
+    _run([REF_BIN, "--fastx_revcomp", tmp + "/q.fa", "--fastaout", tmp + "/rc.fa", "--fasta_width", "0", "--quiet"])
+    rc = [l for l in open(tmp + "/rc.fa").read().splitlines() if not l.startswith(">")]
+    assert len(rc) == len(qs) and any(set(r) - set("ACGTN") for r in rc)
+    n = len(qs)
+    idx = np.arange(n, dtype=np.uint32)
+    with Aligner() as al:
+        both = al.sequences(qs, both_strands=True)
+        assert len(both) == 2 * n
+        T = al.sequences(ts)
+        dev = al.align_pairs(both, T, np.concatenate([idx, idx + n]), np.concatenate([idx, idx]))
+        ref_plus = al.align_pairs(al.sequences(qs), T, idx, idx)
+        ref_minus = al.align_pairs(al.sequences(rc), T, idx, idx)
+    for k in range(n):
+        assert dev.row(k) == ref_plus.row(k), k
+        assert dev.row(n + k) == ref_minus.row(k), (k, qs[k], rc[k])
+    assert sum(1 for k in range(n) if ref_minus.row(k)[2] > 10) > 20

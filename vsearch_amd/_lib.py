@@ -16,7 +16,7 @@ SENTINEL = 32767
 # every symbol include/vsx.h declares
 SYMBOLS = [
     "vsx_version_string", "vsx_device_count", "vsx_last_error", "vsx_create", "vsx_destroy",
-    "vsx_seqset_create", "vsx_seqset_create_from_device", "vsx_seqset_destroy", "vsx_seqset_count",
+    "vsx_seqset_create", "vsx_seqset_create_both_strands", "vsx_seqset_create_from_device", "vsx_seqset_destroy", "vsx_seqset_count",
     "vsx_plan_create", "vsx_plan_run", "vsx_plan_sync", "vsx_plan_fetch", "vsx_plan_export_hits", "vsx_plan_export_runs",
     "vsx_cigar_from_runs", "vsx_plan_destroy",
     "vsx_align_pairs", "vsx_align_pairs_filtered", "vsx_plan_set_filter", "vsx_results_free", "vsx_plan_describe",
@@ -141,6 +141,7 @@ def load():
     lib.vsx_destroy.argtypes = [vp]
     lib.vsx_destroy.restype = None
     lib.vsx_seqset_create.argtypes = [vp, C.POINTER(vp), C.c_uint64, vp, C.c_uint64, vp, vp]
+    lib.vsx_seqset_create_both_strands.argtypes = [vp, C.POINTER(vp), C.c_uint64, vp, C.c_uint64, vp, vp]
     lib.vsx_seqset_create_from_device.argtypes = [vp, C.POINTER(vp), C.c_uint64, vp, C.c_uint64, vp, vp]
     lib.vsx_seqset_destroy.argtypes = [vp]
     lib.vsx_seqset_destroy.restype = None

@@ -114,7 +114,7 @@ class RawResults:
 class SequenceSet:
     """Device-resident sequences (mirror of Database: core/db.hpp getsequence/getsequencelen)."""
 
-    def __init__(self, aligner, seqs=None, blob=None, offsets=None, lengths=None, device_ptr=None):
+    def __init__(self, aligner, seqs=None, blob=None, offsets=None, lengths=None, device_ptr=None, both_strands=False):
         self.aligner = aligner
         aligner._children.add(self)
         lib = _lib.load()
@@ -141,8 +141,14 @@ class SequenceSet:
             else:
                 self._keep = bytes(blob)
                 p, nbytes = C.cast(C.c_char_p(self._keep), C.c_void_p), len(self._keep)
-            check(lib.vsx_seqset_create(aligner.h, C.byref(self.h), self.n, p, nbytes,
-                                        _ptr(self.offsets), _ptr(self.lengths)), "vsx_seqset_create")
+            if both_strands:
+                # sequences n .. 2n-1 = the reverse complements, computed on the device (vsx_seqset_create_both_strands)
+                check(lib.vsx_seqset_create_both_strands(aligner.h, C.byref(self.h), self.n, p, nbytes,
+                                                         _ptr(self.offsets), _ptr(self.lengths)), "vsx_seqset_create_both_strands")
+                self.n *= 2
+            else:
+                check(lib.vsx_seqset_create(aligner.h, C.byref(self.h), self.n, p, nbytes,
+                                            _ptr(self.offsets), _ptr(self.lengths)), "vsx_seqset_create")
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -290,8 +296,8 @@ class Aligner:
         self.close()
 
     # -- the reference's per-query interface -------------------------------------------------
-    def sequences(self, seqs):
-        return SequenceSet(self, seqs=seqs)
+    def sequences(self, seqs, both_strands=False):
+        return SequenceSet(self, seqs=seqs, both_strands=both_strands)
 
     def qprep(self, qseq):
         """search16_qprep (align_simd.cpp:1406-1428): bind the query of the following search16 calls."""

@@ -528,7 +528,7 @@ void vsx_destroy(vsx_ctx * c)
 }
 
 static int seqset_common(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const void * blob, bool blob_on_device,
-                         uint64_t blob_bytes, const uint64_t * offsets, const uint32_t * lengths)
+                         uint64_t blob_bytes, const uint64_t * offsets, const uint32_t * lengths, bool both_strands = false)
 {
   if (!ctx || !out || (n && (!offsets || !lengths)) || (blob_bytes && !blob))
     return fail(VSX_EINVAL, "vsx_seqset_create: null argument");
@@ -544,17 +544,27 @@ static int seqset_common(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const voi
   s->bytes = blob_bytes;
   s->off.assign(offsets, offsets + n);
   s->len.assign(lengths, lengths + n);
+  uint64_t code_bytes = blob_bytes;
+  if (both_strands)
+    {
+      // the minus strands follow the plus strands' codes, packed in sequence order
+      s->n = 2 * n;
+      s->off.resize(2 * n);
+      s->len.resize(2 * n);
+      for (uint64_t k = 0; k < n; ++k) { s->off[n + k] = code_bytes; s->len[n + k] = lengths[k]; code_bytes += lengths[k]; }
+      s->bytes = code_bytes;
+    }
   hipError_t e = hipSuccess;
   DevBuf<uint8_t> staging;
   const uint8_t * d_ascii = static_cast<const uint8_t *>(blob);
   do {
-    if ((e = s->d_codes.alloc(blob_bytes + 2 * VSX_CODE_SLACK)) != hipSuccess) break;
-    if ((e = s->d_off.alloc(n)) != hipSuccess) break;
-    if ((e = s->d_len.alloc(n)) != hipSuccess) break;
+    if ((e = s->d_codes.alloc(code_bytes + 2 * VSX_CODE_SLACK)) != hipSuccess) break;
+    if ((e = s->d_off.alloc(s->n)) != hipSuccess) break;
+    if ((e = s->d_len.alloc(s->n)) != hipSuccess) break;
     if (n)
       {
-        if ((e = hipMemcpyAsync(s->d_off.p, offsets, n * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
-        if ((e = hipMemcpyAsync(s->d_len.p, lengths, n * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(s->d_off.p, s->off.data(), s->n * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(s->d_len.p, s->len.data(), s->n * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
       }
     if (!blob_on_device && blob_bytes)
       {
@@ -563,6 +573,7 @@ static int seqset_common(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const voi
         d_ascii = staging.p;
       }
     if ((e = vsx_launch_encode(d_ascii, s->codes(), blob_bytes, ctx->stream)) != hipSuccess) break;
+    if (both_strands && (e = vsx_launch_revcomp(s->codes(), s->d_off.p, s->d_off.p + n, s->d_len.p, n, ctx->stream)) != hipSuccess) break;
     e = hipStreamSynchronize(ctx->stream);
   } while (false);
   if (e != hipSuccess)
@@ -578,6 +589,12 @@ int vsx_seqset_create(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const char *
                       const uint64_t * offsets, const uint32_t * lengths)
 {
   return seqset_common(ctx, out, n, blob, false, blob_bytes, offsets, lengths);
+}
+
+int vsx_seqset_create_both_strands(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const char * blob, uint64_t blob_bytes,
+                                   const uint64_t * offsets, const uint32_t * lengths)
+{
+  return seqset_common(ctx, out, n, blob, false, blob_bytes, offsets, lengths, true);
 }
 
 int vsx_seqset_create_from_device(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const void * d_blob,

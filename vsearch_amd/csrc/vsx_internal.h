@@ -93,6 +93,10 @@ hipError_t vsx_launch_cigar_text(const VsxPairOut * d_out, const uint32_t * d_pa
                                  uint8_t * d_text, uint64_t text_capacity, unsigned long long * d_text_cursor,
                                  VsxSoaOut soa, hipStream_t st);
 
+// reverse complement of sequences [0, nseq) in the code domain, written to d_dst_off inside the same code buffer
+hipError_t vsx_launch_revcomp(uint8_t * d_codes, const uint64_t * d_src_off, const uint64_t * d_dst_off,
+                              const uint32_t * d_len, uint64_t nseq, hipStream_t st);
+
 // launchers implemented in vsx_device.hip (host code compiled by hipcc)
 hipError_t vsx_launch_encode(const uint8_t * d_ascii, uint8_t * d_codes, uint64_t nbytes, hipStream_t st);
 hipError_t vsx_launch_purity(const uint8_t * d_codes, const uint64_t * d_off, const uint32_t * d_len,

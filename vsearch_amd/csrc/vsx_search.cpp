@@ -474,7 +474,9 @@ static vsx_filter make_filter(const vsx_searcher & S)
 
 // Fill a hit from one alignment result (searchcore.cpp:806-857 == allpairs_global.cpp:447-508): linear-memory
 // fallback on the sentinel, derived fields, align_trim.  Returns VSX_OK or an error code.
-static int fill_hit(const vsx_searcher & S, const char * q, int64_t ql, Hit & h, const vsx_results & res, uint64_t r,
+// (qtext() yields the query as text; it is only called on the sentinel path -- minus-strand queries have no text otherwise)
+template <typename FQ>
+static int fill_hit(const vsx_searcher & S, FQ qtext, int64_t ql, Hit & h, const vsx_results & res, uint64_t r,
                     uint64_t & sentinels)
 {
   int64_t alnlen = res.aligned[r], nm = res.matches[r], nmm = res.mismatches[r];
@@ -484,7 +486,7 @@ static int fill_hit(const vsx_searcher & S, const char * q, int64_t ql, Hit & h,
     {
       ++sentinels;
       char * cg = nullptr;
-      const int rc = vsx_lma_align(&S.scoring, q, (uint64_t) ql, S.blob.data() + S.off[h.target], (uint64_t) dl,
+      const int rc = vsx_lma_align(&S.scoring, qtext(), (uint64_t) ql, S.blob.data() + S.off[h.target], (uint64_t) dl,
                                    &nwscore, &alnlen, &nm, &nmm, &nwgaps, &cg);
       if (rc != VSX_OK) return rc;
       h.cigar = cg;
@@ -553,8 +555,10 @@ struct Acct { double t_align = 0, t_advance = 0, t_replay = 0; uint64_t pairs = 
 // The staged search of a window: every open query contributes its next align_delayed batch, all batches go to the
 // GPU as one plan, then the reference's bookkeeping (:782-878) is replayed per query.  qseq/qlen/qidx map a window
 // slot to its sequence, length and index inside `qset`.
-template <typename FSeq, typename FLen, typename FIdx, typename FMeta>
-static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qseq, FLen qlen, FIdx qidx, FMeta qmeta,
+// qseq(k): the query for the symbol-comparing filters (only dereferenced when idprefix / idsuffix / selfid are set);
+// qtext(k): the query as text for the linear-memory fallback (sentinel pairs only; may build it on demand).
+template <typename FSeq, typename FText, typename FLen, typename FIdx, typename FMeta>
+static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qseq, FText qtext, FLen qlen, FIdx qidx, FMeta qmeta,
                       const vsx_seqset * qset, Acct & acct)
 {
   const uint64_t wn = st.size();
@@ -644,7 +648,7 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
                           ++q.rejects;
                           continue;
                         }
-                      const int frc = fill_hit(S, qseq(k), ql, h, res, r, a.sentinels);
+                      const int frc = fill_hit(S, [&]() { return qtext(k); }, ql, h, res, r, a.sentinels);
                       if (frc != VSX_OK) { err[(size_t) tid] = frc; return; }
                       const bool acc = acceptable_aligned(S, ql, h, qmeta(k).qsize);
                       if (verdict != VSX_VERDICT_UNDECIDED && (acc != (verdict == VSX_VERDICT_ACCEPTED) || (!acc && !h.weak)))
@@ -1030,13 +1034,19 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
   const bool dev_kmer = device_kmer_ok(*S);
   KmerAcct kacct;
   const bool both = S->o.strand_both != 0;
+  // does any host step read a minus-strand query as text? (host k-mer path; idprefix / idsuffix / selfid compare symbols;
+  // the '*' penalties send every pair to the linear-memory aligner; VSX_RC_TEXT=1 forces it for tests)
+  static const bool rc_text_env = std::getenv("VSX_RC_TEXT") != nullptr;
+  const bool need_rc_text = both && (!dev_kmer || S->o.idprefix > 0 || S->o.idsuffix > 0 || S->o.selfid != 0 || S->o.gap_infinite != 0 || rc_text_env);
 
   struct Window {
     uint64_t w0 = 0, wn = 0, ns = 0, mn = 0, hi = 0;
     std::vector<QState> st;
     std::vector<uint64_t> lo;
     std::vector<uint32_t> ln;
-    std::string rc, joined;
+    std::string joined;                            // plus strands + reverse complements as text (only when the host needs them)
+    std::vector<std::string> lazy_rc;              // otherwise: single minus strands, built when the fallback aligner asks
+    uint64_t rc_off0 = 0;
     const char * wblob = nullptr;
     std::vector<std::vector<uint32_t>> words;      // device k-mer path: unique words per state
     int krc = VSX_OK;
@@ -1057,27 +1067,54 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       W->mn = mn; W->hi = hi;
       W->lo.resize(ns); W->ln.resize(ns);
       for (uint64_t k = 0; k < wn; ++k) { W->lo[k] = qoff[w0 + k] - mn; W->ln[k] = qlen[w0 + k]; }
+      // --strand both.  The minus strands exist as TEXT on the host only where the host needs text: the host k-mer path, the
+      // prefix / suffix / self filters, the linear-memory fallback.  The aligner's copy is made on the device from the plus
+      // strands' codes (vsx_seqset_create_both_strands) and the minus strand's words are the reverse complements of the plus
+      // strand's words, so by default no reverse-complemented string is built at all.
+      W->wblob = qblob + mn;
       if (both)
         {
           uint64_t tot = 0;
-          for (uint64_t k = 0; k < wn; ++k) tot += qlen[w0 + k];
-          W->rc.resize(tot);
-          uint64_t p = 0;
-          for (uint64_t k = 0; k < wn; ++k)
+          for (uint64_t k = 0; k < wn; ++k) { W->lo[wn + k] = (hi - mn) + tot; W->ln[wn + k] = qlen[w0 + k]; tot += qlen[w0 + k]; }
+          W->rc_off0 = hi - mn;
+          if (need_rc_text)
             {
-              const char * q = qblob + qoff[w0 + k];
-              const uint32_t L = qlen[w0 + k];
-              W->lo[wn + k] = (hi - mn) + p; W->ln[wn + k] = L;
-              for (uint32_t x = 0; x < L; ++x) W->rc[p + x] = complement((unsigned char) q[L - 1 - x]);
-              p += L;
+              W->joined.assign(qblob + mn, hi - mn);
+              W->joined.resize((hi - mn) + tot);
+              for (uint64_t k = 0; k < wn; ++k)
+                {
+                  const char * q = qblob + qoff[w0 + k];
+                  const uint32_t L = qlen[w0 + k];
+                  char * d = &W->joined[W->lo[wn + k]];
+                  for (uint32_t x = 0; x < L; ++x) d[x] = complement((unsigned char) q[L - 1 - x]);
+                }
+              W->wblob = W->joined.data();
             }
         }
-      W->wblob = qblob + mn;
-      if (both) { W->joined.assign(qblob + mn, hi - mn); W->joined += W->rc; W->wblob = W->joined.data(); }
       Window * w = W.get();
       const double t0 = now_s();
       if (dev_kmer)
-        kmer_words(S, ns, [w](uint64_t k) { return w->wblob + w->lo[k]; }, [w](uint64_t k) { return (int64_t) w->ln[k]; }, w->words);
+        {
+          kmer_words(S, wn, [w](uint64_t k) { return w->wblob + w->lo[k]; }, [w](uint64_t k) { return (int64_t) w->ln[k]; }, w->words);
+          if (both)
+            {
+              // unique words of the reverse complement = reverse complements of the unique words (a word over unmasked
+              // symbols stays one; unique_count's set semantics, core/unique.cpp:155-352): reverse the 2-bit symbols, complement
+              w->words.resize(ns);
+              const int wl = S->w;
+              for (uint64_t k = 0; k < wn; ++k)
+                {
+                  std::vector<uint32_t> & dst = w->words[wn + k];
+                  dst.resize(w->words[k].size());
+                  for (size_t x = 0; x < dst.size(); ++x)
+                    {
+                      uint32_t v = ~w->words[k][x], r = 0;
+                      for (int b = 0; b < wl; ++b) { r = (r << 2) | (v & 3u); v >>= 2; }
+                      dst[x] = r;
+                    }
+                }
+            }
+        }
       w->t_kmer = now_s() - t0;
       return W;
   };
@@ -1109,7 +1146,9 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       vsx_seqset * qset = nullptr;
       const double tq = now_s();
       {
-        int rc2 = vsx_seqset_create(S->ctx, &qset, ns, W.wblob, (W.hi - W.mn) + W.rc.size(), W.lo.data(), W.ln.data());
+        // both strands: the plus strands are uploaded, the minus strands are made on the device
+        int rc2 = both ? vsx_seqset_create_both_strands(S->ctx, &qset, wn, qblob + W.mn, W.hi - W.mn, W.lo.data(), W.ln.data())
+                       : vsx_seqset_create(S->ctx, &qset, ns, W.wblob, W.hi - W.mn, W.lo.data(), W.ln.data());
         if (rc2 != VSX_OK) return rc2;
       }
       t_qset += now_s() - tq;
@@ -1119,7 +1158,21 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
           const uint64_t qi = w0 + (k < wn ? k : k - wn);
           return QMeta {(qmeta && qmeta->abundance) ? (int64_t) qmeta->abundance[qi] : 1, (qmeta && qmeta->label) ? qmeta->label[qi] : nullptr};
         };
-        const int src = run_stages(*S, st, seq_of, [&](uint64_t k) { return (int64_t) W.ln[k]; },
+        // a minus-strand query as text, built on demand (one thread works on a query at a time)
+        auto text_of = [&](uint64_t k) -> const char * {
+          if (k < wn || !W.joined.empty()) return W.wblob + W.lo[k];
+          std::string & r = W.lazy_rc[k - wn];
+          if (r.empty() && W.ln[k])
+            {
+              const char * q = qblob + qoff[w0 + (k - wn)];
+              const uint32_t L = W.ln[k];
+              r.resize(L);
+              for (uint32_t x = 0; x < L; ++x) r[x] = complement((unsigned char) q[L - 1 - x]);
+            }
+          return r.c_str();
+        };
+        if (both && W.joined.empty()) W.lazy_rc.assign(wn, std::string());
+        const int src = run_stages(*S, st, seq_of, text_of, [&](uint64_t k) { return (int64_t) W.ln[k]; },
                                    [&](uint64_t k) { return (uint32_t) k; }, meta_of, qset, acct);
         t_adv += acct.t_advance; t_rep += acct.t_replay;
         t_align += acct.t_align; pairs += acct.pairs; cells += acct.cells; stages += acct.stages; sentinels += acct.sentinels;
@@ -1304,7 +1357,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
               pcells[(size_t) tid] += (uint64_t) ql * S->len[h.target];
               const uint8_t verdict = res.verdict ? res.verdict[r] : (uint8_t) VSX_VERDICT_UNDECIDED;
               if (verdict == VSX_VERDICT_REJECTED || verdict == VSX_VERDICT_WEAK) continue;      // only accepted hits are kept (:509-527)
-              const int frc = fill_hit(*S, q, ql, h, res, r, psent[(size_t) tid]);
+              const int frc = fill_hit(*S, [&]() { return q; }, ql, h, res, r, psent[(size_t) tid]);
               if (frc != VSX_OK) { err[(size_t) tid] = frc; return; }
               const bool acc = acceptall || acceptable_aligned(*S, ql, h, S->abundance(qi));
               if (verdict == VSX_VERDICT_ACCEPTED && !acc) { err[(size_t) tid] = VSX_EHIP; return; }
@@ -1464,7 +1517,8 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       t_kmer += now_s() - t0;
 
       // ---- phase 1b: staged GPU search (queries and targets both live in the database sequence set) ----
-      int rc = run_stages(*S, st, [&](uint64_t k) { return seq_of(s0 + k); }, [&](uint64_t k) { return (int64_t) S->len[s0 + k]; },
+      int rc = run_stages(*S, st, [&](uint64_t k) { return seq_of(s0 + k); }, [&](uint64_t k) { return seq_of(s0 + k); },
+                          [&](uint64_t k) { return (int64_t) S->len[s0 + k]; },
                           [&](uint64_t k) { return (uint32_t) (s0 + k); }, [&](uint64_t k) { return S->meta_of(s0 + k); }, S->dbset, acct);
       if (rc != VSX_OK) return rc;
 
@@ -1600,7 +1654,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
                               rp = &one; ri = 0;
                             }
                           acct.cells += (uint64_t) ql * S->len[h.target];
-                          rc = fill_hit(*S, seq_of(seqno), ql, h, *rp, (uint64_t) ri, acct.sentinels);
+                          rc = fill_hit(*S, [&]() { return seq_of(seqno); }, ql, h, *rp, (uint64_t) ri, acct.sentinels);
                           vsx_results_free(&one);
                           if (rc != VSX_OK) { vsx_results_free(&spec); return sfail(rc, "vsx_cluster_fast: fallback aligner failed"); }
                         }

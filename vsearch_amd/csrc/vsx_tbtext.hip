@@ -92,6 +92,36 @@ vsx_cigar_text_kernel(const VsxPairOut * __restrict__ out, const u32 * __restric
   soa.text_off[pid] = off;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Reverse complement in the 4-bit code domain (utils/reverse_complement.cpp:70-82 + chrmap_complement, utils/maps.cpp:
+// 121-150): the complement of an IUPAC set code is its bit reversal (A1 <-> T8, C2 <-> G4, R5 <-> Y10, ...); a symbol
+// that is no IUPAC letter (code 0) complements to 'N' = 15, as the reference's table does.  One workgroup per sequence:
+// sequence k of `src` is read backwards and written forwards as sequence k of `dst`.  HBM-bound, 1 B in / 1 B out.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+vsx_revcomp_kernel(const uint8_t * __restrict__ codes, const uint64_t * __restrict__ src_off, const uint64_t * __restrict__ dst_off,
+                   const uint32_t * __restrict__ len)
+{
+  const uint64_t k = blockIdx.x;
+  const uint8_t * __restrict__ s = codes + src_off[k];
+  uint8_t * __restrict__ d = const_cast<uint8_t *>(codes) + dst_off[k];
+  const u32 L = len[k];
+  for (u32 x = threadIdx.x; x < L; x += 256)
+    {
+      const u32 c = s[L - 1 - x] & 15u;
+      const u32 r = ((c & 1u) << 3) | ((c & 2u) << 1) | ((c & 4u) >> 1) | ((c & 8u) >> 3);
+      d[x] = (uint8_t) (c == 0u ? 15u : r);
+    }
+}
+
+extern "C" hipError_t vsx_launch_revcomp(uint8_t * d_codes, const uint64_t * d_src_off, const uint64_t * d_dst_off,
+                                         const uint32_t * d_len, uint64_t nseq, hipStream_t st)
+{
+  if (nseq == 0) return hipSuccess;
+  hipLaunchKernelGGL(vsx_revcomp_kernel, dim3((unsigned) nseq), dim3(256), 0, st, d_codes, d_src_off, d_dst_off, d_len);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t vsx_launch_cigar_text(const VsxPairOut * d_out, const uint32_t * d_pair_ids, uint32_t npairs,
                                             const uint32_t * d_runs, uint64_t runs_capacity,
                                             uint8_t * d_text, uint64_t text_capacity, unsigned long long * d_text_cursor,
