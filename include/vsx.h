@@ -190,6 +190,30 @@ int vsx_align_pairs(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset 
                     vsx_results * out);
 void vsx_results_free(vsx_results * r);
 
+/* Ranking and compaction on the device: of a pair list grouped by query (all pairs of a query contiguous)
+   only the pairs the filter KEEPS come back -- verdict ACCEPTED, plus WEAK with keep_weak -- already in report order:
+   queries in list order, inside a query identity descending, then list order (= target ascending when the caller lists
+   targets ascending): hit_compare_byid (core/searchcore.cpp:133-179), allpairs_hit_compare (commands/allpairs_global.cpp:
+   116-138).  `id` is the identity the filter compared (iddef of the filter).  Pairs the 16-bit aligner refused (sentinel)
+   are listed in `undecided` for the caller's fallback.  The filter is required. */
+typedef struct vsx_ranked {
+  uint64_t   n_pairs, n_hits;
+  uint32_t * pair;          /* n_hits indices into the caller's pair list */
+  int16_t  * score;
+  uint16_t * aligned, * matches, * mismatches, * gaps;
+  uint8_t  * verdict;
+  double   * id;
+  uint64_t * cigar_off;
+  char     * cigar_blob;
+  uint64_t   cigar_bytes;
+  uint64_t   n_undecided;
+  uint32_t * undecided;
+} vsx_ranked;
+int vsx_align_pairs_ranked(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets,
+                           uint64_t n_pairs, const uint32_t * qidx, const uint32_t * tidx,
+                           const vsx_filter * filter, int keep_weak, vsx_ranked * out);
+void vsx_ranked_free(vsx_ranked * r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ SYMBOLS = [
     "vsx_seqset_create", "vsx_seqset_create_both_strands", "vsx_seqset_create_from_device", "vsx_seqset_destroy", "vsx_seqset_count",
     "vsx_plan_create", "vsx_plan_run", "vsx_plan_sync", "vsx_plan_fetch", "vsx_plan_export_hits", "vsx_plan_export_runs",
     "vsx_cigar_from_runs", "vsx_plan_destroy",
-    "vsx_align_pairs", "vsx_align_pairs_filtered", "vsx_plan_set_filter", "vsx_results_free", "vsx_plan_describe",
+    "vsx_align_pairs", "vsx_align_pairs_filtered", "vsx_align_pairs_ranked", "vsx_ranked_free", "vsx_plan_set_filter", "vsx_results_free", "vsx_plan_describe",
 ]
 # include/vsx_search.h
 SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
@@ -91,6 +91,15 @@ class Results(C.Structure):
                 ("cigar_blob", C.POINTER(C.c_char)), ("cigar_bytes", C.c_uint64), ("verdict", C.POINTER(C.c_uint8))]
 
 
+class Ranked(C.Structure):
+    """vsx_ranked (include/vsx.h)"""
+    _fields_ = [("n_pairs", C.c_uint64), ("n_hits", C.c_uint64), ("pair", C.POINTER(C.c_uint32)), ("score", C.POINTER(C.c_int16)),
+                ("aligned", C.POINTER(C.c_uint16)), ("matches", C.POINTER(C.c_uint16)), ("mismatches", C.POINTER(C.c_uint16)),
+                ("gaps", C.POINTER(C.c_uint16)), ("verdict", C.POINTER(C.c_uint8)), ("id", C.POINTER(C.c_double)),
+                ("cigar_off", C.POINTER(C.c_uint64)), ("cigar_blob", C.POINTER(C.c_char)), ("cigar_bytes", C.c_uint64),
+                ("n_undecided", C.c_uint64), ("undecided", C.POINTER(C.c_uint32))]
+
+
 class Filter(C.Structure):
     """vsx_filter (include/vsx.h): device-side align_trim + search_acceptable_aligned"""
     _fields_ = [("iddef", C.c_int32), ("leftjust", C.c_int32), ("rightjust", C.c_int32), ("pad", C.c_int32),
@@ -160,6 +169,9 @@ def load():
     lib.vsx_plan_describe.argtypes = [vp, C.POINTER(PlanInfo)]
     lib.vsx_align_pairs.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.POINTER(Results)]
     lib.vsx_align_pairs_filtered.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.POINTER(Filter), C.POINTER(Results)]
+    lib.vsx_align_pairs_ranked.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.POINTER(Filter), C.c_int, C.POINTER(Ranked)]
+    lib.vsx_ranked_free.argtypes = [C.POINTER(Ranked)]
+    lib.vsx_ranked_free.restype = None
     lib.vsx_plan_set_filter.argtypes = [vp, C.POINTER(Filter)]
     lib.vsx_results_free.argtypes = [C.POINTER(Results)]
     lib.vsx_results_free.restype = None

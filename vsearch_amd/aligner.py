@@ -352,6 +352,32 @@ class Aligner:
               "vsx_align_pairs_filtered")
         return RawResults(res)
 
+    def align_pairs_ranked(self, queries, targets, qidx, tidx, filter, keep_weak=False):
+        """vsx_align_pairs_ranked: the pairs the filter keeps, ranked and compacted on the device (queries in list order, id
+        descending, then list order).  -> dict of numpy arrays (pair, score, aligned, matches, mismatches, gaps, verdict, id),
+        cigar list, undecided pair indices"""
+        lib = _lib.load()
+        qidx = np.ascontiguousarray(qidx, np.uint32)
+        tidx = np.ascontiguousarray(tidx, np.uint32)
+        res = _lib.Ranked()
+        f = make_filter(**filter)
+        check(lib.vsx_align_pairs_ranked(self.h, queries.h, targets.h, qidx.size, _ptr(qidx), _ptr(tidx), C.byref(f),
+                                         1 if keep_weak else 0, C.byref(res)), "vsx_align_pairs_ranked")
+        try:
+            n = int(res.n_hits)
+            cp = lambda p, dt: np.ctypeslib.as_array(p, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+            out = {"pair": cp(res.pair, np.uint32), "score": cp(res.score, np.int16), "aligned": cp(res.aligned, np.uint16),
+                   "matches": cp(res.matches, np.uint16), "mismatches": cp(res.mismatches, np.uint16), "gaps": cp(res.gaps, np.uint16),
+                   "verdict": cp(res.verdict, np.uint8), "id": cp(res.id, np.float64)}
+            off = cp(res.cigar_off, np.uint64)
+            blob = C.string_at(res.cigar_blob, int(res.cigar_bytes)) if res.cigar_bytes else b""
+            out["cigar"] = [blob[int(o):blob.index(b"\0", int(o))].decode() for o in off]
+            nu = int(res.n_undecided)
+            out["undecided"] = np.ctypeslib.as_array(res.undecided, shape=(nu,)).astype(np.uint32, copy=True) if nu else np.zeros(0, np.uint32)
+            return out
+        finally:
+            lib.vsx_ranked_free(C.byref(res))
+
     def align(self, q, t):
         """one pair -> (score, aligned, matches, mismatches, gaps, cigar)"""
         qs, ts = SequenceSet(self, seqs=[q]), SequenceSet(self, seqs=[t])

@@ -260,6 +260,15 @@ struct Chunk {
 }  // namespace
 
 extern "C" int vsx_internal_usable_cpus(void);
+template <typename T>
+static T * dup_array(const std::vector<T> & v)
+{
+  T * p = (T *) std::malloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (p && !v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+  return p;
+}
+
+
 // threads for a memory-bound host pass over `bytes` bytes
 static int copy_threads(uint64_t bytes)
 {
@@ -1158,7 +1167,8 @@ struct FetchDest {
   char ** blob; uint64_t * blob_used;      // text is appended at *blob_used (the blob is realloc'ed); offsets are rebased by it
 };
 
-static int fetch_core(vsx_plan * pl, const FetchDest & D)
+// wait for a plan's kernels; re-run what overflowed (run buffer: the whole plan; text buffer: the formatting kernel)
+static int settle(vsx_plan * pl, unsigned long long & used, unsigned long long & text_used)
 {
   vsx_ctx * ctx = pl->ctx;
   if (!pl->ran) { int rc = vsx_plan_run(pl); if (rc != VSX_OK) return rc; }
@@ -1166,8 +1176,7 @@ static int fetch_core(vsx_plan * pl, const FetchDest & D)
   if (rc != VSX_OK) return rc;
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-
-  unsigned long long used = pl->h_cursor[0], text_used = pl->h_cursor[1];
+  used = pl->h_cursor[0]; text_used = pl->h_cursor[1];
   if (used > pl->runs_capacity)
     {
       // the dense run buffer was sized for typical alignments; size it exactly and run again
@@ -1191,6 +1200,27 @@ static int fetch_core(vsx_plan * pl, const FetchDest & D)
       text_used = pl->h_cursor[1];
       if (text_used > pl->text_capacity) return fail(VSX_EHIP, "vsx_plan_fetch: text buffer overflow after resize");
     }
+  return VSX_OK;
+}
+
+// pinned staging of at least `need` bytes (caller holds ctx->stage_mu)
+static int stage_reserve(vsx_ctx * ctx, uint64_t need)
+{
+  if (need <= ctx->stage_bytes) return VSX_OK;
+  if (ctx->stage) { (void) hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+  const uint64_t want = need + need / 4 + (1u << 20);
+  if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), want, hipHostMallocDefault) != hipSuccess)
+    { (void) hipGetLastError(); return fail(VSX_ENOMEM, "vsx_plan_fetch: pinned staging allocation failed"); }
+  ctx->stage_bytes = want;
+  return VSX_OK;
+}
+
+static int fetch_core(vsx_plan * pl, const FetchDest & D)
+{
+  vsx_ctx * ctx = pl->ctx;
+  unsigned long long used = 0, text_used = 0;
+  int rc = settle(pl, used, text_used);
+  if (rc != VSX_OK) return rc;
 
   const uint64_t n = pl->n_pairs;
   // the rare pairs answered on the host get their strings behind the device text
@@ -1211,15 +1241,7 @@ static int fetch_core(vsx_plan * pl, const FetchDest & D)
   {
     // one PCIe crossing into pinned memory (arrays + text), then host threads spread it over the result arrays
     std::lock_guard<std::mutex> lk(ctx->stage_mu);
-    const uint64_t need = pl->soa_bytes + ((text_used + 15) & ~15ull);
-    if (need > ctx->stage_bytes)
-      {
-        if (ctx->stage) { (void) hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
-        const uint64_t want = need + need / 4 + (1u << 20);
-        if (hipHostMalloc(reinterpret_cast<void **>(&ctx->stage), want, hipHostMallocDefault) != hipSuccess)
-          { (void) hipGetLastError(); return fail(VSX_ENOMEM, "vsx_plan_fetch: pinned staging allocation failed"); }
-        ctx->stage_bytes = want;
-      }
+    if ((rc = stage_reserve(ctx, pl->soa_bytes + ((text_used + 15) & ~15ull))) != VSX_OK) return rc;
     hipError_t e = hipSuccess;
     // (the plan's kernels are done -- vsx_plan_sync above -- so the copies need no ordering against `stream`, where the next
     //  slice of a pipeline may already be running)
@@ -1263,6 +1285,128 @@ static int fetch_core(vsx_plan * pl, const FetchDest & D)
       blob[at++] = '\0';
     }
   *D.blob_used = at;
+  return VSX_OK;
+}
+
+// Ranked fetch (vsx_rank.hip): only the pairs the plan's filter kept, in report order, appended to a sink.
+struct RankedSink {
+  std::vector<uint32_t> pair, undecided;
+  std::vector<int16_t> score;
+  std::vector<uint16_t> aligned, matches, mismatches, gaps;
+  std::vector<uint8_t> verdict;
+  std::vector<double> id;
+  std::vector<uint64_t> cigar_off;
+  char * blob = nullptr;
+  uint64_t blob_used = 0;
+  int keep_weak = 0;
+  ~RankedSink() { std::free(blob); }
+};
+
+// `first` = index of the plan's pair 0 in the caller's list; `qkey` = the caller's query index per pair (plan-local view)
+static int fetch_ranked_core(vsx_plan * pl, uint64_t first, const uint32_t * qkey, RankedSink & S)
+{
+  vsx_ctx * ctx = pl->ctx;
+  unsigned long long used = 0, text_used = 0;
+  int rc = settle(pl, used, text_used);
+  if (rc != VSX_OK) return rc;
+  const uint64_t n = pl->n_pairs;
+  for (uint32_t k : pl->host_pairs) S.undecided.push_back((uint32_t) (first + k));
+  if (n == 0) return VSX_OK;
+  hipStream_t st = ctx->stream_dn;             // the plan's kernels are done; the next slice may own `stream`
+
+  // query groups of the pair list (pairs of one query are contiguous)
+  std::vector<uint32_t> qstart;
+  for (uint64_t k = 0; k < n; ++k) if (k == 0 || qkey[k] != qkey[k - 1]) qstart.push_back((uint32_t) k);
+  const uint32_t G = (uint32_t) qstart.size();
+  qstart.push_back((uint32_t) n);
+
+  PoolBuf<uint32_t> d_flag, d_pos, d_qstart, d_seg, d_val_in, d_val_out;
+  PoolBuf<double> d_id, d_key_in, d_key_out;
+  PoolBuf<uint8_t> d_temp, d_rank;
+  HIPCHK(d_flag.alloc(&ctx->pool, n + 1));
+  HIPCHK(d_pos.alloc(&ctx->pool, n + 1));
+  HIPCHK(d_id.alloc(&ctx->pool, n));
+  HIPCHK(d_qstart.alloc(&ctx->pool, G + 1));
+  HIPCHK(d_seg.alloc(&ctx->pool, G + 1));
+  HIPCHK(hipMemcpyAsync(d_qstart.p, qstart.data(), (G + 1) * 4, hipMemcpyHostToDevice, st));
+  size_t tb = 0;
+  HIPCHK(vsx_rank_flag_scan(pl->filter, S.keep_weak, pl->d_out.p, pl->d_pair_ids.p, pl->d_pair_slot.p, pl->d_tasks.p, (uint32_t) pl->pair_ids.size(),
+                            (uint32_t) n, pl->d_runs.p, pl->runs_capacity, d_flag.p, d_pos.p, d_id.p, nullptr, &tb, st));
+  HIPCHK(d_temp.alloc(&ctx->pool, tb + 16));
+  HIPCHK(vsx_rank_flag_scan(pl->filter, S.keep_weak, pl->d_out.p, pl->d_pair_ids.p, pl->d_pair_slot.p, pl->d_tasks.p, (uint32_t) pl->pair_ids.size(),
+                            (uint32_t) n, pl->d_runs.p, pl->runs_capacity, d_flag.p, d_pos.p, d_id.p, d_temp.p, &tb, st));
+  uint32_t kept = 0;
+  HIPCHK(hipMemcpyAsync(&kept, d_pos.p + n, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+
+  const uint64_t k1 = std::max<uint32_t>(kept, 1);
+  // compact output arrays in one block: pair u32, id f64, text_off u64, 5 x 16 bit, verdict u8 (16-byte aligned sections)
+  const uint64_t width[9] = {4, 8, 8, 2, 2, 2, 2, 2, 1};
+  uint64_t off[9], at = 0;
+  for (int x = 0; x < 9; ++x) { off[x] = at; at += (k1 * width[x] + 15) & ~15ull; }
+  const uint64_t rank_bytes = at;
+  HIPCHK(d_rank.alloc(&ctx->pool, rank_bytes));
+  VsxRankedOut R;
+  R.pair = reinterpret_cast<uint32_t *>(d_rank.p + off[0]);
+  R.id = reinterpret_cast<double *>(d_rank.p + off[1]);
+  R.text_off = reinterpret_cast<uint64_t *>(d_rank.p + off[2]);
+  R.score = reinterpret_cast<int16_t *>(d_rank.p + off[3]);
+  R.aligned = reinterpret_cast<uint16_t *>(d_rank.p + off[4]);
+  R.matches = reinterpret_cast<uint16_t *>(d_rank.p + off[5]);
+  R.mismatches = reinterpret_cast<uint16_t *>(d_rank.p + off[6]);
+  R.gaps = reinterpret_cast<uint16_t *>(d_rank.p + off[7]);
+  R.verdict = d_rank.p + off[8];
+  if (kept)
+    {
+      HIPCHK(d_key_in.alloc(&ctx->pool, kept)); HIPCHK(d_key_out.alloc(&ctx->pool, kept));
+      HIPCHK(d_val_in.alloc(&ctx->pool, kept)); HIPCHK(d_val_out.alloc(&ctx->pool, kept));
+      size_t sb = 0;
+      HIPCHK(vsx_rank_sort_gather(d_flag.p, d_pos.p, d_id.p, (uint32_t) n, kept, d_qstart.p, G, d_key_in.p, d_key_out.p, d_val_in.p, d_val_out.p,
+                                  d_seg.p, pl->d_out.p, pl->soa.text_off, R, nullptr, &sb, st));
+      PoolBuf<uint8_t> d_temp2;
+      HIPCHK(d_temp2.alloc(&ctx->pool, sb + 16));
+      HIPCHK(vsx_rank_sort_gather(d_flag.p, d_pos.p, d_id.p, (uint32_t) n, kept, d_qstart.p, G, d_key_in.p, d_key_out.p, d_val_in.p, d_val_out.p,
+                                  d_seg.p, pl->d_out.p, pl->soa.text_off, R, d_temp2.p, &sb, st));
+      HIPCHK(hipStreamSynchronize(st));        // d_temp2 goes back to the pool at the end of this scope
+    }
+
+  // text: the whole device blob crosses (rejected pairs hold 4 bytes each), then only the kept strings are copied out
+  std::lock_guard<std::mutex> lk(ctx->stage_mu);
+  if ((rc = stage_reserve(ctx, rank_bytes + ((text_used + 15) & ~15ull))) != VSX_OK) return rc;
+  if (kept) HIPCHK(hipMemcpyAsync(ctx->stage, d_rank.p, rank_bytes, hipMemcpyDeviceToHost, st));
+  if (kept && text_used) HIPCHK(hipMemcpyAsync(ctx->stage + rank_bytes, pl->d_text.p, text_used, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (!kept) return VSX_OK;
+  const uint8_t * sg = ctx->stage;
+  const char * text = reinterpret_cast<const char *>(sg + rank_bytes);
+  const uint32_t * h_pair = reinterpret_cast<const uint32_t *>(sg + off[0]);
+  const double * h_id = reinterpret_cast<const double *>(sg + off[1]);
+  const uint64_t * h_toff = reinterpret_cast<const uint64_t *>(sg + off[2]);
+  const size_t base = S.pair.size();
+  S.pair.resize(base + kept); S.id.resize(base + kept); S.cigar_off.resize(base + kept);
+  S.score.resize(base + kept); S.aligned.resize(base + kept); S.matches.resize(base + kept);
+  S.mismatches.resize(base + kept); S.gaps.resize(base + kept); S.verdict.resize(base + kept);
+  std::memcpy(S.id.data() + base, h_id, kept * 8);
+  std::memcpy(S.score.data() + base, sg + off[3], kept * 2);
+  std::memcpy(S.aligned.data() + base, sg + off[4], kept * 2);
+  std::memcpy(S.matches.data() + base, sg + off[5], kept * 2);
+  std::memcpy(S.mismatches.data() + base, sg + off[6], kept * 2);
+  std::memcpy(S.gaps.data() + base, sg + off[7], kept * 2);
+  std::memcpy(S.verdict.data() + base, sg + off[8], kept);
+  // string lengths first (one realloc), then the copies
+  uint64_t need = 0;
+  std::vector<uint32_t> slen(kept);
+  for (uint32_t j = 0; j < kept; ++j) { slen[j] = (uint32_t) std::strlen(text + h_toff[j]) + 1; need += slen[j]; }
+  char * nb = (char *) std::realloc(S.blob, std::max<uint64_t>(S.blob_used + need, 1));
+  if (!nb) return fail(VSX_ENOMEM, "vsx_align_pairs_ranked: host allocation failed");
+  S.blob = nb;
+  for (uint32_t j = 0; j < kept; ++j)
+    {
+      S.pair[base + j] = (uint32_t) (first + h_pair[j]);
+      S.cigar_off[base + j] = S.blob_used;
+      std::memcpy(S.blob + S.blob_used, text + h_toff[j], slen[j]);
+      S.blob_used += slen[j];
+    }
   return VSX_OK;
 }
 
@@ -1368,7 +1512,8 @@ int vsx_align_pairs(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset 
 
 // one plan: create, run, fetch, destroy
 static int align_pairs_single(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
-                              const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, vsx_results * out)
+                              const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, vsx_results * out,
+                              RankedSink * sink = nullptr)
 {
   static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1381,7 +1526,7 @@ static int align_pairs_single(vsx_ctx * ctx, const vsx_seqset * queries, const v
   rc = vsx_plan_run(pl);
   double t2 = t1, t3 = t1;
   if (rc == VSX_OK) { rc = vsx_plan_sync(pl, nullptr); t2 = now(); }
-  if (rc == VSX_OK) { rc = vsx_plan_fetch(pl, out); t3 = now(); }
+  if (rc == VSX_OK) { rc = sink ? fetch_ranked_core(pl, 0, qidx, *sink) : vsx_plan_fetch(pl, out); t3 = now(); }
   vsx_plan_destroy(pl);
   if (timing)
     std::fprintf(stderr, "vsx_align_pairs: %llu pairs: plan %.3f s, run+sync %.3f s, fetch %.3f s, destroy %.3f s\n",
@@ -1393,20 +1538,20 @@ static int align_pairs_single(vsx_ctx * ctx, const vsx_seqset * queries, const v
 // i+1 (host grouping, task upload) while the GPU runs slice i and the caller's thread fetches slice i-1 (download, CIGAR
 // text); the slices' results are concatenated.  Same results as one plan -- a pair's alignment does not depend on its
 // batch.  VSX_PIPELINE=0 switches it off.
-int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
-                             const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, vsx_results * out)
+static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
+                            const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, vsx_results * out, RankedSink * sink)
 {
   static const bool pipeline_off = std::getenv("VSX_PIPELINE") && std::strcmp(std::getenv("VSX_PIPELINE"), "0") == 0;
   // slice size: VSX_PIPELINE_SLICE, else a quarter of the list within [128 k, 2 M] pairs -- mid-sized lists (one search
   // stage of 100 k queries = 800 k pairs) overlap planning, kernels and the fetch as well; below 256 k pairs one plan
   static const uint64_t forced_slice = std::getenv("VSX_PIPELINE_SLICE") ? std::max<uint64_t>(64, std::strtoull(std::getenv("VSX_PIPELINE_SLICE"), nullptr, 10)) : 0;
   const uint64_t slice_pairs = forced_slice ? forced_slice : std::min<uint64_t>(2ull << 20, std::max<uint64_t>(128ull << 10, n_pairs / 4));
-  if (pipeline_off || !ctx || !out || !queries || !targets || !qidx || !tidx || n_pairs < 2 * slice_pairs)
-    return align_pairs_single(ctx, queries, targets, n_pairs, qidx, tidx, filter, out);
+  if (pipeline_off || !ctx || (!out && !sink) || !queries || !targets || !qidx || !tidx || n_pairs < 2 * slice_pairs)
+    return align_pairs_single(ctx, queries, targets, n_pairs, qidx, tidx, filter, out, sink);
   static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = now();
-  std::memset(out, 0, sizeof *out);
+  if (out) std::memset(out, 0, sizeof *out);
   if (hipSetDevice(ctx->device) != hipSuccess) return fail(VSX_EHIP, "vsx_align_pairs: hipSetDevice failed");
 
   // slices of about slice_pairs pairs, cut where the query changes (a query's pairs then share tasks as in one plan)
@@ -1421,7 +1566,7 @@ int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vs
       else if (left <= slice_pairs / 2 + slice_pairs / 8) want = left;
       else if (left <= slice_pairs + slice_pairs / 2) want = left - slice_pairs / 2;
       uint64_t e = std::min<uint64_t>(n_pairs, cut.back() + want);
-      const uint64_t limit = std::min<uint64_t>(n_pairs, e + want / 2);
+      const uint64_t limit = sink ? n_pairs : std::min<uint64_t>(n_pairs, e + want / 2);      // ranked: a query is never split
       while (e < limit && qidx[e] == qidx[e - 1]) ++e;
       if (n_pairs - e < slice_pairs / 8) e = n_pairs;
       cut.push_back(e);
@@ -1431,10 +1576,11 @@ int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vs
   std::vector<vsx_plan *> plans(S, nullptr);
   std::vector<int> plan_rc(S, VSX_OK);
   std::vector<std::string> plan_msg(S);
-  {
-    const int arc = results_alloc(out, n_pairs, filter && ctx->ckpt);
-    if (arc != VSX_OK) return arc;
-  }
+  if (!sink)
+    {
+      const int arc = results_alloc(out, n_pairs, filter && ctx->ckpt);
+      if (arc != VSX_OK) return arc;
+    }
   std::mutex mu;
   std::condition_variable cv;
   size_t ready = 0, consumed = 0;
@@ -1462,7 +1608,7 @@ int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vs
   std::string msg;
   size_t launched = 0;
   auto finish = [&](size_t i) {           // fetch slice i straight into its part of the result arrays, release it
-    int frc = fetch_core(plans[i], dest_at(out, cut[i]));
+    int frc = sink ? fetch_ranked_core(plans[i], cut[i], qidx + cut[i], *sink) : fetch_core(plans[i], dest_at(out, cut[i]));
     vsx_plan_destroy(plans[i]);
     plans[i] = nullptr;
     { std::lock_guard<std::mutex> lk(mu); consumed = i + 1; }
@@ -1492,13 +1638,55 @@ int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vs
     if (plans[i]) { vsx_plan_destroy(plans[i]); plans[i] = nullptr; }
   if (rc != VSX_OK)
     {
-      vsx_results_free(out);
+      if (out) vsx_results_free(out);
       vsx_internal_set_error(msg.c_str());
       return rc;
     }
   if (timing)
     std::fprintf(stderr, "vsx_align_pairs: %llu pairs in %zu pipelined slices: %.3f s\n", (unsigned long long) n_pairs, S, now() - t_begin);
   return VSX_OK;
+}
+
+int vsx_align_pairs_filtered(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
+                             const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, vsx_results * out)
+{
+  if (!out) return fail(VSX_EINVAL, "vsx_align_pairs: null argument");
+  return align_pairs_impl(ctx, queries, targets, n_pairs, qidx, tidx, filter, out, nullptr);
+}
+
+int vsx_align_pairs_ranked(vsx_ctx * ctx, const vsx_seqset * queries, const vsx_seqset * targets, uint64_t n_pairs,
+                           const uint32_t * qidx, const uint32_t * tidx, const vsx_filter * filter, int keep_weak, vsx_ranked * out)
+{
+  if (!ctx || !out || !queries || !targets || (n_pairs && (!qidx || !tidx))) return fail(VSX_EINVAL, "vsx_align_pairs_ranked: null argument");
+  std::memset(out, 0, sizeof *out);
+  if (!filter) return fail(VSX_EINVAL, "vsx_align_pairs_ranked: the ranking needs the accept filter");
+  if (!ctx->ckpt) return fail(VSX_EINVAL, "vsx_align_pairs_ranked: needs the checkpoint traceback (VSX_TRACEBACK=dirs is set)");
+  RankedSink sink;
+  sink.keep_weak = keep_weak ? 1 : 0;
+  const int rc = align_pairs_impl(ctx, queries, targets, n_pairs, qidx, tidx, filter, nullptr, &sink);
+  if (rc != VSX_OK) return rc;
+  out->n_pairs = n_pairs;
+  out->n_hits = sink.pair.size();
+  out->pair = dup_array(sink.pair); out->score = dup_array(sink.score); out->aligned = dup_array(sink.aligned);
+  out->matches = dup_array(sink.matches); out->mismatches = dup_array(sink.mismatches); out->gaps = dup_array(sink.gaps);
+  out->verdict = dup_array(sink.verdict); out->id = dup_array(sink.id); out->cigar_off = dup_array(sink.cigar_off);
+  out->n_undecided = sink.undecided.size();
+  out->undecided = dup_array(sink.undecided);
+  out->cigar_blob = sink.blob ? sink.blob : (char *) std::malloc(1);
+  out->cigar_bytes = sink.blob_used;
+  sink.blob = nullptr;
+  if (!out->pair || !out->score || !out->aligned || !out->matches || !out->mismatches || !out->gaps || !out->verdict || !out->id ||
+      !out->cigar_off || !out->undecided || !out->cigar_blob)
+    { vsx_ranked_free(out); return fail(VSX_ENOMEM, "vsx_align_pairs_ranked: host allocation failed"); }
+  return VSX_OK;
+}
+
+void vsx_ranked_free(vsx_ranked * r)
+{
+  if (!r) return;
+  std::free(r->pair); std::free(r->score); std::free(r->aligned); std::free(r->matches); std::free(r->mismatches); std::free(r->gaps);
+  std::free(r->verdict); std::free(r->id); std::free(r->cigar_off); std::free(r->cigar_blob); std::free(r->undecided);
+  std::memset(r, 0, sizeof *r);
 }
 
 void vsx_results_free(vsx_results * r)

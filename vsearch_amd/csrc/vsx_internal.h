@@ -83,9 +83,30 @@ struct VsxSoaOut {
   uint64_t * text_off;
 };
 
+// Ranked, compacted hits in HBM (vsx_rank.hip): entry j = the j-th kept pair in report order
+struct VsxRankedOut {
+  uint32_t * pair;
+  int16_t  * score;
+  uint16_t * aligned, * matches, * mismatches, * gaps;
+  uint8_t  * verdict;
+  double   * id;
+  uint64_t * text_off;
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+// vsx_rank.hip: keep flags + identities + exclusive scan (d_temp == NULL: only *temp_bytes is set) ...
+hipError_t vsx_rank_flag_scan(VsxFilterDev F, int keep_weak, const VsxPairOut * d_out, const uint32_t * d_pair_ids,
+                              const uint32_t * d_pair_slot, const VsxTask * d_tasks, uint32_t ngpu_pairs, uint32_t n_pairs,
+                              const uint32_t * d_runs, uint64_t runs_capacity, uint32_t * d_flag, uint32_t * d_pos, double * d_id,
+                              void * d_temp, size_t * temp_bytes, hipStream_t st);
+// ... then compaction, per-query stable sort by identity (descending) and the gather of the kept pairs' fields
+hipError_t vsx_rank_sort_gather(const uint32_t * d_flag, const uint32_t * d_pos, const double * d_id, uint32_t n_pairs, uint32_t kept,
+                                const uint32_t * d_qstart, uint32_t ngroups, double * d_key_in, double * d_key_out,
+                                uint32_t * d_val_in, uint32_t * d_val_out, uint32_t * d_seg, const VsxPairOut * d_out,
+                                const uint64_t * d_text_off, VsxRankedOut r, void * d_temp, size_t * temp_bytes, hipStream_t st);
 
 // vsx_tbtext.hip: run lists -> CIGAR text (pushop / finishop, align_simd.cpp:1013-1049) + records -> output arrays
 hipError_t vsx_launch_cigar_text(const VsxPairOut * d_out, const uint32_t * d_pair_ids, uint32_t npairs,

@@ -1327,19 +1327,117 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
         std::copy(tl[k].begin(), tl[k].end(), pt.begin() + (int64_t) qfirst[k]);
       }
   }
-  vsx_results res;
   double t0 = now_s();
   const vsx_filter flt = make_filter(*S);
-  int rc = vsx_align_pairs_filtered(S->ctx, S->dbset, S->dbset, pq.size(), pq.data(), pt.data(),
-                                    (acceptall || S->o.gap_infinite || S->o.cluster_unoise) ? nullptr : &flt, &res);
-  const double t_align = now_s() - t0;
-  if (rc != VSX_OK) return rc;
   std::vector<std::vector<Hit>> kept(count);
   uint64_t cells = 0, sentinels = 0;
+  for (uint64_t k = 0; k < count; ++k)
+    {
+      uint64_t tl = 0;
+      for (uint64_t r = qfirst[k]; r < qfirst[k + 1]; ++r) tl += S->len[pt[r]];
+      cells += (uint64_t) S->len[first + k] * tl;
+    }
+  int rc = VSX_OK;
+  double t_align = 0;
+  const bool device_decides = !(acceptall || S->o.gap_infinite || S->o.cluster_unoise);
+  static const bool rank_off = std::getenv("VSX_RANK") && std::strcmp(std::getenv("VSX_RANK"), "host") == 0;     // A/B, tests
+  if (device_decides && !rank_off)
+    {
+      // Ranked path (vsx_rank.hip): the device filters, orders (id desc, target asc per query: allpairs_hit_compare :116-138)
+      // and compacts; only accepted pairs come back.  The host completes the derived fields of those, nothing else.
+      vsx_ranked rk;
+      rc = vsx_align_pairs_ranked(S->ctx, S->dbset, S->dbset, pq.size(), pq.data(), pt.data(), &flt, 0, &rk);
+      t_align = now_s() - t0;
+      if (rc != VSX_OK) return rc;
+      vsx_results view;
+      std::memset(&view, 0, sizeof view);
+      view.n_pairs = rk.n_hits; view.score = rk.score; view.aligned = rk.aligned; view.matches = rk.matches;
+      view.mismatches = rk.mismatches; view.gaps = rk.gaps; view.cigar_off = rk.cigar_off; view.cigar_blob = rk.cigar_blob;
+      // hits are grouped by query in list order: group boundaries by one sweep
+      std::vector<uint64_t> hfirst(count + 1, 0);
+      {
+        uint64_t j = 0;
+        for (uint64_t k = 0; k < count; ++k)
+          {
+            hfirst[k] = j;
+            while (j < rk.n_hits && rk.pair[j] < qfirst[k + 1]) ++j;      // (inside a group the pair indices follow the ranking)
+          }
+        hfirst[count] = j;
+      }
+      const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, S->threads), count / 8));
+      std::vector<int> err((size_t) nth, VSX_OK);
+      std::atomic<uint64_t> next {0};
+      auto work = [&](int tid) {
+        uint64_t dummy = 0;
+        for (;;)
+          {
+            const uint64_t k = next.fetch_add(1);
+            if (k >= count) break;
+            const uint64_t qi = first + k;
+            const char * q = S->blob.data() + S->off[qi];
+            const int64_t ql = S->len[qi];
+            kept[k].reserve(hfirst[k + 1] - hfirst[k]);
+            for (uint64_t j = hfirst[k]; j < hfirst[k + 1]; ++j)
+              {
+                Hit h;
+                h.target = pt[rk.pair[j]];
+                const int frc = fill_hit(*S, [&]() { return q; }, ql, h, view, j, dummy);
+                if (frc != VSX_OK) { err[(size_t) tid] = frc; return; }
+                if (!acceptable_aligned(*S, ql, h, S->abundance(qi)) || h.id != rk.id[j]) { err[(size_t) tid] = VSX_EHIP; return; }
+                kept[k].push_back(std::move(h));
+              }
+          }
+      };
+      {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto & th : pool) th.join();
+      }
+      for (int t = 0; t < nth; ++t)
+        if (err[(size_t) t] != VSX_OK)
+          {
+            vsx_ranked_free(&rk);
+            return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "vsx_allpairs_block: device and host accept filters disagree"
+                                                                       : "vsx_allpairs_block: fallback aligner failed");
+          }
+      // pairs the 16-bit aligner refused: linear-memory fallback, host filter, ordered insertion (rare)
+      for (uint64_t u = 0; u < rk.n_undecided; ++u)
+        {
+          const uint64_t r = rk.undecided[u];
+          const uint64_t k = (uint64_t) (std::upper_bound(qfirst.begin(), qfirst.end(), r) - qfirst.begin()) - 1;
+          const uint64_t qi = first + k;
+          int16_t sc = VSX_SCORE_SENTINEL; uint16_t z = 0; uint64_t zo = 0; char e0 = 0;
+          vsx_results one;
+          std::memset(&one, 0, sizeof one);
+          one.n_pairs = 1; one.score = &sc; one.aligned = &z; one.matches = &z; one.mismatches = &z; one.gaps = &z; one.cigar_off = &zo; one.cigar_blob = &e0;
+          Hit h;
+          h.target = pt[r];
+          const char * q = S->blob.data() + S->off[qi];
+          const int frc = fill_hit(*S, [&]() { return q; }, (int64_t) S->len[qi], h, one, 0, sentinels);
+          if (frc != VSX_OK) { vsx_ranked_free(&rk); return sfail(frc, "vsx_allpairs_block: fallback aligner failed"); }
+          if (acceptable_aligned(*S, S->len[qi], h, S->abundance(qi)))
+            {
+              kept[k].push_back(std::move(h));
+              std::stable_sort(kept[k].begin(), kept[k].end(), [](const Hit & a, const Hit & b) {
+                if (a.id != b.id) return a.id > b.id;
+                return a.target < b.target;
+              });
+            }
+        }
+      vsx_ranked_free(&rk);
+    }
+  else
+  {
+  vsx_results res;
+  rc = vsx_align_pairs_filtered(S->ctx, S->dbset, S->dbset, pq.size(), pq.data(), pt.data(),
+                                    device_decides ? &flt : nullptr, &res);
+  t_align = now_s() - t0;
+  if (rc != VSX_OK) return rc;
   {
     // per query: complete the accepted hits (derived fields, fallback on the sentinel) and order them -- host threads
     const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, S->threads), count / 8));
-    std::vector<uint64_t> pcells((size_t) nth, 0), psent((size_t) nth, 0);
+    std::vector<uint64_t> psent((size_t) nth, 0);
     std::vector<int> err((size_t) nth, VSX_OK);
     std::atomic<uint64_t> next {0};
     auto work = [&](int tid) {
@@ -1354,7 +1452,6 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
             {
               Hit h;
               h.target = pt[r];
-              pcells[(size_t) tid] += (uint64_t) ql * S->len[h.target];
               const uint8_t verdict = res.verdict ? res.verdict[r] : (uint8_t) VSX_VERDICT_UNDECIDED;
               if (verdict == VSX_VERDICT_REJECTED || verdict == VSX_VERDICT_WEAK) continue;      // only accepted hits are kept (:509-527)
               const int frc = fill_hit(*S, [&]() { return q; }, ql, h, res, r, psent[(size_t) tid]);
@@ -1375,7 +1472,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
     for (auto & th : pool) th.join();
     for (int t = 0; t < nth; ++t)
       {
-        cells += pcells[(size_t) t]; sentinels += psent[(size_t) t];
+        sentinels += psent[(size_t) t];
         if (err[(size_t) t] != VSX_OK)
           {
             vsx_results_free(&res);
@@ -1385,6 +1482,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
       }
   }
   vsx_results_free(&res);
+  }
   rc = marshal_hits(kept, out);
   if (rc != VSX_OK) return rc;
   for (uint64_t k = 0; k < out->n_hits; ++k) out->hit[k].query += (uint32_t) first;
