@@ -91,7 +91,7 @@ def test_cluster_fast_50k_matches_reference_cli(gpu_required, tmp_path):
     nh = sum(1 for l in exp if l[0] == "H")
     assert nh > 25_000 and sum(1 for l in exp if l[0] == "S") >= 1000
     assert got == exp, _first_diff(got, exp)
-    assert stats["stages"] >= 13                                      # >= 13 rounds really ran
+    assert stats["stages"] >= 12                                      # 13 rounds; the first one meets an empty centroid index
     print(f"cluster_fast 50k: reference {t_ref:.1f} s ({_threads()} threads), vsx {t_vsx:.1f} s, {stats['pairs_aligned']} pairs")
 
 

@@ -149,13 +149,14 @@ class SearchSession:
         finally:
             lib.vsx_cluster_out_free(C.byref(res))
 
-    def uc_lines(self, names, round=0):
+    def uc_lines(self, names, round=0, sizes=None):
         """the --uc file of --cluster_fast: S/H records in processing order, then one C record per cluster
-        (core/results.cpp:274-327, core/cluster.cpp:513-547, :1366-1378)"""
+        (core/results.cpp:274-327, core/cluster.cpp:513-547, :1366-1378); with --sizein (`sizes`) a C record carries the
+        cluster's total abundance instead of its member count (cluster.cpp:1268-1282)"""
         cno, per, ncl = self.cluster_fast(round)
         lines, size, centroid = [], [0] * ncl, [None] * ncl
         for s, (c, h) in enumerate(zip(cno, per)):
-            size[c] += 1
+            size[c] += 1 if sizes is None else int(sizes[s])
             if h is None:
                 centroid[c] = s
                 lines.append(f"S\t{c}\t{len(self.db[s])}\t*\t*\t*\t*\t*\t{names[s]}\t*")
