@@ -153,22 +153,17 @@ def main():
     t_plan = time.time() - t0             # host: pairs -> wavefront tasks, task upload, checkpoint buffer (one-time hipMalloc)
     n_pairs = len(qidx)
     cells = int((q_len[qidx].astype(np.int64) * db_len[tidx].astype(np.int64)).sum())
-    hits = torch.empty((n_pairs, sharding.HIT_RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
-    runs_buf = None
+    scratch = {}
     gathered = None
 
     def step():
-        nonlocal runs_buf, gathered
+        nonlocal gathered
         plan.run()
         tm = plan.sync()
         if world > 1:
             # the only collective on the path: final gather of the hit records and the CIGAR run words over RCCL/xGMI
-            plan.export_hits(hits.data_ptr(), hits.numel())
-            n_runs = plan.export_runs()
-            if runs_buf is None or runs_buf.numel() < n_runs:
-                runs_buf = torch.empty(n_runs + n_runs // 8 + 1024, dtype=torch.int32, device=dev)
-            plan.export_runs(runs_buf.data_ptr(), runs_buf.numel() * 4)
-            gathered = sharding.gather_results(hits, runs_buf[:n_runs], dist)
+            # (the same function the world-2 tests drive: vsearch_amd/sharding.py)
+            gathered = sharding.export_and_gather(plan, n_pairs, dist, dev, scratch)
         return tm
 
     def barrier():
@@ -208,7 +203,7 @@ def main():
         # rank 0 holds every rank's pairs: its own block must come back unchanged, offsets of the others rebased past it
         rec_all, runs_all, counts = gathered
         mine = sharding.decode_records(rec_all[:n_pairs])
-        own = sharding.decode_records(hits)
+        own = sharding.decode_records(scratch["rec"])
         other = sharding.decode_records(rec_all[n_pairs:2 * n_pairs])
         n_runs0 = int(own["nruns"].sum())
         gather_check = bool(counts == [n_pairs] * world and np.array_equal(mine["score"], own["score"])

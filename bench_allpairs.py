@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--len", type=int, default=400)
     ap.add_argument("--block", type=int, default=1000)
     ap.add_argument("--id", type=float, default=0.8)
+    ap.add_argument("--parity-prefix", type=int, default=1500,
+                    help="cross-check the hits among the first N sequences against the reference CLI (0 = skip)")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_allpairs.py needs a GPU (no CPU fallback)")
@@ -49,6 +51,8 @@ def main():
                                       len(blob), vp(db_off), vp(db_len)), "vsx_searcher_create")
         try:
             tot = {"pairs": 0, "cells": 0, "hits": 0, "align_s": 0.0}
+            npfx = min(a.parity_prefix, a.n)
+            sample = []                                  # userout lines (query, target, id, caln) of the pairs inside the prefix
             per_block = []
             t0 = time.perf_counter()
             for first in range(0, a.n, a.block):
@@ -61,10 +65,25 @@ def main():
                 tot["cells"] += int(hits.cells_aligned)
                 tot["hits"] += int(hits.n_hits)
                 tot["align_s"] += float(hits.seconds_align)
+                if first < npfx and hits.n_hits:
+                    harr = np.ctypeslib.as_array(hits.hit, shape=(int(hits.n_hits),))
+                    cig = C.string_at(hits.cigar_blob, int(hits.cigar_bytes))
+                    for r in harr[(harr["query"] < npfx) & (harr["target"] < npfx)]:
+                        o = int(r["cigar_off"])
+                        sample.append("t%d\tt%d\t%.1f\t%s" % (r["query"], r["target"], r["id"], cig[o:cig.index(b"\0", o)].decode()))
                 lib.vsx_hits_free(C.byref(hits))
             wall = time.perf_counter() - t0
         finally:
             lib.vsx_searcher_destroy(h)
+    parity = None
+    if npfx > 1:
+        from oracle import refcli
+        if refcli.available():
+            seqs = [blob[int(db_off[i]):int(db_off[i]) + int(db_len[i])] for i in range(npfx)]
+            exp, ref_s = refcli.allpairs_userout([f"t{i}" for i in range(npfx)], seqs, a.id)
+            parity = {"parity_sample_match": bool(sorted(sample) == exp), "sample": f"all {npfx * (npfx - 1) // 2} pairs among the first {npfx} "
+                      f"sequences vs vsearch_ref --allpairs_global --userout query+target+id+caln ({len(exp)} accepted pairs)",
+                      "reference_s": round(ref_s, 2), "reference_threads": refcli.usable_cpus()}
     # same-family pairs (what --id 0.8 should keep at 10 % divergence from a common ancestor)
     same = int(sum(c * (c - 1) // 2 for c in np.bincount(fam)))
     print(json.dumps({
@@ -73,7 +92,7 @@ def main():
         "config": {"workload": f"{a.n} x {a.len} bp, families of 50 at 10 % divergence, --id {a.id}, blocks of {a.block} queries"},
         "pairs": tot["pairs"], "pairs_per_s": round(tot["pairs"] / wall, 1), "cells": tot["cells"], "wall_s": round(wall, 3),
         "align_calls_s": round(tot["align_s"], 3), "accepted_hits": tot["hits"], "same_family_pairs": same,
-        "block_s": per_block}))
+        "block_s": per_block, "parity": parity}))
 
 
 if __name__ == "__main__":

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--len", type=int, default=300)
     ap.add_argument("--round", type=int, default=4096)
     ap.add_argument("--id", type=float, default=0.97)
+    ap.add_argument("--parity-prefix", type=int, default=30000,
+                    help="cross-check the S/H records of the first N sequences against the reference CLI run on that prefix (0 = skip)")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_cluster.py needs a GPU (no CPU fallback)")
@@ -66,6 +68,30 @@ def main():
                    "pairs_aligned": int(out.hits.pairs_aligned), "cells_aligned": int(out.hits.cells_aligned),
                    "seconds_kmer_host": round(out.hits.seconds_kmer, 3), "seconds_align_calls": round(out.hits.seconds_align, 3),
                    "stages": int(out.hits.stages)}
+            npfx = min(a.parity_prefix, a.n)
+            if npfx > 0:
+                # greedy clustering is causal: the records of the first N sequences equal a clustering of that prefix alone
+                from oracle import refcli
+                if refcli.available():
+                    names = [f"s{i:08d}" for i in range(npfx)]          # labels ascending = our order (ties of equal length)
+                    seqs = [blob[int(offs[i]):int(offs[i]) + int(lens[i])] for i in range(npfx)]
+                    exp, ref_s = refcli.cluster_fast_uc(names, seqs, a.id)
+                    exp = [l for l in exp if l[0] in "SH"]
+                    cno = np.ctypeslib.as_array(out.clusterno, shape=(a.n,))
+                    hfirst = np.ctypeslib.as_array(out.hits.first, shape=(a.n + 1,))
+                    cig = C.string_at(out.hits.cigar_blob, int(out.hits.cigar_bytes)) if out.hits.cigar_bytes else b""
+                    got = []
+                    for s_ in range(npfx):
+                        if hfirst[s_] == hfirst[s_ + 1]:
+                            got.append(f"S\t{cno[s_]}\t{lens[s_]}\t*\t*\t*\t*\t*\t{names[s_]}\t*")
+                        else:
+                            hh = out.hits.hit[int(hfirst[s_])]
+                            o_ = int(hh.cigar_off)
+                            aln = "=" if hh.matches == hh.internal_alignmentlength else cig[o_:cig.index(b"\0", o_)].decode()
+                            got.append(f"H\t{cno[s_]}\t{lens[s_]}\t{hh.id:.1f}\t+\t0\t0\t{aln}\t{names[s_]}\t{names[hh.target]}")
+                    res["parity"] = {"parity_sample_match": bool(got == exp), "sample": f"S/H records of the first {npfx} sequences vs "
+                                     f"vsearch_ref --cluster_fast --uc on that prefix ({sum(1 for l in exp if l[0] == 'H')} H records)",
+                                     "reference_s": round(ref_s, 2), "reference_threads": refcli.usable_cpus()}
             lib.vsx_cluster_out_free(C.byref(out))
         finally:
             lib.vsx_searcher_destroy(h)

@@ -128,6 +128,10 @@ void vsx_hits_free(vsx_hits * h);
    those accepted (or all with acceptall), ordered id desc, target asc.  vsx_hit.query is the database
    sequence number.  Callers walk the database in blocks to bound the result size. */
 int vsx_allpairs_block(vsx_searcher * s, int32_t acceptall, uint64_t first, uint64_t count, vsx_hits * out);
+/* the same for an arbitrary ascending list of query rows -- the multi-GPU form: the triangular pair space is sharded by
+   interleaved rows (vsearch_amd/sharding.py shard_allpairs_rows), every rank runs its rows against its DB replica.
+   hits.first has count + 1 entries (entry k = rows[k]); vsx_hit.query is the database sequence number. */
+int vsx_allpairs_rows(vsx_searcher * s, int32_t acceptall, const uint32_t * rows, uint64_t count, vsx_hits * out);
 
 /* Candidate list of ONE query exactly as search_topscores + minheap_sort produce it (best first):
    fills up to `cap` (target, count) pairs, returns the number of candidates. For tests / tooling. */

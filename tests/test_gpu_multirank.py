@@ -1,0 +1,70 @@
+"""-m gpu: the multi-GPU path with world_size 2 on ONE GPU: two ranks, each with its own context on device 0,
+collectives over gloo.  The code under test is what bench.py --gpus N runs per rank (vsearch_amd/sharding.py):
+query-sharded alignment + the final gather of hit records AND CIGAR run words; row-sharded allpairs."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, random
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from vsearch_amd import Aligner, SearchSession, sharding
+from tests import common
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+rng = random.Random(77)
+db, fam = common.family_db(rng, 8, 8, 320, div=0.07)
+db += ["", "ACGTNNRYacgtu" * 9]
+qs, src = common.queries_from_db(rng, db[:64], 41, 150)
+qs += ["", common.rnd_seq(rng, 200, "ACGTRYN")]
+qidx = np.repeat(np.arange(len(qs)), 5)
+tidx = np.array([rng.randrange(len(db)) for _ in qidx])
+with Aligner(device=0) as al:
+    Q, T = al.sequences(qs), al.sequences(db)
+    rec_all, runs_all, counts, order = sharding.sharded_align(al, Q, T, qidx, tidx, len(qs), dist)
+    assert sum(counts) == len(qidx) and sorted(order.tolist()) == list(range(len(qidx)))
+    assert counts[rank] == int(((qidx >= sharding.shard_queries(len(qs), world, rank)[0]) & (qidx < sharding.shard_queries(len(qs), world, rank)[1])).sum())
+    # every rank holds everything: compare with a single-rank run of ALL pairs on this rank's GPU context
+    one = al.align_pairs(Q, T, qidx, tidx)
+    d = sharding.decode_records(rec_all)
+    cig = sharding.cigars_from_gather(rec_all, runs_all)
+    for j, g in enumerate(order):
+        got = (int(d["score"][j]), int(d["aligned"][j]), int(d["matches"][j]), int(d["mismatches"][j]), int(d["gaps"][j]), cig[j])
+        assert got == one.row(int(g)), (rank, j, int(g), got, one.row(int(g)))
+    assert sum(1 for c in cig if c) > 150
+
+    # allpairs: interleaved rows (config 4's sharding); the union over the ranks must be the single-rank result
+    ss = SearchSession(al, db[:48], id=0.8)
+    rows = sharding.shard_allpairs_rows(48, world, rank)
+    mine = ss.allpairs_rows(rows)
+    allh = [None] * world
+    dist.all_gather_object(allh, (rows.tolist(), mine))
+    full = ss.allpairs(0, 48)
+    merged = [None] * 48
+    for rws, hl in allh:
+        for r, h in zip(rws, hl):
+            assert merged[r] is None
+            merged[r] = h
+    assert merged == full
+    assert sum(len(h) for h in full) > 100
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_alignment_and_gather_world2(gpu_required, tmp_path):
+    script = tmp_path / "worker_gpu.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29547", str(script), ROOT]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert p.stdout.count("ok") == 2

@@ -101,6 +101,92 @@ def test_gather_world2_gloo(tmp_path):
     assert p.stdout.count("ok") == 2
 
 
+WORKER_RUNS = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from vsearch_amd import sharding
+from oracle import pyoracle
+from tests import common
+import random
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = random.Random(5)
+db, fam = common.family_db(rng, 5, 6, 180, div=0.08)
+qs, src = common.queries_from_db(rng, db, 23, 90)
+qidx = np.repeat(np.arange(len(qs)), 4)
+tidx = np.array([rng.randrange(len(db)) for _ in qidx])
+orc = pyoracle.Oracle()
+rows = [orc.align(qs[q], db[t]) for q, t in zip(qidx, tidx)]            # the single-rank answer for every pair
+
+# this rank's share, as a GPU rank would export it: records + a dense run buffer with rank-LOCAL offsets, in an
+# allocation order of its own (the device allocates runs with an atomic cursor: any order)
+lq, lt, gi, (lo, hi) = sharding.shard_pairs(qidx, tidx, len(qs), world, rank)
+perm = list(range(len(gi))); random.Random(rank).shuffle(perm)
+off, chunks = {}, []
+at = 0
+for k in perm:
+    w = sharding.runs_from_cigar(rows[gi[k]][5])
+    off[k] = at; at += len(w); chunks.append(w)
+runs = np.concatenate(chunks) if chunks else np.zeros(0, np.uint32)
+rec = sharding.pack_records([rows[g][0] for g in gi], [rows[g][1] for g in gi], [rows[g][2] for g in gi], [rows[g][3] for g in gi],
+                            [rows[g][4] for g in gi], [len(sharding.runs_from_cigar(rows[g][5])) for g in gi], [off[k] for k in range(len(gi))])
+rec_all, runs_all, counts = sharding.gather_results(torch.from_numpy(rec), torch.from_numpy(runs.view(np.int32)), dist)
+order = np.concatenate([sharding.shard_pairs(qidx, tidx, len(qs), world, r)[2] for r in range(world)])
+assert sum(counts) == len(qidx) and sorted(order.tolist()) == list(range(len(qidx)))
+d = sharding.decode_records(rec_all)
+cig = sharding.cigars_from_gather(rec_all, runs_all)
+for j, g in enumerate(order):
+    assert (int(d["score"][j]), int(d["aligned"][j]), int(d["matches"][j]), int(d["mismatches"][j]), int(d["gaps"][j]), cig[j]) == tuple(rows[g]), (j, g)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_gather_records_and_cigar_runs_world2_gloo(tmp_path, oracle):
+    """the final gather carries the hit records AND the CIGAR run words; rank-local run offsets are rebased.
+    Two gloo ranks hold oracle-made records of their query blocks; every rank must be able to rebuild every pair's
+    score, statistics and CIGAR exactly as a single rank reports them."""
+    script = tmp_path / "worker_runs.py"
+    script.write_text(WORKER_RUNS)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29543", str(script), ROOT]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert p.stdout.count("ok") == 2
+
+
+def test_allpairs_row_sharding_partition():
+    """config 4 (allpairs, 1 -> 8 GPUs): interleaved rows -- every pair (i < j) belongs to exactly one rank, pair and cell
+    counts balance"""
+    from vsearch_amd.sharding import shard_allpairs_rows, allpairs_row_cost
+    rng = np.random.default_rng(2)
+    for n, world in [(2000, 8), (50_000, 8), (1001, 2), (17, 4)]:
+        length = rng.integers(350, 450, n)
+        owner = np.full(n, -1)
+        pairs, cells = [], []
+        for r in range(world):
+            rows = shard_allpairs_rows(n, world, r)
+            assert (owner[rows] == -1).all()
+            owner[rows] = r
+            pairs.append(allpairs_row_cost(n, rows))
+            cells.append(allpairs_row_cost(n, rows, length))
+        assert (owner >= 0).all() and sum(pairs) == n * (n - 1) // 2
+        if n >= 1000:
+            assert max(pairs) - min(pairs) <= 2 * n                   # within two rows of each other
+            assert max(cells) / min(cells) < (1.03 if n < 10_000 else 1.005)
+    # the explicit pair sets of a small case
+    n, world = 17, 4
+    seen = set()
+    for r in range(world):
+        for i in shard_allpairs_rows(n, world, r):
+            for j in range(int(i) + 1, n):
+                assert (int(i), j) not in seen
+                seen.add((int(i), j))
+    assert len(seen) == n * (n - 1) // 2
+
+
 def test_workload_generator_shapes():
     """the synthetic generator of bench.py (device='cpu' here): family structure + query identity"""
     import torch

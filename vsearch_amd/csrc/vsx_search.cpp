@@ -1286,12 +1286,13 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
 // allpairs_global (commands/allpairs_global.cpp:394-527): queries [first, first+count) of the database, each
 // against every LATER sequence that passes the unaligned filters (or all of them with acceptall); one GPU
 // plan for the whole block; hits kept if acceptall or accepted; order allpairs_hit_compare (:116-138).
-int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint64_t count, vsx_hits * out)
+int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows, uint64_t count, vsx_hits * out)
 {
-  if (!S || !out) return sfail(VSX_EINVAL, "vsx_allpairs_block: null argument");
+  if (!S || !out || (count && !rows)) return sfail(VSX_EINVAL, "vsx_allpairs_rows: null argument");
   std::memset(out, 0, sizeof *out);
   const uint64_t n = S->len.size();
-  if (first > n || count > n - first) return sfail(VSX_EINVAL, "vsx_allpairs_block: query block out of range");
+  for (uint64_t k = 0; k < count; ++k)
+    if (rows[k] >= n || (k && rows[k] <= rows[k - 1])) return sfail(VSX_EINVAL, "vsx_allpairs_rows: rows must be ascending database sequence numbers");
   const double t_begin = now_s();
   // the pair list: each query of the block against every later sequence that passes the unaligned filters -- per-query
   // target lists on host threads, concatenated in query order
@@ -1306,7 +1307,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
         {
           const uint64_t k = next.fetch_add(1);
           if (k >= count) break;
-          const uint64_t qi = first + k;
+          const uint64_t qi = rows[k];
           std::vector<uint32_t> & v = tl[k];
           v.reserve(n - qi);
           for (uint64_t t = qi + 1; t < n; ++t)
@@ -1323,7 +1324,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
     pq.resize(total); pt.resize(total);
     for (uint64_t k = 0; k < count; ++k)
       {
-        std::fill(pq.begin() + (int64_t) qfirst[k], pq.begin() + (int64_t) qfirst[k + 1], (uint32_t) (first + k));
+        std::fill(pq.begin() + (int64_t) qfirst[k], pq.begin() + (int64_t) qfirst[k + 1], rows[k]);
         std::copy(tl[k].begin(), tl[k].end(), pt.begin() + (int64_t) qfirst[k]);
       }
   }
@@ -1335,7 +1336,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
     {
       uint64_t tl = 0;
       for (uint64_t r = qfirst[k]; r < qfirst[k + 1]; ++r) tl += S->len[pt[r]];
-      cells += (uint64_t) S->len[first + k] * tl;
+      cells += (uint64_t) S->len[rows[k]] * tl;
     }
   int rc = VSX_OK;
   double t_align = 0;
@@ -1373,7 +1374,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
           {
             const uint64_t k = next.fetch_add(1);
             if (k >= count) break;
-            const uint64_t qi = first + k;
+            const uint64_t qi = rows[k];
             const char * q = S->blob.data() + S->off[qi];
             const int64_t ql = S->len[qi];
             kept[k].reserve(hfirst[k + 1] - hfirst[k]);
@@ -1398,15 +1399,15 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
         if (err[(size_t) t] != VSX_OK)
           {
             vsx_ranked_free(&rk);
-            return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "vsx_allpairs_block: device and host accept filters disagree"
-                                                                       : "vsx_allpairs_block: fallback aligner failed");
+            return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "vsx_allpairs_rows: device and host accept filters disagree"
+                                                                       : "vsx_allpairs_rows: fallback aligner failed");
           }
       // pairs the 16-bit aligner refused: linear-memory fallback, host filter, ordered insertion (rare)
       for (uint64_t u = 0; u < rk.n_undecided; ++u)
         {
           const uint64_t r = rk.undecided[u];
           const uint64_t k = (uint64_t) (std::upper_bound(qfirst.begin(), qfirst.end(), r) - qfirst.begin()) - 1;
-          const uint64_t qi = first + k;
+          const uint64_t qi = rows[k];
           int16_t sc = VSX_SCORE_SENTINEL; uint16_t z = 0; uint64_t zo = 0; char e0 = 0;
           vsx_results one;
           std::memset(&one, 0, sizeof one);
@@ -1415,7 +1416,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
           h.target = pt[r];
           const char * q = S->blob.data() + S->off[qi];
           const int frc = fill_hit(*S, [&]() { return q; }, (int64_t) S->len[qi], h, one, 0, sentinels);
-          if (frc != VSX_OK) { vsx_ranked_free(&rk); return sfail(frc, "vsx_allpairs_block: fallback aligner failed"); }
+          if (frc != VSX_OK) { vsx_ranked_free(&rk); return sfail(frc, "vsx_allpairs_rows: fallback aligner failed"); }
           if (acceptable_aligned(*S, S->len[qi], h, S->abundance(qi)))
             {
               kept[k].push_back(std::move(h));
@@ -1445,7 +1446,7 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
         {
           const uint64_t k = next.fetch_add(1);
           if (k >= count) break;
-          const uint64_t qi = first + k;
+          const uint64_t qi = rows[k];
           const char * q = S->blob.data() + S->off[qi];
           const int64_t ql = S->len[qi];
           for (uint64_t r = qfirst[k]; r < qfirst[k + 1]; ++r)
@@ -1476,8 +1477,8 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
         if (err[(size_t) t] != VSX_OK)
           {
             vsx_results_free(&res);
-            return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "vsx_allpairs_block: device and host accept filters disagree"
-                                                                       : "vsx_allpairs_block: fallback aligner failed");
+            return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "vsx_allpairs_rows: device and host accept filters disagree"
+                                                                       : "vsx_allpairs_rows: fallback aligner failed");
           }
       }
   }
@@ -1485,10 +1486,21 @@ int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint
   }
   rc = marshal_hits(kept, out);
   if (rc != VSX_OK) return rc;
-  for (uint64_t k = 0; k < out->n_hits; ++k) out->hit[k].query += (uint32_t) first;
+  for (uint64_t k = 0; k < out->n_hits; ++k) out->hit[k].query = rows[out->hit[k].query];       // vsx_hit.query = database sequence number
   out->pairs_aligned = pq.size(); out->cells_aligned = cells; out->stages = 1; out->sentinel_pairs = sentinels;
   out->seconds_align = t_align; out->seconds_total = now_s() - t_begin;
   return VSX_OK;
+}
+
+int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint64_t count, vsx_hits * out)
+{
+  if (!S || !out) return sfail(VSX_EINVAL, "vsx_allpairs_block: null argument");
+  std::memset(out, 0, sizeof *out);
+  const uint64_t n = S->len.size();
+  if (first > n || count > n - first) return sfail(VSX_EINVAL, "vsx_allpairs_block: query block out of range");
+  std::vector<uint32_t> rows(count);
+  for (uint64_t k = 0; k < count; ++k) rows[k] = (uint32_t) (first + k);
+  return vsx_allpairs_rows(S, acceptall, rows.data(), count, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -121,6 +121,15 @@ class SearchSession:
         check(lib.vsx_allpairs_block(self.h, 1 if acceptall else 0, first, count, C.byref(res)), "vsx_allpairs_block")
         return self._unpack(res)
 
+    def allpairs_rows(self, rows, acceptall=False):
+        """allpairs_global for an ascending list of query rows (a rank's share under sharding.shard_allpairs_rows):
+        per-row hit lists, entry k = rows[k]"""
+        lib = _lib.load()
+        r = np.ascontiguousarray(rows, np.uint32)
+        res = Hits()
+        check(lib.vsx_allpairs_rows(self.h, 1 if acceptall else 0, r.ctypes.data_as(C.c_void_p), r.size, C.byref(res)), "vsx_allpairs_rows")
+        return self._unpack(res)
+
     def cluster_fast(self, round=0):
         """greedy centroid clustering of the session's sequences in their given order (sort them first).
         -> (clusterno list, per-sequence hit dict or None, number of clusters)"""

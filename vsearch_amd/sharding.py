@@ -127,3 +127,80 @@ def cigars_from_gather(records, runs, which=None):
     r = runs.cpu().numpy().view(np.uint32) if hasattr(runs, "cpu") else np.asarray(runs).view(np.uint32)
     ks = range(len(d["nruns"])) if which is None else which
     return [cigar_from_runs(r[int(d["run_off"][k]):int(d["run_off"][k]) + int(d["nruns"][k])]) for k in ks]
+
+
+def pack_records(score, aligned, matches, mismatches, gaps, nruns, run_off, verdict=None):
+    """numpy arrays -> (n, 24) uint8 hit records (the layout vsx_plan_export_hits writes); for tests and tools"""
+    n = len(score)
+    a = np.zeros((n, HIT_RECORD_BYTES), np.uint8)
+    h = np.zeros((n, 6), np.uint16)
+    h[:, 0] = np.asarray(score, np.int16).view(np.uint16)
+    h[:, 1], h[:, 2], h[:, 3], h[:, 4] = aligned, matches, mismatches, gaps
+    if verdict is not None:
+        h[:, 5] = verdict
+    a[:, :12] = h.view(np.uint8).reshape(n, 12)
+    a[:, 12:16] = np.asarray(nruns, np.uint32).reshape(n, 1).view(np.uint8)
+    a[:, 16:24] = np.asarray(run_off, np.uint64).reshape(n, 1).view(np.uint8)
+    return a
+
+
+def runs_from_cigar(cigar):
+    """CIGAR text -> run words in traceback order ((length << 2) | op, last column first): the inverse of vsx_cigar_from_runs"""
+    import re
+    ops = {"M": 0, "I": 1, "D": 2}
+    w = [((int(n) if n else 1) << 2) | ops[o] for n, o in re.findall(r"(\d*)([MID])", cigar)]
+    return np.array(w[::-1], np.uint32)
+
+
+def export_and_gather(plan, n_local, dist=None, device=None, scratch=None):
+    """The gather step of a rank whose plan has run: hit records and run words leave the plan device-to-device
+    (vsx_plan_export_hits / vsx_plan_export_runs) and go through gather_results.  `scratch` (a dict) keeps the export
+    buffers between calls (bench.py's step loop)."""
+    import torch
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    scratch = scratch if scratch is not None else {}
+    rec = scratch.get("rec")
+    if rec is None or rec.shape[0] != n_local:
+        rec = scratch["rec"] = torch.empty((n_local, HIT_RECORD_BYTES), dtype=torch.uint8, device=dev)
+    if n_local:
+        plan.export_hits(rec.data_ptr(), rec.numel())
+    n_runs = plan.export_runs()
+    buf = scratch.get("runs")
+    if buf is None or buf.numel() < n_runs:
+        buf = scratch["runs"] = torch.empty(n_runs + n_runs // 8 + 1024, dtype=torch.int32, device=dev)
+    if n_runs:
+        plan.export_runs(buf.data_ptr(), buf.numel() * 4)
+    runs = buf[:n_runs]
+    if dist is not None and dist.get_backend() == "gloo":       # CPU collectives (tests on one GPU): stage through host memory
+        rec, runs = rec.cpu(), runs.cpu()
+    return gather_results(rec, runs, dist)
+
+
+def sharded_align(aligner, queries, targets, qidx, tidx, n_queries, dist=None, device=None):
+    """One query-sharded alignment job: this rank aligns the pairs of its query block on ITS GPU (one plan:
+    vsx_plan_run, results stay in HBM), exports the hit records and the run buffer (vsx_plan_export_hits / _runs) and
+    takes part in the final gather.  `queries` / `targets` are this rank's SequenceSets holding ALL queries / the DB replica.
+    -> (records_all, runs_all, counts, global pair order of the concatenated blocks) on every rank; bench.py's step and the
+    world-2 tests are this function."""
+    import torch
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    qidx = np.asarray(qidx)
+    tidx = np.asarray(tidx)
+    lo, hi = shard_queries(n_queries, world, rank)
+    sel = np.nonzero((qidx >= lo) & (qidx < hi))[0]
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    plan = aligner.plan(queries, targets, qidx[sel].astype(np.uint32), tidx[sel].astype(np.uint32))
+    try:
+        plan.run()
+        plan.sync()
+        rec_all, runs_all, counts = export_and_gather(plan, len(sel), dist, dev)
+    finally:
+        plan.close()
+    # blocks are contiguous in query order, so the concatenation of the ranks' selections is the list of global indices
+    if dist is not None and world > 1:
+        order = np.concatenate([np.nonzero((qidx >= shard_queries(n_queries, world, r)[0]) & (qidx < shard_queries(n_queries, world, r)[1]))[0]
+                                for r in range(world)])
+    else:
+        order = sel
+    return rec_all, runs_all, counts, order
