@@ -124,6 +124,11 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * scoring, int device);
 /* search16_exit (align_simd.cpp:1379-1403). */
 void vsx_destroy(vsx_ctx * ctx);
 
+/* Threading (as s16info_s, LIBRARY_API.md:962-1000): one vsx_ctx per host thread -- a context's entry points are not
+   re-entrant; any number of contexts per GPU.  A vsx_seqset is read-only device memory once created: contexts of the SAME
+   device may share it (e.g. one Database mirror for all worker threads); it must outlive every plan that uses it and the
+   context that created it must outlive it. */
+
 /* Database::add / getsequence / getsequencelen (core/db.hpp:146-152,172,198):
    n ASCII sequences (any case, IUPAC; blob + offsets + lengths) are encoded to
    4-bit codes (utils/maps.cpp:75-117) ON THE DEVICE and kept resident in HBM.

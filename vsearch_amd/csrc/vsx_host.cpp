@@ -691,7 +691,10 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   if (!ctx || !out || !queries || !targets || (n_pairs && (!qidx || !tidx)))
     return fail(VSX_EINVAL, "vsx_plan_create: null argument");
   *out = nullptr;
-  if (queries->ctx != ctx || targets->ctx != ctx) return fail(VSX_EINVAL, "vsx_plan_create: seqset belongs to another context");
+  // a sequence set is device memory: any context of the same GPU may align against it (one Database mirror serves all the
+  // worker threads' contexts, shim/vsx_search16_shim.cpp); it must outlive the plans that use it
+  if (queries->device != ctx->device || targets->device != ctx->device)
+    return fail(VSX_EINVAL, "vsx_plan_create: seqset lives on another device");
   if (n_pairs > 0xffffffffull / 8) return fail(VSX_EINVAL, "vsx_plan_create: too many pairs for one plan");
   static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
