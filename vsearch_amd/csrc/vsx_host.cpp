@@ -293,6 +293,7 @@ struct vsx_plan {
   std::vector<VsxPairOut> host_out;      // answers of the closed-form / sentinel pairs, parallel to host_pairs
   std::vector<std::string> host_cigar;   // only for the Q == 0 closed form
   std::vector<uint32_t> host_cigar_pair;
+  std::vector<uint32_t> host_cigar_run;  // the same alignments as run words ((D << 2) | I), for the exported run buffer
 
   std::vector<VsxTask> tasks;
   std::vector<uint32_t> pair_slot, pair_ids;
@@ -782,6 +783,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
                   o.score = (int16_t) (uint16_t) (std::max(a, b) & 0xffff);   // plain narrowing cast :1515
                   pl->host_cigar.push_back(std::to_string(D) + "I");
                   pl->host_cigar_pair.push_back(k);
+                  pl->host_cigar_run.push_back(((uint32_t) D << 2) | 1u);
                 }
               continue;
             }
@@ -1104,6 +1106,7 @@ int vsx_plan_run(vsx_plan * pl)
   HIPCHK(hipMemcpyAsync(pl->h_cursor, pl->d_cursor.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(pl->ev_end, st));
   pl->ran = true;
+  pl->host_patched = false;            // the exported records of host-answered pairs point behind THIS run's device runs
   return VSX_OK;
 }
 
@@ -1459,9 +1462,16 @@ int vsx_plan_export_hits(vsx_plan * pl, void * d_dst, uint64_t dst_bytes)
   hipStream_t st = pl->ctx->stream;
   if (!pl->host_patched)
     {
-      // pairs answered without DP live on the host: patch them into the device array once
-      for (size_t h = 0; h < pl->host_pairs.size(); ++h)
-        HIPCHK(hipMemcpyAsync(pl->d_out.p + pl->host_pairs[h], &pl->host_out[h], sizeof(VsxPairOut), hipMemcpyHostToDevice, st));
+      // pairs answered without DP live on the host: patch them into the device array once; their CIGARs (the Q == 0 closed
+      // form, one 'I' run) follow the device runs in the exported run buffer (vsx_plan_export_runs)
+      HIPCHK(hipEventSynchronize(pl->ev_end));
+      const uint64_t used = pl->h_cursor[0];
+      for (size_t h = 0, hc = 0; h < pl->host_pairs.size(); ++h)
+        {
+          VsxPairOut o = pl->host_out[h];
+          if (hc < pl->host_cigar_pair.size() && pl->host_cigar_pair[hc] == pl->host_pairs[h]) { o.nruns = 1; o.run_off = used + hc; ++hc; }
+          HIPCHK(hipMemcpy(pl->d_out.p + pl->host_pairs[h], &o, sizeof(VsxPairOut), hipMemcpyHostToDevice));
+        }
       pl->host_patched = true;
     }
   HIPCHK(hipMemcpyAsync(d_dst, pl->d_out.p, pl->n_pairs * sizeof(VsxPairOut), hipMemcpyDeviceToDevice, st));
@@ -1477,14 +1487,13 @@ int vsx_plan_export_runs(vsx_plan * pl, void * d_dst, uint64_t dst_bytes, uint64
   HIPCHK(hipEventSynchronize(pl->ev_end));
   const uint64_t used = pl->h_cursor[0];
   if (used > pl->runs_capacity) return fail(VSX_EINVAL, "vsx_plan_export_runs: the run buffer overflowed; call vsx_plan_fetch first (it resizes and re-runs)");
-  *n_runs = used;
+  const uint64_t extra = pl->host_cigar_run.size();          // run words of the pairs answered on the host, behind the device's
+  *n_runs = used + extra;
   if (!d_dst) return VSX_OK;                     // size query
-  if (dst_bytes < used * 4) return fail(VSX_EINVAL, "vsx_plan_export_runs: destination too small");
-  if (used)
-    {
-      HIPCHK(hipMemcpyAsync(d_dst, pl->d_runs.p, used * 4, hipMemcpyDeviceToDevice, pl->ctx->stream));
-      HIPCHK(hipStreamSynchronize(pl->ctx->stream));
-    }
+  if (dst_bytes < (used + extra) * 4) return fail(VSX_EINVAL, "vsx_plan_export_runs: destination too small");
+  if (used) HIPCHK(hipMemcpyAsync(d_dst, pl->d_runs.p, used * 4, hipMemcpyDeviceToDevice, pl->ctx->stream));
+  if (extra) HIPCHK(hipMemcpyAsync(static_cast<uint32_t *>(d_dst) + used, pl->host_cigar_run.data(), extra * 4, hipMemcpyHostToDevice, pl->ctx->stream));
+  HIPCHK(hipStreamSynchronize(pl->ctx->stream));
   return VSX_OK;
 }
 
