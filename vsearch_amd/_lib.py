@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvsx.so")
+# VSX_LIBRARY: another build of the same library (A/B builds of the kernels under build/variants/); default: the in-tree one
+LIB_PATH = os.environ.get("VSX_LIBRARY") or os.path.join(HERE, "libvsx.so")
 
 VSX_OK, VSX_EINVAL, VSX_ENODEVICE, VSX_ENOMEM, VSX_EHIP = 0, -1, -2, -3, -4
 SENTINEL = 32767

@@ -105,6 +105,9 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 #ifndef VSX_COLCK_CG
 #define VSX_COLCK_CG 64     // lanes per group of the compressed layout: [group][block][lane in group][4] dwords
 #endif
+// transposed layout (VSX_CKT, vsx_internal.h): one block = 64 slots x 12 dwords = 3 KB, written as three 1 KB stores
+#define VSX_CKT_BLOCK_DW 768
+#define VSX_COLCK_NCHUNK(R_) ((VSX_COLCK_NB(R_, true) + 2) / 3)      // 48-byte chunks per lane and column checkpoint
 #define VSX_COLCK_CDW(NB_, lane_, block_) ((((size_t) ((lane_) / VSX_COLCK_CG) * (size_t) (NB_) + (size_t) (block_)) * VSX_COLCK_CG + (size_t) ((lane_) % VSX_COLCK_CG)) * 4)
 // TILT = true (a sub-class of TOPPAD: checkpoints, LDS profile, no tracking): the kernel runs in TILTED coordinates,
 //   X*(i, j) = X(i, j) + (i + j) g   for X in {H, E, F},   g = the interior gap extension (both sides equal),
@@ -144,7 +147,14 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   auto vmax = [](u32 a, u32 b) -> u32 { return TILT ? pmaxu(a, b) : pmax(a, b); };
   // GENERIC: query profile in LDS, QP[target code][row of the strip] = S[code][query symbol of the row] (int16).
   // Any IUPAC / unknown symbol on either side is handled by construction; one v_perm_b32 per row packs the two targets.
-  __shared__ __attribute__((aligned(16))) int16_t QP[GENERIC ? 16 * 16 * R : 8];
+  // TILT + VSX_CKT: the primed scores are 0 .. 255 (planner-checked), so the profile holds BYTES (half the LDS, half the reads;
+  // the same single v_perm_b32 per row widens them): QPb[code][position][RP rows], RP = R rounded up to a multiple of 4
+  constexpr bool QP8 = TILT && (VSX_CKT != 0);
+  constexpr int RP = (R + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) int16_t QP[GENERIC ? (QP8 ? (16 * 16 * RP) / 2 : 16 * 16 * R) : 8];
+  uint8_t * const QPb = reinterpret_cast<uint8_t *>(QP);
+  // checkpoint staging of the transposed layout: [slot][12 dwords]
+  __shared__ __attribute__((aligned(16))) u32 RS[QP8 ? 64 * 12 : 4];
   // feed block of the column pipeline: [lane group][column of the 16-block] (sym, QR_t, R_t, H) and F -- written once per 16
   // steps by the 16 lanes of a group, read back one column per step for lane 0 (replaces five v_mov_b32_dpp row_ror rotations)
   __shared__ uint4 FEED4[4 * 16];
@@ -190,6 +200,26 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       if (GENERIC)
         {
           __syncthreads();                           // previous strip's readers are done
+          if (QP8)
+            {
+              for (int idx = lane; idx < 16 * 16 * RP; idx += 64)
+                {
+                  const int code = idx / (16 * RP), row = idx % (16 * RP);
+                  const int Lr = 16 * s + row / RP, rr = row % RP;
+                  int v = 0;
+                  if (rr < R)
+                    {
+                      if (Lr == 0 && rr < pad) v = -P.top_step + 2 * tl;
+                      else if (Lr < total_lanes)
+                        {
+                          const int gi = (Lr == 0) ? rr - pad : rcnt0 + (Lr - 1) * R + rr;
+                          v = P.matrix[code * 16 + (int) qq[gi]];
+                        }
+                    }
+                  QPb[idx] = (uint8_t) v;
+                }
+            }
+          else
           for (int idx = lane; idx < 16 * 16 * R; idx += 64)
             {
               const int code = idx / (16 * R), row = idx % (16 * R);
@@ -271,6 +301,21 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       const int ck_slot = VSX_CK_SLOT(TILT, g, l);
       u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps) >> 1) * 64 + ck_slot) * CK_LANE_DW;         // + (t >> 1) * VSX_ROWCK_PAIR_DW
       u32 * const cck_base = dir + T.dir_off + ck_rowdw + (size_t) s * ck_nblk * CK_COL_DW;                        // + (t >> 4) * CK_COL_DW
+      // transposed layout: block bases (steps is a multiple of 8 there); a lane adds (k * 64 + lane) * 4 dwords per store
+      u32 * const rck_blk = dir + T.dir_off + (((size_t) s * steps) >> 3) * VSX_CKT_BLOCK_DW;                       // + (t >> 3) * 768
+      u32 * const cck_blk = dir + T.dir_off + (((size_t) nstrips * steps) >> 3) * VSX_CKT_BLOCK_DW
+                            + (size_t) s * ck_nblk * VSX_COLCK_NCHUNK(R) * VSX_CKT_BLOCK_DW;                        // + ((t >> 4) * NCHUNK + c) * 768
+      // one 3 KB block: LDS -> HBM as it lies (three full 1 KB stores); the barriers order the lanes' LDS accesses (one wave)
+      auto flush_block = [&](u32 * gdst) __attribute__((always_inline)) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(RS + (k * 64 + lane) * 4);
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(gdst + (k * 64 + lane) * 4));
+          }
+        __syncthreads();
+      };
 
       // STEADY (the part of phase A after the pipeline has filled, t >= 15): every lane that owns rows is inside its targets, so the
       // per-lane activity test and its EXEC mask are dropped (lanes beyond the query's positions compute junk nobody reads).
@@ -347,7 +392,17 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               for (int r = 0; r < R; ++r)
                 {
                   u32 V;
-                  if (GENERIC)
+                  if (GENERIC && QP8)
+                    {
+                      if ((r & 3) == 0)
+                        {
+                          pa = *reinterpret_cast<const u32 *>(QPb + (code & 0xFu) * (16 * RP) + l * RP + r);
+                          pb = *reinterpret_cast<const u32 *>(QPb + (code >> 16) * (16 * RP) + l * RP + r);
+                        }
+                      // byte r & 3 of the A rows -> low half, of the B rows -> high half, zero-extended (selector 0x0C = 0x00)
+                      V = __builtin_amdgcn_perm(pb, pa, 0x0C040C00u + 0x00010001u * (u32) (r & 3));
+                    }
+                  else if (GENERIC)
                     {
                       if (R % 2 == 0)
                         {
@@ -453,7 +508,22 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                 }
               if (l == 15 && s + 1 < nstrips) strip_outp[j] = make_uint2(outH, outF);
             }
-          if (CKPT)
+          if (CKPT && QP8)
+            {
+              // transposed layout: the two-step pair goes to the lane's 48-byte segment of the staging block -- H of step i at
+              // dword i, the four difference bytes of the pair at dword 8 + i / 2 -- and every 8 steps the block leaves as it lies
+              if (!ODD) pend_on = active;
+              else
+                {
+                  const u32 dpk = __builtin_amdgcn_perm(psubw(outH, outF), psubw(pendH, pendF), 0x06040200u);
+                  u32 * rs = RS + ck_slot * 12;
+                  const int i = t & 7;
+                  *reinterpret_cast<uint2 *>(rs + (i - 1)) = make_uint2(pendH, outH);
+                  rs[8 + (i >> 1)] = dpk;
+                  if (i == 7) flush_block(rck_blk + (size_t) (t >> 3) * VSX_CKT_BLOCK_DW);
+                }
+            }
+          else if (CKPT)
             {
               // row checkpoints [two-step pair][lane][2] uint2: one 16-byte store per lane and pair, so a wave writes
               // 1 KB of full lines (steps is even: a pair never straddles two strips); halves that were not active hold junk
@@ -461,7 +531,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               if (!ODD) pend_on = active;
               else if (pend_on || active)
                 {
-                  if (TILT)
+                  if (TILT && !QP8)
                     {
                       // bytes 0 / 2 of the two wrapped differences = the signed 8-bit H - F of the lo / hi target, steps t-1 and t
                       const u32 dpk = __builtin_amdgcn_perm(psubw(outH, outF), psubw(pendH, pendF), 0x06040200u);
@@ -489,9 +559,30 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                       }
                     return 0u;
                   };
+                  if (QP8)
+                    {
+                      // chunks of three 16-byte pieces per lane through the staging block: a lane's checkpoint is NCHUNK
+                      // contiguous 48-byte segments in HBM
+                      constexpr int NBC = VSX_COLCK_NB(R, true);
+#pragma unroll
+                      for (int c = 0; c < VSX_COLCK_NCHUNK(R); ++c)
+                        {
+#pragma unroll
+                          for (int pc = 0; pc < 3; ++pc)
+                            {
+                              const int z = 4 * (3 * c + pc);
+                              if (3 * c + pc < NBC)
+                                *reinterpret_cast<u32x4 *>(RS + ck_slot * 12 + pc * 4) = (u32x4) {flatc(z), flatc(z + 1), flatc(z + 2), flatc(z + 3)};
+                            }
+                          flush_block(cck_blk + ((size_t) (t >> 4) * VSX_COLCK_NCHUNK(R) + c) * VSX_CKT_BLOCK_DW);
+                        }
+                    }
+                  else
+                    {
 #pragma unroll
                   for (int z = 0; z < 4 * VSX_COLCK_NB(R, true); z += 4)
                     __builtin_nontemporal_store((u32x4) {flatc(z), flatc(z + 1), flatc(z + 2), flatc(z + 3)}, reinterpret_cast<u32x4 *>(cb + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), ck_slot, z >> 2)));
+                    }
                 }
               else if (R % 2 == 0)
                 {
@@ -530,8 +621,11 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           step(t, hprev, hnext, std::true_type {}, std::false_type {}, std::false_type {});
           step(t + 1, hnext, hprev, std::true_type {}, std::true_type {}, std::false_type {});
         }
-      if (!TRACK && Dpg > 0)                                  // (a group without targets never becomes active; with overflow
-                                                              //  tracking the junk of the idle lanes would reach the min/max)
+      if (!TRACK && (QP8 || Dpg > 0))                         // (a group without targets never becomes active; with overflow
+                                                              //  tracking the junk of the idle lanes would reach the min/max.
+                                                              //  The transposed checkpoint stores need EVERY lane of the wave in
+                                                              //  the step -- each copies its share of the staging block -- so
+                                                              //  there the lanes of empty groups run along on junk)
         for (; t < t_switch; t += 2)
           {
             step(t, hprev, hnext, std::true_type {}, std::false_type {}, std::true_type {});
@@ -784,7 +878,8 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   const size_t steps = T.steps;
   const size_t nblk = (steps + 15) >> 4;
   const size_t rowsteps = ((size_t) nstrips * steps + 1) & ~(size_t) 1;
-  const size_t rowck_dw = (rowsteps >> 1) * VSX_ROWCK_PAIR_DW(CK8);
+  constexpr bool CKT = CK8 && (VSX_CKT != 0);      // transposed checkpoint layout (vsx_internal.h)
+  const size_t rowck_dw = CKT ? (((size_t) nstrips * steps) >> 3) * VSX_CKT_BLOCK_DW : (rowsteps >> 1) * VSX_ROWCK_PAIR_DW(CK8);
   constexpr size_t COL_DW = CK8 ? (size_t) 64 * 4 * VSX_COLCK_NB(R, true) : (size_t) 64 * (2 * R);     // column checkpoint dwords per wave
   const u32 * __restrict__ rowck = ck + T.dir_off;
   const u32 * __restrict__ colck = ck + T.dir_off + rowck_dw;
@@ -851,6 +946,37 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         dst[(2 * e) * 64] = __builtin_amdgcn_perm(v[e].y, v[e].x, half_sel) ^ bias2;
         dst[(2 * e + 1) * 64] = __builtin_amdgcn_perm(v[e].w, v[e].z, half_sel) ^ bias2;
       }
+  };
+  // transposed layout: the 17 steps gstart .. gstart + 16 of pipeline slot `slot` lie in (at most) three consecutive 8-step
+  // blocks, 48 contiguous bytes each: {H of the 8 steps, the 8 x 2 difference bytes}.  Nine 16-byte loads from <= 3 segments;
+  // entry cc + 1 of tbL = step gstart + cc.  Blocks outside [0, maxblk] are clamped (their entries are never used).
+  auto stage_top_t = [&](const u32 * rowbase, int slot, long gstart, long maxblk) {
+    const long b0 = gstart >> 3;                                 // floor, also for gstart = -1
+    const int o = (int) (gstart - 8 * b0);                       // 0 .. 7
+    Quad q[3][3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+      {
+        long b = b0 + e;
+        b = b < 0 ? 0 : (b > maxblk ? maxblk : b);
+        const u32 * src = rowbase + (size_t) b * VSX_CKT_BLOCK_DW + (size_t) slot * 12;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) q[e][pc] = *reinterpret_cast<const Quad *>(src + pc * 4);
+      }
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        {
+          const Quad & hq = q[e][i >> 2];
+          const u32 hw = (i & 3) == 0 ? hq.x : (i & 3) == 1 ? hq.y : (i & 3) == 2 ? hq.z : hq.w;
+          const Quad & dq = q[e][2];
+          const u32 dw2 = (i >> 1) == 0 ? dq.x : (i >> 1) == 1 ? dq.y : (i >> 1) == 2 ? dq.z : dq.w;
+          const u32 h = half_lo(hw, hi) & 0xffffu;
+          const int dd = (int) (int8_t) ((dw2 >> (8 * ((i & 1) * 2 + (hi ? 1 : 0)))) & 0xffu);
+          const int cc = 8 * e + i - o;
+          if (cc >= 0 && cc <= 16) tbL[(cc + 1) * 64 + tid] = h | ((h - (u32) dd) << 16);
+        }
   };
   auto inck = [&](u32 lo16) -> u32 { return FAST ? ((lo16 & 0xffffu) ^ ckb) : lo16; };     // a checkpoint value -> A's domain
   auto stage_symbols = [&](int c0) {
@@ -925,6 +1051,9 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         {
           const int Lp = L - 1;
           const int sp = Lp >> 4, lp = Lp & 15;
+          if (CKT)
+            stage_top_t(rowck, VSX_CK_SLOT(true, g, lp), (long) ((size_t) sp * steps) + (long) (c0 - 1 + lp), (long) ((((size_t) nstrips * steps) >> 3)) - 1);
+          else
           stage_top(rowck + (size_t) VSX_CK_SLOT(CK8, g, lp) * (CK8 ? 3 : 4), VSX_ROWCK_PAIR_DW(CK8), (long) ((size_t) sp * steps) + (long) (c0 - 1 + lp),
                     (long) (rowsteps >> 1) - 1);
           if (c0 == 0) tbL[64 + tid] = A::in((u32) (uint16_t) P.hleft[i0 - 1]);     // corner H(i0-1, -1)
@@ -964,11 +1093,21 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         {
           if (CK8)
             {
-              const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * COL_DW + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), VSX_CK_SLOT(true, g, l), 0);
               constexpr int NBQ = VSX_COLCK_NB(R, true);
               Quad fq[NBQ];
+              if (CKT)
+                {
+                  // piece b of the lane's checkpoint = piece b % 3 of its 48-byte segment in chunk b / 3
+                  const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * VSX_COLCK_NCHUNK(R) * VSX_CKT_BLOCK_DW + (size_t) VSX_CK_SLOT(true, g, l) * 12;
 #pragma unroll
-              for (int b = 0; b < NBQ; ++b) fq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * (4 * VSX_COLCK_CG));
+                  for (int b = 0; b < NBQ; ++b) fq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) (b / 3) * VSX_CKT_BLOCK_DW + (b % 3) * 4);
+                }
+              else
+                {
+                  const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * COL_DW + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), VSX_CK_SLOT(true, g, l), 0);
+#pragma unroll
+                  for (int b = 0; b < NBQ; ++b) fq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * (4 * VSX_COLCK_CG));
+                }
               auto flat = [&](int z) -> u32 {
                 const Quad & qd = fq[z >> 2];
                 return (z & 3) == 0 ? qd.x : (z & 3) == 1 ? qd.y : (z & 3) == 2 ? qd.z : qd.w;
@@ -1383,7 +1522,9 @@ extern "C" hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams
 // dwords of checkpoint storage one task needs (row + column checkpoints)
 extern "C" uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t rows, int tilt)
 {
-  const uint64_t rowck = (((nstrips * steps) + 1) >> 1) * VSX_ROWCK_PAIR_DW(tilt != 0);
   const uint64_t nblk = (steps + 15) >> 4;
+  if (tilt && VSX_CKT)      // transposed layout: 3 KB blocks; steps is a multiple of 8
+    return ((nstrips * steps) >> 3) * VSX_CKT_BLOCK_DW + nstrips * nblk * (uint64_t) VSX_COLCK_NCHUNK(rows) * VSX_CKT_BLOCK_DW;
+  const uint64_t rowck = (((nstrips * steps) + 1) >> 1) * VSX_ROWCK_PAIR_DW(tilt != 0);
   return rowck + nstrips * nblk * (tilt ? 64 * 4 * (uint64_t) VSX_COLCK_NB(rows, true) : 64 * 2 * rows);
 }

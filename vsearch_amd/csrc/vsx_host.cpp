@@ -488,6 +488,7 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   // (mismatch + 2g >= 0, the dummy rows' -ge(query left) + 2g >= 0).
   if (geqi == geti && geti > 0 && P.share_sub && c->ckpt && !c->tb_packed && !c->force_fallback &&
       std::min(match, mism) + 2 * geti >= 0 && 2 * geti - geql >= 0 &&
+      std::max(match, mism) + 2 * geti <= 255 && 2 * geti - geql <= 255 &&       // the LDS query profile of the class holds bytes
       // compressed checkpoints: H - F(next row) and H - E(next column) lie in [-g, max QR'] (plus the dummy rows' seed
       // go_ql + ge_ql + QR'): they must fit a signed byte
       geti <= 127 && std::max({goqi, goti, goqr + geqr - geti, gotr + getr - geti, goql + geql + goqi}) <= 127 &&
@@ -910,6 +911,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
           }
         t.steps = dmax + 16;                                // pipeline drain (15) rounded to an even step count: the DP
                                                             // kernel stores row checkpoints two steps at a time
+        if (pt.tilt && VSX_CKT) t.steps = (t.steps + 7u) & ~7u;   // ... and in blocks of 8 steps in the transposed layout
         const uint64_t total_lanes = (t.qlen + pt.rows - 1) / pt.rows;
         const uint64_t nstrips = (total_lanes + 15) / 16;
         const uint64_t nd = (uint64_t) (pt.rows + 3) / 4;

@@ -11,6 +11,16 @@
 #define VSX_MAX_SEQLEN_PRODUCT 25000000LL // reference core/align_simd.cpp:88
 #define VSX_TABLE_LEN (65536 + 64)
 #define VSX_CODE_SLACK 64          // readable bytes before and after a sequence set's 4-bit codes
+// TILT class: checkpoints leave the DP kernel through an LDS transposition, so that in HBM every pipeline lane owns CONTIGUOUS
+// 48-byte segments (8 steps of row checkpoints; a third of a column checkpoint at R = 16) while every store instruction still
+// writes 1 KB of full lines -- the traceback then reads whole segments instead of 12-16 bytes out of fifteen 128-byte lines per
+// tile (vsx_device.hip).  The step count of such a task is a multiple of 8.  MEASURED (r02, profiles/r02_ckt_ab.txt): the
+// traceback fetches 35 % fewer bytes (FETCH_SIZE 9.68e6 -> 6.26e6 KiB per launch) but runs only 1.7 % faster -- it is bound by
+// latency at 2.5 waves per SIMD, not by HBM -- while the DP kernel pays 5 % for the barriers and the extra LDS traffic:
+// 6 634 -> 6 384 GCUPS.  Kept as an A/B build (-DVSX_CKT=1), default OFF.
+#ifndef VSX_CKT
+#define VSX_CKT 0
+#endif
 
 // Device-side constants derived from the 14 post-fixup penalties (reference search16_init,
 // core/align_simd.cpp:1282-1376 and the QR/R vectors at :1629-1649).  "pk" = the int16 value

@@ -61,10 +61,18 @@ extern "C" int vsx_msa(uint32_t n, const char * const * seqs, const uint32_t * l
       if (!cigars[i]) return VSX_EINVAL;
       runs[i] = parse_cigar(cigars[i]);
       int64_t pos = 0;
+      char prev = 0;
       for (const Run & r : runs[i])
         {
           if (r.op == 'M' || r.op == 'I') pos += r.n;
-          else if (r.op == 'D') { if (pos > clen) return VSX_EINVAL; maxins[(size_t) pos] = std::max(maxins[(size_t) pos], r.n); }
+          else if (r.op == 'D')
+            {
+              // two adjacent 'D' runs would put more member symbols in front of one centroid position than maxins accounts
+              // for (the row fill below would run past alnlen); no aligner emits them, vsx_msa_device rejects them too
+              if (pos > clen || prev == 'D') return VSX_EINVAL;
+              maxins[(size_t) pos] = std::max(maxins[(size_t) pos], r.n);
+            }
+          prev = r.op;
         }
       if (pos != clen) return VSX_EINVAL;          // the CIGAR must span the centroid
     }
