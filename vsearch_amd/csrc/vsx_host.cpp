@@ -175,7 +175,9 @@ struct SharedSlot {
     std::lock_guard<std::mutex> lk(mu);
     if (cur && cur->bytes >= bytes) { out = cur; return hipSuccess; }
     auto b = std::make_shared<SharedBlock>();
-    hipError_t e = pool->get(bytes, &b->p, &b->bytes);
+    // a little headroom: the slices of a pipeline differ by a few per cent, and replacing a multi-GB block costs a hipMalloc
+    hipError_t e = pool->get(bytes + bytes / 8, &b->p, &b->bytes);
+    if (e == hipErrorOutOfMemory) { (void) hipGetLastError(); e = pool->get(bytes, &b->p, &b->bytes); }
     if (e != hipSuccess) { b->p = nullptr; return e; }
     b->pool = pool;
     cur = b;
@@ -215,7 +217,14 @@ struct vsx_ctx {
   VsxDevParams Pt {};               // the same scoring in TILTED coordinates (VsxDevParams::tilt, vsx_forward_kernel TILT); Pt.tilt == 0: unavailable
   DevBuf<int16_t> d_htop_t, d_hleft_t, d_matrix_t;
   ScratchPool pool;
-  SharedSlot shared_dir, shared_slab;   // declared after the pool: released first
+  // Two checkpoint blocks, used alternately by the plans of the context: the DP kernels of plan i+1 run while the traceback of
+  // plan i still reads its block, so the launch tails of one fill with the other's waves (a pipeline of small plans lost 15 %
+  // to tails when every plan waited for its predecessor's traceback: r02 timeline in DESIGN 5).  ev_tb[s] = "the last traceback
+  // that read block s has finished".
+  SharedSlot shared_dir[2], shared_slab;   // declared after the pool: released first
+  hipEvent_t ev_tb[2] = {nullptr, nullptr};
+  bool ev_tb_used[2] = {false, false};
+  std::atomic<unsigned> plan_seq {0};
   // pinned host memory: results cross PCIe into it (vsx_plan_fetch), one fetch at a time; grow-only
   std::mutex stage_mu;
   uint8_t * stage = nullptr;
@@ -223,6 +232,7 @@ struct vsx_ctx {
   std::vector<unsigned long long *> cursor_slots;   // idle pinned {run cursor, text cursor} pairs of finished plans
   ~vsx_ctx()
   {
+    for (hipEvent_t e : ev_tb) if (e) (void) hipEventDestroy(e);
     if (stage) (void) hipHostFree(stage);
     for (auto * c : cursor_slots) (void) hipHostFree(c);
   }
@@ -305,6 +315,7 @@ struct vsx_plan {
   PoolBuf<VsxTask> d_tasks;
   PoolBuf<uint32_t> d_pair_slot, d_pair_ids;
   SharedBuf<uint32_t> d_dir[1], d_slab;         // stream-ordered scratch shared by the context's plans
+  int dir_slot = 0;                             // which of the context's two checkpoint blocks
   PoolBuf<uint32_t> d_runs;
   PoolBuf<uint64_t> d_slab_off;
   PoolBuf<uint2> d_strip;
@@ -467,6 +478,8 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
       (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&c->stream_dn, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_tb[0], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_tb[1], hipEventDisableTiming)) != hipSuccess ||
       (e = c->d_htop.alloc(VSX_TABLE_LEN)) != hipSuccess || (e = c->d_hleft.alloc(VSX_TABLE_LEN)) != hipSuccess ||
       (e = c->d_matrix.alloc(256)) != hipSuccess ||
       (e = hipMemcpy(c->d_htop.p, htop.data(), VSX_TABLE_LEN * 2, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -532,7 +545,8 @@ void vsx_destroy(vsx_ctx * c)
   if (c->stream2) { (void) hipStreamSynchronize(c->stream2); (void) hipStreamDestroy(c->stream2); }
   if (c->stream_up) { (void) hipStreamSynchronize(c->stream_up); (void) hipStreamDestroy(c->stream_up); }
   if (c->stream_dn) { (void) hipStreamSynchronize(c->stream_dn); (void) hipStreamDestroy(c->stream_dn); }
-  c->shared_dir.reset();
+  c->shared_dir[0].reset();
+  c->shared_dir[1].reset();
   c->shared_slab.reset();
   c->pool.trim();
   delete c;
@@ -723,6 +737,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
 
   std::unique_ptr<vsx_plan> pl(new vsx_plan);
   pl->ctx = ctx; pl->Q = queries; pl->T = targets; pl->n_pairs = n_pairs;
+  pl->dir_slot = (int) (ctx->plan_seq.fetch_add(1) & 1u);
 
   // ---- the reference's closed-form / sentinel cases (no DP) ----
   // host threads classify contiguous slices: the common case (a pair for the GPU) is handled in place, the rare closed-form
@@ -870,11 +885,11 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
     {
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
-      free_b += ctx->pool.idle_bytes() + ctx->shared_dir.bytes();   // blocks this context can hand straight back / already holds
+      free_b += ctx->pool.idle_bytes() + ctx->shared_dir[pl->dir_slot].bytes();   // blocks this context can hand straight back / already holds
       dir_budget_bytes = std::min<uint64_t>((uint64_t) (free_b * 0.4), 128ull << 30);
       // stay inside the context's current checkpoint block unless it is less than half of what could be had: a slightly
       // larger request would cost another multi-second hipMalloc
-      const uint64_t have = ctx->shared_dir.bytes();
+      const uint64_t have = ctx->shared_dir[pl->dir_slot].bytes();
       if (have >= dir_budget_bytes / 2) dir_budget_bytes = have;
     }
   const uint64_t budget_dwords = std::max<uint64_t>(dir_budget_bytes / 4, 1);
@@ -1017,7 +1032,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   if (!pl->h_cursor) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&pl->h_cursor), 64, hipHostMallocDefault));
   // one checkpoint buffer, reused chunk after chunk: overlapping chunk k's traceback with chunk k+1's DP bought nothing
   // (both are issue-bound), while a second buffer doubled a multi-second hipMalloc
-  HIPCHK(pl->d_dir[0].alloc(ctx->shared_dir, &ctx->pool, max_dir));
+  HIPCHK(pl->d_dir[0].alloc(ctx->shared_dir[pl->dir_slot], &ctx->pool, max_dir));
   HIPCHK(pl->d_strip.alloc(&ctx->pool, max_strip));
   HIPCHK(pl->d_slab.alloc(ctx->shared_slab, &ctx->pool, max_slab));
   HIPCHK(pl->d_runs.alloc(&ctx->pool, pl->runs_capacity));
@@ -1070,14 +1085,17 @@ int vsx_plan_run(vsx_plan * pl)
   vsx_ctx * ctx = pl->ctx;
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream, st2 = ctx->stream2;
+  const int slot = pl->dir_slot;
   HIPCHK(hipMemsetAsync(pl->d_cursor.p, 0, 2 * sizeof(unsigned long long), st));
   HIPCHK(hipEventRecord(pl->ev_begin, st));
-  // per chunk: DP kernels on `st`, then its traceback on `st2`; the next chunk's DP waits for it (one checkpoint buffer)
+  // DP kernels on `st`, tracebacks + text on `st2`.  A plan's DP waits only for the last traceback that read ITS checkpoint
+  // block (the context alternates two), so it overlaps the previous plan's traceback; inside a plan the chunks share the block.
   for (size_t k = 0; k < pl->chunks.size(); ++k)
     {
       Chunk & c = pl->chunks[k];
       uint32_t * dir = pl->d_dir[0].p;
       if (k >= 1) HIPCHK(hipStreamWaitEvent(st, pl->chunks[k - 1].e2, 0));      // buffer reuse: the previous traceback is done
+      else if (ctx->ev_tb_used[slot]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_tb[slot], 0));
       HIPCHK(hipEventRecord(c.e0, st));
       for (const Launch & L : c.launches)
         HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, L.tilt ? ctx->Pt : ctx->P, pl->d_tasks.p + L.first, L.count,
@@ -1101,12 +1119,14 @@ int vsx_plan_run(vsx_plan * pl)
                                     pl->d_cursor.p, pl->d_out.p, st2));
       HIPCHK(hipEventRecord(c.e2, st2));
     }
-  if (!pl->chunks.empty()) HIPCHK(hipStreamWaitEvent(st, pl->chunks.back().e2, 0));   // st2 is in order
-  // run lists -> CIGAR text, records -> output arrays (pushop / finishop are part of the reference's timed path)
+  if (pl->chunks.empty()) HIPCHK(hipStreamWaitEvent(st2, pl->ev_begin, 0));          // (the cursor memset precedes the text kernel)
+  HIPCHK(hipEventRecord(ctx->ev_tb[slot], st2));
+  ctx->ev_tb_used[slot] = true;
+  // run lists -> CIGAR text, records -> output arrays (pushop / finishop are part of the reference's timed path); st2 is in order
   HIPCHK(vsx_launch_cigar_text(pl->d_out.p, pl->d_pair_ids.p, (uint32_t) pl->pair_ids.size(), pl->d_runs.p, pl->runs_capacity,
-                               pl->d_text.p, pl->text_capacity, pl->d_cursor.p + 1, pl->soa, st));
-  HIPCHK(hipMemcpyAsync(pl->h_cursor, pl->d_cursor.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipEventRecord(pl->ev_end, st));
+                               pl->d_text.p, pl->text_capacity, pl->d_cursor.p + 1, pl->soa, st2));
+  HIPCHK(hipMemcpyAsync(pl->h_cursor, pl->d_cursor.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st2));
+  HIPCHK(hipEventRecord(pl->ev_end, st2));
   pl->ran = true;
   pl->host_patched = false;            // the exported records of host-answered pairs point behind THIS run's device runs
   return VSX_OK;
@@ -1462,6 +1482,7 @@ int vsx_plan_export_hits(vsx_plan * pl, void * d_dst, uint64_t dst_bytes)
   if (dst_bytes < pl->n_pairs * sizeof(VsxPairOut)) return fail(VSX_EINVAL, "vsx_plan_export_hits: destination too small");
   HIPCHK(hipSetDevice(pl->ctx->device));
   hipStream_t st = pl->ctx->stream;
+  HIPCHK(hipEventSynchronize(pl->ev_end));          // the records are written on the traceback stream
   if (!pl->host_patched)
     {
       // pairs answered without DP live on the host: patch them into the device array once; their CIGARs (the Q == 0 closed
@@ -1605,13 +1626,14 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
       {
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return stop || i < consumed + 3; });      // at most three plans alive beyond the fetched ones
+          cv.wait(lk, [&] { return stop || i < consumed + 4; });      // at most four plans alive beyond the fetched ones
           if (stop) return;
         }
         vsx_plan * pl = nullptr;
         int rc = vsx_plan_create(ctx, &pl, queries, targets, cut[i + 1] - cut[i], qidx + cut[i], tidx + cut[i], slice_budget);
         if (rc == VSX_OK && filter && ctx->ckpt) rc = vsx_plan_set_filter(pl, filter);
         if (rc != VSX_OK) { plan_msg[i] = vsx_last_error(); if (pl) vsx_plan_destroy(pl); pl = nullptr; }
+        if (timing) std::fprintf(stderr, "  slice %zu (%llu pairs): planned at %.1f ms\n", i, (unsigned long long) (cut[i + 1] - cut[i]), (now() - t_begin) * 1e3);
         std::lock_guard<std::mutex> lk(mu);
         plans[i] = pl; plan_rc[i] = rc; ready = i + 1;
         cv.notify_all();
@@ -1622,7 +1644,15 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
   std::string msg;
   size_t launched = 0;
   auto finish = [&](size_t i) {           // fetch slice i straight into its part of the result arrays, release it
+    const double tf0 = now();
     int frc = sink ? fetch_ranked_core(plans[i], cut[i], qidx + cut[i], *sink) : fetch_core(plans[i], dest_at(out, cut[i]));
+    if (timing)
+      {
+        vsx_timing tm;
+        if (vsx_plan_sync(plans[i], &tm) == VSX_OK)
+          std::fprintf(stderr, "  slice %zu: fetch %.1f .. %.1f ms, kernels %.2f ms (fwd %.2f tb %.2f)\n", i, (tf0 - t_begin) * 1e3, (now() - t_begin) * 1e3,
+                       tm.total_ms, tm.forward_ms, tm.traceback_ms);
+      }
     vsx_plan_destroy(plans[i]);
     plans[i] = nullptr;
     { std::lock_guard<std::mutex> lk(mu); consumed = i + 1; }
@@ -1637,11 +1667,15 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
       }
       if (plan_rc[i] != VSX_OK) { rc = plan_rc[i]; msg = plan_msg[i]; break; }
       rc = vsx_plan_run(plans[i]);                       // asynchronous: queued behind slice i-1 on the context's streams
+      if (timing) std::fprintf(stderr, "  slice %zu: queued at %.1f ms\n", i, (now() - t_begin) * 1e3);
       if (rc != VSX_OK) { msg = vsx_last_error(); break; }
       launched = i + 1;
-      if (i > 0) { rc = finish(i - 1); if (rc != VSX_OK) msg = vsx_last_error(); }
+      // two slices stay queued behind the one being fetched: the DP kernels of slice i+1 overlap the traceback of slice i, so
+      // the GPU needs the next launch in its queue before the previous slice has drained
+      if (i >= 2) { rc = finish(i - 2); if (rc != VSX_OK) msg = vsx_last_error(); }
     }
-  if (rc == VSX_OK && launched == S) { rc = finish(S - 1); if (rc != VSX_OK) msg = vsx_last_error(); }
+  for (size_t i = (launched >= 2 ? launched - 2 : 0); i < launched && rc == VSX_OK && launched == S; ++i)
+    { rc = finish(i); if (rc != VSX_OK) msg = vsx_last_error(); }
   {
     std::lock_guard<std::mutex> lk(mu);
     stop = true;
