@@ -277,7 +277,24 @@ def main():
         "gen_s": round(t_gen, 2),
     }
     if pmc:
-        out["roofline"]["pmc"] = {k: pmc[k] for k in ("kernel_source_sha", "forward", "traceback", "valu_issue") if k in pmc}
+        sq = pmc["forward"].get("sq", {})
+        tb = pmc.get("traceback", {})
+        block = {"kernel_source_sha": pmc["kernel_source_sha"],
+                 "forward": {k: pmc["forward"].get(k) for k in ("hbm_bytes_per_launch", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch")},
+                 "traceback": {"hbm_bytes_per_launch": tb.get("hbm_bytes_per_launch"), "SQ_INSTS_VALU": tb.get("sq", {}).get("SQ_INSTS_VALU"),
+                               "SQ_WAIT_ANY_over_WAVE_CYCLES": round(tb["sq"]["SQ_WAIT_ANY"] / tb["sq"]["SQ_WAVE_CYCLES"], 3)
+                               if tb.get("sq", {}).get("SQ_WAVE_CYCLES") else None,
+                               "note": "latency / occupancy bound (10 waves per CU), not HBM bound: profiles/r02_ckt_ab.txt"},
+                 "forward_sq": {k: sq.get(k) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
+                                                       "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE")}}
+        if sq.get("SQ_INSTS_VALU"):
+            # measured VALU issue occupancy of the DP kernel: wave-instructions x issue cycles per instruction of the steady loop's
+            # mix (ISA count per two steps: 128 v_pk_max_u16 + 40 v_perm_b32 + 26 v_pk_sub_i16 + 6 DPP at 4 cycles, 69 v_add / v_sub_u32
+            # + ~30 other VOP2 at 2: 1000 cycles / 300 instructions) over SIMD-cycles of the launch measured in THIS run
+            cpi = 1000.0 / 300.0
+            block["valu_issue_occupancy"] = round(sq["SQ_INSTS_VALU"] * cpi / (256 * 4 * fwd_avg_ms * 1e-3 * 2.4e9), 3)
+            block["valu_instructions_per_lane_row"] = round(sq["SQ_INSTS_VALU"] * 64 / (cells_per_launch / 2.0), 2)
+        out["roofline"]["pmc"] = block
     else:
         out["roofline"]["traffic_note"] = pmc_note
     if gather_check is not None:

@@ -41,7 +41,11 @@ typedef struct vsx_search_opts {
   int64_t wordlength;       /* 8   (3..15)                                                        */
   int64_t minwordmatches;   /* -1 = table minwordmatches_defaults (core/searchcore.hpp:75-76)     */
   int32_t iddef;            /* 2                                                                  */
-  int32_t soft_mask;        /* 0: --qmask/--dbmask none (lower case searchable); 1: soft (lower case excluded from k-mers) */
+  int32_t soft_mask;        /* 0: --qmask/--dbmask none (lower case searchable); 1: soft (lower case excluded from k-mers).
+                               PRECONDITION: the reference commands default to --qmask dust --dbmask dust; DUST is not part of this
+                               path -- a caller that wants the default behaviour dust-masks first (lower-casing the masked
+                               regions, as core/mask.cpp does) and sets soft_mask = 1 (host k-mer path); byte parity with the
+                               reference CLI is tested with --qmask none --dbmask none */
   int64_t maxsubs, maxgaps, mincols, maxdiffs;
   double  query_cov, target_cov, maxid, mid;
   int32_t leftjust, rightjust;

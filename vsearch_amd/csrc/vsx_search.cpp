@@ -1534,6 +1534,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
   uint32_t nclusters = 0;
   Acct acct;
   double t_kmer = 0;
+  double tm_words = 0, tm_rebuild = 0, tm_rank = 0, tm_stages = 0, tm_near = 0, tm_spec = 0, tm_recon = 0;      // VSX_DEBUG_TIMING
   const int64_t hit_capacity = std::min<int64_t>(S->ma + S->mr - 1, S->tophits);
 
   const int nth = std::max(1, S->threads);
@@ -1589,16 +1590,21 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
             work(0);
             for (auto & th : pool) th.join();
           }
+          tm_words += now_s() - t0;
+          const double tb0 = now_s();
           if (centroid_list.size() != cix_built)
             {
               const int irc = vsx_kmer_index_rebuild(cix.get(), centroid_list.data(), centroid_list.size());
               if (irc != VSX_OK) return irc;
               cix_built = centroid_list.size();
             }
+          tm_rebuild += now_s() - tb0;
+          const double tr0 = now_s();
           std::vector<std::vector<Cand>> cands(wn);
           const int krc = device_rank(S, cix.get(), &centroid_list, wn, kmers, (uint32_t) std::max<int64_t>(S->tophits, 1), 1024, true,
                                       cands, fallback, kacct);
           if (krc != VSX_OK) return krc;
+          tm_rank += now_s() - tr0;
           for (uint64_t k = 0; k < wn; ++k) st[k].cands = std::move(cands[k]);
           for (uint64_t k : fallback)
             {
@@ -1627,10 +1633,12 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       t_kmer += now_s() - t0;
 
       // ---- phase 1b: staged GPU search (queries and targets both live in the database sequence set) ----
+      const double ts0 = now_s();
       int rc = run_stages(*S, st, [&](uint64_t k) { return seq_of(s0 + k); }, [&](uint64_t k) { return seq_of(s0 + k); },
                           [&](uint64_t k) { return (int64_t) S->len[s0 + k]; },
                           [&](uint64_t k) { return (uint32_t) (s0 + k); }, [&](uint64_t k) { return S->meta_of(s0 + k); }, S->dbset, acct);
       if (rc != VSX_OK) return rc;
+      tm_stages += now_s() - ts0;
 
       // ---- phase 1c: intra-round shared k-mer counts (unique_count_shared, core/unique.cpp:356-395) and the
       //      speculative alignments of (member i, earlier member k) pairs that the fix-up could ask for ----
@@ -1692,6 +1700,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
           }
       }
       t_kmer += now_s() - t0;
+      tm_near += now_s() - t0;
       vsx_results spec;
       std::memset(&spec, 0, sizeof spec);
       if (!sq.empty())
@@ -1699,11 +1708,13 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
           t0 = now_s();
           rc = vsx_align_pairs(S->ctx, S->dbset, S->dbset, sq.size(), sq.data(), stg.data(), &spec);
           acct.t_align += now_s() - t0;
+          tm_spec += now_s() - t0;
           if (rc != VSX_OK) return rc;
           acct.pairs += sq.size();
         }
 
       // ---- phase 2: sequential reconciliation in processing order ----
+      const double t20 = now_s();
       std::vector<uint32_t> extras;                                  // round members that became centroids, in order
       for (uint64_t i = 0; i < wn; ++i)
         {
@@ -1804,7 +1815,12 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
             }
         }
       vsx_results_free(&spec);
+      tm_recon += now_s() - t20;
     }
+  if (std::getenv("VSX_DEBUG_TIMING"))
+    std::fprintf(stderr, "vsx_cluster_fast: words %.2f  centroid-index rebuild %.2f  rank vs centroids %.2f  staged search %.2f (align calls %.2f)  "
+                         "intra-round counts %.2f  speculative align %.2f  reconcile %.2f  total %.2f s\n",
+                 tm_words, tm_rebuild, tm_rank, tm_stages, acct.t_align - tm_spec, tm_near, tm_spec, tm_recon, now_s() - t_begin);
 
   int rc = marshal_hits(kept, &out->hits);
   if (rc != VSX_OK) return rc;
