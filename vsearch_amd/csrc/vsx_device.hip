@@ -835,8 +835,12 @@ struct __attribute__((aligned(4))) Trio { u32 x, y, z; };
 #include "vsx_accept.h"
 
 // CK8 = the compressed checkpoint layout of the TILT class (VSX_ROWCK_PAIR_DW / VSX_COLCK_NB): FAST arithmetic, tilted constants
+// Occupancy (r02 PMC: the kernel is latency bound -- 40 % of the wave cycles in s_waitcnt at 10 waves per CU, profiles/r02_ckt_ab.txt):
+// a workgroup is TWO independent waves (no barrier after the table set-up) that share the score table, the symbols of a tile are
+// packed two to a byte, the boundary keeps only the 17 entries that are read and the tilted class stores its scores (0 .. 255) as
+// bytes: 13.0 KB of LDS per wave at R = 16 instead of 14.75 -> 12 waves per CU = the 3 per SIMD the 168 VGPRs allow.
 template <int R, bool FAST, bool CK8 = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((R == 14 || R == 16) ? 3 : (R >= 28 ? 2 : 1), 8)))      // R = 14, 16: <= 168 VGPRs, R >= 28: <= 256
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu((R == 14 || R == 16) ? 3 : (R >= 28 ? 2 : 1), 8)))      // R = 14, 16: <= 168 VGPRs, R >= 28: <= 256
 vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTask * __restrict__ tasks,
                         const u32 * __restrict__ pair_slot, const u32 * __restrict__ pair_ids, u32 npairs,
                         const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
@@ -850,17 +854,22 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   static_assert(!CK8 || FAST, "compressed checkpoints belong to the TILT class");
   constexpr int ND = (R + 3) / 4;
   constexpr bool TOPPAD = FAST;                    // slot layout of position 0, see vsx_forward_kernel
-  __shared__ int16_t Ssh[512];                     // S[target code][query code], row stride 32; query "code" 16 = a dummy row
-  __shared__ uint16_t bitsL[16 * ND * 64];         // [column in tile][4-row group][lane]: this pair's 16 direction bits
-  __shared__ u32 tbL[19 * 64];                     // top boundary of the tile: H (low 16) | F (high 16); entry cc + 1 = column c0 - 1 + cc
-  __shared__ uint8_t symL[16 * 64];                // target symbols of the tile's columns
-  const int tid = (int) threadIdx.x;
-  for (int x = tid; x < 512; x += 64)
-    Ssh[x] = ((x & 31) < 16) ? P.matrix[(x >> 5) * 16 + (x & 15)] : (int16_t) (-P.top_step + 2 * P.tilt);
+  typedef typename std::conditional<CK8, uint8_t, int16_t>::type SshT;      // tilted scores are 0 .. 255 (planner-checked)
+  __shared__ SshT Ssh[512];                        // S[target code][query code], row stride 32; query "code" 16 = a dummy row
+  __shared__ uint16_t bitsL_all[2 * 16 * ND * 64]; // per wave: [column in tile][4-row group][lane]: this pair's 16 direction bits
+  __shared__ u32 tbL_all[2 * 17 * 64];             // per wave: top boundary of the tile, H (low 16) | F (high 16), entries 1 .. 17 (entry cc + 1 = column c0 - 1 + cc)
+  __shared__ uint8_t symL_all[2 * 8 * 64];         // per wave: target symbols of the tile's columns, two columns per byte
+  const int tid = (int) (threadIdx.x & 63);        // lane; the two waves of a workgroup never synchronise after the set-up
+  const int wv = (int) (threadIdx.x >> 6);
+  uint16_t * const bitsL = bitsL_all + wv * (16 * ND * 64);
+  u32 * const tbL = tbL_all + wv * (17 * 64) - 64;         // indexed 1 .. 17
+  uint8_t * const symL = symL_all + wv * (8 * 64);
+  for (int x = (int) threadIdx.x; x < 512; x += 128)
+    Ssh[x] = (SshT) (((x & 31) < 16) ? P.matrix[(x >> 5) * 16 + (x & 15)] : (int16_t) (-P.top_step + 2 * P.tilt));
   __syncthreads();
 
   // every lane of the wave stays in the tile loop until all are done (wave-uniform bounds, shuffles)
-  const u32 k = blockIdx.x * 64 + tid;
+  const u32 k = blockIdx.x * 128 + (u32) threadIdx.x;
   const bool valid = k < npairs;
   const u32 ts = pair_slot[valid ? k : 0];
   const u32 task = ts >> 3, sl = ts & 7;
@@ -926,8 +935,8 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
             const u32 h0 = half_lo(v3[e].x, hi) & 0xffffu, h1 = half_lo(v3[e].y, hi) & 0xffffu;
             const u32 dd = hi ? (v3[e].z >> 8) : v3[e].z;
             const int d0 = (int) (int8_t) (dd & 0xffu), d1 = (int) (int8_t) ((dd >> 16) & 0xffu);
-            dst[(2 * e) * 64] = h0 | ((h0 - (u32) d0) << 16);
-            dst[(2 * e + 1) * 64] = h1 | ((h1 - (u32) d1) << 16);
+            if (e > 0 || par == 0) dst[(2 * e) * 64] = h0 | ((h0 - (u32) d0) << 16);          // entry 0 does not exist
+            if (e < 8 || par == 1) dst[(2 * e + 1) * 64] = h1 | ((h1 - (u32) d1) << 16);      // nor entry 18
           }
         return;
       }
@@ -943,8 +952,8 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
 #pragma unroll
     for (int e = 0; e < 9; ++e)
       {
-        dst[(2 * e) * 64] = __builtin_amdgcn_perm(v[e].y, v[e].x, half_sel) ^ bias2;
-        dst[(2 * e + 1) * 64] = __builtin_amdgcn_perm(v[e].w, v[e].z, half_sel) ^ bias2;
+        if (e > 0 || par == 0) dst[(2 * e) * 64] = __builtin_amdgcn_perm(v[e].y, v[e].x, half_sel) ^ bias2;
+        if (e < 8 || par == 1) dst[(2 * e + 1) * 64] = __builtin_amdgcn_perm(v[e].w, v[e].z, half_sel) ^ bias2;
       }
   };
   // transposed layout: the 17 steps gstart .. gstart + 16 of pipeline slot `slot` lie in (at most) three consecutive 8-step
@@ -984,7 +993,11 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
 #pragma unroll
     for (int e = 0; e < 4; ++e) w[e] = *reinterpret_cast<const u32_unaligned *>(d + c0 + 4 * e);   // VSX_CODE_SLACK bytes follow the codes
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) symL[cc * 64 + tid] = (uint8_t) ((w[cc >> 2] >> (8 * (cc & 3))) & 15u);
+    for (int c2 = 0; c2 < 8; ++c2)
+      {
+        const u32 lo = (w[c2 >> 1] >> (16 * (c2 & 1))) & 15u, hi4 = (w[c2 >> 1] >> (16 * (c2 & 1) + 8)) & 15u;
+        symL[c2 * 64 + tid] = (uint8_t) (lo | (hi4 << 4));
+      }
   };
 
   int i = live ? Q - 1 : -1, j = live ? D - 1 : -1;
@@ -1174,12 +1187,12 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
           const u32 tbv = tbL[(cc + 2) * 64 + tid];
           const u32 topH = tbv & 0xffffu;
           u32 F = (L == 0) ? A::sub(topH, qrt) : (tbv >> 16);
-          const u32 b16 = (u32) symL[cc * 64 + tid] * 32u;
+          const u32 b16 = (((u32) symL[(cc >> 1) * 64 + tid] >> (4 * (cc & 1))) & 15u) * 32u;
           u32 Hd = diag;
           u32 acc = 0;
           auto row = [&](int x, auto int_tag) __attribute__((always_inline)) {
             constexpr bool INT = decltype(int_tag)::value;
-            const u32 V = A::score(Ssh[b16 + qa[x]]);
+            const u32 V = A::score((int16_t) Ssh[b16 + qa[x]]);
             const u32 h0 = A::add(Hd, V);
             const u32 dU = A::dif(h0, F);
             const u32 h1 = A::max(h0, F);
@@ -1494,7 +1507,7 @@ static hipError_t launch_tbck(const VsxDevParams & P, const VsxFilterDev & F, co
                               const uint32_t * ck, const VsxSlotOut * slot, uint32_t * slab, const uint64_t * slab_off,
                               uint32_t * runs, uint64_t cap, unsigned long long * cursor, VsxPairOut * out, hipStream_t st)
 {
-  hipLaunchKernelGGL((vsx_traceback_ck_kernel<R, FAST, CK8>), dim3((npairs + 63) / 64), dim3(64), 0, st,
+  hipLaunchKernelGGL((vsx_traceback_ck_kernel<R, FAST, CK8>), dim3((npairs + 127) / 128), dim3(128), 0, st,
                      P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, cap, cursor, out);
   return hipGetLastError();
 }
