@@ -53,6 +53,7 @@ def main():
         o = _lib.SearchOpts()
         lib.vsx_search_opts_default(C.byref(o))
         o.id = a.id
+        o.maxrejects = 8            # --cluster_fast default (cli.cc:4163-4167); the library default 32 is usearch_global's
         h = C.c_void_p()
         check(lib.vsx_searcher_create(al.h, C.byref(h), C.byref(o), len(lens), C.cast(C.c_char_p(blob), C.c_void_p),
                                       len(blob), vp(offs), vp(lens)), "vsx_searcher_create")

@@ -1551,9 +1551,15 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
   // members of the current round (the intra-round shared-word counts of evaluate_extra_hits)
   const bool dev_kmer = device_kmer_ok(*S);
   struct IxDel { void operator()(VsxKmerIndex * p) const { vsx_kmer_index_destroy(p); } };
-  std::unique_ptr<VsxKmerIndex, IxDel> cix, rix;
+  // The centroid index grows by up to `round` sequences per round (Dbindex::add_sequence, cluster.cpp:1009).  Rebuilding it
+  // every round cost 15 % of a 1 M-sequence run and grows quadratically; instead a MAIN index is rebuilt only when the DELTA
+  // index over the centroids added since has grown past an eighth of it, the small delta is rebuilt every round, and a query is
+  // counted against both: a centroid lives in exactly one of them, thresholds are per sequence, and the union of the two
+  // top-N selections contains the top N of the union.
+  std::unique_ptr<VsxKmerIndex, IxDel> cix, dix, rix;
   std::vector<uint32_t> centroid_list;                   // sequence numbers of the centroids, ascending
-  size_t cix_built = 0;
+  std::vector<uint32_t> delta_list;                      // the tail of centroid_list the delta index stands for
+  size_t main_n = 0, delta_built = 0;                    // centroids in the main index; centroid count when the delta was last built
   KmerAcct kacct;
   if (dev_kmer)
     {
@@ -1561,8 +1567,35 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       int irc = vsx_kmer_index_create_empty(S->ctx, S->dbset, S->w, &a);
       cix.reset(a);
       if (irc == VSX_OK) { irc = vsx_kmer_index_create_empty(S->ctx, S->dbset, S->w, &b); rix.reset(b); }
+      if (irc == VSX_OK) { VsxKmerIndex * d = nullptr; irc = vsx_kmer_index_create_empty(S->ctx, S->dbset, S->w, &d); dix.reset(d); }
       if (irc != VSX_OK) return irc;
     }
+
+  // unique words of a round's members do not depend on any result: a helper computes them one round ahead (device k-mer path)
+  std::vector<std::vector<uint32_t>> pre_kmers;
+  uint64_t pre_s0 = UINT64_MAX;
+  std::thread pre_thread;
+  std::vector<std::vector<uint64_t>> pre_seen;
+  auto words_of_round = [&](uint64_t a0, std::vector<std::vector<uint32_t>> & dst, std::vector<std::vector<uint64_t>> & seen, int threads) {
+    const uint64_t cnt = std::min<uint64_t>(round, n - a0);
+    dst.assign(cnt, {});
+    if (seen.size() < (size_t) threads) seen.resize((size_t) threads, std::vector<uint64_t>(S->w < 10 ? (nk + 63) / 64 : 1, 0));
+    std::atomic<uint64_t> next {0};
+    auto work = [&](int tid) {
+      for (;;)
+        {
+          const uint64_t k = next.fetch_add(16);
+          if (k >= cnt) break;
+          for (uint64_t x = k; x < std::min(cnt, k + 16); ++x) unique_kmers(seq_of(a0 + x), S->len[a0 + x], S->w, false, dst[x], seen[(size_t) tid]);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto & th : pool) th.join();
+  };
+  struct Joiner { std::thread & t; ~Joiner() { if (t.joinable()) t.join(); } } joiner {pre_thread};
+  std::vector<std::vector<uint64_t>> main_seen;
 
   for (uint64_t s0 = 0; s0 < n; s0 += round)
     {
@@ -1575,35 +1608,72 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       double t0 = now_s();
       if (dev_kmer)
         {
-          {
-            std::atomic<uint64_t> next {0};
-            auto work = [&](int tid) {
-              for (;;)
-                {
-                  const uint64_t k = next.fetch_add(1);
-                  if (k >= wn) break;
-                  unique_kmers(seq_of(s0 + k), S->len[s0 + k], S->w, false, kmers[k], scratch[(size_t) tid].seen);
-                }
-            };
-            std::vector<std::thread> pool;
-            for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
-            work(0);
-            for (auto & th : pool) th.join();
-          }
+          if (pre_thread.joinable()) pre_thread.join();
+          if (pre_s0 == s0) kmers.swap(pre_kmers);
+          else words_of_round(s0, kmers, main_seen, nth);
+          if (s0 + round < n)
+            {
+              pre_s0 = s0 + round;
+              pre_thread = std::thread([&, a0 = s0 + round]() { words_of_round(a0, pre_kmers, pre_seen, std::max(1, nth / 2)); });
+            }
           tm_words += now_s() - t0;
           const double tb0 = now_s();
-          if (centroid_list.size() != cix_built)
+          if (centroid_list.size() != delta_built)
             {
-              const int irc = vsx_kmer_index_rebuild(cix.get(), centroid_list.data(), centroid_list.size());
-              if (irc != VSX_OK) return irc;
-              cix_built = centroid_list.size();
+              const size_t total = centroid_list.size();
+              if (total - main_n > main_n / 8 + 2 * round)
+                {
+                  const int irc = vsx_kmer_index_rebuild(cix.get(), centroid_list.data(), total);       // main: everything
+                  if (irc != VSX_OK) return irc;
+                  main_n = total;
+                  delta_list.clear();
+                  static const uint32_t none = 0;                                                        // (a null list would mean "the whole set")
+                  const int drc = vsx_kmer_index_rebuild(dix.get(), &none, 0);
+                  if (drc != VSX_OK) return drc;
+                }
+              else
+                {
+                  delta_list.assign(centroid_list.begin() + (long) main_n, centroid_list.end());
+                  const int drc = vsx_kmer_index_rebuild(dix.get(), delta_list.data(), delta_list.size());
+                  if (drc != VSX_OK) return drc;
+                }
+              delta_built = total;
             }
           tm_rebuild += now_s() - tb0;
           const double tr0 = now_s();
           std::vector<std::vector<Cand>> cands(wn);
-          const int krc = device_rank(S, cix.get(), &centroid_list, wn, kmers, (uint32_t) std::max<int64_t>(S->tophits, 1), 1024, true,
-                                      cands, fallback, kacct);
+          const uint32_t keep_n = (uint32_t) std::max<int64_t>(S->tophits, 1);
+          int krc = device_rank(S, cix.get(), &centroid_list, wn, kmers, keep_n, 1024, true, cands, fallback, kacct);
           if (krc != VSX_OK) return krc;
+          if (!delta_list.empty())
+            {
+              std::vector<std::vector<Cand>> dc(wn);
+              std::vector<uint64_t> fb2;
+              krc = device_rank(S, dix.get(), &delta_list, wn, kmers, keep_n, 1024, true, dc, fb2, kacct);
+              if (krc != VSX_OK) return krc;
+              // union of the two selections, the heap's total order, the heap's size
+              std::atomic<uint64_t> nx {0};
+              auto merge = [&]() {
+                for (;;)
+                  {
+                    const uint64_t k = nx.fetch_add(64);
+                    if (k >= wn) break;
+                    for (uint64_t x = k; x < std::min<uint64_t>(wn, k + 64); ++x)
+                      {
+                        if (dc[x].empty()) continue;
+                        std::vector<Cand> & c = cands[x];
+                        c.insert(c.end(), dc[x].begin(), dc[x].end());
+                        const size_t kp = std::min<size_t>(c.size(), (size_t) keep_n);
+                        std::partial_sort(c.begin(), c.begin() + (long) kp, c.end(), cand_better);
+                        c.resize(kp);
+                      }
+                  }
+              };
+              std::vector<std::thread> pool;
+              for (int t = 1; t < std::min(nth, 8); ++t) pool.emplace_back(merge);
+              merge();
+              for (auto & th : pool) th.join();
+            }
           tm_rank += now_s() - tr0;
           for (uint64_t k = 0; k < wn; ++k) st[k].cands = std::move(cands[k]);
           for (uint64_t k : fallback)
