@@ -1786,6 +1786,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       // ---- phase 2: sequential reconciliation in processing order ----
       const double t20 = now_s();
       std::vector<uint32_t> extras;                                  // round members that became centroids, in order
+      std::vector<uint8_t> is_extra(wn, 0);
       for (uint64_t i = 0; i < wn; ++i)
         {
           const uint64_t seqno = s0 + i;
@@ -1796,25 +1797,38 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
           // evaluate_extra_hits (:601-856)
           int added = 0;
           {
-            size_t np = 0;                                           // near[i] is sorted by k, extras is increasing too
-            for (uint32_t k : extras)
+            // candidates = this round's new centroids (extras, increasing) with enough shared words.  A member with words and a
+            // positive threshold can only qualify through a near[] entry (shared >= 1), so walk near[i] (sorted by k) and keep the
+            // entries that are extras -- the same subsequence the loop over all extras would visit, without its O(extras) cost;
+            // members without words (every extra qualifies: enough_kmers with kmersamplecount 0) take the full loop
+            auto try_insert = [&](uint32_t k, uint32_t shared) {
+              if (!enough_kmers(*S, shared, (uint32_t) kmers[i].size())) return;
+              const uint32_t length = S->len[s0 + k];
+              int64_t x = (int64_t) hits.size();
+              while (x > 0 && ((hits[(size_t) x - 1].count < shared) ||
+                               (hits[(size_t) x - 1].count == shared && S->len[hits[(size_t) x - 1].target] > length)))
+                --x;
+              if (x < hit_capacity)
+                {
+                  if ((int64_t) hits.size() >= hit_capacity) hits.pop_back();
+                  Hit h;
+                  h.target = (uint32_t) (s0 + k);
+                  h.count = shared;
+                  hits.insert(hits.begin() + x, std::move(h));
+                  ++added;
+                }
+            };
+            if (!kmers[i].empty() && S->minwordmatches > 0)
               {
-                while (np < near[i].size() && near[i][np].k < k) ++np;
-                const uint32_t shared = (np < near[i].size() && near[i][np].k == k) ? near[i][np].shared : 0;
-                if (!enough_kmers(*S, shared, (uint32_t) kmers[i].size())) continue;
-                const uint32_t length = S->len[s0 + k];
-                int64_t x = (int64_t) hits.size();
-                while (x > 0 && ((hits[(size_t) x - 1].count < shared) ||
-                                 (hits[(size_t) x - 1].count == shared && S->len[hits[(size_t) x - 1].target] > length)))
-                  --x;
-                if (x < hit_capacity)
+                for (const Near & nr : near[i]) if (is_extra[nr.k]) try_insert(nr.k, nr.shared);
+              }
+            else
+              {
+                size_t np = 0;                                           // near[i] is sorted by k, extras is increasing too
+                for (uint32_t k : extras)
                   {
-                    if ((int64_t) hits.size() >= hit_capacity) hits.pop_back();
-                    Hit h;
-                    h.target = (uint32_t) (s0 + k);
-                    h.count = shared;
-                    hits.insert(hits.begin() + x, std::move(h));
-                    ++added;
+                    while (np < near[i].size() && near[i][np].k < k) ++np;
+                    try_insert(k, (np < near[i].size() && near[i][np].k == k) ? near[i][np].shared : 0);
                   }
               }
           }
@@ -1878,6 +1892,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
             {
               clusterno[seqno] = nclusters++;
               extras.push_back((uint32_t) i);
+              is_extra[i] = 1;
               S->is_centroid[seqno] = 1;
               for (uint32_t km : kmers[i]) inc.post[km].push_back((uint32_t) seqno);    // Dbindex::add_sequence (:1009)
               centroid_list.push_back((uint32_t) seqno);
