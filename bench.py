@@ -163,7 +163,7 @@ def main():
         if world > 1:
             # the only collective on the path: final gather of the hit records and the CIGAR run words over RCCL/xGMI
             # (the same function the world-2 tests drive: vsearch_amd/sharding.py)
-            gathered = sharding.export_and_gather(plan, n_pairs, dist, dev, scratch)
+            gathered = sharding.export_and_gather(plan, n_pairs, dist, dev, scratch, dst=0)      # to rank 0, which would write the output
         return tm
 
     def barrier():

@@ -138,6 +138,13 @@ d = sharding.decode_records(rec_all)
 cig = sharding.cigars_from_gather(rec_all, runs_all)
 for j, g in enumerate(order):
     assert (int(d["score"][j]), int(d["aligned"][j]), int(d["matches"][j]), int(d["mismatches"][j]), int(d["gaps"][j]), cig[j]) == tuple(rows[g]), (j, g)
+# the production shape: only rank 0 receives
+r0, u0, c0 = sharding.gather_results(torch.from_numpy(rec), torch.from_numpy(runs.view(np.int32)), dist, dst=0)
+assert c0 == counts
+if rank == 0:
+    assert torch.equal(r0, rec_all) and torch.equal(u0, runs_all)
+else:
+    assert r0 is None and u0 is None
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

@@ -36,8 +36,11 @@ void vsx_kmer_index_destroy(VsxKmerIndex * ix);
 // out: per query the (target, count) records with count >= minmatch[query] that survive the device selection.
 // keep = size of the reference's heap (tophits): per query the device keeps every record whose count is >= the
 // keep-th largest count (a superset of the heap under any tie-break); the caller applies the total order.
+// Thread-safe against other count batches on the same index (each call leases its own scratch set and stream; at most two run
+// at once, further callers wait), NOT against vsx_kmer_index_rebuild.  stats_out: this call's kernel time / increments / records.
 int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_start, const uint32_t * qk,
-                         const uint32_t * minmatch, uint32_t keep, VsxKmerResult & out, uint32_t cap_hint = 0);
+                         const uint32_t * minmatch, uint32_t keep, VsxKmerResult & out, uint32_t cap_hint = 0,
+                         VsxKmerStats * stats_out = nullptr);
 const VsxKmerStats * vsx_kmer_stats(const VsxKmerIndex * ix);
 
 #endif

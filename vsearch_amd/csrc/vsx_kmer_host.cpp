@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
 
 extern "C" void vsx_internal_set_error(const char * msg);
@@ -41,6 +43,27 @@ template <typename T> struct Buf {
 
 }  // namespace
 
+// Per-call state of a counting batch.  The index itself is read-only between rebuilds, so several batches may count against
+// it at once, each with its own scratch and stream: the search runs two windows' k-mer stages concurrently, one's host work
+// (CSR, uploads, record download, ranking) under the other's counting kernel.
+struct KmerScratch {
+  hipStream_t st = nullptr;
+  Buf<uint64_t> d_qk_start;
+  Buf<uint32_t> d_qk, d_minmatch;
+  Buf<uint64_t> d_rec, d_dense, d_sel_mn, d_sel_off;    // uint2 records (target, count); (kept, seen) per slot
+  Buf<uint32_t> d_qcount;
+  Buf<unsigned long long> d_cursor;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  uint64_t records = 0;
+  bool busy = false;
+  ~KmerScratch()
+  {
+    if (e0) (void) hipEventDestroy(e0);
+    if (e1) (void) hipEventDestroy(e1);
+    if (st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
+  }
+};
+
 struct VsxKmerIndex {
   vsx_ctx * ctx = nullptr;
   const vsx_seqset * db = nullptr;
@@ -53,13 +76,11 @@ struct VsxKmerIndex {
   Buf<uint32_t> d_post, d_count, d_list;
   std::vector<uint32_t> h_count;
   std::vector<uint64_t> h_start;
-  // per-batch scratch, grown on demand
-  Buf<uint64_t> d_qk_start;
-  Buf<uint32_t> d_qk, d_minmatch;
-  Buf<uint64_t> d_rec, d_dense, d_sel_mn, d_sel_off;    // uint2 records (target, count); (kept, seen) per slot
-  Buf<uint32_t> d_qcount;
-  Buf<unsigned long long> d_cursor;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  // per-batch scratch sets (at most VSX_KMER_SCRATCH_MAX), handed out under the lock
+  std::vector<std::unique_ptr<KmerScratch>> scratch;
+  std::mutex mu;
+  std::condition_variable cv;
+  hipEvent_t e0 = nullptr, e1 = nullptr;                 // build timing
   VsxKmerStats stats;
   std::vector<uint64_t> word_total;   // postings per word over all tiles
   bool own_stream = false;
@@ -91,7 +112,6 @@ int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIn
   KCHK(hipSetDevice(ix->device));
   KCHK(hipEventCreate(&ix->e0));
   KCHK(hipEventCreate(&ix->e1));
-  KCHK(ix->d_cursor.alloc(1));
   const int rc = vsx_kmer_index_rebuild(ix.get(), nullptr, 0);
   if (rc != VSX_OK) return rc;
   *out = ix.release();
@@ -109,7 +129,6 @@ int vsx_kmer_index_create_empty(vsx_ctx * ctx, const vsx_seqset * db, int w, Vsx
   KCHK(hipSetDevice(ix->device));
   KCHK(hipEventCreate(&ix->e0));
   KCHK(hipEventCreate(&ix->e1));
-  KCHK(ix->d_cursor.alloc(1));
   *out = ix.release();
   return VSX_OK;
 }
@@ -200,42 +219,42 @@ const VsxKmerStats * vsx_kmer_stats(const VsxKmerIndex * ix) { return ix ? &ix->
 namespace {
 
 // one counting + selection pass over `nslots` query slots (slot -> query through qlist, or identity); appends to recs
-int count_pass(VsxKmerIndex * ix, uint32_t nslots, const uint32_t * d_qlist, const std::vector<uint32_t> * h_qlist, uint32_t cap,
+int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, const uint32_t * d_qlist, const std::vector<uint32_t> * h_qlist, uint32_t cap,
                uint32_t keep, VsxKmerResult & out, std::vector<uint32_t> & overflow, uint32_t & overflow_max, float & ms_total)
 {
-  KCHK(ix->d_rec.ensure((size_t) nslots * cap));
-  KCHK(ix->d_qcount.ensure(nslots));
-  KCHK(ix->d_sel_mn.ensure(nslots));
-  KCHK(ix->d_sel_off.ensure(nslots));
-  KCHK(hipMemsetAsync(ix->d_qcount.p, 0, (size_t) nslots * 4, ix->st));
-  KCHK(hipEventRecord(ix->e0, ix->st));
-  KCHK(vsx_kmer_launch_count(ix->d_post.p, ix->d_start.p, ix->ntiles, ix->nseq, nslots, ix->d_qk_start.p, ix->d_qk.p,
-                             ix->d_minmatch.p, d_qlist, ix->d_rec.p, cap, ix->d_qcount.p, ix->st));
-  uint64_t capacity = std::max<uint64_t>(ix->d_dense.n, std::max<uint64_t>(1u << 20, (uint64_t) nslots * 128));
+  KCHK(sc->d_rec.ensure((size_t) nslots * cap));
+  KCHK(sc->d_qcount.ensure(nslots));
+  KCHK(sc->d_sel_mn.ensure(nslots));
+  KCHK(sc->d_sel_off.ensure(nslots));
+  KCHK(hipMemsetAsync(sc->d_qcount.p, 0, (size_t) nslots * 4, sc->st));
+  KCHK(hipEventRecord(sc->e0, sc->st));
+  KCHK(vsx_kmer_launch_count(ix->d_post.p, ix->d_start.p, ix->ntiles, ix->nseq, nslots, sc->d_qk_start.p, sc->d_qk.p,
+                             sc->d_minmatch.p, d_qlist, sc->d_rec.p, cap, sc->d_qcount.p, sc->st));
+  uint64_t capacity = std::max<uint64_t>(sc->d_dense.n, std::max<uint64_t>(1u << 20, (uint64_t) nslots * 128));
   unsigned long long produced = 0;
   for (int attempt = 0; attempt < 2; ++attempt)
     {
-      KCHK(ix->d_dense.ensure(capacity));
-      KCHK(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), ix->st));
-      KCHK(vsx_kmer_launch_select(ix->d_rec.p, cap, ix->d_qcount.p, nslots, keep, ix->d_dense.p, ix->d_cursor.p, ix->d_dense.n,
-                                  ix->d_sel_mn.p, ix->d_sel_off.p, ix->st));
-      KCHK(hipEventRecord(ix->e1, ix->st));
-      KCHK(hipMemcpyAsync(&produced, ix->d_cursor.p, sizeof produced, hipMemcpyDeviceToHost, ix->st));
-      KCHK(hipStreamSynchronize(ix->st));
-      if (produced <= ix->d_dense.n) break;
+      KCHK(sc->d_dense.ensure(capacity));
+      KCHK(hipMemsetAsync(sc->d_cursor.p, 0, sizeof(unsigned long long), sc->st));
+      KCHK(vsx_kmer_launch_select(sc->d_rec.p, cap, sc->d_qcount.p, nslots, keep, sc->d_dense.p, sc->d_cursor.p, sc->d_dense.n,
+                                  sc->d_sel_mn.p, sc->d_sel_off.p, sc->st));
+      KCHK(hipEventRecord(sc->e1, sc->st));
+      KCHK(hipMemcpyAsync(&produced, sc->d_cursor.p, sizeof produced, hipMemcpyDeviceToHost, sc->st));
+      KCHK(hipStreamSynchronize(sc->st));
+      if (produced <= sc->d_dense.n) break;
       capacity = produced;
       if (attempt == 1) { vsx_internal_set_error("vsx_kmer_count_batch: selection buffer overflow"); return VSX_EHIP; }
     }
   float ms = 0;
-  KCHK(hipEventElapsedTime(&ms, ix->e0, ix->e1));
+  KCHK(hipEventElapsedTime(&ms, sc->e0, sc->e1));
   ms_total += ms;
   std::vector<uint64_t> mn(nslots), off(nslots);
-  KCHK(hipMemcpy(mn.data(), ix->d_sel_mn.p, (size_t) nslots * 8, hipMemcpyDeviceToHost));
-  KCHK(hipMemcpy(off.data(), ix->d_sel_off.p, (size_t) nslots * 8, hipMemcpyDeviceToHost));
+  KCHK(hipMemcpy(mn.data(), sc->d_sel_mn.p, (size_t) nslots * 8, hipMemcpyDeviceToHost));
+  KCHK(hipMemcpy(off.data(), sc->d_sel_off.p, (size_t) nslots * 8, hipMemcpyDeviceToHost));
   // the dense buffer is already grouped by slot: append it wholesale and record each query's range
   const size_t before = out.rec.size();
   out.rec.resize(before + produced);
-  if (produced) KCHK(hipMemcpy(out.rec.data() + before, ix->d_dense.p, produced * 8, hipMemcpyDeviceToHost));
+  if (produced) KCHK(hipMemcpy(out.rec.data() + before, sc->d_dense.p, produced * 8, hipMemcpyDeviceToHost));
   for (uint32_t s = 0; s < nslots; ++s)
     {
       const uint32_t m = (uint32_t) (mn[s] & 0xffffffffu), n = (uint32_t) (mn[s] >> 32);
@@ -244,35 +263,65 @@ int count_pass(VsxKmerIndex * ix, uint32_t nslots, const uint32_t * d_qlist, con
       out.off[q] = before + off[s];
       out.cnt[q] = m;
     }
-  ix->stats.records += produced;
+  sc->records += produced;
   return VSX_OK;
 }
 
 }  // namespace
 
+#define VSX_KMER_SCRATCH_MAX 2
+
+namespace {
+struct ScratchLease {
+  VsxKmerIndex * ix; KmerScratch * sc;
+  ~ScratchLease() { if (sc) { { std::lock_guard<std::mutex> lk(ix->mu); sc->busy = false; } ix->cv.notify_all(); } }
+};
+}  // namespace
+
 int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_start, const uint32_t * qk,
-                         const uint32_t * minmatch, uint32_t keep, VsxKmerResult & out, uint32_t cap_hint)
+                         const uint32_t * minmatch, uint32_t keep, VsxKmerResult & out, uint32_t cap_hint, VsxKmerStats * stats_out)
 {
   out.rec.clear();
   out.off.assign(nq, 0);
   out.cnt.assign(nq, 0);
+  if (stats_out) *stats_out = VsxKmerStats {};
   if (!ix || (nq && (!qk_start || !minmatch))) { vsx_internal_set_error("vsx_kmer_count_batch: null argument"); return VSX_EINVAL; }
   if (nq == 0 || ix->nseq == 0) return VSX_OK;
   if (nq >= (1ull << 22)) { vsx_internal_set_error("vsx_kmer_count_batch: at most 4 M queries per batch"); return VSX_EINVAL; }
   KCHK(hipSetDevice(ix->device));
-  const uint64_t nk = qk_start[nq];
+  // a free scratch set, or a new one, or wait for one
+  ScratchLease lease {ix, nullptr};
   {
-    uint64_t inc = 0;
-    for (uint64_t x = 0; x < nk; ++x) inc += ix->word_total[qk[x]];
-    ix->stats.increments = inc;
+    std::unique_lock<std::mutex> lk(ix->mu);
+    for (;;)
+      {
+        for (auto & p : ix->scratch) if (!p->busy) { lease.sc = p.get(); break; }
+        if (lease.sc) break;
+        if (ix->scratch.size() < VSX_KMER_SCRATCH_MAX)
+          {
+            std::unique_ptr<KmerScratch> p(new KmerScratch);
+            if (hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&p->e0) != hipSuccess ||
+                hipEventCreate(&p->e1) != hipSuccess || p->d_cursor.alloc(1) != hipSuccess)
+              { (void) hipGetLastError(); vsx_internal_set_error("vsx_kmer_count_batch: scratch allocation failed"); return VSX_EHIP; }
+            lease.sc = p.get();
+            ix->scratch.push_back(std::move(p));
+            break;
+          }
+        ix->cv.wait(lk);
+      }
+    lease.sc->busy = true;
   }
-  ix->stats.records = 0;
-  KCHK(ix->d_qk_start.ensure(nq + 1));
-  KCHK(ix->d_qk.ensure(nk));
-  KCHK(ix->d_minmatch.ensure(nq));
-  KCHK(hipMemcpyAsync(ix->d_qk_start.p, qk_start, (nq + 1) * 8, hipMemcpyHostToDevice, ix->st));
-  if (nk) KCHK(hipMemcpyAsync(ix->d_qk.p, qk, nk * 4, hipMemcpyHostToDevice, ix->st));
-  KCHK(hipMemcpyAsync(ix->d_minmatch.p, minmatch, nq * 4, hipMemcpyHostToDevice, ix->st));
+  KmerScratch * sc = lease.sc;
+  const uint64_t nk = qk_start[nq];
+  uint64_t increments = 0;
+  for (uint64_t x = 0; x < nk; ++x) increments += ix->word_total[qk[x]];
+  sc->records = 0;
+  KCHK(sc->d_qk_start.ensure(nq + 1));
+  KCHK(sc->d_qk.ensure(nk));
+  KCHK(sc->d_minmatch.ensure(nq));
+  KCHK(hipMemcpyAsync(sc->d_qk_start.p, qk_start, (nq + 1) * 8, hipMemcpyHostToDevice, sc->st));
+  if (nk) KCHK(hipMemcpyAsync(sc->d_qk.p, qk, nk * 4, hipMemcpyHostToDevice, sc->st));
+  KCHK(hipMemcpyAsync(sc->d_minmatch.p, minmatch, nq * 4, hipMemcpyHostToDevice, sc->st));
   float ms = 0;
   std::vector<uint32_t> overflow;
   uint32_t overflow_max = 0;
@@ -280,7 +329,7 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
   // words (chance runs of shared 11..13-mers), so 8 192 x 8 B = 64 KB per query; HBM is plentiful (100 k queries = 6.5 GB)
   uint32_t cap = cap_hint ? cap_hint : (nq <= (1u << 18) ? 8192 : 2048);
   if (const char * c = std::getenv("VSX_KMER_CAP")) cap = (uint32_t) std::max(1, std::atoi(c));      // tests: force the second pass
-  int rc = count_pass(ix, (uint32_t) nq, nullptr, nullptr, cap, keep, out, overflow, overflow_max, ms);
+  int rc = count_pass(ix, sc, (uint32_t) nq, nullptr, nullptr, cap, keep, out, overflow, overflow_max, ms);
   if (rc != VSX_OK) return rc;
   if (std::getenv("VSX_KMER_DEBUG")) std::fprintf(stderr, "kmer: %zu of %llu queries overflowed cap %u (max %u records), %.1f ms\n", overflow.size(), (unsigned long long) nq, cap, overflow_max, ms);
   if (!overflow.empty())
@@ -289,14 +338,18 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
       // just these, with regions of the size the first pass measured
       Buf<uint32_t> d_qlist;
       KCHK(d_qlist.alloc(overflow.size()));
-      KCHK(hipMemcpyAsync(d_qlist.p, overflow.data(), overflow.size() * 4, hipMemcpyHostToDevice, ix->st));
+      KCHK(hipMemcpyAsync(d_qlist.p, overflow.data(), overflow.size() * 4, hipMemcpyHostToDevice, sc->st));
       std::vector<uint32_t> again;
       uint32_t again_max = 0;
       const std::vector<uint32_t> list = overflow;
-      rc = count_pass(ix, (uint32_t) list.size(), d_qlist.p, &list, overflow_max, keep, out, again, again_max, ms);
+      rc = count_pass(ix, sc, (uint32_t) list.size(), d_qlist.p, &list, overflow_max, keep, out, again, again_max, ms);
       if (rc != VSX_OK) return rc;
       if (!again.empty()) { vsx_internal_set_error("vsx_kmer_count_batch: record region overflow in the second pass"); return VSX_EHIP; }
     }
-  ix->stats.count_ms = ms;
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->stats.count_ms = ms; ix->stats.increments = increments; ix->stats.records = sc->records;
+    if (stats_out) { *stats_out = ix->stats; }
+  }
   return VSX_OK;
 }

@@ -741,10 +741,15 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
     if (minmatch[k] != 0xffffffffu) std::copy(words[k].begin(), words[k].end(), qk.begin() + (int64_t) qk_start[k]);
   // count on the device; the records come back grouped by query
   VsxKmerResult res;
-  const int rc = vsx_kmer_count_batch(ix, nq, qk_start.data(), qk.data(), minmatch.data(), keep, res, cap_hint);
+  VsxKmerStats kst;
+  const int rc = vsx_kmer_count_batch(ix, nq, qk_start.data(), qk.data(), minmatch.data(), keep, res, cap_hint, &kst);
   if (rc != VSX_OK) return rc;
-  acct.kernel_ms += vsx_kmer_stats(ix)->count_ms;
-  acct.streamed += vsx_kmer_stats(ix)->increments;
+  {
+    static std::mutex acct_mu;                       // two windows' k-mer stages may finish at once
+    std::lock_guard<std::mutex> lk(acct_mu);
+    acct.kernel_ms += kst.count_ms;
+    acct.streamed += kst.increments;
+  }
   // per query: the heap's total order (count desc, length asc, seqno asc) and size
   const int nth = std::max(1, S->threads);
   std::atomic<uint64_t> next {0};
@@ -809,13 +814,17 @@ static int kmer_rank(vsx_searcher * S, uint64_t nq, FSeq qseq, FLen qlen, const 
 {
   static const bool kdebug = std::getenv("VSX_KMER_DEBUG") != nullptr;
   cands.assign(nq, {});
-  if (!S->kidx)
-    {
-      const int rc = vsx_kmer_index_create(S->ctx, S->dbset, S->w, &S->kidx);
-      if (rc != VSX_OK) return rc;
-      acct.build_ms = vsx_kmer_stats(S->kidx)->build_ms;
-    }
-  acct.postings = vsx_kmer_stats(S->kidx)->postings;
+  static std::mutex once_mu;                           // two windows' k-mer stages may run at once (vsx_search_batch)
+  {
+    std::lock_guard<std::mutex> lk(once_mu);
+    if (!S->kidx)
+      {
+        const int rc = vsx_kmer_index_create(S->ctx, S->dbset, S->w, &S->kidx);
+        if (rc != VSX_OK) return rc;
+        acct.build_ms = vsx_kmer_stats(S->kidx)->build_ms;
+      }
+    acct.postings = vsx_kmer_stats(S->kidx)->postings;
+  }
   std::vector<uint64_t> fallback;
   const double tw1 = now_s();
   {
@@ -825,6 +834,7 @@ static int kmer_rank(vsx_searcher * S, uint64_t nq, FSeq qseq, FLen qlen, const 
   if (kdebug) std::fprintf(stderr, "kmer_rank: %llu queries: %.3f s\n", (unsigned long long) nq, now_s() - tw1);
   if (!fallback.empty())
     {
+      std::lock_guard<std::mutex> lk(once_mu);         // the host index is built on first use
       const uint64_t nwords = 1ull << (2 * S->w);
       build_index(S);
       std::vector<uint16_t> counts(S->len.size(), 0);
@@ -1239,7 +1249,12 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
           if (!s1.put(prepare_words(w0))) break;
         s1.finish();
       });
-      std::thread stage_rank([&]() {
+      // two rank workers: one window's host work (CSR, uploads, record download, ranking) runs under the other's counting
+      // kernel (vsx_kmer_count_batch leases a scratch set and a stream per call); windows may reach the aligner out of order,
+      // a query's hits do not depend on it
+      const int n_rank = dev_kmer ? 2 : 1;
+      std::atomic<int> rank_live {n_rank};
+      auto rank_worker = [&]() {
         for (;;)
           {
             std::unique_ptr<Window> W = s1.get();
@@ -1249,8 +1264,10 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
             if (!s2.put(std::move(W)) || failed) break;
           }
         s1.abort();
-        s2.finish();
-      });
+        if (rank_live.fetch_sub(1) == 1) s2.finish();
+      };
+      std::thread stage_rank(rank_worker), stage_rank2;
+      if (n_rank == 2) stage_rank2 = std::thread(rank_worker);
       int rc = VSX_OK;
       std::string msg;
       for (;;)
@@ -1266,6 +1283,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       s1.abort();
       stage_words.join();
       stage_rank.join();
+      if (stage_rank2.joinable()) stage_rank2.join();
       if (rc != VSX_OK) { vsx_internal_set_error(msg.c_str()); return rc; }
     }
 

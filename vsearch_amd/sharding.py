@@ -49,10 +49,13 @@ def allpairs_row_cost(n, rows, length=None):
     return int((length[rows] * suffix[rows]).sum())
 
 
-def _all_gather_var(t, dist):
-    """all-gather of 1-D/2-D tensors whose first dimension differs per rank -> (list of per-rank tensors, counts)"""
+def _gather_var(t, dist, dst=None):
+    """gather of 1-D/2-D tensors whose first dimension differs per rank -> (list of per-rank tensors, counts).
+    dst=None: all-gather (every rank receives everything); dst=r: only rank r receives the payload (point-to-point sends
+    over the peers' direct xGMI links to r -- SURVEY 8e: "to rank 0"), the others get ([], counts)."""
     import torch
     world = dist.get_world_size()
+    rank = dist.get_rank()
     dev = t.device
     n_local = torch.tensor([t.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -61,25 +64,39 @@ def _all_gather_var(t, dist):
     cap = max(counts + [1])
     pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
     pad[:t.shape[0]] = t
-    parts = [torch.zeros_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad)
+    if dst is None:
+        parts = [torch.zeros_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+    elif rank == dst:
+        parts = [torch.zeros_like(pad) for _ in range(world)]
+        dist.gather(pad, parts, dst=dst)
+    else:
+        dist.gather(pad, None, dst=dst)
+        return [], counts
     return [parts[r][:counts[r]] for r in range(world)], counts
 
 
-def gather_results(records, runs, dist=None):
+def _all_gather_var(t, dist):
+    return _gather_var(t, dist, None)
+
+
+def gather_results(records, runs, dist=None, dst=None):
     """The final gather of SURVEY 8e: every rank contributes its hit records (n_local, 24) uint8 -- in its local pair
-    order -- and its dense run buffer (r_local,) int32 (vsx_plan_export_hits / vsx_plan_export_runs); every rank receives
+    order -- and its dense run buffer (r_local,) int32 (vsx_plan_export_hits / vsx_plan_export_runs); the receiver(s) get
     (records_all, runs_all, record_counts): the records of rank 0, 1, ... back to back with cigar_run_offset REBASED into
     runs_all (= the ranks' run buffers back to back).  With contiguous query blocks that is the global pair order.
-    Two collectives of counts, two of payload; no data-path collective before this point."""
+    dst=None: every rank receives (all-gather); dst=0: only rank 0 does (the production shape: rank 0 writes the output),
+    other ranks get (None, None, counts).  Two collectives of counts, two of payload; no data-path collective before."""
     import torch
     if records.dtype != torch.uint8 or records.dim() != 2 or records.shape[1] != HIT_RECORD_BYTES:
         raise ValueError("records must be a (n, 24) uint8 tensor")
     runs = runs.view(torch.int32) if runs.dtype != torch.int32 else runs
     if dist is None or dist.get_world_size() == 1:
         return records.clone(), runs.clone(), [int(records.shape[0])]
-    rec_parts, rec_counts = _all_gather_var(records.contiguous(), dist)
-    run_parts, run_counts = _all_gather_var(runs.contiguous(), dist)
+    rec_parts, rec_counts = _gather_var(records.contiguous(), dist, dst)
+    run_parts, run_counts = _gather_var(runs.contiguous(), dist, dst)
+    if dst is not None and dist.get_rank() != dst:
+        return None, None, rec_counts
     base = 0
     out = []
     for r, part in enumerate(rec_parts):
@@ -152,7 +169,7 @@ def runs_from_cigar(cigar):
     return np.array(w[::-1], np.uint32)
 
 
-def export_and_gather(plan, n_local, dist=None, device=None, scratch=None):
+def export_and_gather(plan, n_local, dist=None, device=None, scratch=None, dst=None):
     """The gather step of a rank whose plan has run: hit records and run words leave the plan device-to-device
     (vsx_plan_export_hits / vsx_plan_export_runs) and go through gather_results.  `scratch` (a dict) keeps the export
     buffers between calls (bench.py's step loop)."""
@@ -173,7 +190,7 @@ def export_and_gather(plan, n_local, dist=None, device=None, scratch=None):
     runs = buf[:n_runs]
     if dist is not None and dist.get_backend() == "gloo":       # CPU collectives (tests on one GPU): stage through host memory
         rec, runs = rec.cpu(), runs.cpu()
-    return gather_results(rec, runs, dist)
+    return gather_results(rec, runs, dist, dst)
 
 
 def sharded_align(aligner, queries, targets, qidx, tidx, n_queries, dist=None, device=None):
