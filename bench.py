@@ -284,7 +284,7 @@ def main():
                  "traceback": {"hbm_bytes_per_launch": tb.get("hbm_bytes_per_launch"), "SQ_INSTS_VALU": tb.get("sq", {}).get("SQ_INSTS_VALU"),
                                "SQ_WAIT_ANY_over_WAVE_CYCLES": round(tb["sq"]["SQ_WAIT_ANY"] / tb["sq"]["SQ_WAVE_CYCLES"], 3)
                                if tb.get("sq", {}).get("SQ_WAVE_CYCLES") else None,
-                               "note": "latency / occupancy bound (10 waves per CU), not HBM bound: profiles/r02_ckt_ab.txt"},
+                               "note": "latency / occupancy bound (12 waves per CU at R <= 16), not HBM bound: profiles/r02_ckt_ab.txt"},
                  "forward_sq": {k: sq.get(k) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
                                                        "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE")}}
         if sq.get("SQ_INSTS_VALU"):
