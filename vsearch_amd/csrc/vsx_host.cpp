@@ -24,6 +24,8 @@
 #include <condition_variable>
 #include <mutex>
 #include <chrono>
+#include <deque>
+#include <functional>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -285,13 +287,83 @@ static int copy_threads(uint64_t bytes)
   return (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) vsx_internal_usable_cpus(), bytes >> 21));
 }
 
+// Host worker pool: a plan is built in a dozen short parallel passes (validation, classification, grouping, task tables; the
+// fetch spreads its copies); spawning std::threads for each cost more than the passes themselves on 200 k-pair slices.  Workers
+// are created once per process; a parallel region pushes its tasks, runs task 0 itself, helps with the queue and waits for its
+// own tasks only -- regions of different host threads (the planner of a pipeline, the fetching caller) interleave freely.
+namespace {
+class WorkerPool {
+ public:
+  static WorkerPool & get() { static WorkerPool p; return p; }
+  template <typename F>
+  void run(int nth, F && f)
+  {
+    if (nth <= 1) { f(0); return; }
+    struct Region { std::atomic<int> left; std::mutex m; std::condition_variable cv; };
+    Region rg;
+    rg.left.store(nth - 1);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (int t = 1; t < nth; ++t)
+        queue_.push_back([&f, &rg, t]() {
+          f(t);
+          if (rg.left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk2(rg.m); rg.cv.notify_all(); }
+        });
+    }
+    cv_.notify_all();
+    f(0);
+    // help: run queued tasks (ours or another region's) instead of sleeping while ours are pending
+    for (;;)
+      {
+        if (rg.left.load() == 0) break;
+        std::function<void()> job;
+        {
+          std::lock_guard<std::mutex> lk(mu_);
+          if (!queue_.empty()) { job = std::move(queue_.front()); queue_.pop_front(); }
+        }
+        if (job) { job(); continue; }
+        std::unique_lock<std::mutex> lk(rg.m);
+        rg.cv.wait_for(lk, std::chrono::microseconds(50), [&] { return rg.left.load() == 0; });
+      }
+  }
+ private:
+  WorkerPool()
+  {
+    const int n = std::max(1, vsx_internal_usable_cpus() - 1);
+    for (int i = 0; i < n; ++i)
+      workers_.emplace_back([this]() {
+        for (;;)
+          {
+            std::function<void()> job;
+            {
+              std::unique_lock<std::mutex> lk(mu_);
+              cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+              if (stop_ && queue_.empty()) return;
+              job = std::move(queue_.front());
+              queue_.pop_front();
+            }
+            job();
+          }
+      });
+  }
+  ~WorkerPool()
+  {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto & w : workers_) w.join();
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> queue_;
+  std::vector<std::thread> workers_;
+  bool stop_ = false;
+};
+}  // namespace
+
 template <typename F>
 static void run_threads(int nth, F && f)
 {
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nth; ++t) pool.emplace_back(f, t);
-  f(0);
-  for (auto & th : pool) th.join();
+  WorkerPool::get().run(nth, f);
 }
 
 struct vsx_plan {
@@ -723,10 +795,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       for (uint64_t k = lo; k < hi; ++k)
         if (qidx[k] >= queries->n || tidx[k] >= targets->n) { bad[(size_t) t] = k; return; }
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nthc; ++t) pool.emplace_back(check, t);
-    check(0);
-    for (auto & th : pool) th.join();
+    run_threads(nthc, check);
     for (int t = 0; t < nthc; ++t)
       if (bad[(size_t) t] != UINT64_MAX)
         return fail(VSX_EINVAL, "vsx_plan_create: pair %" PRIu64 " references a sequence out of range", bad[(size_t) t]);
@@ -759,12 +828,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
         }
       pcells[(size_t) t] = cells;
     };
-    {
-      std::vector<std::thread> pool;
-      for (int t = 1; t < nthc; ++t) pool.emplace_back(classify, t);
-      classify(0);
-      for (auto & th : pool) th.join();
-    }
+    run_threads(nthc, classify);
     size_t total = 0;
     for (auto & v : gp) total += v.size();
     gpu_pairs.resize(total);
@@ -773,10 +837,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       size_t acc = 0;
       for (int t = 0; t < nthc; ++t) { base[(size_t) t] = acc; acc += gp[(size_t) t].size(); pl->cells += pcells[(size_t) t]; }
       auto place = [&](int t) { if (!gp[(size_t) t].empty()) std::memcpy(gpu_pairs.data() + base[(size_t) t], gp[(size_t) t].data(), gp[(size_t) t].size() * 4); };
-      std::vector<std::thread> pool;
-      for (int t = 1; t < nthc; ++t) pool.emplace_back(place, t);
-      place(0);
-      for (auto & th : pool) th.join();
+      run_threads(nthc, place);
     }
     for (int t = 0; t < nthc; ++t)
       for (uint32_t k : special[(size_t) t])
@@ -858,12 +919,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
           }
       }
   };
-  {
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto & th : pool) th.join();
-  }
+  run_threads(nth, work);
   std::vector<ProtoTask> protos;
   {
     size_t total = 0;
