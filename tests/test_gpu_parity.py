@@ -348,6 +348,12 @@ with Aligner() as al:
         if flt:
             h.update(np.ascontiguousarray(res.verdict).tobytes())
         h.update("\n".join(res.cigar).encode())
+    # the ranked form (filter + per-query order + compaction on the device): slices are cut at query boundaries only
+    rk = al.align_pairs_ranked(ss, ss, qi, ti, dict(id=0.8, weak_id=0.7), keep_weak=True)
+    for key in ("pair", "score", "aligned", "matches", "mismatches", "gaps", "verdict", "id"):
+        h.update(np.ascontiguousarray(rk[key]).tobytes())
+    h.update("\n".join(rk["cigar"]).encode())
+    h.update(np.sort(rk["undecided"]).tobytes())
     ss.close()
 print("HASH", h.hexdigest())
 """
@@ -356,7 +362,8 @@ print("HASH", h.hexdigest())
 @pytest.mark.gpu
 def test_pipelined_slices_equal_one_plan(gpu_required):
     """vsx_align_pairs pipelines large pair lists as several plans (planner thread + GPU + fetch): with the slice size forced
-    down to 700 pairs a 9 000-pair call (unfiltered and filtered, incl. closed-form pairs) must return the same bytes as one plan"""
+    down to 700 pairs a 9 000-pair call (unfiltered, filtered and ranked, incl. closed-form pairs) must return the same bytes as one
+    plan -- with the slices overlapping on the context's two checkpoint blocks and two of them queued behind the fetched one"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -164,6 +164,25 @@ def test_gather_records_and_cigar_runs_world2_gloo(tmp_path, oracle):
     assert p.stdout.count("ok") == 2
 
 
+def test_cigar_from_runs_and_back():
+    """vsx_cigar_from_runs (pushop / finishop on the host, no device needed) against the oracle's CIGARs: run words in
+    traceback order -> text, count omitted when 1"""
+    import random
+    from vsearch_amd import cigar_from_runs
+    from vsearch_amd.sharding import runs_from_cigar
+    assert cigar_from_runs(np.array([(3 << 2) | 0, (1 << 2) | 2, (12 << 2) | 0, (375 << 2) | 1], np.uint32)) == "375I12MD3M"
+    assert cigar_from_runs(np.zeros(0, np.uint32)) == ""
+    rng = random.Random(4)
+    for _ in range(200):
+        ops = []
+        for _ in range(rng.randint(1, 30)):
+            op = rng.choice("MID")
+            if not ops or ops[-1][1] != op:
+                ops.append((rng.choice([1, 1, 2, 9, 10, 99, 100, 1000, 65535]), op))
+        text = "".join((str(n) if n > 1 else "") + o for n, o in ops)
+        assert cigar_from_runs(runs_from_cigar(text)) == text
+
+
 def test_allpairs_row_sharding_partition():
     """config 4 (allpairs, 1 -> 8 GPUs): interleaved rows -- every pair (i < j) belongs to exactly one rank, pair and cell
     counts balance"""

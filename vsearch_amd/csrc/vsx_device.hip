@@ -149,16 +149,18 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   // Any IUPAC / unknown symbol on either side is handled by construction; one v_perm_b32 per row packs the two targets.
   // TILT + VSX_CKT: the primed scores are 0 .. 255 (planner-checked), so the profile holds BYTES (half the LDS, half the reads;
   // the same single v_perm_b32 per row widens them): QPb[code][position][RP rows], RP = R rounded up to a multiple of 4
-  constexpr bool QP8 = TILT && (VSX_CKT != 0);
+  constexpr bool CKST = TILT && (VSX_CKT != 0);     // LDS-transposed checkpoint stores (A/B build)
+  constexpr bool QPL = TILT && (VSX_QPL != 0);      // byte profile, read one step ahead
+  constexpr bool QP8 = CKST || QPL;
   constexpr int RP = (R + 3) & ~3;
   __shared__ __attribute__((aligned(16))) int16_t QP[GENERIC ? (QP8 ? (16 * 16 * RP) / 2 : 16 * 16 * R) : 8];
   uint8_t * const QPb = reinterpret_cast<uint8_t *>(QP);
   // checkpoint staging of the transposed layout: [slot][12 dwords]
-  __shared__ __attribute__((aligned(16))) u32 RS[QP8 ? 64 * 12 : 4];
+  __shared__ __attribute__((aligned(16))) u32 RS[CKST ? 64 * 12 : 4];
   // feed block of the column pipeline: [lane group][column of the 16-block] (sym, QR_t, R_t, H) and F -- written once per 16
   // steps by the 16 lanes of a group, read back one column per step for lane 0 (replaces five v_mov_b32_dpp row_ror rotations)
-  __shared__ uint4 FEED4[4 * 16];
-  __shared__ u32 FEEDF[4 * 16], FEEDN[GENERIC ? 1 : 4 * 16];
+  __shared__ uint4 FEED4[(TILT && VSX_QPL ? 2 : 1) * 4 * 16];         // QPL: two blocks (the next one is built a step early)
+  __shared__ u32 FEEDF[(TILT && VSX_QPL ? 2 : 1) * 4 * 16], FEEDN[GENERIC ? 1 : 4 * 16];
 
   const VsxTask & T = tasks[blockIdx.x];
   const int lane = (int) threadIdx.x;
@@ -287,6 +289,61 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       };
       prefetch(0);
 
+      // feed block `blk` = columns 16 blk .. 16 blk + 15 (lane l describes column 16 blk + l), built from the prefetched symbols;
+      // prefetches the symbols of the block after it
+      auto build_feed = [&](int blk) __attribute__((always_inline)) {
+              const int c = 16 * blk + l;
+              auto mne = [&](u32 code) -> int {     // score of an unambiguous query row vs `code` when codes differ
+                const bool unamb = (code != 0) && ((code & (code - 1)) == 0);
+                return unamb ? P.mismatch : ((P.n_mismatch && code == 15) ? P.mismatch : 0);
+              };
+              const u32 ndA = (u32) (mne(rawA) - P.match) & 0xffffu;
+              const u32 ndB = (u32) (mne(rawB) - P.match) & 0xffffu;
+              const u32 qA = (u32) ((c < DA - 1) ? P.qrt_i : P.qrt_r) & 0xffffu;   // :1719-1753
+              const u32 qB = (u32) ((c < DB - 1) ? P.qrt_i : P.qrt_r) & 0xffffu;
+              const u32 rA = (u32) ((c < DA - 1) ? P.rt_i : P.rt_r) & 0xffffu;
+              const u32 rB = (u32) ((c < DB - 1) ? P.rt_i : P.rt_r) & 0xffffu;
+              const u32 sA = rawA | ((c == DA - 1) ? 0x100u : 0u) | ((c < DpA) ? 0x200u : 0u);
+              const u32 sB = rawB | ((c == DB - 1) ? 0x100u : 0u) | ((c < DpB) ? 0x200u : 0u);
+              f_sym = sA | (sB << 16);
+              f_nd = ndA | (ndB << 16);
+              f_qrt = qA | (qB << 16);
+              f_rt = rA | (rB << 16);
+              if (s == 0)
+                {
+                  f_H = pack16(rawH - pad * tl) ^ BIAS;     // H(-1, j) = Htop(j) (tilted: it enters at row -pad - 1)
+                  f_F = vsub(f_H, f_qrt);              // f = v_sub(f, QR_t) at block entry (:830-833)
+                }
+              else
+                {
+                  f_H = rawS.x;                        // handed over by the previous strip's last lane
+                  f_F = rawS.y;
+                }
+              const int fo = QPL ? (blk & 1) * 64 : 0;
+              FEED4[fo + g * 16 + l] = make_uint4(f_sym, f_qrt, f_rt, f_H);
+              FEEDF[fo + g * 16 + l] = f_F;
+              if (!GENERIC) FEEDN[g * 16 + l] = f_nd;
+              prefetch(blk + 1);
+      };
+      // QPL: byte profile rows of BOTH targets for one step, in registers ([target][4 rows per dword]); two sets ping-pong with
+      // the two-step unrolling: the set of step t+1 is requested at the top of step t, from the symbols the lane will hold then
+      // (its neighbour's current ones)
+      constexpr int PD = RP / 4;
+      u32 profA[2][QPL ? PD : 1], profB[2][QPL ? PD : 1];
+      auto load_profile = [&](u32 (&buf)[2][QPL ? PD : 1], u32 sy) __attribute__((always_inline)) {
+        const u32 cd = sy & 0x000F000Fu;
+        const u32 * a = reinterpret_cast<const u32 *>(QPb + (cd & 0xFu) * (16 * RP) + l * RP);
+        const u32 * b = reinterpret_cast<const u32 *>(QPb + (cd >> 16) * (16 * RP) + l * RP);
+#pragma unroll
+        for (int k = 0; k < (QPL ? PD : 1); ++k) { buf[0][k] = a[k]; buf[1][k] = b[k]; }
+      };
+      if (QPL)
+        {
+          build_feed(0);
+          sym = dpp_shr1(FEED4[g * 16].x, 0u);           // the symbols of step 0
+          load_profile(profA, sym);
+        }
+
       // one pipeline step; reads the left-neighbour row state from hin[] and writes hout[] (the caller ping-pongs the two
       // arrays over an even number of steps, so no per-step register copies remain)
       // INTERIOR (phase A of the strip, see the loops below): no lane of the wave has reached a last / padded column yet, so
@@ -319,50 +376,27 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
 
       // STEADY (the part of phase A after the pipeline has filled, t >= 15): every lane that owns rows is inside its targets, so the
       // per-lane activity test and its EXEC mask are dropped (lanes beyond the query's positions compute junk nobody reads).
-      auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R], auto interior_tag, auto odd_tag, auto steady_tag) __attribute__((always_inline)) {
+      auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R], u32 (&pc)[2][QPL ? PD : 1], u32 (&pn)[2][QPL ? PD : 1],
+                      auto interior_tag, auto odd_tag, auto steady_tag) __attribute__((always_inline)) {
           constexpr bool INTERIOR = decltype(interior_tag)::value;
           constexpr bool ODD = decltype(odd_tag)::value;
           constexpr bool STEADY = decltype(steady_tag)::value;
-          if ((t & 15) == 0)
-            {
-              // build the feed block for columns 16k..16k+15 (lane l describes column 16k+l)
-              const int c = t + l;
-              auto mne = [&](u32 code) -> int {     // score of an unambiguous query row vs `code` when codes differ
-                const bool unamb = (code != 0) && ((code & (code - 1)) == 0);
-                return unamb ? P.mismatch : ((P.n_mismatch && code == 15) ? P.mismatch : 0);
-              };
-              const u32 ndA = (u32) (mne(rawA) - P.match) & 0xffffu;
-              const u32 ndB = (u32) (mne(rawB) - P.match) & 0xffffu;
-              const u32 qA = (u32) ((c < DA - 1) ? P.qrt_i : P.qrt_r) & 0xffffu;   // :1719-1753
-              const u32 qB = (u32) ((c < DB - 1) ? P.qrt_i : P.qrt_r) & 0xffffu;
-              const u32 rA = (u32) ((c < DA - 1) ? P.rt_i : P.rt_r) & 0xffffu;
-              const u32 rB = (u32) ((c < DB - 1) ? P.rt_i : P.rt_r) & 0xffffu;
-              const u32 sA = rawA | ((c == DA - 1) ? 0x100u : 0u) | ((c < DpA) ? 0x200u : 0u);
-              const u32 sB = rawB | ((c == DB - 1) ? 0x100u : 0u) | ((c < DpB) ? 0x200u : 0u);
-              f_sym = sA | (sB << 16);
-              f_nd = ndA | (ndB << 16);
-              f_qrt = qA | (qB << 16);
-              f_rt = rA | (rB << 16);
-              if (s == 0)
-                {
-                  f_H = pack16(rawH - pad * tl) ^ BIAS;     // H(-1, j) = Htop(j) (tilted: it enters at row -pad - 1)
-                  f_F = vsub(f_H, f_qrt);              // f = v_sub(f, QR_t) at block entry (:830-833)
-                }
-              else
-                {
-                  f_H = rawS.x;                        // handed over by the previous strip's last lane
-                  f_F = rawS.y;
-                }
-              FEED4[g * 16 + l] = make_uint4(f_sym, f_qrt, f_rt, f_H);
-              FEEDF[g * 16 + l] = f_F;
-              if (!GENERIC) FEEDN[g * 16 + l] = f_nd;
-              prefetch((t >> 4) + 1);
-            }
+          u32 symn = 0;
+          if (QPL) { if ((t & 15) == 15) build_feed((t >> 4) + 1); }      // the next block, one step early (look-ahead below)
+          else if ((t & 15) == 0) build_feed(t >> 4);
 
           // ---- systolic shift (all lanes, full EXEC) ----
-          const uint4 fv = FEED4[g * 16 + (t & 15)];
-          const u32 fF = FEEDF[g * 16 + (t & 15)];
-          sym = dpp_shr1(fv.x, sym);
+          const int fo = QPL ? ((t >> 4) & 1) * 64 : 0;
+          const uint4 fv = FEED4[fo + g * 16 + (t & 15)];
+          const u32 fF = FEEDF[fo + g * 16 + (t & 15)];
+          if (QPL)
+            {
+              // `sym` already holds this step's symbols; look one step ahead and request that step's profile rows now
+              const int t1 = t + 1;
+              symn = dpp_shr1(FEED4[((t1 >> 4) & 1) * 64 + g * 16 + (t1 & 15)].x, sym);
+              load_profile(pn, symn);
+            }
+          else sym = dpp_shr1(fv.x, sym);
           if (!GENERIC) nd = dpp_shr1(FEEDN[g * 16 + (t & 15)], nd);
           if (!INTERIOR) { qrt = dpp_shr1(fv.y, qrt); rt = dpp_shr1(fv.z, rt); }
           const u32 inH = dpp_shr1(fv.w, outH);
@@ -396,8 +430,12 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                     {
                       if ((r & 3) == 0)
                         {
-                          pa = *reinterpret_cast<const u32 *>(QPb + (code & 0xFu) * (16 * RP) + l * RP + r);
-                          pb = *reinterpret_cast<const u32 *>(QPb + (code >> 16) * (16 * RP) + l * RP + r);
+                          if (QPL) { pa = pc[0][r >> 2]; pb = pc[1][r >> 2]; }
+                          else
+                            {
+                              pa = *reinterpret_cast<const u32 *>(QPb + (code & 0xFu) * (16 * RP) + l * RP + r);
+                              pb = *reinterpret_cast<const u32 *>(QPb + (code >> 16) * (16 * RP) + l * RP + r);
+                            }
                         }
                       // byte r & 3 of the A rows -> low half, of the B rows -> high half, zero-extended (selector 0x0C = 0x00)
                       V = __builtin_amdgcn_perm(pb, pa, 0x0C040C00u + 0x00010001u * (u32) (r & 3));
@@ -508,7 +546,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                 }
               if (l == 15 && s + 1 < nstrips) strip_outp[j] = make_uint2(outH, outF);
             }
-          if (CKPT && QP8)
+          if (CKPT && CKST)
             {
               // transposed layout: the two-step pair goes to the lane's 48-byte segment of the staging block -- H of step i at
               // dword i, the four difference bytes of the pair at dword 8 + i / 2 -- and every 8 steps the block leaves as it lies
@@ -531,7 +569,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               if (!ODD) pend_on = active;
               else if (pend_on || active)
                 {
-                  if (TILT && !QP8)
+                  if (TILT && !CKST)
                     {
                       // bytes 0 / 2 of the two wrapped differences = the signed 8-bit H - F of the lo / hi target, steps t-1 and t
                       const u32 dpk = __builtin_amdgcn_perm(psubw(outH, outF), psubw(pendH, pendF), 0x06040200u);
@@ -559,7 +597,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                       }
                     return 0u;
                   };
-                  if (QP8)
+                  if (CKST)
                     {
                       // chunks of three 16-byte pieces per lane through the staging block: a lane's checkpoint is NCHUNK
                       // contiguous 48-byte segments in HBM
@@ -599,6 +637,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   for (int x = 0; x < R; ++x) { cp[x] = hout[x]; cp[R + x] = E[x]; }
                 }
             }
+          if (QPL) sym = symn;                      // the look-ahead becomes the next step's symbols
       };
       // Phase A: steps before ANY lane of the wave reaches column D - 1 of one of its targets (lane l works on column
       // t - l <= t): every column in flight is interior.  Needs QR_q(interior) == QR_t(interior) for the shared
@@ -618,23 +657,23 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       qrt = qrt_i_pk; rt = pack16(P.rt_i);
       for (; t < t_switch && (TRACK || t < 16); t += 2)       // the pipeline fills (TRACK: the whole interior phase)
         {
-          step(t, hprev, hnext, std::true_type {}, std::false_type {}, std::false_type {});
-          step(t + 1, hnext, hprev, std::true_type {}, std::true_type {}, std::false_type {});
+          step(t, hprev, hnext, profA, profB, std::true_type {}, std::false_type {}, std::false_type {});
+          step(t + 1, hnext, hprev, profB, profA, std::true_type {}, std::true_type {}, std::false_type {});
         }
-      if (!TRACK && (QP8 || Dpg > 0))                         // (a group without targets never becomes active; with overflow
+      if (!TRACK && (CKST || Dpg > 0))                                // (a group without targets never becomes active; with overflow
                                                               //  tracking the junk of the idle lanes would reach the min/max.
                                                               //  The transposed checkpoint stores need EVERY lane of the wave in
                                                               //  the step -- each copies its share of the staging block -- so
                                                               //  there the lanes of empty groups run along on junk)
         for (; t < t_switch; t += 2)
           {
-            step(t, hprev, hnext, std::true_type {}, std::false_type {}, std::true_type {});
-            step(t + 1, hnext, hprev, std::true_type {}, std::true_type {}, std::true_type {});
+            step(t, hprev, hnext, profA, profB, std::true_type {}, std::false_type {}, std::true_type {});
+            step(t + 1, hnext, hprev, profB, profA, std::true_type {}, std::true_type {}, std::true_type {});
           }
       for (; t < steps; t += 2)
         {
-          step(t, hprev, hnext, std::false_type {}, std::false_type {}, std::false_type {});
-          step(t + 1, hnext, hprev, std::false_type {}, std::true_type {}, std::false_type {});
+          step(t, hprev, hnext, profA, profB, std::false_type {}, std::false_type {}, std::false_type {});
+          step(t + 1, hnext, hprev, profB, profA, std::false_type {}, std::true_type {}, std::false_type {});
         }
 
       if (s + 1 < nstrips)

@@ -21,6 +21,12 @@
 #ifndef VSX_CKT
 #define VSX_CKT 0
 #endif
+// TILT class: byte query profile in LDS (primed scores are 0 .. 255) read ONE STEP AHEAD: a lane's column symbol of step t+1 is
+// its neighbour's symbol of step t, so the profile rows of the next step are requested while the current step's rows are computed
+// and the step never starts with an LDS round trip.  0 = int16 profile read at the top of the step (r01).
+#ifndef VSX_QPL
+#define VSX_QPL 1
+#endif
 
 // Device-side constants derived from the 14 post-fixup penalties (reference search16_init,
 // core/align_simd.cpp:1282-1376 and the QR/R vectors at :1629-1649).  "pk" = the int16 value
