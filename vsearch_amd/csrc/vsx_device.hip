@@ -94,7 +94,8 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // bytes d_t(lo) d_t(hi) d_t+1(lo) d_t+1(hi)} instead of 4; column checkpoints: hprev[R] followed by R/2 dwords of the bytes
 // d_r(lo) d_r(hi) d_r+1(lo) d_r+1(hi), padded to blocks of 4 dwords: 12 instead of 16 bytes per lane-step.
 #define VSX_ROWCK_PAIR_DW(TILT_) ((TILT_) ? 192 : 256)                       // dwords of one two-step pair of a wave
-#define VSX_COLCK_NB(R_, TILT_) ((TILT_) ? ((R_) + ((R_) + 1) / 2 + 3) / 4 : (2 * (R_)) / 4)   // 4-dword blocks per lane and column checkpoint
+#define VSX_COLCK_NBH(RT_) (((RT_) + ((RT_) + 1) / 2 + 3) / 4)                                  // ... of ONE half of RT rows (mid-row class)
+#define VSX_COLCK_NB(R_, TILT_) ((TILT_) ? (VSX_MID(R_, true) ? 2 * VSX_COLCK_NBH((R_) / 2) : ((R_) + ((R_) + 1) / 2 + 3) / 4) : (2 * (R_)) / 4)   // 4-dword blocks per lane and column checkpoint
 // Slot of pipeline lane (g, l) inside a wave's checkpoint chunk (TILT class).  1: l * 4 + g -- the four lane groups of a task
 // (= its 8 targets, whose tracebacks move through the same tiles most of the time) sit next to each other, so the lanes of
 // a traceback wave that work on one task read the same lines; 0: g * 16 + l (lane order).
@@ -149,6 +150,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   // Any IUPAC / unknown symbol on either side is handled by construction; one v_perm_b32 per row packs the two targets.
   // TILT + VSX_CKT: the primed scores are 0 .. 255 (planner-checked), so the profile holds BYTES (half the LDS, half the reads;
   // the same single v_perm_b32 per row widens them): QPb[code][position][RP rows], RP = R rounded up to a multiple of 4
+  constexpr bool MIDCK = VSX_MID(R, TILT);          // second row checkpoint after row R/2 - 1, column checkpoints per half
+  constexpr int RT = MIDCK ? R / 2 : R;
   constexpr bool CKST = TILT && (VSX_CKT != 0);     // LDS-transposed checkpoint stores (A/B build)
   constexpr bool QPL = TILT && (VSX_QPL != 0);      // byte profile, read one step ahead
   constexpr bool QP8 = CKST || QPL;
@@ -349,6 +352,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       // INTERIOR (phase A of the strip, see the loops below): no lane of the wave has reached a last / padded column yet, so
       // the column penalties are the interior constants (not pipelined), H - QR is shared by E and F, no score capture.
       u32 pendH = 0, pendF = 0;                    // row checkpoint of the even step, stored together with the odd step's
+      u32 pendMH = 0, pendMF = 0, curMH = 0, curMF = 0;          // the same for the mid-row checkpoint (MIDCK)
       bool pend_on = false;
       // per-lane base addresses of this strip's checkpoint regions (computed once: the step only adds a uniform offset)
       const size_t ck_rowdw = ((((size_t) nstrips * steps + 1) & ~(size_t) 1) >> 1) * VSX_ROWCK_PAIR_DW(TILT);
@@ -358,6 +362,9 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       const int ck_slot = VSX_CK_SLOT(TILT, g, l);
       u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps) >> 1) * 64 + ck_slot) * CK_LANE_DW;         // + (t >> 1) * VSX_ROWCK_PAIR_DW
       u32 * const cck_base = dir + T.dir_off + ck_rowdw + (size_t) s * ck_nblk * CK_COL_DW;                        // + (t >> 4) * CK_COL_DW
+      // mid-row checkpoints: a third region behind the column checkpoints, laid out like the row checkpoints
+      u32 * const mck_base = dir + T.dir_off + ck_rowdw + (size_t) nstrips * ck_nblk * CK_COL_DW
+                             + ((((size_t) s * steps) >> 1) * 64 + ck_slot) * CK_LANE_DW;                           // + (t >> 1) * 192
       // transposed layout: block bases (steps is a multiple of 8 there); a lane adds (k * 64 + lane) * 4 dwords per store
       u32 * const rck_blk = dir + T.dir_off + (((size_t) s * steps) >> 3) * VSX_CKT_BLOCK_DW;                       // + (t >> 3) * 768
       u32 * const cck_blk = dir + T.dir_off + (((size_t) nstrips * steps) >> 3) * VSX_CKT_BLOCK_DW
@@ -417,6 +424,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               u32 capH = 0, capF = 0, capmn = 0, capmx = 0;    // position 0: state after its last real row
               u32 dw[ND];
               u32 lastL = 0, lastEL = 0;
+              u32 midH = 0, midF = 0;
               // SHARED: the interior query-row and target-column gap penalties coincide (planner flag P.share_sub) and no
               // lane of the wave is in a last / padded column this step, so H - QR is the same number for E and for F in
               // every row but R-1: 9 instead of 10 instructions per lane-row.
@@ -489,6 +497,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                     }
                   F = vmax(f, hf);
                   E[r] = vmax(e, he);
+                  if (MIDCK && r == RT - 1) { midH = h2; midF = F; }          // what row R/2 - 1 hands to row R/2
                   // position 0 holds only rcnt0 rows: its later rows compute junk that never leaves the lane
                   if (!TOPPAD && __builtin_expect(rc0 == r + 1, 0)) { capH = h2; capF = F; capmn = smn; capmx = smx; }   // wave-uniform branch
                 }
@@ -532,6 +541,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               if (CKPT)
                 {
                   if (!ODD) { pendH = outH; pendF = outF; }             // stored by the odd step below
+                  if (MIDCK) { if (!ODD) { pendMH = midH; pendMF = midF; } else { curMH = midH; curMF = midF; } }
                 }
               else
                 {
@@ -574,6 +584,11 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                       // bytes 0 / 2 of the two wrapped differences = the signed 8-bit H - F of the lo / hi target, steps t-1 and t
                       const u32 dpk = __builtin_amdgcn_perm(psubw(outH, outF), psubw(pendH, pendF), 0x06040200u);
                       __builtin_nontemporal_store((u32x3) {pendH, outH, dpk}, reinterpret_cast<u32x3 *>(rck_base + (size_t) (t >> 1) * 192));
+                      if (MIDCK)
+                        {
+                          const u32 dpm = __builtin_amdgcn_perm(psubw(curMH, curMF), psubw(pendMH, pendMF), 0x06040200u);
+                          __builtin_nontemporal_store((u32x3) {pendMH, curMH, dpm}, reinterpret_cast<u32x3 *>(mck_base + (size_t) (t >> 1) * 192));
+                        }
                     }
                   else
                     __builtin_nontemporal_store((u32x4) {pendH, pendF, outH, outF}, reinterpret_cast<u32x4 *>(rck_base + (size_t) (t >> 1) * 256));
@@ -588,7 +603,20 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                 {
                   // hprev[0..R), then the byte differences of two rows per dword; zero-padded to whole blocks
                   constexpr int NF = R + (R + 1) / 2;
+                  // MIDCK: per half of RT rows {H of the half's rows, then its difference bytes}, each half padded to whole blocks
+                  constexpr int NFH = RT + (RT + 1) / 2, ZH = 4 * VSX_COLCK_NBH(RT);
                   auto flatc = [&](int z) -> u32 {
+                    if (MIDCK)
+                      {
+                        const int hh = z / ZH, zz = z % ZH, r00 = hh * RT;
+                        if (zz < RT) return hout[r00 + zz];
+                        if (zz < NFH)
+                          {
+                            const int r0 = r00 + 2 * (zz - RT), r1 = (r0 + 1 < r00 + RT) ? r0 + 1 : r0;
+                            return __builtin_amdgcn_perm(psubw(hout[r1], E[r1]), psubw(hout[r0], E[r0]), 0x06040200u);
+                          }
+                        return 0u;
+                      }
                     if (z < R) return hout[z];
                     if (z < NF)
                       {
@@ -878,8 +906,8 @@ struct __attribute__((aligned(4))) Trio { u32 x, y, z; };
 // a workgroup is TWO independent waves (no barrier after the table set-up) that share the score table, the symbols of a tile are
 // packed two to a byte, the boundary keeps only the 17 entries that are read and the tilted class stores its scores (0 .. 255) as
 // bytes: 13.0 KB of LDS per wave at R = 16 instead of 14.75 -> 12 waves per CU = the 3 per SIMD the 168 VGPRs allow.
-template <int R, bool FAST, bool CK8 = false>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu((R == 14 || R == 16) ? 3 : (R >= 28 ? 2 : 1), 8)))      // R = 14, 16: <= 168 VGPRs, R >= 28: <= 256
+template <int R, bool FAST, bool CK8 = false, bool MID = false>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MID ? 3 : ((R == 14 || R == 16) ? 3 : (R >= 28 ? 2 : 1)), 8)))      // R = 14, 16: <= 168 VGPRs, R >= 28: <= 256
 vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTask * __restrict__ tasks,
                         const u32 * __restrict__ pair_slot, const u32 * __restrict__ pair_ids, u32 npairs,
                         const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
@@ -891,7 +919,12 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   typedef TbOps<FAST> A;
   static_assert(VSX_RB == 1, "the tile staging below reads row checkpoints as two-step (16-byte) pairs");
   static_assert(!CK8 || FAST, "compressed checkpoints belong to the TILT class");
-  constexpr int ND = (R + 3) / 4;
+  // MID (vsx_internal.h VSX_MID): the DP kernel also stored a row checkpoint after row R/2 - 1 of every position and laid the
+  // column checkpoints out per half, so a tile is one HALF of a position: RT = R/2 rows.  The cursor keeps its position-level
+  // row index r; hh = r / RT names the half, the tile's rows are slots hh * RT .. hh * RT + RT - 1 of the position.
+  static_assert(!MID || (CK8 && R % 2 == 0 && !VSX_CKT), "half-height tiles belong to the TILT class");
+  constexpr int RT = MID ? R / 2 : R;
+  constexpr int ND = (RT + 3) / 4;
   constexpr bool TOPPAD = FAST;                    // slot layout of position 0, see vsx_forward_kernel
   typedef typename std::conditional<CK8, uint8_t, int16_t>::type SshT;      // tilted scores are 0 .. 255 (planner-checked)
   __shared__ SshT Ssh[512];                        // S[target code][query code], row stride 32; query "code" 16 = a dummy row
@@ -931,6 +964,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   constexpr size_t COL_DW = CK8 ? (size_t) 64 * 4 * VSX_COLCK_NB(R, true) : (size_t) 64 * (2 * R);     // column checkpoint dwords per wave
   const u32 * __restrict__ rowck = ck + T.dir_off;
   const u32 * __restrict__ colck = ck + T.dir_off + rowck_dw;
+  const u32 * __restrict__ midck = colck + (size_t) nstrips * nblk * COL_DW;      // MID: the mid-row checkpoints, laid out like rowck
   // column checkpoint element x (0 .. 2R-1: hprev[R], E[R]) of pipeline lane `lanepos`, strip sp, 16-step block mb
   auto colck_at = [&](int sp, int mb, int lanepos, int x) -> u32 {
     const u32 * cb = colck + ((size_t) sp * nblk + (size_t) mb) * COL_DW;
@@ -1081,14 +1115,31 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
       if (c0 < 0) c0 = 0;
       const int i0 = (L == 0) ? -pad : rcnt0 + (L - 1) * R;
       const bool lastpos = (L == total_lanes - 1);
-      const int rr = busy ? r : 0;
+      const int hh = (MID && busy && r >= RT) ? 1 : 0;            // which half of the position (per lane)
+      const int r0h = hh * RT;                                    // first slot of the tile
+      const int rr = busy ? r - r0h : 0;
       const int rmax_raw = __builtin_amdgcn_readfirstlane(wave_max_i32(rr));
-      const bool one_row = (rmax_raw == 0) && (R >= 4);           // e.g. the left-terminal run in query row 0
+      const bool one_row = (rmax_raw == 0) && (RT >= 4);          // e.g. the left-terminal run in query row 0
       const int rmax = one_row ? 0 : (rmax_raw | 3);              // rows are funnelled four to a dword
       const int cmax = __builtin_amdgcn_readfirstlane(wave_max_i32(jj - c0));     // columns c0 .. c0 + cmax
 
       // top boundary for columns c0-1 .. c0+15 (entry 1 is the corner column c0 - 1) and the target symbols
-      if (L == 0)
+      if (MID && hh == 1)
+        {
+          // lower half: the boundary is the mid-row checkpoint of THIS position (column c at step c + l)
+          stage_top(midck + (size_t) VSX_CK_SLOT(true, g, l) * 3, VSX_ROWCK_PAIR_DW(true), (long) ((size_t) s * steps) + (long) (c0 - 1 + l),
+                    (long) (rowsteps >> 1) - 1);
+          if (c0 == 0)
+            {
+              // corner H(slot RT - 1, -1): the left border of the row above the tile, as the DP kernel seeded it
+              const int xs = RT - 1;
+              int ii = i0 + xs; if (ii > Q - 1) ii = Q - 1;
+              u32 cv = A::in((u32) (uint16_t) P.hleft[ii < 0 ? 0 : ii]);
+              if (TOPPAD && L == 0 && xs < pad) cv = A::in((u32) (uint16_t) (((xs == pad - 1) ? 0 : -P.top_open) + (xs - pad - 1) * tl));
+              tbL[64 + tid] = cv;
+            }
+        }
+      else if (L == 0)
         {
 #pragma unroll
           for (int cc = 0; cc < 17; ++cc)
@@ -1113,17 +1164,18 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
       stage_symbols(c0);
 
       // left boundary (state after column c0 - 1)
-      u32 hp[R], ee[R], qa[R];
+      u32 hp[RT], ee[RT], qa[RT];
       const u32 qrq_i = pen_pk(P.qrq_i_pk);
       const u32 rq_i = pen_pk(P.rq_i_pk);
-      const u32 qrq_last = lastpos ? pen_pk(P.qrq_r_pk) : qrq_i;
-      const u32 rq_last = lastpos ? pen_pk(P.rq_r_pk) : rq_i;
+      const bool lastrow_here = lastpos && (!MID || hh == 1);    // slot RT - 1 of this tile is the query's last row
+      const u32 qrq_last = lastrow_here ? pen_pk(P.qrq_r_pk) : qrq_i;
+      const u32 rq_last = lastrow_here ? pen_pk(P.rq_r_pk) : rq_i;
       if (m == 0)
         {
 #pragma unroll
-          for (int x = 0; x < R; ++x)
+          for (int x = 0; x < RT; ++x)
             {
-              int ii = i0 + x; if (ii > Q - 1) ii = Q - 1;
+              int ii = i0 + r0h + x; if (ii > Q - 1) ii = Q - 1;
               if (ii < 0) ii = 0;
               const u32 hl = A::in((u32) (uint16_t) P.hleft[ii]);
               hp[x] = hl;
@@ -1132,11 +1184,12 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
           if (TOPPAD && L == 0 && pad > 0)                       // border state of the dummy rows, as seeded by the DP kernel
             {
 #pragma unroll
-              for (int x = 0; x < R - 1; ++x)
-                if (x < pad)
+              for (int x = 0; x < RT; ++x)
+                if (r0h + x < pad)                                  // (pad <= R - 1: slot R - 1 is always a real row)
                   {
-                    const int sh = (x - pad - 1) * tl;                  // tilt of (i, -1), i = x - pad
-                    hp[x] = A::in((u32) (uint16_t) (((x == pad - 1) ? 0 : -P.top_open) + sh));
+                    const int xs = r0h + x;
+                    const int sh = (xs - pad - 1) * tl;                 // tilt of (i, -1), i = xs - pad
+                    hp[x] = A::in((u32) (uint16_t) (((xs == pad - 1) ? 0 : -P.top_open) + sh));
                     ee[x] = A::sub(A::in((u32) (uint16_t) (-P.top_open - P.top_step + sh)), qrq_i);
                   }
             }
@@ -1145,9 +1198,16 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
         {
           if (CK8)
             {
-              constexpr int NBQ = VSX_COLCK_NB(R, true);
+              constexpr int NBQ = MID ? VSX_COLCK_NBH(RT) : VSX_COLCK_NB(R, true);      // MID: the blocks of this tile's half only
               Quad fq[NBQ];
-              if (CKT)
+              if (MID)
+                {
+                  const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * COL_DW + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), VSX_CK_SLOT(true, g, l), 0)
+                                   + (size_t) (hh * NBQ) * (4 * VSX_COLCK_CG);
+#pragma unroll
+                  for (int b = 0; b < NBQ; ++b) fq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * (4 * VSX_COLCK_CG));
+                }
+              else if (CKT)
                 {
                   // piece b of the lane's checkpoint = piece b % 3 of its 48-byte segment in chunk b / 3
                   const u32 * cb = colck + ((size_t) s * nblk + (size_t) (m - 1)) * VSX_COLCK_NCHUNK(R) * VSX_CKT_BLOCK_DW + (size_t) VSX_CK_SLOT(true, g, l) * 12;
@@ -1165,10 +1225,10 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
                 return (z & 3) == 0 ? qd.x : (z & 3) == 1 ? qd.y : (z & 3) == 2 ? qd.z : qd.w;
               };
 #pragma unroll
-              for (int x = 0; x < R; ++x)
+              for (int x = 0; x < RT; ++x)
                 {
                   const u32 h = half_lo(flat(x), hi) & 0xffffu;                       // stored biased: already in A's domain
-                  const u32 dd = flat(R + (x >> 1)) >> (8 * ((x & 1) * 2 + (hi ? 1 : 0)));
+                  const u32 dd = flat(RT + (x >> 1)) >> (8 * ((x & 1) * 2 + (hi ? 1 : 0)));
                   hp[x] = h;
                   ee[x] = h - (u32) (int) (int8_t) (dd & 0xffu);
                 }
@@ -1198,17 +1258,17 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
             }
         }
       {
-        u32 w[(R + 3) / 4];
+        u32 w[(RT + 3) / 4];
 #pragma unroll
-        for (int e = 0; e < (R + 3) / 4; ++e) w[e] = *reinterpret_cast<const u32_unaligned *>(q + i0 + 4 * e);   // VSX_CODE_SLACK on both sides
+        for (int e = 0; e < (RT + 3) / 4; ++e) w[e] = *reinterpret_cast<const u32_unaligned *>(q + i0 + r0h + 4 * e);   // VSX_CODE_SLACK on both sides
 #pragma unroll
-        for (int x = 0; x < R; ++x)
+        for (int x = 0; x < RT; ++x)
           qa[x] = (w[x >> 2] >> (8 * (x & 3))) & 15u;
         if (TOPPAD && L == 0)
           {
 #pragma unroll
-            for (int x = 0; x < R - 1; ++x)
-              if (x < pad) qa[x] = 16u;                                                   // dummy row: score -ge
+            for (int x = 0; x < RT; ++x)
+              if (r0h + x < pad) qa[x] = 16u;                                             // dummy row: score -ge
           }
       }
       u32 diag = tbL[64 + tid] & 0xffffu;
@@ -1217,7 +1277,8 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
       // INT (tilted class only): every column of the tile is an interior column of every lane's target, so R_t' = 0 and, for the
       // rows below R-1, R_q' = 0 and QR_q' = QR_t': F - R, E - R and the second H - QR are not computed (14 instead of 17
       // instructions per cell).  Wave-uniform choice per tile.
-      const bool tile_int = CK8 && R > 1 && R <= 16 && !__any(busy && (c0 + cmax >= D - 1));     // (R > 16: the second row body costs more registers than it saves)
+      const bool tile_int = CK8 && RT > 1 && RT <= 16 && !__any(busy && (c0 + cmax >= D - 1));     // (tiles higher than 16 rows: the second row body costs more registers than it saves)
+      const bool top_is_border = (L == 0) && (hh == 0);           // F of the tile's first row comes from Htop, not from a checkpoint
       for (int cc = 0; cc <= cmax; ++cc)
         {
           const int c = c0 + cc;
@@ -1225,7 +1286,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
           const u32 rt = (c < D - 1) ? rt_i16 : rt_r16;
           const u32 tbv = tbL[(cc + 2) * 64 + tid];
           const u32 topH = tbv & 0xffffu;
-          u32 F = (L == 0) ? A::sub(topH, qrt) : (tbv >> 16);
+          u32 F = top_is_border ? A::sub(topH, qrt) : (tbv >> 16);
           const u32 b16 = (((u32) symL[(cc >> 1) * 64 + tid] >> (4 * (cc & 1))) & 15u) * 32u;
           u32 Hd = diag;
           u32 acc = 0;
@@ -1239,9 +1300,9 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
             const u32 h2 = A::max(h1, ee[x]);
             Hd = hp[x];
             hp[x] = h2;
-            const bool plain = INT && x < R - 1;                 // compile-time per unrolled row
-            const u32 qrq = (x == R - 1) ? qrq_last : qrq_i;
-            const u32 rq = (x == R - 1) ? rq_last : rq_i;
+            const bool plain = INT && x < RT - 1;                // compile-time per unrolled row
+            const u32 qrq = (x == RT - 1) ? qrq_last : qrq_i;
+            const u32 rq = (x == RT - 1) ? rq_last : rq_i;
             const u32 hf = A::sub(h2, qrt);
             const u32 f = INT ? F : A::sub(F, rt);
             const u32 dEU = A::dif(hf, f);
@@ -1260,20 +1321,20 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
           else
             {
 #pragma unroll
-              for (int x4 = 0; x4 < R; x4 += 4)
+              for (int x4 = 0; x4 < RT; x4 += 4)
                 if (x4 <= rmax)                                  // skip the rows no lane needs
                   {
                     if (tile_int)
                       {
 #pragma unroll
                         for (int y = 0; y < 4; ++y)
-                          if (x4 + y < R) row(x4 + y, std::true_type {});
+                          if (x4 + y < RT) row(x4 + y, std::true_type {});
                       }
                     else
                       {
 #pragma unroll
                         for (int y = 0; y < 4; ++y)
-                          if (x4 + y < R) row(x4 + y, std::false_type {});
+                          if (x4 + y < RT) row(x4 + y, std::false_type {});
                       }
                     bitsL[(cc * ND + (x4 >> 2)) * 64 + tid] = (uint16_t) acc;
                   }
@@ -1284,13 +1345,14 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
       // ---- walk inside the tile (backtrack16 :1137-1211); matches are counted from the finished CIGAR below ----
       if (busy)
         {
-          while (r >= 0 && j >= c0 && (!TOPPAD || i >= 0))
+          while (r >= r0h && j >= c0 && (!TOPPAD || i >= 0))
             {
               const int cw = j - c0;
-              const u32 w = bitsL[(cw * ND + (r >> 2)) * 64 + tid];
-              int rid = R - 4 * (r >> 2);
+              const int rv = r - r0h;                            // row inside the tile
+              const u32 w = bitsL[(cw * ND + (rv >> 2)) * 64 + tid];
+              int rid = RT - 4 * (rv >> 2);
               if (rid > 4) rid = 4;
-              const u32 bts = A::nibble(w, rid, r & 3);
+              const u32 bts = A::nibble(w, rid, rv & 3);
               ++al;
               if (op == 1 && (bts & A::EXT_LEFT)) { --j; push(1); }
               else if (op == 2 && (bts & A::EXT_UP)) { --i; --r; push(2); }
@@ -1540,13 +1602,13 @@ extern "C" hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tas
   return hipGetLastError();
 }
 
-template <int R, bool FAST, bool CK8 = false>
+template <int R, bool FAST, bool CK8 = false, bool MID = false>
 static hipError_t launch_tbck(const VsxDevParams & P, const VsxFilterDev & F, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
                               const uint32_t * d_pair_ids, uint32_t npairs, const uint8_t * q, const uint8_t * t,
                               const uint32_t * ck, const VsxSlotOut * slot, uint32_t * slab, const uint64_t * slab_off,
                               uint32_t * runs, uint64_t cap, unsigned long long * cursor, VsxPairOut * out, hipStream_t st)
 {
-  hipLaunchKernelGGL((vsx_traceback_ck_kernel<R, FAST, CK8>), dim3((npairs + 127) / 128), dim3(128), 0, st,
+  hipLaunchKernelGGL((vsx_traceback_ck_kernel<R, FAST, CK8, MID>), dim3((npairs + 127) / 128), dim3(128), 0, st,
                      P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, cap, cursor, out);
   return hipGetLastError();
 }
@@ -1560,7 +1622,7 @@ extern "C" hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams
                                               VsxPairOut * out, hipStream_t st)
 {
   if (npairs == 0) return hipSuccess;
-#define TBCK(RR) case RR: return (fast16 && P.tilt != 0) ? launch_tbck<RR, true, true>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
+#define TBCK(RR) case RR: return (fast16 && P.tilt != 0) ? launch_tbck<RR, true, true, VSX_MID(RR, true)>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
                                  : fast16 ? launch_tbck<RR, true>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
                                         : launch_tbck<RR, false>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st)
   switch (rows)
@@ -1578,5 +1640,14 @@ extern "C" uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t r
   if (tilt && VSX_CKT)      // transposed layout: 3 KB blocks; steps is a multiple of 8
     return ((nstrips * steps) >> 3) * VSX_CKT_BLOCK_DW + nstrips * nblk * (uint64_t) VSX_COLCK_NCHUNK(rows) * VSX_CKT_BLOCK_DW;
   const uint64_t rowck = (((nstrips * steps) + 1) >> 1) * VSX_ROWCK_PAIR_DW(tilt != 0);
-  return rowck + nstrips * nblk * (tilt ? 64 * 4 * (uint64_t) VSX_COLCK_NB(rows, true) : 64 * 2 * rows);
+  if (tilt)
+    {
+      // (VSX_COLCK_NB needs a compile-time row count inside the kernels; here the same arithmetic at run time)
+      const bool mid = VSX_MID(rows, true);
+      const uint64_t rt = mid ? rows / 2 : rows;
+      const uint64_t nbh = (rt + (rt + 1) / 2 + 3) / 4;
+      const uint64_t nb = mid ? 2 * nbh : nbh;
+      return rowck + nstrips * nblk * 64 * 4 * nb + (mid ? rowck : 0);          // mid-row checkpoints: a second row-checkpoint region
+    }
+  return rowck + nstrips * nblk * 64 * 2 * rows;
 }

@@ -27,6 +27,14 @@
 #ifndef VSX_QPL
 #define VSX_QPL 1
 #endif
+// TILT class, R >= VSX_MID_MIN_ROWS rows per lane: the DP kernel stores a SECOND row checkpoint per step, after the middle row of
+// every pipeline position, and lays the column checkpoints out per half; the traceback's tiles are then R/2 rows high -- half the
+// recompute area per crossing and half the register state per lane (the R >= 18 tracebacks sat at 2 waves per SIMD on registers).
+// +6 B per lane-step of checkpoint stores in those classes only (square-ish shapes, where the traceback was 40 % of the step).
+#ifndef VSX_MID_MIN_ROWS
+#define VSX_MID_MIN_ROWS 18
+#endif
+#define VSX_MID(R_, TILT_) ((TILT_) && (R_) >= VSX_MID_MIN_ROWS && !VSX_CKT)
 
 // Device-side constants derived from the 14 post-fixup penalties (reference search16_init,
 // core/align_simd.cpp:1282-1376 and the QR/R vectors at :1629-1649).  "pk" = the int16 value
