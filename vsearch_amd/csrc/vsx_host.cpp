@@ -299,15 +299,18 @@ class WorkerPool {
   void run(int nth, F && f)
   {
     if (nth <= 1) { f(0); return; }
-    struct Region { std::atomic<int> left; std::mutex m; std::condition_variable cv; };
+    // `left` is only touched under `m`: a worker's last access to the region is its unlock, and the caller can see left == 0 only
+    // after locking behind it -- the region lives on the caller's stack and must not be touched once run() returns
+    struct Region { int left; std::mutex m; std::condition_variable cv; };
     Region rg;
-    rg.left.store(nth - 1);
+    rg.left = nth - 1;
     {
       std::lock_guard<std::mutex> lk(mu_);
       for (int t = 1; t < nth; ++t)
         queue_.push_back([&f, &rg, t]() {
           f(t);
-          if (rg.left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk2(rg.m); rg.cv.notify_all(); }
+          std::lock_guard<std::mutex> lk2(rg.m);
+          if (--rg.left == 0) rg.cv.notify_all();
         });
     }
     cv_.notify_all();
@@ -315,7 +318,7 @@ class WorkerPool {
     // help: run queued tasks (ours or another region's) instead of sleeping while ours are pending
     for (;;)
       {
-        if (rg.left.load() == 0) break;
+        { std::lock_guard<std::mutex> lk(rg.m); if (rg.left == 0) break; }
         std::function<void()> job;
         {
           std::lock_guard<std::mutex> lk(mu_);
@@ -323,7 +326,7 @@ class WorkerPool {
         }
         if (job) { job(); continue; }
         std::unique_lock<std::mutex> lk(rg.m);
-        rg.cv.wait_for(lk, std::chrono::microseconds(50), [&] { return rg.left.load() == 0; });
+        if (rg.cv.wait_for(lk, std::chrono::microseconds(50), [&] { return rg.left == 0; })) break;
       }
   }
  private:
