@@ -164,6 +164,17 @@ def test_gather_records_and_cigar_runs_world2_gloo(tmp_path, oracle):
     assert p.stdout.count("ok") == 2
 
 
+def test_host_worker_pool_selftest():
+    """the persistent worker pool behind the planner's and the fetch's parallel passes: 40 000 short regions from two host threads
+    at once (the shape that let a worker touch a returned caller's stack before the region counter moved under its mutex)"""
+    import ctypes as C
+    from vsearch_amd import _lib
+    lib = _lib.load()
+    lib.vsx_internal_pool_selftest.argtypes = [C.c_int, C.c_int]
+    lib.vsx_internal_pool_selftest.restype = C.c_int
+    assert lib.vsx_internal_pool_selftest(20000, 12) == 0
+
+
 def test_cigar_from_runs_and_back():
     """vsx_cigar_from_runs (pushop / finishop on the host, no device needed) against the oracle's CIGARs: run words in
     traceback order -> text, count omitted when 1"""

@@ -443,6 +443,30 @@ int vsx_internal_usable_cpus(void)
     }
   return std::max(1, n);
 }
+// Self-test of the host worker pool (no device): `regions` short parallel regions of `width` tasks each, issued from TWO
+// host threads at once (as the planner of a pipeline and the fetching caller do); every task adds its index into a per-region
+// slot on the issuing thread's stack.  Returns 0 if every region saw exactly the sum of its task indices.
+int vsx_internal_pool_selftest(int regions, int width)
+{
+  std::atomic<int> bad {0};
+  auto driver = [&](int salt) {
+    for (int r = 0; r < regions; ++r)
+      {
+        const int w = 1 + (r * 7 + salt) % std::max(1, width);
+        std::vector<long long> part((size_t) w, 0);
+        volatile long long guard_before = 0x1122334455667788ll;
+        run_threads(w, [&](int t) { part[(size_t) t] += (long long) t + 1; });
+        volatile long long guard_after = 0x1122334455667788ll;
+        long long sum = 0;
+        for (long long v : part) sum += v;
+        if (sum != (long long) w * (w + 1) / 2 || guard_before != guard_after) bad.fetch_add(1);
+      }
+  };
+  std::thread other(driver, 3);
+  driver(0);
+  other.join();
+  return bad.load();
+}
 int vsx_internal_device(const vsx_ctx * ctx) { return ctx->device; }
 hipStream_t vsx_internal_stream(const vsx_ctx * ctx) { return ctx->stream; }
 void vsx_internal_seqset_device(const vsx_seqset * s, const uint8_t ** codes, const uint64_t ** off, const uint32_t ** len, uint64_t * n)
