@@ -41,11 +41,15 @@ typedef struct vsx_search_opts {
   int64_t wordlength;       /* 8   (3..15)                                                        */
   int64_t minwordmatches;   /* -1 = table minwordmatches_defaults (core/searchcore.hpp:75-76)     */
   int32_t iddef;            /* 2                                                                  */
-  int32_t soft_mask;        /* 0: --qmask/--dbmask none (lower case searchable); 1: soft (lower case excluded from k-mers).
-                               PRECONDITION: the reference commands default to --qmask dust --dbmask dust; DUST is not part of this
-                               path -- a caller that wants the default behaviour dust-masks first (lower-casing the masked
-                               regions, as core/mask.cpp does) and sets soft_mask = 1 (host k-mer path); byte parity with the
-                               reference CLI is tested with --qmask none --dbmask none */
+  int32_t soft_mask;        /* masking of BOTH sides before the k-mer stage (--qmask / --dbmask; unique_count masks lower case for
+                               every mode but "none", core/unique.cpp:198-199):
+                                 0  none  lower case searchable
+                                 1  soft  lower-case symbols are left out of the k-mers
+                                 2  dust  the reference's DEFAULT: the database is DUST-masked on the device when the
+                                          searcher is created (vsx_mask.hip), every query -- each strand on its own -- on the
+                                          host threads (core/mask.cpp:79-199, core/search.cpp:294-303), then as 1.
+                               All three stay on the device k-mer path (a per-symbol case bitmap beside the 4-bit codes);
+                               the alignment itself never reads the case.  --hardmask is not provided. */
   int64_t maxsubs, maxgaps, mincols, maxdiffs;
   double  query_cov, target_cov, maxid, mid;
   int32_t leftjust, rightjust;
@@ -126,6 +130,11 @@ int vsx_search_batch(vsx_searcher * s, uint64_t n_queries, const char * qblob, u
 int vsx_search_batch_meta(vsx_searcher * s, uint64_t n_queries, const char * qblob, uint64_t qblob_bytes,
                           const uint64_t * qoffsets, const uint32_t * qlengths, const vsx_seq_meta * qmeta, vsx_hits * out);
 void vsx_hits_free(vsx_hits * h);
+
+/* DUST-mask sequences in place, as dust() of the reference does (core/mask.cpp:127-199): everything upper case, the
+   low-complexity intervals lower case.  Host threads (threads <= 0: all usable CPUs); sequences must not overlap.  What
+   soft_mask = 2 applies to the queries; exported for callers that prepare their own text. */
+int vsx_dust_mask(char * blob, uint64_t n, const uint64_t * offsets, const uint32_t * lengths, int32_t threads);
 
 /* allpairs_global (commands/allpairs_global.cpp:394-527): database sequences [first, first+count) as
    queries, each against every LATER sequence (unaligned filters applied unless acceptall); kept hits are

@@ -4,7 +4,7 @@
 no /root/reference).  The fixtures pin both oracle/nw_oracle.c and the HIP path.
 
   python oracle/gen_golden.py            # writes tests/golden/search16_golden.json,
-                                         #        tests/golden/ref_api_examples.json
+                                         #        tests/golden/ref_api_examples.json, lma_golden.json, dust_golden.json
   python oracle/gen_golden.py --fuzz N   # additionally: N random pairs oracle-vs-reference (no file)
 """
 import argparse
@@ -210,18 +210,70 @@ def gen_lma(path, seed=77, per_scoring=40):
     print(f"wrote {path}: {len(cases)} cases")
 
 
+def dust_inputs(rng, n):
+    """sequences with low-complexity stretches of every period, window-boundary lengths, some lower case and IUPAC codes"""
+    def lowc(k):
+        p = rng.choice([1, 2, 3, 4, 5, 7])
+        u = "".join(rng.choice("ACGT") for _ in range(p))
+        return (u * (k // p + 1))[:k]
+    seqs = []
+    edge = [1, 5, 7, 8, 9, 31, 32, 33, 63, 64, 65, 95, 96, 97, 100, 127, 128, 129, 150, 250, 400, 1000]
+    for i in range(n):
+        L = edge[i] if i < len(edge) else rng.randint(1, 500)
+        s = []
+        while len(s) < L:
+            if rng.random() < 0.3:
+                s += list(lowc(rng.randint(4, 90)))
+            else:
+                s += [rng.choice("ACGT") for _ in range(rng.randint(1, 80))]
+        s = s[:L]
+        for j in range(len(s)):
+            r = rng.random()
+            if r < 0.02:
+                s[j] = rng.choice("NRYKMSW")
+            elif r < 0.06:
+                s[j] = s[j].lower()
+        seqs.append("".join(s))
+    return seqs
+
+
+def gen_dust(path, n=400):
+    """DUST masking (core/mask.cpp) through the reference CLI: --fastx_mask --qmask dust"""
+    import subprocess
+    import tempfile
+    from oracle import refcli
+    assert refcli.available(), "oracle/_ref/vsearch_ref missing: make -C oracle ref_full"
+    rng = random.Random(20)
+    seqs = dust_inputs(rng, n)
+    with tempfile.TemporaryDirectory(prefix="vsxdust_") as tmp:
+        fa, out = os.path.join(tmp, "in.fa"), os.path.join(tmp, "out.fa")
+        refcli.write_fasta(fa, [f"s{i}" for i in range(len(seqs))], seqs)
+        subprocess.run([refcli.REF_BIN, "--fastx_mask", fa, "--qmask", "dust", "--fastaout", out, "--fasta_width", "0", "--quiet"], check=True)
+        exp = [line.strip() for line in open(out) if not line.startswith(">")]
+    assert len(exp) == len(seqs)
+    doc = {"generator": "oracle/gen_golden.py gen_dust (reference CLI --fastx_mask --qmask dust)", "in": seqs, "exp": exp}
+    with open(path, "w") as f:
+        json.dump(doc, f, separators=(",", ":"))
+    print(f"wrote {path}: {len(seqs)} sequences, {sum(1 for e in exp if any(c.islower() for c in e))} with a masked interval")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="write just this fixture: dust")
     ap.add_argument("--fuzz", type=int, default=0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-write", action="store_true")
     a = ap.parse_args()
     pyoracle.build(ref=True)
+    if a.only == "dust":
+        gen_dust(os.path.join(GOLD, "dust_golden.json"))
+        return
     if not a.no_write:
         os.makedirs(GOLD, exist_ok=True)
         gen_search16(os.path.join(GOLD, "search16_golden.json"))
         gen_api_examples(os.path.join(GOLD, "ref_api_examples.json"))
         gen_lma(os.path.join(GOLD, "lma_golden.json"))
+        gen_dust(os.path.join(GOLD, "dust_golden.json"))
     if a.fuzz:
         sys.exit(1 if fuzz(a.fuzz, a.seed) else 0)
 

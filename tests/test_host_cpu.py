@@ -284,3 +284,18 @@ def test_lma_vs_live_reference():
             b = common.mutate(rng, a, 0.2) + common.rnd_seq(rng, rng.randint(0, 40))
             assert tuple(ref.lma(a, b)) == _lma(P, nmm, a, b), (a, b)
         ref.close()
+
+
+def test_dust_mask_matches_reference_fixture():
+    """host DUST (vsx_mask.cpp = what soft_mask=2 applies to queries) against the reference CLI's --fastx_mask --qmask dust
+    output (tests/golden/dust_golden.json, made by oracle/gen_golden.py gen_dust)"""
+    import json
+    from vsearch_amd import dust_mask
+    doc = json.load(open(os.path.join(ROOT, "tests", "golden", "dust_golden.json")))
+    got = [g.decode() for g in dust_mask(doc["in"], threads=4)]
+    bad = [(i, doc["in"][i], got[i], doc["exp"][i]) for i in range(len(got)) if got[i] != doc["exp"][i]]
+    assert not bad, bad[:1]
+    assert sum(1 for e in doc["exp"] if any(c.islower() for c in e)) > 200
+    # idempotent, and the empty / shorter-than-a-region sequences come back upper-cased
+    assert [g.decode() for g in dust_mask(got)] == got
+    assert [g.decode() for g in dust_mask(["", "acg", "aaaaaaa"])] == ["", "ACG", "AAAAAAA"]

@@ -5,7 +5,7 @@ The package is a thin host-side mirror of the reference's aligner interface over
 """
 from .aligner import (Aligner, SequenceSet, Plan, AlignmentResults, RawResults, DEFAULT_SCORING,  # noqa: F401
                       scoring_from_tuple, cigar_from_runs)
-from .search import SearchSession, msa, msa_batch  # noqa: F401
+from .search import SearchSession, msa, msa_batch, dust_mask  # noqa: F401
 from ._lib import SENTINEL, VsxError, load as load_library  # noqa: F401
 
 __all__ = ["Aligner", "SequenceSet", "Plan", "AlignmentResults", "RawResults", "cigar_from_runs", "DEFAULT_SCORING", "scoring_from_tuple",

@@ -251,6 +251,10 @@ struct vsx_seqset {
   uint8_t * codes() const { return d_codes.p + VSX_CODE_SLACK; }
   DevBuf<uint64_t> d_off;
   DevBuf<uint32_t> d_len;
+  // soft masking for the k-mer index only (vsx_internal_seqset_create_cased): one bit per blob byte, set where the symbol was
+  // not an upper-case A C G T U.  The aligner never sees it: alignment is case-blind in the reference too (chrmap_4bit)
+  DevBuf<uint8_t> d_lower;
+  uint64_t lower_bytes = 0;
   // VSX_SCORE=arith only: per-sequence "contains a non-ACGT symbol", computed on first use (vsx_purity_kernel) under the lock
   mutable std::mutex impure_mu;
   mutable std::vector<uint8_t> impure;
@@ -652,7 +656,8 @@ void vsx_destroy(vsx_ctx * c)
 }
 
 static int seqset_common(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const void * blob, bool blob_on_device,
-                         uint64_t blob_bytes, const uint64_t * offsets, const uint32_t * lengths, bool both_strands = false)
+                         uint64_t blob_bytes, const uint64_t * offsets, const uint32_t * lengths, bool both_strands = false,
+                         int case_bits = 0 /* 1: soft masking, 2: DUST */)
 {
   if (!ctx || !out || (n && (!offsets || !lengths)) || (blob_bytes && !blob))
     return fail(VSX_EINVAL, "vsx_seqset_create: null argument");
@@ -697,6 +702,15 @@ static int seqset_common(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const voi
         d_ascii = staging.p;
       }
     if ((e = vsx_launch_encode(d_ascii, s->codes(), blob_bytes, ctx->stream)) != hipSuccess) break;
+    if (case_bits)
+      {
+        const uint64_t nb = (blob_bytes + 7) / 8 + 16;             // the sweep reads a dword at any byte of the map
+        if ((e = s->d_lower.alloc(nb)) != hipSuccess) break;
+        if ((e = hipMemsetAsync(s->d_lower.p, 0, nb, ctx->stream)) != hipSuccess) break;
+        if ((e = vsx_kmer_launch_case_bits(d_ascii, blob_bytes, s->d_lower.p, case_bits == 2, ctx->stream)) != hipSuccess) break;
+        if (case_bits == 2 && (e = vsx_launch_dust(s->codes(), s->d_off.p, s->d_len.p, n, s->d_lower.p, ctx->stream)) != hipSuccess) break;
+        s->lower_bytes = (blob_bytes + 7) / 8;
+      }
     if (both_strands && (e = vsx_launch_revcomp(s->codes(), s->d_off.p, s->d_off.p + n, s->d_len.p, n, ctx->stream)) != hipSuccess) break;
     e = hipStreamSynchronize(ctx->stream);
   } while (false);
@@ -719,6 +733,36 @@ int vsx_seqset_create_both_strands(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n,
                                    const uint64_t * offsets, const uint32_t * lengths)
 {
   return seqset_common(ctx, out, n, blob, false, blob_bytes, offsets, lengths, true);
+}
+
+// internal (vsx_search.cpp, soft_mask): the set also keeps the case bitmap its k-mer index honours
+// (mode 1: the bitmap is the input's case; mode 2: the input is upper-cased and DUST-masked on the device, vsx_mask.hip)
+int vsx_internal_seqset_create_cased(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const char * blob, uint64_t blob_bytes,
+                                     const uint64_t * offsets, const uint32_t * lengths, int mode)
+{
+  if (mode != 1 && mode != 2) return fail(VSX_EINVAL, "vsx_internal_seqset_create_cased: mode must be 1 (soft) or 2 (dust)");
+  return seqset_common(ctx, out, n, blob, false, blob_bytes, offsets, lengths, false, mode);
+}
+const uint8_t * vsx_internal_seqset_lower(const vsx_seqset * s) { return s ? s->d_lower.p : nullptr; }
+// the bitmap on the host: bit i of byte i / 8 = blob byte i is masked
+int vsx_internal_seqset_lower_download(const vsx_seqset * s, uint8_t * dst, uint64_t nbytes)
+{
+  if (!s || !s->d_lower.p || nbytes > s->lower_bytes) return fail(VSX_EINVAL, "vsx_internal_seqset_lower_download: no case bitmap of that size");
+  HIPCHK(hipSetDevice(s->device));
+  if (nbytes) HIPCHK(hipMemcpy(dst, s->d_lower.p, nbytes, hipMemcpyDeviceToHost));
+  return VSX_OK;
+}
+
+// test hook (tests/test_gpu_mask.py): the case bitmap a mode-1 / mode-2 set ends up with, (blob_bytes + 7) / 8 bytes
+int vsx_internal_mask_bits(vsx_ctx * ctx, uint64_t n, const char * blob, uint64_t blob_bytes, const uint64_t * offsets,
+                           const uint32_t * lengths, int mode, uint8_t * bits_out)
+{
+  vsx_seqset * s = nullptr;
+  int rc = vsx_internal_seqset_create_cased(ctx, &s, n, blob, blob_bytes, offsets, lengths, mode);
+  if (rc != VSX_OK) return rc;
+  rc = vsx_internal_seqset_lower_download(s, bits_out, (blob_bytes + 7) / 8);
+  vsx_seqset_destroy(s);
+  return rc;
 }
 
 int vsx_seqset_create_from_device(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const void * d_blob,

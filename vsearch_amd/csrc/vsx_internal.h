@@ -172,7 +172,12 @@ const int * vsx_supported_rows(int * count);
 // launchers implemented in vsx_kmer.hip (k-mer candidate counting)
 hipError_t vsx_kmer_launch_sweep(int fill, const uint8_t * codes, const uint64_t * off, const uint32_t * len,
                                  const uint32_t * seq_list, uint32_t nseq, int w, uint32_t ntiles, uint32_t * bucket_count,
-                                 const uint64_t * bucket_start, uint32_t * postings, hipStream_t st);
+                                 const uint64_t * bucket_start, uint32_t * postings, const uint8_t * lower_bits, hipStream_t st);
+hipError_t vsx_kmer_launch_case_bits(const uint8_t * d_ascii, uint64_t nbytes, uint8_t * d_bits /* (nbytes + 7) / 8 */, int fold_case,
+                                     hipStream_t st);
+// vsx_mask.hip: DUST intervals of every sequence OR-ed into the case bitmap (dword-aligned, zero-padded to a dword)
+hipError_t vsx_launch_dust(const uint8_t * d_codes, const uint64_t * d_off, const uint32_t * d_len, uint64_t nseq, uint8_t * d_bits,
+                           hipStream_t st);
 hipError_t vsx_kmer_launch_count(const uint32_t * postings, const uint64_t * bucket_start, uint32_t ntiles,
                                  uint32_t nseq, uint32_t nslots, const uint64_t * qk_start, const uint32_t * qk,
                                  const uint32_t * minmatch, const uint32_t * qlist, void * rec, uint32_t cap,

@@ -25,7 +25,8 @@ struct VsxKmerStats {
   uint64_t index_bytes = 0;
 };
 
-// words of length w (3..8) over the sequence set's 4-bit codes; ambiguous symbols poison the words that cover them
+// words of length w (3..8) over the sequence set's 4-bit codes; ambiguous symbols poison the words that cover them, and so do
+// lower-case symbols when the set was made with its case bitmap (soft masking, vsx_internal_seqset_create_cased)
 int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIndex ** out);
 // an index with nothing in it yet; vsx_kmer_index_rebuild(ix, list, n) (re)builds it over the listed sequences of `db`
 // (index position i = sequence list[i]; targets in the records are POSITIONS) or, with list == nullptr, over all of them.

@@ -34,7 +34,11 @@ typedef u32 u32_una __attribute__((aligned(1)));
 // word starting at position p of a sequence of 4-bit codes: valid iff all w symbols are A/C/G/T(U) (one-hot codes),
 // i.e. chrmap_mask_ambig == 0 over the window (core/unique.cpp:199-238); value as the reference builds it, first symbol
 // in the most significant bit pair (2-bit map A0 C1 G2 T3, utils/maps.cpp:156-186)
-__device__ __forceinline__ bool word_at(const uint8_t * __restrict__ s, int p, int w, u32 & word)
+// Soft masking (--qmask / --dbmask soft or dust: maskmap = map_mask_lower for every mode but "none", core/unique.cpp:198-199):
+// `lower` = one bit per symbol of the set's blob, set where the ASCII symbol was anything but an upper-case A C G T U
+// (vsx_kmer_case_bits_kernel); a word is valid iff none of its w bits is set.  lower == nullptr: hard masking.
+__device__ __forceinline__ bool word_at(const uint8_t * __restrict__ s, int p, int w, u32 & word,
+                                        const uint8_t * __restrict__ lower = nullptr, u64 base = 0)
 {
   // 8 symbols per pair of unaligned dword loads (VSX_CODE_SLACK bytes follow the codes); w <= 8 here
   const u32 lo = *reinterpret_cast<const u32_una *>(s + p);
@@ -50,7 +54,34 @@ __device__ __forceinline__ bool word_at(const uint8_t * __restrict__ s, int p, i
         v = (v << 2) | ((c >> 1) - (c >> 3));
       }
   word = v;
+  if (lower)
+    {
+      const u64 i = base + (u64) p;
+      const uint8_t * b = lower + (i >> 3);
+      const u32 b0 = *reinterpret_cast<const u32_una *>(b);
+      const u32 wnd = (b0 >> (u32) (i & 7)) & 0xffffu;        // 16 bits >= the 8 of a word, whatever the phase
+      ok = ok && ((wnd & ((1u << w) - 1u)) == 0u);
+    }
   return ok;
+}
+
+// one lane per 8 symbols of the ASCII blob -> one byte of the case bitmap
+__global__ void __launch_bounds__(256)
+vsx_kmer_case_bits_kernel(const uint8_t * __restrict__ ascii, u64 nbytes, uint8_t * __restrict__ bits, int fold)
+{
+  const u64 g = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (g * 8 >= nbytes) return;
+  u32 m = 0;
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+    {
+      const u64 i = g * 8 + (u64) x;
+      u32 c = i < nbytes ? (u32) ascii[i] : (u32) 'A';
+      if (fold && c >= 'a' && c <= 'z') c -= 32u;                 // DUST upper-cases the sequence first (core/mask.cpp:137-144)
+      const bool upper_nt = (c == 'A') || (c == 'C') || (c == 'G') || (c == 'T') || (c == 'U');
+      m |= (upper_nt ? 0u : 1u) << x;
+    }
+  bits[g] = (uint8_t) m;
 }
 
 // One wave per sequence.  FILL = false: bucket histogram; FILL = true: scatter the sequence number into its buckets.
@@ -60,7 +91,7 @@ __global__ void __launch_bounds__(256)
 vsx_kmer_sweep_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict__ off, const u32 * __restrict__ len,
                       const u32 * __restrict__ seq_list, u32 nseq,
                       int w, u32 ntiles, u32 * __restrict__ bucket_count, const u64 * __restrict__ bucket_start,
-                      uint16_t * __restrict__ postings)
+                      uint16_t * __restrict__ postings, const uint8_t * __restrict__ lower)
 {
   extern __shared__ u32 bm_all[];                       // 4 waves x (4^w / 32) words
   const int lane = (int) (threadIdx.x & 63), wave = (int) (threadIdx.x >> 6);
@@ -70,14 +101,15 @@ vsx_kmer_sweep_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict
   const u32 seq = blockIdx.x * 4 + wave;                 // position in the index
   if (seq >= nseq) return;
   const u32 sid = seq_list ? seq_list[seq] : seq;        // sequence of the set it stands for (subset index: clustering)
-  const uint8_t * __restrict__ s = codes + off[sid];
+  const u64 base = off[sid];
+  const uint8_t * __restrict__ s = codes + base;
   const int L = (int) len[sid];
   const u32 tile = seq >> KM_TILE_SHIFT;
   for (int p0 = 0; p0 + w <= L; p0 += 64)
     {
       const int p = p0 + lane;
       u32 word = 0;
-      if (p + w <= L && word_at(s, p, w, word))
+      if (p + w <= L && word_at(s, p, w, word, lower, base))
         {
           const u32 bit = 1u << (word & 31);
           const u32 old = atomicOr(&bm[word >> 5], bit);
@@ -279,17 +311,26 @@ vsx_kmer_select_kernel(const uint2 * __restrict__ rec, u32 cap, const u32 * __re
 
 extern "C" hipError_t vsx_kmer_launch_sweep(int fill, const uint8_t * codes, const uint64_t * off, const uint32_t * len,
                                             const uint32_t * seq_list, uint32_t nseq, int w, uint32_t ntiles, uint32_t * bucket_count,
-                                            const uint64_t * bucket_start, uint32_t * postings, hipStream_t st)   // postings: dwords of two 16-bit indices
+                                            const uint64_t * bucket_start, uint32_t * postings, const uint8_t * lower_bits,
+                                            hipStream_t st)   // postings: dwords of two 16-bit indices; lower_bits: soft masking or NULL
 {
   if (nseq == 0) return hipSuccess;
   const size_t lds = (size_t) 4 * (((1u << (2 * w)) >> 5) ? ((1u << (2 * w)) >> 5) : 1) * 4;
   const dim3 grid((nseq + 3) / 4), block(256);
   if (fill)
     hipLaunchKernelGGL(vsx_kmer_sweep_kernel<true>, grid, block, lds, st, codes, (const u64 *) off, len, seq_list, nseq, w, ntiles,
-                       bucket_count, (const u64 *) bucket_start, (uint16_t *) postings);
+                       bucket_count, (const u64 *) bucket_start, (uint16_t *) postings, lower_bits);
   else
     hipLaunchKernelGGL(vsx_kmer_sweep_kernel<false>, grid, block, lds, st, codes, (const u64 *) off, len, seq_list, nseq, w, ntiles,
-                       bucket_count, (const u64 *) bucket_start, (uint16_t *) postings);
+                       bucket_count, (const u64 *) bucket_start, (uint16_t *) postings, lower_bits);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t vsx_kmer_launch_case_bits(const uint8_t * d_ascii, uint64_t nbytes, uint8_t * d_bits, int fold_case, hipStream_t st)
+{
+  if (nbytes == 0) return hipSuccess;
+  const u64 lanes = (nbytes + 7) / 8;
+  hipLaunchKernelGGL(vsx_kmer_case_bits_kernel, dim3((unsigned) ((lanes + 255) / 256)), dim3(256), 0, st, d_ascii, (u64) nbytes, d_bits, fold_case);
   return hipGetLastError();
 }
 

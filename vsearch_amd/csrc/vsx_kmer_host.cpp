@@ -17,6 +17,8 @@ extern "C" int vsx_internal_device(const vsx_ctx * ctx);
 extern "C" hipStream_t vsx_internal_stream(const vsx_ctx * ctx);
 extern "C" void vsx_internal_seqset_device(const vsx_seqset * s, const uint8_t ** codes, const uint64_t ** off,
                                            const uint32_t ** len, uint64_t * n);
+// the set's case bitmap (soft masking) or NULL: an index over a set that has one leaves out every word over a lower-case symbol
+extern "C" const uint8_t * vsx_internal_seqset_lower(const vsx_seqset * s);
 
 namespace {
 
@@ -162,7 +164,7 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   KCHK(ix->d_start.ensure(ix->nbuckets + 1));
   KCHK(hipEventRecord(ix->e0, ix->st));
   KCHK(hipMemsetAsync(ix->d_count.p, 0, ix->nbuckets * 4, ix->st));
-  KCHK(vsx_kmer_launch_sweep(0, codes, off, len, d_list, ix->nseq, w, ix->ntiles, ix->d_count.p, nullptr, nullptr, ix->st));
+  KCHK(vsx_kmer_launch_sweep(0, codes, off, len, d_list, ix->nseq, w, ix->ntiles, ix->d_count.p, nullptr, nullptr, vsx_internal_seqset_lower(ix->db), ix->st));
   // bucket table: exclusive prefix sum on the host (4^w x ntiles entries: 8 MB for 1 M sequences, w = 8)
   std::vector<uint32_t> & cnt = ix->h_count;
   cnt.resize(ix->nbuckets);
@@ -196,7 +198,7 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   if (acc) KCHK(hipMemsetAsync(ix->d_post.p, 0xff, acc * 4, ix->st));
   KCHK(hipMemcpyAsync(ix->d_start.p, start.data(), (ix->nbuckets + 1) * 8, hipMemcpyHostToDevice, ix->st));
   KCHK(hipMemsetAsync(ix->d_count.p, 0, ix->nbuckets * 4, ix->st));
-  KCHK(vsx_kmer_launch_sweep(1, codes, off, len, d_list, ix->nseq, w, ix->ntiles, ix->d_count.p, ix->d_start.p, ix->d_post.p, ix->st));
+  KCHK(vsx_kmer_launch_sweep(1, codes, off, len, d_list, ix->nseq, w, ix->ntiles, ix->d_count.p, ix->d_start.p, ix->d_post.p, vsx_internal_seqset_lower(ix->db), ix->st));
   KCHK(hipEventRecord(ix->e1, ix->st));
   KCHK(hipStreamSynchronize(ix->st));
   float ms = 0;

@@ -33,6 +33,10 @@
 
 extern "C" void vsx_internal_set_error(const char * msg);
 extern "C" const vsx_scoring * vsx_internal_scoring(const vsx_ctx * ctx);
+extern "C" int vsx_internal_seqset_create_cased(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const char * blob, uint64_t blob_bytes,
+                                                const uint64_t * offsets, const uint32_t * lengths, int mode);
+extern "C" int vsx_internal_seqset_lower_download(const vsx_seqset * s, uint8_t * dst, uint64_t nbytes);
+void vsx_internal_dust_one(char * seq, int64_t len, std::vector<char> & scratch);        // vsx_mask.cpp
 
 namespace {
 
@@ -712,7 +716,7 @@ static void build_index(vsx_searcher * S)
 static bool device_kmer_ok(const vsx_searcher & S)
 {
   static const bool forced_host = std::getenv("VSX_KMER") && std::strcmp(std::getenv("VSX_KMER"), "host") == 0;
-  return !forced_host && S.w >= 3 && S.w <= 8 && S.o.soft_mask == 0 && !S.len.empty();
+  return !forced_host && S.w >= 3 && S.w <= 8 && !S.len.empty();
 }
 
 struct KmerAcct { double kernel_ms = 0, build_ms = 0; uint64_t streamed = 0, postings = 0; };
@@ -783,6 +787,29 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
   return VSX_OK;
 }
 
+// DUST of raw queries (soft_mask == 2): the reference masks every query -- and each strand of it separately -- in place before
+// anything else reads it (core/search.cpp:294-303, commands/usearch_global.cpp:386-392); text[off(k) .. + len(k)) for k < n.
+// The sequences must not overlap in the blob.
+template <typename FOff, typename FLen>
+static void dust_states(const vsx_searcher * S, char * text, uint64_t n, FOff off, FLen len)
+{
+  const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, S->threads), n / 32 + 1));
+  std::atomic<uint64_t> next {0};
+  auto work = [&]() {
+    std::vector<char> scratch;
+    for (;;)
+      {
+        const uint64_t k0 = next.fetch_add(32);
+        if (k0 >= n) break;
+        for (uint64_t k = k0; k < std::min(n, k0 + 32); ++k) vsx_internal_dust_one(text + off(k), (int64_t) len(k), scratch);
+      }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nth; ++t) pool.emplace_back(work);
+  work();
+  for (auto & th : pool) th.join();
+}
+
 // device path of search_topscores, stage 1: unique words per query (host threads; unique_count, core/unique.cpp:155-352)
 template <typename FSeq, typename FLen>
 static void kmer_words(const vsx_searcher * S, uint64_t nq, FSeq qseq, FLen qlen, std::vector<std::vector<uint32_t>> & words)
@@ -797,7 +824,7 @@ static void kmer_words(const vsx_searcher * S, uint64_t nq, FSeq qseq, FLen qlen
       {
         const uint64_t k = next.fetch_add(1);
         if (k >= nq) break;
-        unique_kmers(qseq(k), qlen(k), S->w, false, words[k], seen[(size_t) tid]);
+        unique_kmers(qseq(k), qlen(k), S->w, S->o.soft_mask != 0, words[k], seen[(size_t) tid]);
       }
   };
   std::vector<std::thread> pool;
@@ -929,8 +956,37 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
   S->tophits = std::min<int64_t>(S->mr + S->ma + 8, sc);
   S->threads = opts->threads > 0 ? opts->threads : usable_cpus();
 
-  int rc = vsx_seqset_create(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths);
+  // soft masking: the set keeps a case bitmap for its device k-mer index (the alignment itself is case-blind)
+  // (2 = DUST: the device masks the set, vsx_mask.hip, and the host copy takes the result over -- from here on a dust-masked
+  //  database is a soft-masked one, exactly as in the reference where dust_all rewrites the Database's text, mask.cpp:233-249)
+  if (S->o.soft_mask < 0 || S->o.soft_mask > 2) return sfail(VSX_EINVAL, "vsx_searcher_create: soft_mask must be 0 (none), 1 (soft) or 2 (dust)");
+  int rc = S->o.soft_mask ? vsx_internal_seqset_create_cased(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths, S->o.soft_mask)
+                          : vsx_seqset_create(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths);
   if (rc != VSX_OK) return rc;
+  if (S->o.soft_mask == 2 && blob_bytes)
+    {
+      std::vector<uint8_t> bits((blob_bytes + 7) / 8);
+      rc = vsx_internal_seqset_lower_download(S->dbset, bits.data(), bits.size());
+      if (rc != VSX_OK) { vsx_seqset_destroy(S->dbset); return rc; }
+      char * const text = S->blob.data();
+      const int nth = std::max(1, S->threads);
+      const uint64_t step = (blob_bytes + (uint64_t) nth - 1) / (uint64_t) nth;
+      auto fold = [&](int t) {
+        const uint64_t lo = std::min<uint64_t>(blob_bytes, step * (uint64_t) t), hi = std::min<uint64_t>(blob_bytes, lo + step);
+        for (uint64_t i = lo; i < hi; ++i)
+          {
+            unsigned char c = (unsigned char) text[i];
+            if (c >= 'a' && c <= 'z') c = (unsigned char) (c - 32);
+            // (a masked ambiguity code stays upper case: it is masked either way, and no k-mer or alignment step reads the case)
+            if (((bits[i >> 3] >> (i & 7)) & 1u) && (c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'U')) c = (unsigned char) (c | 0x20u);
+            text[i] = (char) c;
+          }
+      };
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nth; ++t) pool.emplace_back(fold, t);
+      fold(0);
+      for (auto & th : pool) th.join();
+    }
   *out = S.release();
   return VSX_OK;
 }
@@ -967,6 +1023,8 @@ int64_t vsx_search_candidates(vsx_searcher * S, const char * q, uint32_t qlen, u
   std::vector<uint32_t> touched, km;
   std::vector<uint64_t> seen(S->w < 10 ? ((1ull << (2 * S->w)) + 63) / 64 : 1, 0);
   std::vector<Cand> c;
+  std::vector<char> masked, scratch;
+  if (S->o.soft_mask == 2 && qlen) { masked.assign(q, q + qlen); vsx_internal_dust_one(masked.data(), qlen, scratch); q = masked.data(); }
   candidates_for(*S, q, qlen, cnt, touched, km, seen, c);
   for (size_t i = 0; i < c.size() && i < cap; ++i) { targets[i] = c[i].target; counts[i] = c[i].count; }
   return (int64_t) c.size();
@@ -980,10 +1038,17 @@ int vsx_search_candidates_batch(vsx_searcher * S, int32_t device, uint64_t nq, c
   for (uint64_t i = 0; i < nq; ++i)
     if (qoff[i] + qlen[i] > qbytes) return sfail(VSX_EINVAL, "vsx_search_candidates_batch: query exceeds the blob");
   if (device && !device_kmer_ok(*S))
-    return sfail(VSX_EINVAL, "vsx_search_candidates_batch: the device path needs wordlength 3..8, hard masking, a non-empty database");
+    return sfail(VSX_EINVAL, "vsx_search_candidates_batch: the device path needs wordlength 3..8 and a non-empty database");
   const double t0 = now_s();
   std::vector<std::vector<Cand>> cands;
   KmerAcct acct;
+  std::string masked;
+  if (S->o.soft_mask == 2 && qbytes)
+    {
+      masked.assign(qblob, qbytes);
+      dust_states(S, &masked[0], nq, [&](uint64_t k) { return qoff[k]; }, [&](uint64_t k) { return qlen[k]; });
+      qblob = masked.data();
+    }
   const int rc = batch_candidates(S, device != 0, nq, [&](uint64_t k) { return qblob + qoff[k]; },
                                   [&](uint64_t k) { return (int64_t) qlen[k]; }, cands, acct);
   if (rc != VSX_OK) return rc;
@@ -1047,7 +1112,8 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
   // does any host step read a minus-strand query as text? (host k-mer path; idprefix / idsuffix / selfid compare symbols;
   // the '*' penalties send every pair to the linear-memory aligner; VSX_RC_TEXT=1 forces it for tests)
   static const bool rc_text_env = std::getenv("VSX_RC_TEXT") != nullptr;
-  const bool need_rc_text = both && (!dev_kmer || S->o.idprefix > 0 || S->o.idsuffix > 0 || S->o.selfid != 0 || S->o.gap_infinite != 0 || rc_text_env);
+  const bool dust = S->o.soft_mask == 2;          // every strand of every query is DUST-masked on its own (search.cpp:294-303)
+  const bool need_rc_text = both && (!dev_kmer || S->o.idprefix > 0 || S->o.idsuffix > 0 || S->o.selfid != 0 || S->o.gap_infinite != 0 || rc_text_env || dust);
 
   struct Window {
     uint64_t w0 = 0, wn = 0, ns = 0, mn = 0, hi = 0;
@@ -1103,10 +1169,17 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
         }
       Window * w = W.get();
       const double t0 = now_s();
+      if (dust)
+        {
+          // masked copies of the window's strands; from here on the window is a soft-masked one
+          if (W->joined.empty()) W->joined.assign(qblob + mn, hi - mn);
+          dust_states(S, &W->joined[0], ns, [w](uint64_t k) { return w->lo[k]; }, [w](uint64_t k) { return w->ln[k]; });
+          W->wblob = W->joined.data();
+        }
       if (dev_kmer)
         {
-          kmer_words(S, wn, [w](uint64_t k) { return w->wblob + w->lo[k]; }, [w](uint64_t k) { return (int64_t) w->ln[k]; }, w->words);
-          if (both)
+          kmer_words(S, dust ? ns : wn, [w](uint64_t k) { return w->wblob + w->lo[k]; }, [w](uint64_t k) { return (int64_t) w->ln[k]; }, w->words);
+          if (both && !dust)
             {
               // unique words of the reverse complement = reverse complements of the unique words (a word over unmasked
               // symbols stays one; unique_count's set semantics, core/unique.cpp:155-352): reverse the 2-bit symbols, complement
@@ -1604,7 +1677,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
         {
           const uint64_t k = next.fetch_add(16);
           if (k >= cnt) break;
-          for (uint64_t x = k; x < std::min(cnt, k + 16); ++x) unique_kmers(seq_of(a0 + x), S->len[a0 + x], S->w, false, dst[x], seen[(size_t) tid]);
+          for (uint64_t x = k; x < std::min(cnt, k + 16); ++x) unique_kmers(seq_of(a0 + x), S->len[a0 + x], S->w, S->o.soft_mask != 0, dst[x], seen[(size_t) tid]);
         }
     };
     std::vector<std::thread> pool;

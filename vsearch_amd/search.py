@@ -44,6 +44,18 @@ def _meta(sizes, labels, n):
     return m, keep
 
 
+def dust_mask(seqs, threads=0):
+    """DUST-masked copies of the sequences (bytes): upper case, low-complexity intervals lower case -- dust() of the
+    reference (core/mask.cpp:127-199), what --qmask dust / --dbmask dust do before the k-mer stage.  Host threads."""
+    lib = _lib.load()
+    blob, off, lens = _blob(seqs)
+    buf = C.create_string_buffer(blob, len(blob) + 1)
+    check(lib.vsx_dust_mask(C.cast(buf, C.c_void_p), len(lens), off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                            int(threads)), "vsx_dust_mask")
+    raw = buf.raw
+    return [raw[int(o):int(o) + int(n)] for o, n in zip(off, lens)]
+
+
 class SearchSession:
     def __init__(self, aligner, db, sizes=None, labels=None, **opts):
         lib = _lib.load()
