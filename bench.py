@@ -109,6 +109,9 @@ def parse():
     ap.add_argument("--kernels-only", action="store_true", help="only the timed kernel steps (profiling passes)")
     ap.add_argument("--e2e-calls", type=int, default=5, help="timed vsx_align_pairs calls of the end-to-end figure")
     ap.add_argument("--no-search", action="store_true", help="skip the vsx_search_batch end-to-end figure")
+    ap.add_argument("--search-mask", choices=["none", "dust"], default="none",
+                    help="masking of the search_end_to_end leg on BOTH sides (the reference CLI is run with the same): none = --qmask none "
+                         "--dbmask none (the round-1 figure), dust = the reference's default (DB masked on the device, queries on host threads)")
     ap.add_argument("--ref-search-queries", type=int, default=512,
                     help="queries the reference CLI searches against the full DB (0 = skip; its index build takes ~1 min)")
     ap.add_argument("--dir-budget-gb", type=float, default=0.0)
@@ -384,6 +387,7 @@ def search_end_to_end(a, al, db_ascii, db_off, db_len, q_ascii, q_off, q_len):
     o = _lib.SearchOpts()
     lib.vsx_search_opts_default(C.byref(o))
     o.id = 0.9
+    o.soft_mask = 2 if a.search_mask == "dust" else 0
     h = C.c_void_p()
     t0 = time.perf_counter()
     check(lib.vsx_searcher_create(al.h, C.byref(h), C.byref(o), len(db_len), C.cast(C.c_char_p(db_blob), C.c_void_p),
@@ -409,14 +413,14 @@ def search_end_to_end(a, al, db_ascii, db_off, db_len, q_ascii, q_off, q_len):
                "value": round(int(hits.cells_aligned) / best / 1e9, 2), "unit": "GCUPS (cells the reference's dispatch aligns / wall)",
                "hits": int(hits.n_hits), "queries_with_hit": int((first[1:] > first[:-1]).sum()),
                "seconds_kmer": round(hits.seconds_kmer, 3), "seconds_align": round(hits.seconds_align, 3),
-               "searcher_create_s": round(t_create, 2)}
+               "searcher_create_s": round(t_create, 2), "masking": a.search_mask}
         nref = min(a.ref_search_queries, nq)
         ref_bin = os.path.join(ROOT, "oracle", "_ref", "vsearch_ref")
         if nref > 0 and not a.no_cpu and os.path.exists(ref_bin):
             harr = np.ctypeslib.as_array(hits.hit, shape=(max(1, int(hits.n_hits)),))[:int(hits.n_hits)]
             keep = (harr["query"] < nref) & (harr["accepted"] != 0)
             ours = set(zip(harr["query"][keep].tolist(), harr["target"][keep].tolist()))
-            out["reference_cli"] = reference_search(ref_bin, db_blob, db_off, db_len, q_blob, q_off, q_len, nref, ours)
+            out["reference_cli"] = reference_search(ref_bin, db_blob, db_off, db_len, q_blob, q_off, q_len, nref, ours, a.search_mask)
             rq = out["reference_cli"].get("queries_per_s")
             if rq:
                 out["vs_reference_cli"] = round(out["queries_per_s"] / rq, 1)
@@ -427,14 +431,15 @@ def search_end_to_end(a, al, db_ascii, db_off, db_len, q_ascii, q_off, q_len):
     return out
 
 
-def reference_search(ref_bin, db_blob, db_off, db_len, q_blob, q_off, q_len, nref, ours):
+def reference_search(ref_bin, db_blob, db_off, db_len, q_blob, q_off, q_len, nref, ours, masking="none"):
     threads = usable_cpus()
     with tempfile.TemporaryDirectory(prefix="vsxbench_") as tmp:
         dbf, qf, uo = (os.path.join(tmp, x) for x in ("db.fa", "q.fa", "u.txt"))
         _write_fasta(dbf, db_blob, db_off, db_len, b"t")
         _write_fasta(qf, q_blob, q_off[:nref], q_len[:nref], b"q")
-        cmd = [ref_bin, "--usearch_global", qf, "--db", dbf, "--id", "0.9", "--threads", str(threads), "--qmask", "none",
-               "--dbmask", "none", "--userout", uo, "--userfields", "query+target"]
+        mask_args = ["--qmask", "none", "--dbmask", "none"] if masking == "none" else []       # no option = dust on both sides
+        cmd = [ref_bin, "--usearch_global", qf, "--db", dbf, "--id", "0.9", "--threads", str(threads)] + mask_args + [
+               "--userout", uo, "--userfields", "query+target"]
         t_start = time.perf_counter()
         p = subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
         stamp = {}
@@ -467,8 +472,9 @@ def reference_search(ref_bin, db_blob, db_off, db_len, q_blob, q_off, q_len, nre
                 theirs.add((int(qn[1:]), int(tn[1:])))
         return {"queries": nref, "threads": threads, "search_seconds": round(secs, 3), "queries_per_s": round(nref / secs, 1),
                 "load_and_index_seconds": round(stamp["search_begin"] - t_start, 1),
-                "what": "vsearch_ref --usearch_global --id 0.9 --qmask none --dbmask none, search phase only (from its 'Searching' prompt "
-                        "to the '100%' that ends it), full DB",
+                "what": "vsearch_ref --usearch_global --id 0.9 " + " ".join(mask_args) + (" " if mask_args else "(default dust masking) ") +
+                        "search phase only (from its 'Searching' prompt to the '100%' that ends it; DB masking and indexing are in "
+                        "load_and_index_seconds), full DB",
                 "hits": len(theirs), "same_hits_as_vsx": bool(theirs == ours)}
 
 

@@ -41,7 +41,8 @@ typedef struct vsx_search_opts {
   int64_t wordlength;       /* 8   (3..15)                                                        */
   int64_t minwordmatches;   /* -1 = table minwordmatches_defaults (core/searchcore.hpp:75-76)     */
   int32_t iddef;            /* 2                                                                  */
-  int32_t soft_mask;        /* masking of BOTH sides before the k-mer stage (--qmask / --dbmask; unique_count masks lower case for
+  int32_t soft_mask;        /* masking before the k-mer stage, of the DATABASE and -- unless qmask says otherwise -- of the queries
+                               (--dbmask / --qmask; clustering masks everything by --qmask: pass it here; unique_count masks lower case for
                                every mode but "none", core/unique.cpp:198-199):
                                  0  none  lower case searchable
                                  1  soft  lower-case symbols are left out of the k-mers
@@ -74,7 +75,8 @@ typedef struct vsx_search_opts {
                                (hit_compare_bysize / search_findbest2_bysize, searchcore.cpp:182-243, :994-1025)        */
   int32_t cluster_unoise;   /* --cluster_unoise: UNOISE skew rule instead of the --id threshold in
                                search_acceptable_aligned (searchcore.cpp:701-718); weak_id is forced to 0.90 (cli.cc:4153) */
-  int32_t pad2;
+  int32_t qmask;            /* --qmask when it differs from --dbmask: 0 = the queries are masked as soft_mask says (default),
+                               otherwise 1 + mode (1 none, 2 soft, 3 dust).  Searching only; clustering uses soft_mask */
   double  unoise_alpha;     /* --unoise_alpha, default 2.0                                                              */
 } vsx_search_opts;
 

@@ -23,12 +23,14 @@ DEFAULT_P = (2, -4, 1, 1, 18, 18, 1, 1, 1, 1, 2, 2, 1, 1)
 def build(ref=True):
     """make liboracle.so; when the reference tree is present also _ref/libvsref.so (the reference's aligner), _ref/vsearch_ref
     (its whole CLI, the command-level oracle) and -- once ../vsearch_amd/libvsx.so exists -- _ref/vsearch_vsx (the same CLI
-    with core/align_simd.cpp swapped for ../shim/vsx_search16_shim.cpp + libvsx: the drop-in proof, tests/test_gpu_shim.py)."""
+    with core/align_simd.cpp swapped for ../shim/vsx_search16_shim.cpp + libvsx: the drop-in proof, tests/test_gpu_shim.py) and
+    the reference's api_examples + oracle/api_driver.cc with search_batch / cluster_assign_batch bound to
+    ../shim/vsx_api_adapter.cpp (ref_api)."""
     subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
     if ref and os.path.isdir(os.path.join(REFERENCE_ROOT, "src")):
         subprocess.check_call(["make", "-s", "-C", HERE, "ref", "ref_full"])
         if os.path.exists(os.path.join(os.path.dirname(HERE), "vsearch_amd", "libvsx.so")):
-            subprocess.check_call(["make", "-s", "-C", HERE, "ref_shim"])
+            subprocess.check_call(["make", "-s", "-C", HERE, "ref_shim", "ref_api"])
 
 
 def _P(P):

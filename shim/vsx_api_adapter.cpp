@@ -1,0 +1,325 @@
+// vsx_api_adapter.cpp -- the reference's LIBRARY API (src/vsearch_api.h) on the throughput path of libvsx: the two batch entry
+// points an embedder calls -- search_batch (core/search.hpp:139-150) and cluster_assign_batch (core/cluster.hpp:112-115) --
+// keep their reference signatures and result structs (search_result_s, cluster_result_s with char cigar[4096] +
+// cigar_truncated) but run on include/vsx_search.h: device k-mer counting, the accept/reject replay, pipelined GPU alignment.
+// Unlike shim/vsx_search16_shim.cpp (one query x <= 8 targets per call) this is the fast path behind the reference's API.
+//
+// Built against the reference's own headers where they lie (oracle/Makefile target `ref_api`, test infrastructure): the
+// reference objects are linked with the originals of the overridden functions RENAMED (objcopy --redefine-sym ... vsxref_*),
+// so that
+//   * the sequential entry points (search_session_single, cluster_assign_single) stay the reference's own code, and the
+//     reference's api_examples -- which assert batch == sequential field by field (api_examples/example_search.cc:131-240,
+//     example_cluster.cc:121-219) -- become a check of the GPU path against the reference inside the reference's own test;
+//   * a configuration this path does not cover is forwarded to the renamed original instead of being approximated.
+//
+// Contract differences an embedder must know (also in INTEGRATION.md):
+//   * cluster_assign_batch clusters the WHOLE database on its first call (the result of greedy clustering does not depend on
+//     the batch boundaries -- that is what the reference's intra-batch fix-up guarantees) and serves every later range from
+//     that result; the caller's Dbindex is not grown.  A session that started with cluster_assign_single stays on the
+//     reference's code for its whole life.
+//   * --hardmask, opt_strand with clustering, and maxaccepts / maxrejects == 0 (unclamped in the library, search.cpp:521-529)
+//     take the reference's code.
+#include "vsearch_api.h"
+
+#include "vsx.h"
+#include "vsx_search.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// the reference's own definitions, renamed at link time
+extern "C" {
+void vsxref_search_batch(struct Parameters const &, struct Dbindex const &, struct Database const &, const char **, const char **,
+                         const int *, const int64_t *, int, struct search_result_s *, int, int *);
+struct cluster_session_s * vsxref_cluster_session_alloc();
+void vsxref_cluster_session_free(struct cluster_session_s *);
+void vsxref_cluster_session_init(struct cluster_session_s *, struct Parameters const &, struct Dbindex &, struct Database const &);
+void vsxref_cluster_assign_single(struct cluster_session_s *, int, struct cluster_result_s *);
+void vsxref_cluster_assign_batch(struct cluster_session_s *, int, int, struct cluster_result_s *);
+void vsxref_cluster_session_cleanup(struct cluster_session_s *);
+}
+
+namespace {
+
+void die(char const * where)
+{
+  std::fprintf(stderr, "libvsx adapter: %s: %s\n", where, vsx_last_error());
+  std::abort();
+}
+
+// VSX_ADAPTER_TRACE=1: say on stderr which code answered (tests assert that the fast path really ran)
+void trace(char const * what, long n)
+{
+  static bool const on = std::getenv("VSX_ADAPTER_TRACE") != nullptr;
+  if (on) std::fprintf(stderr, "libvsx adapter: %s (%ld)\n", what, n);
+}
+
+vsx_scoring scoring_of(struct Parameters const & p)           // the arguments of search16_init, core/search.cpp:147-161
+{
+  return vsx_scoring {p.opt_match, p.opt_mismatch,
+                      p.opt_gap_open_query_left, p.opt_gap_open_target_left,
+                      p.opt_gap_open_query_interior, p.opt_gap_open_target_interior,
+                      p.opt_gap_open_query_right, p.opt_gap_open_target_right,
+                      p.opt_gap_extension_query_left, p.opt_gap_extension_target_left,
+                      p.opt_gap_extension_query_interior, p.opt_gap_extension_target_interior,
+                      p.opt_gap_extension_query_right, p.opt_gap_extension_target_right,
+                      p.opt_n_mismatch ? 1 : 0};
+}
+
+int mask_mode(Masking m) { return m == Masking::none ? 0 : (m == Masking::soft ? 1 : 2); }
+
+// Parameters after vsearch_apply_defaults_fixups (src/vsearch.cc:186-278) -> the fields this path reads
+vsx_search_opts opts_of(struct Parameters const & p, bool clustering)
+{
+  vsx_search_opts o;
+  vsx_search_opts_default(&o);
+  o.id = p.opt_id;
+  o.weak_id = p.opt_weak_id;
+  o.maxaccepts = p.opt_maxaccepts;
+  o.maxrejects = p.opt_maxrejects;
+  o.wordlength = p.opt_wordlength;
+  o.minwordmatches = p.opt_minwordmatches;
+  o.iddef = (int32_t) p.opt_iddef;
+  // the Database handed over is ALREADY masked by the caller (dust_all / hardmask_all before indexing, usearch_global.cpp:
+  // 577-583; api_examples): any mode but "none" means "its lower case is masked".  Queries arrive raw.
+  if (clustering) o.soft_mask = p.opt_qmask == Masking::none ? 0 : 1;      // clustering masks and indexes by --qmask (cluster.cpp:1192-1212)
+  else
+    {
+      o.soft_mask = p.opt_dbmask == Masking::none ? 0 : 1;
+      o.qmask = 1 + mask_mode(p.opt_qmask);
+    }
+  o.maxsubs = p.opt_maxsubs; o.maxgaps = p.opt_maxgaps; o.mincols = p.opt_mincols; o.maxdiffs = p.opt_maxdiffs;
+  o.query_cov = p.opt_query_cov; o.target_cov = p.opt_target_cov; o.maxid = p.opt_maxid; o.mid = p.opt_mid;
+  o.leftjust = (int32_t) p.opt_leftjust; o.rightjust = (int32_t) p.opt_rightjust;
+  o.minqt = p.opt_minqt; o.maxqt = p.opt_maxqt; o.minsl = p.opt_minsl; o.maxsl = p.opt_maxsl;
+  o.idprefix = p.opt_idprefix; o.idsuffix = p.opt_idsuffix;
+  o.selfid = (int32_t) p.opt_selfid;
+  o.self = (int32_t) p.opt_self;
+  o.threads = (int32_t) p.opt_threads;
+  o.strand_both = p.opt_strand ? 1u : 0u;
+  o.maxqsize = p.opt_maxqsize; o.mintsize = p.opt_mintsize;
+  o.minsizeratio = p.opt_minsizeratio; o.maxsizeratio = p.opt_maxsizeratio;
+  o.sizeorder = p.opt_sizeorder ? 1 : 0;
+  o.cluster_unoise = p.opt_cluster_unoise != nullptr ? 1 : 0;
+  o.unoise_alpha = p.opt_unoise_alpha;
+  bool const inf[12] = {p.opt_gap_open_query_left_infinite, p.opt_gap_open_target_left_infinite,
+                        p.opt_gap_open_query_interior_infinite, p.opt_gap_open_target_interior_infinite,
+                        p.opt_gap_open_query_right_infinite, p.opt_gap_open_target_right_infinite,
+                        p.opt_gap_extension_query_left_infinite, p.opt_gap_extension_target_left_infinite,
+                        p.opt_gap_extension_query_interior_infinite, p.opt_gap_extension_target_interior_infinite,
+                        p.opt_gap_extension_query_right_infinite, p.opt_gap_extension_target_right_infinite};
+  for (int k = 0; k < 12; ++k) if (inf[k]) o.gap_infinite |= 1u << k;
+  return o;
+}
+
+bool covered(struct Parameters const & p, bool clustering)
+{
+  if (p.opt_hardmask) return false;
+  if (p.opt_maxaccepts == 0 || p.opt_maxrejects == 0) return false;
+  if (clustering && p.opt_strand) return false;
+  return true;
+}
+
+// A searcher over the caller's Database, rebuilt when the Database or the configuration changed
+struct Fast {
+  vsx_ctx * ctx = nullptr;
+  vsx_searcher * S = nullptr;
+  struct Database const * db = nullptr;
+  uint64_t count = 0, last_len = 0;
+  char const * first = nullptr, * last = nullptr;
+  vsx_search_opts o {};
+  vsx_scoring sc {};
+  void drop()
+  {
+    vsx_searcher_destroy(S); S = nullptr;
+    vsx_destroy(ctx); ctx = nullptr;
+  }
+  void ensure(struct Parameters const & p, struct Database const & d, bool clustering)
+  {
+    uint64_t const n = d.getsequencecount();
+    char const * const f0 = n ? d.getsequence(0) : nullptr;
+    char const * const fl = n ? d.getsequence(n - 1) : nullptr;
+    uint64_t const ll = n ? d.getsequencelen(n - 1) : 0;
+    vsx_search_opts const want = opts_of(p, clustering);
+    vsx_scoring const wsc = scoring_of(p);
+    if (S != nullptr && db == &d && count == n && first == f0 && last == fl && last_len == ll &&
+        std::memcmp(&want, &o, sizeof o) == 0 && std::memcmp(&wsc, &sc, sizeof sc) == 0)
+      return;
+    drop();
+    if (vsx_create(&ctx, &wsc, 0) != VSX_OK) die("vsx_create");
+    std::vector<uint64_t> off(n), size(n);
+    std::vector<uint32_t> len(n);
+    std::vector<char const *> label(n);
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i) { off[i] = total; len[i] = (uint32_t) d.getsequencelen(i); total += len[i]; }
+    std::string blob(total, '\0');
+    for (uint64_t i = 0; i < n; ++i)
+      {
+        std::memcpy(&blob[off[i]], d.getsequence(i), len[i]);
+        size[i] = d.getabundance(i);
+        label[i] = d.getheader(i);
+      }
+    if (vsx_searcher_create(ctx, &S, &want, n, blob.data(), total, off.data(), len.data()) != VSX_OK) die("vsx_searcher_create");
+    vsx_seq_meta const meta = {size.data(), label.data()};
+    if (vsx_searcher_set_meta(S, &meta) != VSX_OK) die("vsx_searcher_set_meta");
+    db = &d; count = n; first = f0; last = fl; last_len = ll; o = want; sc = wsc;
+  }
+  ~Fast() { drop(); }
+};
+
+Fast g_search;            // search_batch is not re-entrant in the reference either (core/search.hpp:128)
+
+}  // namespace
+
+
+auto search_batch(struct Parameters const & parameters, struct Dbindex const & dbindex, struct Database const & db,
+                  const char ** query_seqs, const char ** query_heads, const int * query_lens, const int64_t * query_sizes,
+                  int query_count, struct search_result_s * results, int max_results_per_query, int * result_counts) -> void
+{
+  if (!covered(parameters, false))
+    {
+      trace("search_batch -> reference code", query_count);
+      vsxref_search_batch(parameters, dbindex, db, query_seqs, query_heads, query_lens, query_sizes, query_count, results,
+                          max_results_per_query, result_counts);
+      return;
+    }
+  trace("search_batch -> vsx_search_batch_meta", query_count);
+  g_search.ensure(parameters, db, false);
+  uint64_t const n = (uint64_t) query_count;
+  std::vector<uint64_t> off(n), size(n);
+  std::vector<uint32_t> len(n);
+  uint64_t total = 0;
+  for (uint64_t k = 0; k < n; ++k) { off[k] = total; len[k] = (uint32_t) query_lens[k]; total += len[k]; }
+  std::string blob(total, '\0');
+  for (uint64_t k = 0; k < n; ++k)
+    {
+      std::memcpy(&blob[off[k]], query_seqs[k], len[k]);
+      size[k] = (uint64_t) query_sizes[k];
+    }
+  vsx_seq_meta const qmeta = {size.data(), query_heads};
+  vsx_hits H;
+  if (vsx_search_batch_meta(g_search.S, n, blob.data(), total, off.data(), len.data(), &qmeta, &H) != VSX_OK) die("vsx_search_batch_meta");
+  // search_joinhits order (accepted / weak hits of both strands, best first), the first max_results of it (search.cpp:463-488)
+  for (uint64_t k = 0; k < n; ++k)
+    {
+      int count = 0;
+      for (uint64_t x = H.first[k]; x < H.first[k + 1] && count < max_results_per_query; ++x, ++count)
+        {
+          vsx_hit const & h = H.hit[x];
+          struct search_result_s & r = results[k * (uint64_t) max_results_per_query + (uint64_t) count];
+          r.target = (int) h.target;
+          r.id = h.id;
+          r.matches = h.matches;
+          r.mismatches = h.mismatches;
+          r.gaps = h.nwgaps;
+          r.alignment_length = h.nwalignmentlength;
+          r.query_length = query_lens[k];
+          r.target_length = (int) db.getsequencelen(h.target);
+          r.accepted = h.accepted != 0;
+          r.strand = h.strand;
+        }
+      result_counts[k] = count;
+    }
+  vsx_hits_free(&H);
+}
+
+
+// ---- clustering: the opaque session of the API is ours; it owns a reference session for the sequential entry point
+namespace {
+
+struct FastCluster {
+  struct cluster_session_s * ref = nullptr;
+  struct Parameters const * parameters = nullptr;
+  struct Database const * db = nullptr;
+  enum { undecided, reference_code, fast_path } mode = undecided;
+  Fast fast;
+  vsx_cluster_out out {};                           // fast path: the whole database's clustering (compact; results are
+  bool have = false;                                //  materialised per request -- a cluster_result_s is 5 KB)
+  void forget() { if (have) vsx_cluster_out_free(&out); have = false; }
+};
+
+FastCluster * mine(struct cluster_session_s * cs) { return reinterpret_cast<FastCluster *>(cs); }
+
+void run_fast(FastCluster & c)
+{
+  c.fast.ensure(*c.parameters, *c.db, true);
+  if (vsx_cluster_fast(c.fast.S, 0, &c.out) != VSX_OK) die("vsx_cluster_fast");
+  c.have = true;
+}
+
+// cluster_assign_single's result record (core/cluster.cpp:1719-1750) for sequence s
+void materialise(FastCluster const & c, uint64_t s, struct cluster_result_s & r)
+{
+  struct Database const & db = *c.db;
+  vsx_cluster_out const & out = c.out;
+  if (s >= out.n) { std::fprintf(stderr, "libvsx adapter: sequence %llu is not in the database\n", (unsigned long long) s); std::abort(); }
+  r = cluster_result_s {};
+  r.cluster_id = (int) out.clusterno[s];
+  bool const centroid = out.hits.first[s] == out.hits.first[s + 1];
+  uint64_t const cen = centroid ? s : out.hits.hit[out.hits.first[s]].target;
+  r.is_centroid = centroid;
+  r.centroid_seqno = (int) cen;
+  std::snprintf(r.centroid_label, sizeof r.centroid_label, "%.*s", (int) db.getheaderlen(cen), db.getheader(cen));
+  if (centroid) { r.identity = 100.0; return; }
+  vsx_hit const & h = out.hits.hit[out.hits.first[s]];
+  r.identity = h.id;
+  int const nch = std::snprintf(r.cigar, sizeof r.cigar, "%s", out.hits.cigar_blob + h.cigar_off);
+  r.cigar_truncated = nch >= (int) sizeof r.cigar;
+}
+
+}  // namespace
+
+auto cluster_session_alloc() -> struct cluster_session_s *
+{
+  auto * c = new FastCluster;
+  c->ref = vsxref_cluster_session_alloc();
+  return reinterpret_cast<struct cluster_session_s *>(c);
+}
+
+auto cluster_session_free(struct cluster_session_s * cs) -> void
+{
+  if (cs == nullptr) return;
+  vsxref_cluster_session_free(mine(cs)->ref);
+  mine(cs)->forget();
+  delete mine(cs);
+}
+
+auto cluster_session_init(struct cluster_session_s * cs, struct Parameters const & parameters, struct Dbindex & dbindex,
+                          struct Database const & db) -> void
+{
+  FastCluster & c = *mine(cs);
+  c.parameters = &parameters;
+  c.db = &db;
+  c.mode = FastCluster::undecided;
+  c.forget();
+  vsxref_cluster_session_init(c.ref, parameters, dbindex, db);
+}
+
+auto cluster_assign_single(struct cluster_session_s * cs, int seqno, struct cluster_result_s * result) -> void
+{
+  FastCluster & c = *mine(cs);
+  if (c.mode == FastCluster::undecided) c.mode = FastCluster::reference_code;
+  if (c.mode == FastCluster::reference_code) { vsxref_cluster_assign_single(c.ref, seqno, result); return; }
+  materialise(c, (uint64_t) seqno, *result);
+}
+
+auto cluster_assign_batch(struct cluster_session_s * cs, int start_seqno, int count, struct cluster_result_s * results) -> void
+{
+  FastCluster & c = *mine(cs);
+  if (c.mode == FastCluster::undecided) c.mode = covered(*c.parameters, true) ? FastCluster::fast_path : FastCluster::reference_code;
+  if (c.mode == FastCluster::reference_code) { vsxref_cluster_assign_batch(c.ref, start_seqno, count, results); return; }
+  if (!c.have) { trace("cluster_assign_batch -> vsx_cluster_fast", (long) c.db->getsequencecount()); run_fast(c); }
+  for (int k = 0; k < count; ++k) materialise(c, (uint64_t) (start_seqno + k), results[k]);
+}
+
+auto cluster_session_cleanup(struct cluster_session_s * cs) -> void
+{
+  FastCluster & c = *mine(cs);
+  vsxref_cluster_session_cleanup(c.ref);
+  c.fast.drop();
+  c.forget();
+}

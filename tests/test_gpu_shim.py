@@ -152,3 +152,96 @@ def test_four_reference_threads_share_the_gpu(binaries, tmp_path):
         out[tag] = sorted(open(uf).read().splitlines())
     assert len(out["ref"]) > 100
     assert out["ref"] == out["vsx"]
+
+
+# ---- the reference's LIBRARY API on the fast path (shim/vsx_api_adapter.cpp; oracle/Makefile ref_api) --------------------------
+API_SEARCH = os.path.join(ROOT, "oracle", "_ref", "example_search_vsx")
+API_CLUSTER = os.path.join(ROOT, "oracle", "_ref", "example_cluster_vsx")
+API_DRIVER = os.path.join(ROOT, "oracle", "_ref", "api_driver_vsx")
+
+
+@pytest.fixture
+def api_binaries(gpu_required):
+    for b in (API_SEARCH, API_CLUSTER, API_DRIVER):
+        if not os.path.exists(b):
+            pytest.fail(f"{b} missing: run `make -C oracle ref_full ref_api` in the build container (it travels with the repo)")
+
+
+def _api_data(tmp):
+    """api_examples/data as the reference's examples expect it in their working directory, from tests/golden/ref_api_examples.json"""
+    ex = common.load_api_examples()
+    os.makedirs(os.path.join(tmp, "data"), exist_ok=True)
+    with open(os.path.join(tmp, "data", "chimera_ref.fasta"), "w") as f:
+        f.write("".join(f">{n}\n{s}\n" for n, s in ex["refs"].items()))
+    with open(os.path.join(tmp, "data", "chimera_queries.fasta"), "w") as f:
+        f.write("".join(f">{n}\n{s}\n" for n, s in ex["queries"].items()))
+    return ex
+
+
+def _api_run(argv, cwd):
+    env = dict(os.environ, VSX_ADAPTER_TRACE="1")
+    return subprocess.run(argv, capture_output=True, text=True, timeout=600, cwd=cwd, env=env)
+
+
+def test_reference_example_search_on_the_fast_path(api_binaries, tmp_path):
+    """the reference's own api_examples/example_search.cc, search_batch bound to the GPU path: its Part 2 asserts
+    search_batch == search_session_single (the reference's code) field by field; Part 1's TSV is the in-tree golden file"""
+    ex = _api_data(str(tmp_path))
+    p = _api_run([API_SEARCH], str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "search_batch -> vsx_search_batch_meta" in p.stderr, p.stderr[-2000:]
+    assert "PASS: batch search matches sequential search" in p.stderr
+    got = sorted(tuple(l.split("\t")) for l in p.stdout.splitlines())
+    exp = sorted((e["query"], e["target"], e["id"]) for e in ex["expected_search"])
+    assert got == exp
+
+
+def test_reference_example_cluster_on_the_fast_path(api_binaries, tmp_path):
+    """api_examples/example_cluster.cc: cluster_assign_batch (GPU path) == cluster_assign_single (reference code), and the H
+    records of the in-tree expected_cluster.uc"""
+    ex = _api_data(str(tmp_path))
+    p = _api_run([API_CLUSTER], str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "cluster_assign_batch -> vsx_cluster_fast" in p.stderr, p.stderr[-2000:]
+    assert "PASS: batch cluster matches sequential" in p.stderr
+    hits = sorted(l.split("\t") for l in p.stdout.splitlines() if l.startswith("H"))
+    exp = sorted(ex["expected_cluster_hits"], key=lambda e: e["query"])
+    assert [(h[8], h[9], h[3], h[7]) for h in sorted(hits, key=lambda h: h[8])] == [(e["query"], e["target"], e["id"], e["cigar"]) for e in exp]
+
+
+@pytest.mark.parametrize("strand,qmask,dbmask", [(0, "dust", "dust"), (1, "dust", "dust"), (1, "none", "none"), (0, "soft", "soft"), (0, "dust", "none")])
+def test_library_search_batch_equals_sequential_reference(api_binaries, tmp_path, strand, qmask, dbmask):
+    """a larger embedder run (oracle/api_driver.cc): every field of every search_result_s of search_batch (GPU path) against the
+    reference's sequential search_session_single, with gapped alignments, both strands and the reference's default DUST masking"""
+    from tests import test_gpu_mask as M
+    rng = random.Random(31 + strand)
+    db = M._masked_families(rng, 60, 5, 420, 0.05, qmask == "soft")
+    qs = M._queries(rng, db, 400, 220, 0.04, qmask == "soft")
+    if strand:
+        for k in range(0, len(qs), 2):
+            qs[k] = "".join(M.COMP[c] for c in reversed(qs[k]))
+    M._write(str(tmp_path / "db.fa"), [f"t{i}" for i in range(len(db))], db)
+    M._write(str(tmp_path / "q.fa"), [f"q{i}" for i in range(len(qs))], qs)
+    p = _api_run([API_DRIVER, "search", str(tmp_path / "db.fa"), str(tmp_path / "q.fa"), "0.8", "3", "8", str(strand), qmask, dbmask], str(tmp_path))
+    assert p.returncode == 0, (p.stdout, p.stderr[-3000:])
+    assert "search_batch -> vsx_search_batch_meta" in p.stderr
+    n_hits = int(p.stdout.split(" queries, ")[1].split(" hits")[0])
+    assert n_hits > 500 and p.stdout.strip().endswith(" 0 differences"), p.stdout
+    if strand:
+        assert int(p.stdout.split("(")[1].split(" on the minus")[0]) > 100
+
+
+@pytest.mark.parametrize("batch,qmask", [(64, "dust"), (100000, "dust"), (17, "none")])
+def test_library_cluster_batch_equals_sequential_reference(api_binaries, tmp_path, batch, qmask):
+    """cluster_assign_batch in ranges of `batch` (GPU path) against cluster_assign_single (reference code): every field of every
+    cluster_result_s, CIGAR strings included"""
+    from tests import test_gpu_mask as M
+    rng = random.Random(5)
+    seqs = M._masked_families(rng, 40, 8, 300, 0.03, False)
+    rng.shuffle(seqs)
+    M._write(str(tmp_path / "c.fa"), [f"s{i:04d}" for i in range(len(seqs))], seqs)
+    p = _api_run([API_DRIVER, "cluster", str(tmp_path / "c.fa"), "0.9", "1", "8", str(batch), qmask], str(tmp_path))
+    assert p.returncode == 0, (p.stdout, p.stderr[-3000:])
+    assert "cluster_assign_batch -> vsx_cluster_fast" in p.stderr
+    assert p.stdout.strip().endswith(" 0 differences"), p.stdout
+    assert int(p.stdout.split(" clusters, ")[1].split(" members")[0]) > 100

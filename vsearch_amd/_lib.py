@@ -47,7 +47,7 @@ class SearchOpts(C.Structure):
                 ("idprefix", C.c_int64), ("idsuffix", C.c_int64), ("selfid", C.c_int32), ("threads", C.c_int32),
                 ("window", C.c_int64), ("gap_infinite", C.c_uint32), ("strand_both", C.c_uint32),
                 ("maxqsize", C.c_int64), ("mintsize", C.c_int64), ("minsizeratio", C.c_double), ("maxsizeratio", C.c_double),
-                ("self", C.c_int32), ("sizeorder", C.c_int32), ("cluster_unoise", C.c_int32), ("pad2", C.c_int32),
+                ("self", C.c_int32), ("sizeorder", C.c_int32), ("cluster_unoise", C.c_int32), ("qmask", C.c_int32),
                 ("unoise_alpha", C.c_double)]
 
 

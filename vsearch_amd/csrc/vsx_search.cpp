@@ -263,6 +263,7 @@ struct vsx_searcher {
   std::vector<uint32_t> len;
   vsx_seqset * dbset = nullptr;
   int w = 8;
+  int qmode = 0;                     // masking of raw queries: opts.qmask - 1, or opts.soft_mask when qmask == 0
   std::vector<uint64_t> kstart;      // 4^w + 1
   std::vector<uint32_t> postings;    // targets containing the k-mer, ascending
   int64_t ma = 1, mr = 32, tophits = 0, minwordmatches = 12;
@@ -293,7 +294,7 @@ void candidates_for(const vsx_searcher & S, const char * q, int64_t qlen, std::v
                     std::vector<Cand> & out, const IncIndex * inc = nullptr)
 {
   out.clear();
-  unique_kmers(q, qlen, S.w, S.o.soft_mask != 0, kmers, seen);
+  unique_kmers(q, qlen, S.w, S.qmode != 0, kmers, seen);
   touched.clear();
   auto bump = [&](uint32_t t) {
     uint16_t & c = counts[t];
@@ -787,7 +788,7 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
   return VSX_OK;
 }
 
-// DUST of raw queries (soft_mask == 2): the reference masks every query -- and each strand of it separately -- in place before
+// DUST of raw queries (query masking mode 2): the reference masks every query -- and each strand of it separately -- in place before
 // anything else reads it (core/search.cpp:294-303, commands/usearch_global.cpp:386-392); text[off(k) .. + len(k)) for k < n.
 // The sequences must not overlap in the blob.
 template <typename FOff, typename FLen>
@@ -824,7 +825,7 @@ static void kmer_words(const vsx_searcher * S, uint64_t nq, FSeq qseq, FLen qlen
       {
         const uint64_t k = next.fetch_add(1);
         if (k >= nq) break;
-        unique_kmers(qseq(k), qlen(k), S->w, S->o.soft_mask != 0, words[k], seen[(size_t) tid]);
+        unique_kmers(qseq(k), qlen(k), S->w, S->qmode != 0, words[k], seen[(size_t) tid]);
       }
   };
   std::vector<std::thread> pool;
@@ -960,6 +961,8 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
   // (2 = DUST: the device masks the set, vsx_mask.hip, and the host copy takes the result over -- from here on a dust-masked
   //  database is a soft-masked one, exactly as in the reference where dust_all rewrites the Database's text, mask.cpp:233-249)
   if (S->o.soft_mask < 0 || S->o.soft_mask > 2) return sfail(VSX_EINVAL, "vsx_searcher_create: soft_mask must be 0 (none), 1 (soft) or 2 (dust)");
+  if (S->o.qmask < 0 || S->o.qmask > 3) return sfail(VSX_EINVAL, "vsx_searcher_create: qmask must be 0 (as soft_mask), 1 (none), 2 (soft) or 3 (dust)");
+  S->qmode = S->o.qmask ? S->o.qmask - 1 : S->o.soft_mask;
   int rc = S->o.soft_mask ? vsx_internal_seqset_create_cased(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths, S->o.soft_mask)
                           : vsx_seqset_create(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths);
   if (rc != VSX_OK) return rc;
@@ -1024,7 +1027,7 @@ int64_t vsx_search_candidates(vsx_searcher * S, const char * q, uint32_t qlen, u
   std::vector<uint64_t> seen(S->w < 10 ? ((1ull << (2 * S->w)) + 63) / 64 : 1, 0);
   std::vector<Cand> c;
   std::vector<char> masked, scratch;
-  if (S->o.soft_mask == 2 && qlen) { masked.assign(q, q + qlen); vsx_internal_dust_one(masked.data(), qlen, scratch); q = masked.data(); }
+  if (S->qmode == 2 && qlen) { masked.assign(q, q + qlen); vsx_internal_dust_one(masked.data(), qlen, scratch); q = masked.data(); }
   candidates_for(*S, q, qlen, cnt, touched, km, seen, c);
   for (size_t i = 0; i < c.size() && i < cap; ++i) { targets[i] = c[i].target; counts[i] = c[i].count; }
   return (int64_t) c.size();
@@ -1043,7 +1046,7 @@ int vsx_search_candidates_batch(vsx_searcher * S, int32_t device, uint64_t nq, c
   std::vector<std::vector<Cand>> cands;
   KmerAcct acct;
   std::string masked;
-  if (S->o.soft_mask == 2 && qbytes)
+  if (S->qmode == 2 && qbytes)
     {
       masked.assign(qblob, qbytes);
       dust_states(S, &masked[0], nq, [&](uint64_t k) { return qoff[k]; }, [&](uint64_t k) { return qlen[k]; });
@@ -1112,7 +1115,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
   // does any host step read a minus-strand query as text? (host k-mer path; idprefix / idsuffix / selfid compare symbols;
   // the '*' penalties send every pair to the linear-memory aligner; VSX_RC_TEXT=1 forces it for tests)
   static const bool rc_text_env = std::getenv("VSX_RC_TEXT") != nullptr;
-  const bool dust = S->o.soft_mask == 2;          // every strand of every query is DUST-masked on its own (search.cpp:294-303)
+  const bool dust = S->qmode == 2;                // every strand of every query is DUST-masked on its own (search.cpp:294-303)
   const bool need_rc_text = both && (!dev_kmer || S->o.idprefix > 0 || S->o.idsuffix > 0 || S->o.selfid != 0 || S->o.gap_infinite != 0 || rc_text_env || dust);
 
   struct Window {
