@@ -313,7 +313,7 @@ def main():
 
     # ---- CPU baseline: the reference's own SSE2 search16 (oracle/_ref, built from /root/reference) on a
     #      bounded sample of the SAME workload; falls back to the scalar port if _ref was not shipped ----
-    if not a.no_cpu and not a.kernels_only:
+    if not a.no_cpu and not a.kernels_only and world == 1:          # rank 0 at N = 1 only: the other ranks would idle in the barrier
         try:
             out["cpu_baseline"] = cpu_baseline(a, db_ascii, db_off, db_len, q_ascii, q_off, q_len, qidx, tidx, res)
             if "value_end_to_end" in out and out["cpu_baseline"].get("value"):

@@ -54,6 +54,18 @@ with Aligner(device=0) as al:
             merged[r] = h
     assert merged == full
     assert sum(len(h) for h in full) > 100
+
+    # --usearch_global sharded over the ranks (config 5's form): block of queries per rank, one gather of hit structs +
+    # counts + CIGAR text to rank 0 == the single-rank search of all queries, hit for hit, field for field
+    for kw in (dict(id=0.8, maxaccepts=3, maxrejects=8), dict(id=0.8, maxaccepts=2, strand_both=1, soft_mask=2)):
+        ss2 = SearchSession(al, db, **kw)
+        got = sharding.sharded_search(ss2, qs, dist, dst=0)
+        if rank == 0:
+            exp = ss2.search_batch(qs)
+            assert SearchSession.hits_as_lists(*got) == exp
+            assert sum(len(h) for h in exp) > 40
+        else:
+            assert got is None
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

@@ -164,6 +164,60 @@ def test_gather_records_and_cigar_runs_world2_gloo(tmp_path, oracle):
     assert p.stdout.count("ok") == 2
 
 
+WORKER_SEARCH = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from vsearch_amd import sharding, _lib
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+HIT = np.dtype(_lib.Hit)
+
+class FakeSession:
+    # stands in for SearchSession.search_batch_raw (which needs a GPU): hits are a pure function of the query text, laid out
+    # exactly as vsx_search_batch lays them out (first[], vsx_hit structs with batch-local query numbers, NUL-terminated CIGARs)
+    def search_batch_raw(self, queries, sizes=None, labels=None):
+        first, hits, cig = [0], [], b""
+        for k, q in enumerate(queries):
+            for j in range(len(q) % 4):
+                h = np.zeros((), HIT)
+                h["query"] = k; h["target"] = (len(q) * 7 + j) % 1000; h["matches"] = len(q) - j; h["id"] = 100.0 - j
+                h["accepted"] = 1; h["cigar_off"] = len(cig)
+                cig += (f"{len(q) - j}M{j}I" if j else f"{len(q)}M").encode() + b"\0"
+                hits.append(h)
+            first.append(len(hits))
+        return np.array(first, np.uint64), (np.array(hits, HIT) if hits else np.zeros(0, HIT)), cig
+
+qs = ["A" * (5 + (i * 37) % 23) for i in range(45)] + [""]
+ss = FakeSession()
+exp = ss.search_batch_raw(qs)
+for dst in (None, 0):
+    got = sharding.sharded_search(ss, qs, dist, dst=dst)
+    if dst is not None and rank != dst:
+        assert got is None
+        continue
+    assert np.array_equal(got[0], exp[0]) and got[2] == exp[2]
+    assert got[1].tobytes() == exp[1].tobytes()
+assert len(exp[1]) > 40
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_search_gather_world2_gloo(tmp_path):
+    """sharding.sharded_search (config 5's form: queries sharded, one gather of vsx_hit structs + counts + CIGAR text): with a
+    stand-in for the GPU search, the gathered result must be byte-identical to the single-rank result (query numbers and CIGAR
+    offsets rebased).  The real search runs through it in tests/test_gpu_multirank.py."""
+    script = tmp_path / "worker_search.py"
+    script.write_text(WORKER_SEARCH)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29545", str(script), ROOT]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert p.stdout.count("ok") == 2
+
+
 def test_host_worker_pool_selftest():
     """the persistent worker pool behind the planner's and the fetch's parallel passes: 40 000 short regions from two host threads
     at once (the shape that let a worker touch a returned caller's stack before the region counter moved under its mutex)"""

@@ -200,6 +200,43 @@ class SearchSession:
               "vsx_search_batch_meta")
         return self._unpack(res)
 
+    def search_batch_raw(self, queries, sizes=None, labels=None):
+        """search_batch without the per-hit Python objects: (first[n + 1] uint64, hits = structured array of vsx_hit,
+        cigar blob bytes) -- copies, the C result is released.  What sharding.sharded_search gathers."""
+        lib = _lib.load()
+        blob, off, lens = _blob(queries)
+        res = Hits()
+        m, keep = _meta(sizes, labels, len(lens))
+        check(lib.vsx_search_batch_meta(self.h, len(lens), C.cast(C.c_char_p(blob), C.c_void_p), len(blob),
+                                        off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                                        C.byref(m) if keep else None, C.byref(res)),
+              "vsx_search_batch_meta")
+        try:
+            n, nh = int(res.n_queries), int(res.n_hits)
+            first = np.ctypeslib.as_array(res.first, shape=(n + 1,)).copy()
+            hits = np.ctypeslib.as_array(res.hit, shape=(max(nh, 1),))[:nh].copy()
+            cig = C.string_at(res.cigar_blob, int(res.cigar_bytes)) if res.cigar_bytes else b""
+            self.stats = {nm: getattr(res, nm) for nm in ("pairs_aligned", "cells_aligned", "stages", "sentinel_pairs",
+                                                         "seconds_kmer", "seconds_align", "seconds_total")}
+            return first, hits, cig
+        finally:
+            lib.vsx_hits_free(C.byref(res))
+
+    @staticmethod
+    def hits_as_lists(first, hits, cig):
+        """(first, hits, cigar blob) -> the per-query lists of dicts search_batch returns"""
+        out = []
+        for q in range(len(first) - 1):
+            hs = []
+            for k in range(int(first[q]), int(first[q + 1])):
+                h = hits[k]
+                d = {n: h[n].item() for n in HIT_FIELDS}
+                o = int(h["cigar_off"])
+                d["cigar"] = cig[o:cig.index(b"\0", o)].decode()
+                hs.append(d)
+            out.append(hs)
+        return out
+
     def _unpack(self, res):
         lib = _lib.load()
         try:

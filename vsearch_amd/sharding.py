@@ -221,3 +221,45 @@ def sharded_align(aligner, queries, targets, qidx, tidx, n_queries, dist=None, d
     else:
         order = sel
     return rec_all, runs_all, counts, order
+
+
+def sharded_search(session, queries, dist=None, dst=None, sizes=None, labels=None, device=None):
+    """--usearch_global over the ranks (BASELINE config[5]; SURVEY 8e: queries sharded, DB replicated): this rank searches ITS
+    contiguous block of `queries` against its own replica (vsx_search_batch: device k-mer stage, accept / reject replay, GPU
+    alignment) and takes part in ONE final gather of what a writer needs -- the vsx_hit structs, the per-query hit counts and
+    the CIGAR text -- with the query numbers and CIGAR offsets rebased into the global result.
+    -> (first[n + 1], hits structured array, cigar blob) exactly as a single-rank vsx_search_batch of ALL queries returns them, at
+    the receiver(s) (dst=None: every rank; dst=r: rank r only, the others get None).  No collective before the gather."""
+    import torch
+    from .search import SearchSession  # noqa: F401  (session is one)
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    n = len(queries)
+    lo, hi = shard_queries(n, world, rank)
+    first, hits, cig = session.search_batch_raw(queries[lo:hi], sizes=None if sizes is None else sizes[lo:hi],
+                                                labels=None if labels is None else labels[lo:hi])
+    if world == 1:
+        return first, hits, cig
+    gloo = dist.get_backend() == "gloo"
+    dev = torch.device("cpu") if gloo else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    item = hits.dtype.itemsize
+    t_cnt = torch.from_numpy(np.diff(first.astype(np.int64))).to(dev)
+    t_hit = torch.from_numpy(hits.view(np.uint8).reshape(-1, item).copy() if len(hits) else np.zeros((0, item), np.uint8)).to(dev)
+    t_cig = torch.from_numpy(np.frombuffer(cig, np.uint8).copy()).to(dev)
+    cnt_parts, _ = _gather_var(t_cnt, dist, dst)
+    hit_parts, hit_counts = _gather_var(t_hit, dist, dst)
+    cig_parts, cig_counts = _gather_var(t_cig, dist, dst)
+    if dst is not None and rank != dst:
+        return None
+    all_hits, qbase, cbase = [], 0, 0
+    for r in range(world):
+        part = np.ascontiguousarray(hit_parts[r].cpu().numpy()).view(hits.dtype).reshape(-1).copy()
+        part["query"] += np.uint32(qbase)
+        part["cigar_off"] += np.uint64(cbase)
+        all_hits.append(part)
+        qbase += int(cnt_parts[r].shape[0])
+        cbase += cig_counts[r]
+    counts = np.concatenate([c.cpu().numpy() for c in cnt_parts])
+    first_all = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    cig_all = b"".join(c.cpu().numpy().tobytes() for c in cig_parts)
+    return first_all, np.concatenate(all_hits), cig_all
