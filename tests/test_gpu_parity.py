@@ -243,6 +243,29 @@ def test_long_targets_leave_column_beyond_int16(gpu_required):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("P,nmm", [
+    ((4, -7, 7, 7, 22, 10, 18, 4, 5, 2, 4, 6, 5, 5), True),      # ge(query left) 5 > ge(query interior) 4: found by oracle/soak.py
+    ((2, -4, 3, 3, 20, 20, 3, 3, 6, 6, 2, 2, 6, 6), False),      # every terminal extension dearer than the interior ones
+    ((3, -5, 0, 0, 9, 9, 0, 0, 4, 1, 3, 3, 1, 4), False),
+])
+def test_terminal_extension_dearer_than_interior(gpu_required, oracle, P, nmm):
+    """a scoring set whose left-terminal query-gap extension exceeds the interior one must not take the TOPPAD / tilted
+    classes (their dummy rows above the query would offer a cheaper way along the top border): long target overhangs on both
+    sides, every field against the oracle (which is the reference's result here, oracle/soak.py)"""
+    from vsearch_amd import Aligner
+    rng = random.Random(4)
+    qs, ts = [], []
+    for _ in range(120):
+        q = common.rnd_seq(rng, rng.randint(40, 230))
+        qs.append(q)
+        ts.append(common.rnd_seq(rng, rng.randint(0, 150)) + common.mutate(rng, q, 0.05) + common.rnd_seq(rng, rng.randint(0, 150)))
+    qi = np.arange(len(qs), dtype=np.uint32)
+    with Aligner(scoring=P, n_mismatch=nmm) as al:
+        res = al.align_pairs(al.sequences(qs), al.sequences(ts), qi, qi)
+    for k in range(len(qs)):
+        assert res.row(k) == tuple(oracle.align(qs[k], ts[k], P, nmm)), (k, qs[k], ts[k])
+
+
 def test_baseline_shape_vs_the_reference_itself(gpu_required):
     """2 500 queries x 8 family candidates of the BASELINE shape (250 bp vs ~1 kbp): every field incl. the CIGAR against the
     reference's own SSE2 search16 (oracle/_ref/libvsref.so, the reference sources compiled in place)"""

@@ -812,7 +812,11 @@ static bool no_overflow_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
       if (ctx->pen[k] < 0) return false;
       if (k < 6) G = std::max<int64_t>(G, ctx->pen[k]); else B = std::max<int64_t>(B, ctx->pen[k]);
     }
-  if (ctx->pen[2] + ctx->pen[8] < ctx->pen[6]) return false;     // TOPPAD dummy rows need QR_q(interior) >= ge(query left)
+  // TOPPAD dummy rows (above query row 0) run the interior recurrence; a horizontal gap opened inside them must never beat the
+  // true top border H(-1, j) = -(go_ql + j ge_ql): after n columns it has lost QR_q(interior) + (n - 1) R_q(interior) against
+  // the border's n ge_ql, so both QR_q(interior) >= ge_ql and R_q(interior) >= ge_ql are needed (found by oracle/soak.py: with
+  // ge_ql = 5 > ge_qi = 4 a 77-column terminal gap was priced through the dummy rows)
+  if (ctx->pen[2] + ctx->pen[8] < ctx->pen[6] || ctx->pen[8] < ctx->pen[6]) return false;
   const int64_t Dp = (D + 3) & ~3ll;
   return 4 * G + (Q + Dp + 16) * B < 32000;
 }
