@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY: randomized soak of vsx_cluster_fast (rounds on the GPU + the intra-round fix-up) against the
+REFERENCE CLI (oracle/_ref/vsearch_ref --cluster_fast / --cluster_size), --uc files byte for byte.
+
+Every round draws the command (length- or abundance-sorted, --sizeorder), --id, maxaccepts / maxrejects, word length, identity
+definition, masking, a scoring set in the CLI's syntax, the ROUND SIZE of the GPU stages (the result must not depend on it) and a
+family-structured data set (amplicon-like, duplicates, low-complexity stretches).
+
+    python oracle/soak_cluster.py --seconds 120 --seed 1 --out gpurun_out/soak_cluster.json
+"""
+import argparse
+import json
+import os
+import random
+import subprocess
+import sys
+import tempfile
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import refcli  # noqa: E402
+from tests import common  # noqa: E402
+from tests import test_gpu_mask as M  # noqa: E402
+
+MASKS = ["none", "soft", "dust"]
+
+
+def draw(rng):
+    o, cli = {}, []
+
+    def put(key, val, flag):
+        o[key] = val
+        cli.extend([flag, repr(val) if isinstance(val, float) else str(val)])
+
+    by_size = rng.random() < 0.35
+    put("id", rng.choice([0.8, 0.9, 0.95, 0.97, 0.99]), "--id")
+    put("maxaccepts", rng.choice([1, 1, 2, 3]), "--maxaccepts")
+    put("maxrejects", rng.choice([2, 8, 8, 16, 32]), "--maxrejects")
+    if rng.random() < 0.4:
+        put("wordlength", rng.choice([5, 6, 7, 8]), "--wordlength")
+    if rng.random() < 0.4:
+        put("iddef", rng.choice([0, 1, 2, 3, 4]), "--iddef")
+    if rng.random() < 0.2:
+        put("maxgaps", rng.choice([1, 4]), "--maxgaps")
+    if rng.random() < 0.15:
+        put("query_cov", rng.choice([0.8, 0.95]), "--query_cov")
+    mask = rng.choice(MASKS)
+    o["soft_mask"] = MASKS.index(mask)
+    cli += ["--qmask", mask]
+    if by_size:
+        cli.append("--sizein")
+        if rng.random() < 0.5:
+            o["sizeorder"] = 1
+            cli.append("--sizeorder")
+    scoring = None
+    if rng.random() < 0.3:
+        match, mism = rng.randint(1, 4), -rng.randint(1, 7)
+        e_i, e_e = rng.randint(1, 3), rng.randint(1, 3)
+        o_i, o_e = e_i + rng.randint(0, 20), e_e + rng.randint(0, 6)
+        cli += ["--match", str(match), "--mismatch", str(mism), "--gapopen", f"{o_i}I/{o_e}E", "--gapext", f"{e_i}I/{e_e}E"]
+        scoring = (match, mism, o_e - e_e, o_e - e_e, o_i - e_i, o_i - e_i, o_e - e_e, o_e - e_e, e_e, e_e, e_i, e_i, e_e, e_e)
+    round_size = rng.choice([3, 7, 16, 50, 200, 100000])
+    return o, scoring, cli, by_size, round_size
+
+
+def data(rng, by_size):
+    lower = rng.random() < 0.3
+    seqs = M._masked_families(rng, rng.randint(6, 25), rng.randint(2, 12), rng.choice([120, 250, 320]), rng.choice([0.01, 0.03, 0.08]), lower)
+    seqs += [common.rnd_seq(rng, rng.randint(60, 340)) for _ in range(rng.randint(0, 15))]
+    for _ in range(rng.randint(0, 6)):                                         # duplicates and near-duplicates
+        s = seqs[rng.randrange(len(seqs))]
+        seqs.append(s if rng.random() < 0.5 else s[:-rng.randint(1, 4)])
+    rng.shuffle(seqs)
+    sz = [rng.choice([1, 1, 1, 2, 3, 5, 9, 30, 200]) for _ in seqs] if by_size else None
+    names = [f"s{i:04d}" + (f";size={sz[i]}" if by_size else "") for i in range(len(seqs))]
+    if by_size:     # Database::sortbyabundance (core/db.cpp:471-486): abundance descending, then label, then input order
+        order = sorted(range(len(seqs)), key=lambda i: (-sz[i], names[i], i))
+    else:           # Database::sortbylength (core/db.cpp:433-450): length descending, abundance, label
+        order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), names[i]))
+    return seqs, names, sz, order
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    if not refcli.available():
+        raise SystemExit("oracle/_ref/vsearch_ref missing: make -C oracle ref_full")
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(a.seed)
+    t_end = time.time() + a.seconds
+    rounds = lines = bad = 0
+    failing = []
+    with tempfile.TemporaryDirectory(prefix="vsxsoakc_") as tmp:
+        fa, uc = os.path.join(tmp, "c.fa"), os.path.join(tmp, "c.uc")
+        while time.time() < t_end:
+            o, scoring, cli, by_size, round_size = draw(rng)
+            seqs, names, sz, order = data(rng, by_size)
+            refcli.write_fasta(fa, names, seqs)
+            p = subprocess.run([refcli.REF_BIN, "--cluster_size" if by_size else "--cluster_fast", fa, "--threads", "1", "--uc", uc, "--quiet"] + cli,
+                               capture_output=True, text=True)
+            rounds += 1
+            if p.returncode != 0:
+                bad += 1
+                failing.append({"cli": cli, "error": p.stderr[-300:]})
+                continue
+            exp = open(uc).read().splitlines()
+            sseqs, snames = [seqs[i] for i in order], [names[i] for i in order]
+            ssz = [sz[i] for i in order] if by_size else None
+            with (Aligner(scoring=scoring) if scoring else Aligner()) as al:
+                ss = SearchSession(al, sseqs, sizes=ssz, labels=snames if by_size else None, **o)
+                got = ss.uc_lines(snames, round=round_size, sizes=ssz, command="cluster_size" if by_size else "cluster_fast")
+            lines += len(exp)
+            if got != exp:
+                bad += 1
+                if len(failing) < 10:
+                    first = next((i for i, (x, y) in enumerate(zip(got, exp)) if x != y), min(len(got), len(exp)))
+                    failing.append({"cli": cli, "by_size": by_size, "round_size": round_size, "scoring": scoring, "n": len(seqs), "lines": [len(got), len(exp)],
+                                    "first_diff": first, "got": got[first] if first < len(got) else None, "exp": exp[first] if first < len(exp) else None,
+                                    "round": rounds - 1})
+    out = {"rounds": rounds, "uc_lines": lines, "failing_rounds": bad, "failures": failing, "seed": a.seed, "seconds": a.seconds,
+           "what": "vsx_cluster_fast (SearchSession.uc_lines) vs vsearch_ref --cluster_fast / --cluster_size --uc with the same randomly drawn options"}
+    print(json.dumps(out))
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(out, f)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -133,7 +133,7 @@ def test_cluster_size_sizeorder_matches_reference_cli(gpu_required, tmp_path):
         sseqs, snames, ssz = [seqs[i] for i in order], [names[i] for i in order], [sz[i] for i in order]
         with Aligner() as al:
             ss = SearchSession(al, sseqs, sizes=ssz, labels=snames, id=0.97, maxaccepts=4, maxrejects=32, sizeorder=so)
-            got = ss.uc_lines(snames, round=37, sizes=ssz)
+            got = ss.uc_lines(snames, round=37, sizes=ssz, command="cluster_size")
         assert sum(1 for l in exp if l[0] == "H") > 40
         assert got == exp, (so, _first_diff(got, exp))
         if so:
@@ -158,7 +158,7 @@ def test_cluster_unoise_matches_reference_cli(gpu_required, tmp_path):
     with Aligner() as al:
         # cluster_unoise runs with the search defaults: --id is not given (the rule replaces it), maxrejects 32
         ss = SearchSession(al, sseqs, sizes=ssz, labels=snames, id=0.0, maxaccepts=1, maxrejects=32, cluster_unoise=1, unoise_alpha=2.0)
-        got = ss.uc_lines(snames, round=29, sizes=ssz)
+        got = ss.uc_lines(snames, round=29, sizes=ssz, command="cluster_unoise")
     assert sum(1 for l in exp if l[0] == "H") > 20 and sum(1 for l in exp if l[0] == "S") > 30
     assert got == exp, _first_diff(got, exp)
 

@@ -374,6 +374,49 @@ def test_strand_both_matches_reference_cli(gpu_required, tmp_path):
     assert got == exp, _first_diff(got, exp)
 
 
+@pytest.mark.parametrize("extra,opts", [
+    (["--id", "0.5", "--maxaccepts", "1", "--maxrejects", "32", "--minwordmatches", "0"], dict(id=0.5, maxaccepts=1, maxrejects=32, minwordmatches=0)),
+    (["--id", "0.8", "--maxaccepts", "2", "--weak_id", "0.5"], dict(id=0.8, maxaccepts=2, weak_id=0.5)),
+])
+def test_strand_both_edge_cases_match_reference_cli(gpu_required, tmp_path, extra, opts):
+    """found by oracle/soak_search.py: (1) queries the device counters cannot serve (--minwordmatches 0, queries without a single
+    word) take the host restatement, which reads the minus strand as TEXT -- it has to exist then; (2) a query that hits one target
+    with the same identity on both strands (its own reverse complement) ties in hit_compare_byid: the reference's qsort (glibc's
+    merge sort) keeps the plus-strand hit first"""
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing")
+    from vsearch_amd import Aligner, SearchSession
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda x: "".join(comp[c] for c in reversed(x))
+    rng = random.Random(515)
+    db, _ = common.family_db(rng, 12, 5, 260, div=0.06)
+    halves = [common.rnd_seq(rng, 90) for _ in range(6)]
+    db += [h + rc(h) for h in halves]                                   # reverse-palindromic targets: both strands align alike
+    qs, _ = common.queries_from_db(rng, db[:60], 50, 140)
+    for k in range(0, len(qs), 2):
+        qs[k] = rc(qs[k])
+    qs += [h + rc(h) for h in halves[:4]] + [common.mutate(rng, halves[4] + rc(halves[4]), 0.03)]
+    qs += ["ACG", "ACGTAC", "T" * 7]                                    # shorter than a word: no k-mers at all
+    flds = FIELDS + ["qstrand"]
+    dbf, qf, uf = str(tmp_path / "db.fa"), str(tmp_path / "q.fa"), str(tmp_path / "u.tsv")
+    with open(dbf, "w") as f:
+        f.write("".join(f">t{i}\n{s}\n" for i, s in enumerate(db)))
+    with open(qf, "w") as f:
+        f.write("".join(f">q{i}\n{s}\n" for i, s in enumerate(qs)))
+    p = subprocess.run([REF_BIN, "--usearch_global", qf, "--db", dbf, "--qmask", "none", "--dbmask", "none", "--threads", "1",
+                        "--userout", uf, "--userfields", "+".join(flds), "--quiet", "--strand", "both"] + extra, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    exp = open(uf).read().splitlines()
+    with Aligner() as al:
+        ss = SearchSession(al, db, strand_both=1, **opts)
+        got = ss.userout(qs, fields=flds)
+    assert sum(1 for l in exp if l.endswith("-")) > 10
+    assert got == exp, _first_diff(got, exp)
+    # the tie really occurs: some query reports the same target and identity on both strands
+    keys = [tuple(l.split("\t")[:3]) for l in exp]
+    assert len(keys) > len(set(keys)) or "weak_id" not in opts
+
+
 def _random_cluster(rng, n, clen, alphabet="ACGT", pins=0.03, pdel=0.03, long_ins=False):
     """a centroid and n-1 members with CIGARs drawn directly (member = query, centroid = target: 'D' = symbols only the member has)"""
     cen = "".join(rng.choice(alphabet) for _ in range(clen))

@@ -1132,6 +1132,23 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
     std::string err;
     double t_kmer = 0;
   };
+  // the window's minus strands as text behind the plus strands (W.lo[wn + k] already point there)
+  auto build_rc_text = [&](Window & W) {
+      if (!W.joined.empty()) return;
+      const uint64_t span = W.hi - W.mn;
+      uint64_t tot = 0;
+      for (uint64_t k = 0; k < W.wn; ++k) tot += qlen[W.w0 + k];
+      W.joined.assign(qblob + W.mn, span);
+      W.joined.resize(span + tot);
+      for (uint64_t k = 0; k < W.wn; ++k)
+        {
+          const char * q = qblob + qoff[W.w0 + k];
+          const uint32_t L = qlen[W.w0 + k];
+          char * d = &W.joined[W.lo[W.wn + k]];
+          for (uint32_t x = 0; x < L; ++x) d[x] = complement((unsigned char) q[L - 1 - x]);
+        }
+      W.wblob = W.joined.data();
+  };
   // stage 1a: the window's sequences (and, on the device k-mer path, their unique words)
   auto prepare_words = [&](uint64_t w0) -> std::unique_ptr<Window> {
       std::unique_ptr<Window> W(new Window);
@@ -1156,19 +1173,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
           uint64_t tot = 0;
           for (uint64_t k = 0; k < wn; ++k) { W->lo[wn + k] = (hi - mn) + tot; W->ln[wn + k] = qlen[w0 + k]; tot += qlen[w0 + k]; }
           W->rc_off0 = hi - mn;
-          if (need_rc_text)
-            {
-              W->joined.assign(qblob + mn, hi - mn);
-              W->joined.resize((hi - mn) + tot);
-              for (uint64_t k = 0; k < wn; ++k)
-                {
-                  const char * q = qblob + qoff[w0 + k];
-                  const uint32_t L = qlen[w0 + k];
-                  char * d = &W->joined[W->lo[wn + k]];
-                  for (uint32_t x = 0; x < L; ++x) d[x] = complement((unsigned char) q[L - 1 - x]);
-                }
-              W->wblob = W->joined.data();
-            }
+          if (need_rc_text) build_rc_text(*W);
         }
       Window * w = W.get();
       const double t0 = now_s();
@@ -1199,6 +1204,15 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
                       dst[x] = r;
                     }
                 }
+              // a query the 16-bit tiles cannot serve -- no words at all or --minwordmatches 0 (every sequence is a candidate,
+              // searchcore.cpp:283-288), more than 32 767 words -- goes through the host restatement, which reads TEXT: the
+              // minus strands must exist as text then (found by oracle/soak_search.py: they were read from unbuilt storage)
+              if (W->joined.empty())
+                for (uint64_t k = 0; k < wn; ++k)
+                  {
+                    const uint64_t nk = w->words[k].size();
+                    if (std::min<int64_t>(S->minwordmatches, (int64_t) nk) == 0 || nk > 32767) { build_rc_text(*W); break; }
+                  }
             }
         }
       w->t_kmer = now_s() - t0;
@@ -1273,7 +1287,9 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
           for (Hit & h : st[k].hits) if (h.accepted || h.weak) dst.push_back(std::move(h));
           if (both)
             for (Hit & h : st[wn + k].hits) if (h.accepted || h.weak) { h.minus = true; dst.push_back(std::move(h)); }
-          std::sort(dst.begin(), dst.end(), [](const Hit & a, const Hit & b) { return hit_compare_byid(a, b) < 0; });
+          // STABLE: the comparator ties when both strands hit the same target with the same identity; the reference's qsort is
+          // glibc's merge sort, which keeps the plus-strand hit first (found by oracle/soak_search.py)
+          std::stable_sort(dst.begin(), dst.end(), [](const Hit & a, const Hit & b) { return hit_compare_byid(a, b) < 0; });
         }
       t_join += now_s() - tj;
       return VSX_OK;
@@ -1616,6 +1632,9 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
 {
   if (!S || !out) return sfail(VSX_EINVAL, "vsx_cluster_fast: null argument");
   std::memset(out, 0, sizeof *out);
+  // (never silently: a caller asking for --strand both must not get plus-strand clusters back)
+  if (S->o.strand_both) return sfail(VSX_EINVAL, "vsx_cluster_fast: clustering with --strand both is not provided");
+  if (S->qmode != S->o.soft_mask) return sfail(VSX_EINVAL, "vsx_cluster_fast: clustering masks everything by soft_mask; qmask must be 0");
   const double t_begin = now_s();
   const uint64_t n = S->len.size();
   if (round == 0) round = 4096;

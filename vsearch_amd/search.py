@@ -170,7 +170,7 @@ class SearchSession:
         finally:
             lib.vsx_cluster_out_free(C.byref(res))
 
-    def uc_lines(self, names, round=0, sizes=None):
+    def uc_lines(self, names, round=0, sizes=None, command="cluster_fast"):
         """the --uc file of --cluster_fast: S/H records in processing order, then one C record per cluster
         (core/results.cpp:274-327, core/cluster.cpp:513-547, :1366-1378); with --sizein (`sizes`) a C record carries the
         cluster's total abundance instead of its member count (cluster.cpp:1268-1282)"""
@@ -182,7 +182,10 @@ class SearchSession:
                 centroid[c] = s
                 lines.append(f"S\t{c}\t{len(self.db[s])}\t*\t*\t*\t*\t*\t{names[s]}\t*")
             else:
-                aln = "=" if h["matches"] == h["internal_alignmentlength"] else h["cigar"]
+                # '=': identical ignoring terminal gaps for cluster_fast, strictly identical for the other commands
+                # (check_if_perfect_match, core/results.cpp:84-95)
+                full = h["internal_alignmentlength"] if command == "cluster_fast" else h["nwalignmentlength"]
+                aln = "=" if h["matches"] == full else h["cigar"]
                 lines.append(f"H\t{c}\t{len(self.db[s])}\t{h['id']:.1f}\t+\t0\t0\t{aln}\t{names[s]}\t{names[h['target']]}")
         for c in range(ncl):
             lines.append(f"C\t{c}\t{size[c]}\t*\t*\t*\t*\t*\t{names[centroid[c]]}\t*")
