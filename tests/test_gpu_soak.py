@@ -1,4 +1,4 @@
-"""-m gpu: a short, seeded run of each randomized soak (oracle/soak.py, oracle/soak_search.py, oracle/soak_cluster.py): random
+"""-m gpu: a short, seeded run of each randomized soak (oracle/soak.py, oracle/soak_search.py, oracle/soak_cluster.py, oracle/soak_allpairs.py): random
 scoring sets / option sets / data against the reference's own search16 and the reference CLI.  The long runs (150 s each, other
 seeds) are recorded in profiles/r02k_soak.json; they found three defects in round 2 (a TOPPAD eligibility hole for scoring sets
 with ge(query left) > ge(query interior), minus-strand text missing for queries the device counters cannot serve, the order of
@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("soak.py", 10, "pairs", 50_000),
     ("soak_search.py", 10, "userout_lines", 3_000),
     ("soak_cluster.py", 10, "uc_lines", 3_000),
+    ("soak_allpairs.py", 8, "userout_lines", 5_000),
 ])
 def test_seeded_soak(gpu_required, tmp_path, script, seconds, count_key, floor):
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "vsearch_ref")):
