@@ -83,6 +83,36 @@ def data(rng, by_size):
     return seqs, names, sz, order
 
 
+def _wrap(seq, width=80):
+    return [seq[i:i + width] for i in range(0, len(seq), width)] or [""]
+
+
+def msa_files(ss, al, sseqs, snames, round_size):
+    """--msaout / --consout / --profile lines from vsx_cluster_fast + vsx_msa_device_batch (format: core/msa.cpp:390-560)"""
+    from vsearch_amd import msa_batch
+    cno, per, ncl = ss.cluster_fast(round=round_size)
+    members = [[] for _ in range(ncl)]
+    for s, c in enumerate(cno):
+        members[c].append(s)
+    results = msa_batch([[sseqs[s] for s in m] for m in members], [[None] + [per[s]["cigar"] for s in m[1:]] for m in members], None, al)
+    msa_lines, cons_lines, prof_lines = [], [], []
+    for c in range(ncl):
+        m, res = members[c], results[c]
+        msa_lines.append("")
+        for k, s in enumerate(m):
+            msa_lines.append(">" + ("*" if k == 0 else "") + snames[s])
+            msa_lines += _wrap(res["rows"][k])
+        msa_lines.append(">consensus")
+        msa_lines += _wrap(res["rows"][-1])
+        cons_lines.append(f">centroid={snames[m[0]]};seqs={len(m)}")
+        cons_lines += _wrap(res["consensus"])
+        prof_lines.append(f">centroid={snames[m[0]]};seqs={len(m)}")
+        for i, (ch, pr) in enumerate(zip(res["rows"][-1], res["profile"])):
+            prof_lines.append("\t".join([str(i), ch] + [str(pr[k]) for k in (0, 1, 2, 3, 5, 4)]))
+        prof_lines.append("")
+    return msa_lines, cons_lines, prof_lines
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
@@ -94,7 +124,7 @@ def main():
     from vsearch_amd import Aligner, SearchSession
     rng = random.Random(a.seed)
     t_end = time.time() + a.seconds
-    rounds = lines = bad = 0
+    rounds = lines = bad = msa_rounds = 0
     failing = []
     with tempfile.TemporaryDirectory(prefix="vsxsoakc_") as tmp:
         fa, uc = os.path.join(tmp, "c.fa"), os.path.join(tmp, "c.uc")
@@ -102,7 +132,11 @@ def main():
             o, scoring, cli, by_size, round_size = draw(rng)
             seqs, names, sz, order = data(rng, by_size)
             refcli.write_fasta(fa, names, seqs)
-            p = subprocess.run([refcli.REF_BIN, "--cluster_size" if by_size else "--cluster_fast", fa, "--threads", "1", "--uc", uc, "--quiet"] + cli,
+            # the CIGAR consumer too (msa.cpp): star MSA, consensus and profile of every cluster, on the device, in half of the
+            # cluster_fast rounds without masking (masking changes the case of the printed rows)
+            want_msa = (not by_size) and o["soft_mask"] == 0 and rng.random() < 0.5
+            msa_args = ["--msaout", tmp + "/m.msa", "--consout", tmp + "/m.cons", "--profile", tmp + "/m.prof"] if want_msa else []
+            p = subprocess.run([refcli.REF_BIN, "--cluster_size" if by_size else "--cluster_fast", fa, "--threads", "1", "--uc", uc, "--quiet"] + cli + msa_args,
                                capture_output=True, text=True)
             rounds += 1
             if p.returncode != 0:
@@ -115,6 +149,12 @@ def main():
             with (Aligner(scoring=scoring) if scoring else Aligner()) as al:
                 ss = SearchSession(al, sseqs, sizes=ssz, labels=snames if by_size else None, **o)
                 got = ss.uc_lines(snames, round=round_size, sizes=ssz, command="cluster_size" if by_size else "cluster_fast")
+                if want_msa:
+                    got_msa = msa_files(ss, al, sseqs, snames, round_size)
+                    exp_msa = tuple(open(tmp + x).read().splitlines() for x in ("/m.msa", "/m.cons", "/m.prof"))
+                    msa_rounds += 1
+                    if got_msa != exp_msa:
+                        got = got + ["<msa / consensus / profile differ>"]
             lines += len(exp)
             if got != exp:
                 bad += 1
@@ -123,7 +163,7 @@ def main():
                     failing.append({"cli": cli, "by_size": by_size, "round_size": round_size, "scoring": scoring, "n": len(seqs), "lines": [len(got), len(exp)],
                                     "first_diff": first, "got": got[first] if first < len(got) else None, "exp": exp[first] if first < len(exp) else None,
                                     "round": rounds - 1})
-    out = {"rounds": rounds, "uc_lines": lines, "failing_rounds": bad, "failures": failing, "seed": a.seed, "seconds": a.seconds,
+    out = {"rounds": rounds, "msa_rounds": msa_rounds, "uc_lines": lines, "failing_rounds": bad, "failures": failing, "seed": a.seed, "seconds": a.seconds,
            "what": "vsx_cluster_fast (SearchSession.uc_lines) vs vsearch_ref --cluster_fast / --cluster_size --uc with the same randomly drawn options"}
     print(json.dumps(out))
     if a.out:
