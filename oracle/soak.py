@@ -47,7 +47,9 @@ def draw_scoring(rng):
 
 def draw_population(rng, nq, nt):
     """nq queries x nt targets each (one reference search16 call per query), one shape class per round"""
-    shape = rng.choice(["related", "unrelated", "iupac", "tiny", "gappy", "long_target", "square", "mixed"])
+    shape = rng.choice(["related", "unrelated", "iupac", "tiny", "gappy", "long_target", "square", "mixed", "multi_strip"])
+    if shape == "multi_strip":      # queries beyond 16 lanes x 32 rows: several strips, handed over through HBM; few, they are big
+        nq = max(2, nq // 16)
     qs, ts = [], []
     for _ in range(nq):
         if shape in ("related", "unrelated", "iupac", "tiny", "gappy"):
@@ -59,6 +61,15 @@ def draw_population(rng, nq, nt):
             for _ in range(nt):
                 core = mutate(rng, q, rng.choice([0.03, 0.1]))
                 tt.append(rnd_seq(rng, rng.randint(0, 700)) + core + rnd_seq(rng, rng.randint(0, 700)))
+        elif shape == "multi_strip":
+            q = rnd_seq(rng, rng.randint(513, 2600))
+            tt = []
+            for _ in range(nt):
+                core = mutate(rng, q, rng.choice([0.02, 0.08]))
+                if rng.random() < 0.5:
+                    a = rng.randint(0, len(core) // 2)
+                    core = core[a:a + rng.randint(200, len(core))]
+                tt.append(rnd_seq(rng, rng.randint(0, 300)) + core + rnd_seq(rng, rng.randint(0, 300)))
         elif shape == "square":
             L = rng.randint(200, 520)
             q = rnd_seq(rng, L)

@@ -42,7 +42,7 @@ def draw_options(rng):
     put("maxaccepts", rng.choice([0, 1, 1, 2, 3, 5]), "--maxaccepts")
     put("maxrejects", rng.choice([0, 2, 8, 16, 32]), "--maxrejects")
     if rng.random() < 0.5:
-        put("wordlength", rng.choice([4, 5, 6, 7, 8]), "--wordlength")
+        put("wordlength", rng.choice([3, 4, 5, 6, 7, 8, 8, 9, 10, 12]), "--wordlength")      # > 8: the host restatement of the k-mer stage
     if rng.random() < 0.2:
         put("minwordmatches", rng.choice([0, 3, 8, 20]), "--minwordmatches")
     if rng.random() < 0.5:
