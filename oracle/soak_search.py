@@ -101,6 +101,10 @@ def draw_data(rng, sizes, use_self):
     qs = M._queries(rng, db, rng.randint(30, 90), rng.choice([90, 150, 220]), rng.choice([0.02, 0.05]), lower)
     qs += [common.mutate(rng, db[rng.randrange(len(db))].upper(), 0.04) for _ in range(10)]
     qs += [db[rng.randrange(len(db))] for _ in range(4)]                      # exact copies (identity 100, --selfid material)
+    if rng.random() < 0.06:     # pairs beyond the 16-bit aligner's size guard (Q x D > 25e6): the sentinel and the linear-memory fallback
+        anc = common.rnd_seq(rng, rng.randint(5200, 6400))
+        db += [common.mutate(rng, anc, 0.03), common.mutate(rng, anc, 0.06)]
+        qs += [common.mutate(rng, anc, 0.02), common.mutate(rng, anc[300:5600], 0.04)]
     if rng.random() < 0.5:
         comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "a": "t", "c": "g", "g": "c", "t": "a", "n": "n"}
         for k in range(0, len(qs), 3):
