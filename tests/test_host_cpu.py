@@ -353,3 +353,45 @@ def test_dust_mask_matches_reference_fixture():
     # idempotent, and the empty / shorter-than-a-region sequences come back upper-cased
     assert [g.decode() for g in dust_mask(got)] == got
     assert [g.decode() for g in dust_mask(["", "acg", "aaaaaaa"])] == ["", "ACG", "AAAAAAA"]
+
+
+def test_soak_harnesses_draw_valid_reference_commands(tmp_path):
+    """the randomized soaks (oracle/soak*.py) run on the GPU box; here, without a GPU, their option generators must keep producing
+    command lines the reference CLI accepts (a harness that silently stopped exercising the reference would pin nothing)"""
+    import random
+    import subprocess
+    from oracle import refcli, soak, soak_allpairs, soak_cluster, soak_search, pyoracle
+    if not refcli.available() or not pyoracle.have_ref():
+        pytest.skip("oracle/_ref not built here")
+    rng = random.Random(1)
+    tmp = str(tmp_path)
+    lines = 0
+    for _ in range(6):
+        o, sc, cli, sizes, use_self = soak_search.draw_options(rng)
+        db, qs, tn, qn, ts, qz = soak_search.draw_data(rng, sizes, use_self)
+        refcli.write_fasta(tmp + "/db.fa", tn, db)
+        refcli.write_fasta(tmp + "/q.fa", qn, qs)
+        p = subprocess.run([refcli.REF_BIN, "--usearch_global", tmp + "/q.fa", "--db", tmp + "/db.fa", "--threads", "1", "--userout", tmp + "/u.tsv",
+                            "--userfields", "+".join(soak_search.FIELDS), "--quiet"] + cli, capture_output=True, text=True)
+        assert p.returncode == 0, (cli, p.stderr[-500:])
+        lines += len(open(tmp + "/u.tsv").read().splitlines())
+        o, sc, cli, by_size, rs = soak_cluster.draw(rng)
+        seqs, names, sz, order = soak_cluster.data(rng, by_size)
+        refcli.write_fasta(tmp + "/c.fa", names, seqs)
+        p = subprocess.run([refcli.REF_BIN, "--cluster_size" if by_size else "--cluster_fast", tmp + "/c.fa", "--threads", "1", "--uc", tmp + "/c.uc",
+                            "--quiet"] + cli, capture_output=True, text=True)
+        assert p.returncode == 0, (cli, p.stderr[-500:])
+        o, sc, cli, aa, sizes = soak_allpairs.draw(rng)
+        seqs, names, sz = soak_allpairs.data(rng, sizes)
+        refcli.write_fasta(tmp + "/a.fa", names, seqs)
+        p = subprocess.run([refcli.REF_BIN, "--allpairs_global", tmp + "/a.fa", "--qmask", "none", "--threads", "1", "--userout", tmp + "/ua.tsv",
+                            "--userfields", "+".join(soak_allpairs.FIELDS), "--quiet"] + cli, capture_output=True, text=True)
+        assert p.returncode == 0, (cli, p.stderr[-500:])
+        P, nmm, kind = soak.draw_scoring(rng)
+        shape, sq, st = soak.draw_population(rng, 4, 3)
+        ref = pyoracle.Reference(P, nmm)
+        try:
+            assert len(ref.search16(sq[0], st[0])) == 3
+        finally:
+            ref.close()
+    assert lines > 100
