@@ -5,8 +5,9 @@
 //            compares every field of every search_result_s;
 //   cluster  cluster_assign_single over the length-sorted database (reference code) against cluster_assign_batch in several
 //            ranges (GPU path), every field of every cluster_result_s.
-// Usage: api_driver search  db.fa q.fa id maxaccepts maxrejects strand(0|1) qmask dbmask   (masks: none|soft|dust)
-//        api_driver cluster db.fa      id maxaccepts maxrejects batch_size qmask
+// Usage: api_driver search  db.fa q.fa id maxaccepts maxrejects strand(0|1) qmask dbmask [key=value ...]  (masks: none|soft|dust)
+//        api_driver cluster db.fa      id maxaccepts maxrejects batch_size qmask        [key=value ...]
+//        key = a CLI option name (wordlength, iddef, maxgaps, ..., match, mismatch, gapopen_i/e, gapext_i/e; sizes=1 reads ";size=")
 // Exit code 0 = identical; differences are listed on stderr.
 #include "vsearch_api.h"
 
@@ -45,13 +46,68 @@ static Masking mask_of(char const * s)
   return Masking::dust;
 }
 
+// trailing key=value arguments -> Parameters fields (the names of the CLI options; sizes = 1: abundances from ";size=" in the labels)
+static bool g_sizes = false;
+static void apply_options(struct Parameters & p, int argc, char ** argv, int first)
+{
+  for (int k = first; k < argc; ++k)
+    {
+      char const * eq = std::strchr(argv[k], '=');
+      if (eq == nullptr) { std::fprintf(stderr, "bad option %s\n", argv[k]); std::exit(2); }
+      std::string const key(argv[k], (size_t) (eq - argv[k]));
+      double const v = std::atof(eq + 1);
+      if (key == "wordlength") p.opt_wordlength = (int64_t) v;
+      else if (key == "minwordmatches") p.opt_minwordmatches = (int64_t) v;
+      else if (key == "iddef") p.opt_iddef = (int64_t) v;
+      else if (key == "weak_id") p.opt_weak_id = v;
+      else if (key == "maxgaps") p.opt_maxgaps = (int64_t) v;
+      else if (key == "maxsubs") p.opt_maxsubs = (int64_t) v;
+      else if (key == "maxdiffs") p.opt_maxdiffs = (int64_t) v;
+      else if (key == "mincols") p.opt_mincols = (int64_t) v;
+      else if (key == "query_cov") p.opt_query_cov = v;
+      else if (key == "target_cov") p.opt_target_cov = v;
+      else if (key == "maxid") p.opt_maxid = v;
+      else if (key == "mid") p.opt_mid = v;
+      else if (key == "minqt") p.opt_minqt = v;
+      else if (key == "maxqt") p.opt_maxqt = v;
+      else if (key == "minsl") p.opt_minsl = v;
+      else if (key == "maxsl") p.opt_maxsl = v;
+      else if (key == "idprefix") p.opt_idprefix = (int64_t) v;
+      else if (key == "idsuffix") p.opt_idsuffix = (int64_t) v;
+      else if (key == "leftjust") p.opt_leftjust = (int64_t) v;
+      else if (key == "rightjust") p.opt_rightjust = (int64_t) v;
+      else if (key == "selfid") p.opt_selfid = (int64_t) v;
+      else if (key == "self") p.opt_self = (int64_t) v;
+      else if (key == "maxqsize") p.opt_maxqsize = (int64_t) v;
+      else if (key == "mintsize") p.opt_mintsize = (int64_t) v;
+      else if (key == "minsizeratio") p.opt_minsizeratio = v;
+      else if (key == "maxsizeratio") p.opt_maxsizeratio = v;
+      else if (key == "sizeorder") p.opt_sizeorder = v != 0;
+      else if (key == "sizes") g_sizes = v != 0;
+      else if (key == "match") p.opt_match = (int64_t) v;
+      else if (key == "mismatch") p.opt_mismatch = (int64_t) v;
+      else if (key == "gapopen_i") { p.opt_gap_open_query_interior = (int) v; p.opt_gap_open_target_interior = (int) v; }
+      else if (key == "gapopen_e") { p.opt_gap_open_query_left = p.opt_gap_open_target_left = p.opt_gap_open_query_right = p.opt_gap_open_target_right = (int) v; }
+      else if (key == "gapext_i") { p.opt_gap_extension_query_interior = (int) v; p.opt_gap_extension_target_interior = (int) v; }
+      else if (key == "gapext_e") { p.opt_gap_extension_query_left = p.opt_gap_extension_target_left = p.opt_gap_extension_query_right = p.opt_gap_extension_target_right = (int) v; }
+      else { std::fprintf(stderr, "unknown option %s\n", key.c_str()); std::exit(2); }
+    }
+}
+
+static int64_t size_of(std::string const & label)
+{
+  if (!g_sizes) return 1;
+  size_t const at = label.find(";size=");
+  return at == std::string::npos ? 1 : std::atoll(label.c_str() + at + 6);
+}
+
 static void load(Database & db, struct Parameters & parameters, char const * path, Masking mode)
 {
   std::vector<std::string> labels, seqs;
   read_fasta(path, labels, seqs);
   db.init();
   for (size_t i = 0; i < labels.size(); ++i)
-    db.add(false, labels[i].c_str(), seqs[i].c_str(), nullptr, labels[i].size(), seqs[i].size(), 1);
+    db.add(false, labels[i].c_str(), seqs[i].c_str(), nullptr, labels[i].size(), seqs[i].size(), size_of(labels[i]));
   if (mode == Masking::dust) dust_all(db, parameters);
 }
 
@@ -67,6 +123,7 @@ static int run_search(int argc, char ** argv)
   parameters.opt_qmask = mask_of(argv[8]);
   parameters.opt_dbmask = mask_of(argv[9]);
   parameters.opt_threads = 4;
+  apply_options(parameters, argc, argv, 10);
   vsearch_session_begin(parameters);
 
   Database db;
@@ -86,7 +143,7 @@ static int run_search(int argc, char ** argv)
   struct search_session_s * ss = search_session_alloc();
   search_session_init(ss, parameters, dbindex, db);
   for (int i = 0; i < nq; ++i)
-    search_session_single(ss, qseqs[i].c_str(), qlabels[i].c_str(), (int) qseqs[i].size(), 1, &seq_results[(size_t) i * per], per, &seq_counts[i]);
+    search_session_single(ss, qseqs[i].c_str(), qlabels[i].c_str(), (int) qseqs[i].size(), size_of(qlabels[i]), &seq_results[(size_t) i * per], per, &seq_counts[i]);
   search_session_cleanup(ss);
   search_session_free(ss);
 
@@ -105,7 +162,7 @@ static int run_search(int argc, char ** argv)
   std::vector<char const *> qs(nq), qh(nq);
   std::vector<int> ql(nq);
   std::vector<int64_t> qz(nq, 1);
-  for (int i = 0; i < nq; ++i) { qs[i] = qseqs[i].c_str(); qh[i] = qlabels[i].c_str(); ql[i] = (int) qseqs[i].size(); }
+  for (int i = 0; i < nq; ++i) { qs[i] = qseqs[i].c_str(); qh[i] = qlabels[i].c_str(); ql[i] = (int) qseqs[i].size(); qz[i] = size_of(qlabels[i]); }
   search_batch(parameters, dbindex, db, qs.data(), qh.data(), ql.data(), qz.data(), nq, batch_results.data(), per, batch_counts.data());
 
   long bad = 0, hits = 0, minus = 0;
@@ -149,6 +206,7 @@ static int run_cluster(int argc, char ** argv)
   int const batch = std::atoi(argv[6]);
   parameters.opt_qmask = mask_of(argv[7]);
   parameters.opt_threads = 4;
+  apply_options(parameters, argc, argv, 8);
   vsearch_session_begin(parameters);
 
   Database db;

@@ -19,9 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("soak_search.py", 10, "userout_lines", 3_000),
     ("soak_cluster.py", 10, "uc_lines", 3_000),
     ("soak_allpairs.py", 8, "userout_lines", 5_000),
+    ("soak_api.py", 8, "search_hits_compared", 100),
 ])
 def test_seeded_soak(gpu_required, tmp_path, script, seconds, count_key, floor):
-    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "vsearch_ref")):
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "vsearch_ref")) or not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "api_driver_vsx")):
         pytest.fail("oracle/_ref missing: run `make -C oracle ref ref_full` in the build container")
     out = str(tmp_path / "soak.json")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", script), "--seconds", str(seconds), "--seed", "20260924", "--out", out],
