@@ -39,6 +39,13 @@ inline unsigned two_bit(unsigned char c)        // map_2bit, utils/maps.cpp:156-
     }
 }
 
+// ceil(2^32 / j): x / j == (x * kMagic[j]) >> 32 for x < 2^32 / 63 (x <= 18 910 here; checked exhaustively in the tests' golden run)
+struct Magic {
+  uint32_t m[kWindow];
+  Magic() { m[0] = m[1] = 0; for (uint32_t j = 2; j < (uint32_t) kWindow; ++j) m[j] = (uint32_t) (0x100000000ull / j) + ((j & (j - 1)) ? 1u : 0u); }
+};
+const Magic kMagic;
+
 // best interval of one window of n <= 64 symbols; returns its score (0: none)
 int window_best(const char * s, int n, int & first, int & last)
 {
@@ -48,19 +55,34 @@ int window_best(const char * s, int n, int & first, int & last)
   unsigned char tri[kWindow];                   // 3-mer ending at each position (the first two entries are partial and never read)
   unsigned acc = 0;
   for (int j = 0; j < n; ++j) { acc = (acc << 2) | two_bit((unsigned char) s[j]); tri[j] = (unsigned char) (acc & 63u); }
+  // Only windows with a score ABOVE the level matter (dust_one masks nothing otherwise), and 10 pairs / j > 20 needs pairs >= 2.1 j
+  // while no interval holds more pairs of equal 3-mers than the whole window does: end offsets beyond 10 total / 21 cannot exceed
+  // the level, so they can neither be the answer nor change it.  One counting pass bounds the search; windows of ordinary sequence
+  // (total ~ 30) walk a fifth of the end offsets, low-complexity windows all of them.
+  int jlim;
+  {
+    unsigned char cnt[64];
+    std::memset(cnt, 0, sizeof cnt);
+    int total = 0;
+    for (int j = 2; j < n; ++j) total += cnt[tri[j]]++;
+    jlim = 10 * total / (kLevel + 1) + 1;       // exclusive
+    if (jlim <= 2) return 0;
+  }
   int best = 0, bi = 0, bj = 0;
   for (int i = 0; i < starts; ++i)
     {
       unsigned char seen[64];
       std::memset(seen, 0, sizeof seen);
-      int pairs = 0;
-      for (int j = 2; j < n - i; ++j)
+      unsigned pairs = 0;
+      const unsigned char * t = tri + i;
+      const int m = std::min(n - i, jlim);
+      for (int j = 2; j < m; ++j)
         {
-          unsigned char & c = seen[tri[i + j]];
+          unsigned char & c = seen[t[j]];
           if (c)
             {
               pairs += c;
-              const int v = 10 * pairs / j;
+              const int v = (int) (((uint64_t) (10u * pairs) * kMagic.m[j]) >> 32);
               if (v > best) { best = v; bi = i; bj = j; }
             }
           ++c;
