@@ -33,6 +33,7 @@
 
 extern "C" void vsx_internal_set_error(const char * msg);
 extern "C" const vsx_scoring * vsx_internal_scoring(const vsx_ctx * ctx);
+extern "C" int vsx_internal_device(const vsx_ctx * ctx);
 extern "C" int vsx_internal_seqset_create_cased(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const char * blob, uint64_t blob_bytes,
                                                 const uint64_t * offsets, const uint32_t * lengths, int mode);
 extern "C" int vsx_internal_seqset_lower_download(const vsx_seqset * s, uint8_t * dst, uint64_t nbytes);
@@ -262,6 +263,7 @@ struct vsx_searcher {
   std::vector<uint64_t> off;
   std::vector<uint32_t> len;
   vsx_seqset * dbset = nullptr;
+  vsx_ctx * ctx2 = nullptr;          // a second aligner context of the same device (owned): the second consumer of the search pipeline
   int w = 8;
   int qmode = 0;                     // masking of raw queries: opts.qmask - 1, or opts.soft_mask when qmask == 0
   std::vector<uint64_t> kstart;      // 4^w + 1
@@ -564,8 +566,9 @@ struct Acct { double t_align = 0, t_advance = 0, t_replay = 0; uint64_t pairs = 
 // qtext(k): the query as text for the linear-memory fallback (sentinel pairs only; may build it on demand).
 template <typename FSeq, typename FText, typename FLen, typename FIdx, typename FMeta>
 static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qseq, FText qtext, FLen qlen, FIdx qidx, FMeta qmeta,
-                      const vsx_seqset * qset, Acct & acct)
+                      const vsx_seqset * qset, Acct & acct, vsx_ctx * ctx = nullptr /* default: the searcher's own */)
 {
+  if (!ctx) ctx = S.ctx;
   const uint64_t wn = st.size();
   std::vector<uint32_t> open(wn);
   for (uint64_t k = 0; k < wn; ++k) open[k] = (uint32_t) k;
@@ -612,7 +615,7 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
       const vsx_filter flt = make_filter(S);
       // with '*' penalties every pair takes the linear-memory fallback and the forbidden-gap test, and the UNOISE rule needs the
       // abundances: nothing for the device to decide
-      int rc = vsx_align_pairs_filtered(S.ctx, qset, S.dbset, pq.size(), pq.data(), pt.data(),
+      int rc = vsx_align_pairs_filtered(ctx, qset, S.dbset, pq.size(), pq.data(), pt.data(),
                                         (S.o.gap_infinite || S.o.cluster_unoise) ? nullptr : &flt, &res);
       acct.t_align += now_s() - t0;
       if (rc != VSX_OK) return rc;
@@ -1015,6 +1018,7 @@ void vsx_searcher_destroy(vsx_searcher * s)
   if (!s) return;
   vsx_kmer_index_destroy(s->kidx);
   vsx_seqset_destroy(s->dbset);
+  vsx_destroy(s->ctx2);
   delete s;
 }
 
@@ -1238,7 +1242,8 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       return W;
   };
   // stage 2: align, replay the accept counters, join the hits
-  auto consume = [&](Window & W) -> int {
+  std::mutex acc_mu;                            // two consumers add to the accounting
+  auto consume = [&](Window & W, vsx_ctx * ctx) -> int {
       const uint64_t w0 = W.w0, wn = W.wn, ns = W.ns;
       auto seq_of = [&](uint64_t k) { return W.wblob + W.lo[k]; };
       std::vector<QState> & st = W.st;
@@ -1247,11 +1252,11 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       const double tq = now_s();
       {
         // both strands: the plus strands are uploaded, the minus strands are made on the device
-        int rc2 = both ? vsx_seqset_create_both_strands(S->ctx, &qset, wn, qblob + W.mn, W.hi - W.mn, W.lo.data(), W.ln.data())
-                       : vsx_seqset_create(S->ctx, &qset, ns, W.wblob, W.hi - W.mn, W.lo.data(), W.ln.data());
+        int rc2 = both ? vsx_seqset_create_both_strands(ctx, &qset, wn, qblob + W.mn, W.hi - W.mn, W.lo.data(), W.ln.data())
+                       : vsx_seqset_create(ctx, &qset, ns, W.wblob, W.hi - W.mn, W.lo.data(), W.ln.data());
         if (rc2 != VSX_OK) return rc2;
       }
-      t_qset += now_s() - tq;
+      const double dq = now_s() - tq;
       {
         Acct acct;
         auto meta_of = [&](uint64_t k) {                       // both strands of a query share its abundance and label
@@ -1273,9 +1278,13 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
         };
         if (both && W.joined.empty()) W.lazy_rc.assign(wn, std::string());
         const int src = run_stages(*S, st, seq_of, text_of, [&](uint64_t k) { return (int64_t) W.ln[k]; },
-                                   [&](uint64_t k) { return (uint32_t) k; }, meta_of, qset, acct);
-        t_adv += acct.t_advance; t_rep += acct.t_replay;
-        t_align += acct.t_align; pairs += acct.pairs; cells += acct.cells; stages += acct.stages; sentinels += acct.sentinels;
+                                   [&](uint64_t k) { return (uint32_t) k; }, meta_of, qset, acct, ctx);
+        {
+          std::lock_guard<std::mutex> lk(acc_mu);
+          t_qset += dq;
+          t_adv += acct.t_advance; t_rep += acct.t_replay;
+          t_align += acct.t_align; pairs += acct.pairs; cells += acct.cells; stages += acct.stages; sentinels += acct.sentinels;
+        }
         if (src != VSX_OK) { vsx_seqset_destroy(qset); return src; }
       }
       vsx_seqset_destroy(qset);
@@ -1291,7 +1300,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
           // glibc's merge sort, which keeps the plus-strand hit first (found by oracle/soak_search.py)
           std::stable_sort(dst.begin(), dst.end(), [](const Hit & a, const Hit & b) { return hit_compare_byid(a, b) < 0; });
         }
-      t_join += now_s() - tj;
+      { std::lock_guard<std::mutex> lk(acc_mu); t_join += now_s() - tj; }
       return VSX_OK;
   };
 
@@ -1302,7 +1311,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
           std::unique_ptr<Window> W = prepare(w0);
           t_kmer += W->t_kmer;
           if (W->krc != VSX_OK) { vsx_internal_set_error(W->err.c_str()); return W->krc; }
-          const int crc = consume(*W);
+          const int crc = consume(*W, S->ctx);
           if (crc != VSX_OK) return crc;
         }
     }
@@ -1360,17 +1369,40 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       };
       std::thread stage_rank(rank_worker), stage_rank2;
       if (n_rank == 2) stage_rank2 = std::thread(rank_worker);
+      // two consumers, each with its own aligner context on the device (a window's plans, fetches and replays are a chain of
+      // short round trips: ~20 ms of wall time for ~5 ms of kernels, so two windows in flight keep the stage off the critical
+      // path); VSX_SEARCH_CONSUMERS=1 keeps one (A/B, tests).  Windows are independent: a query's hits live in its own slot.
+      static const bool one_consumer = std::getenv("VSX_SEARCH_CONSUMERS") && std::atoi(std::getenv("VSX_SEARCH_CONSUMERS")) == 1;
+      if (!one_consumer && !S->ctx2)
+        {
+          const int crc = vsx_create(&S->ctx2, &S->scoring, vsx_internal_device(S->ctx));
+          if (crc != VSX_OK) S->ctx2 = nullptr;                    // (no second context: carry on with one consumer)
+        }
       int rc = VSX_OK;
       std::string msg;
-      for (;;)
-        {
-          std::unique_ptr<Window> W = s2.get();
-          if (!W) break;
-          t_kmer += W->t_kmer;
-          if (W->krc != VSX_OK) { rc = W->krc; msg = W->err; break; }
-          rc = consume(*W);
-          if (rc != VSX_OK) { msg = vsx_last_error(); break; }
-        }
+      std::mutex rc_mu;
+      auto consumer = [&](vsx_ctx * ctx) {
+        for (;;)
+          {
+            std::unique_ptr<Window> W = s2.get();
+            if (!W) break;
+            int crc = W->krc;
+            std::string cmsg = W->err;
+            if (crc == VSX_OK)
+              {
+                crc = consume(*W, ctx);
+                if (crc != VSX_OK) cmsg = vsx_last_error();
+              }
+            std::lock_guard<std::mutex> lk(rc_mu);
+            t_kmer += W->t_kmer;
+            if (crc != VSX_OK) { if (rc == VSX_OK) { rc = crc; msg = cmsg; } break; }
+          }
+        s2.abort();
+      };
+      std::thread consumer2;
+      if (!one_consumer && S->ctx2) consumer2 = std::thread(consumer, S->ctx2);
+      consumer(S->ctx);
+      if (consumer2.joinable()) consumer2.join();
       s2.abort();
       s1.abort();
       stage_words.join();
