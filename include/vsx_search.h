@@ -125,7 +125,11 @@ typedef struct vsx_seq_meta {
 /* annotations of the searcher's database sequences (targets; in allpairs / clustering also the queries) */
 int vsx_searcher_set_meta(vsx_searcher * s, const vsx_seq_meta * meta);
 
-/* search_batch (core/search.hpp:131-145), plus strand only. */
+/* search_batch (core/search.hpp:131-145): every query against the database, --strand plus or both (opts.strand_both).
+   Batches above 32 768 queries run as a pipeline of windows -- unique words (host threads) -> device k-mer counting + ranking (two
+   workers) -> alignment, accept / reject replay and hit joining (two consumers; the second one on an aligner context of its own
+   that the searcher creates on the same device and keeps) -- so one call uses several host threads and two contexts' worth of
+   device scratch.  Results do not depend on the window size or the number of workers.  Not re-entrant per searcher. */
 int vsx_search_batch(vsx_searcher * s, uint64_t n_queries, const char * qblob, uint64_t qblob_bytes,
                      const uint64_t * qoffsets, const uint32_t * qlengths, vsx_hits * out);
 /* the same with the queries' annotations (si->qsize, si->query_head: core/search.cpp:88-94); qmeta may be NULL */
