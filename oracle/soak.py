@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--queries", type=int, default=160)
     ap.add_argument("--targets", type=int, default=8)
     ap.add_argument("--out", default="")
+    ap.add_argument("--max-rounds", type=int, default=0, help="stop after this many rounds (0: run for --seconds): a deterministic set of rounds for a given seed")
     a = ap.parse_args()
     if not pyoracle.have_ref():
         raise SystemExit("oracle/_ref/libvsref.so missing: make -C oracle ref")
@@ -99,7 +100,7 @@ def main():
     t_end = time.time() + a.seconds
     rounds = pairs = bad = sentinels = cells = 0
     by_kind, by_shape, examples, failing = {}, {}, [], []
-    while time.time() < t_end:
+    while time.time() < t_end and (a.max_rounds <= 0 or rounds < a.max_rounds):
         P, nmm, kind = draw_scoring(rng)
         shape, qs, ts = draw_population(rng, a.queries, a.targets)
         flat = [t for tt in ts for t in tt]

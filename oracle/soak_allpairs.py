@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="")
+    ap.add_argument("--max-rounds", type=int, default=0, help="stop after this many rounds (0: run for --seconds): a deterministic set of rounds for a given seed")
     a = ap.parse_args()
     if not refcli.available():
         raise SystemExit("oracle/_ref/vsearch_ref missing: make -C oracle ref_full")
@@ -95,7 +96,7 @@ def main():
     failing = []
     with tempfile.TemporaryDirectory(prefix="vsxsoaka_") as tmp:
         fa, uo = os.path.join(tmp, "a.fa"), os.path.join(tmp, "u.tsv")
-        while time.time() < t_end:
+        while time.time() < t_end and (a.max_rounds <= 0 or rounds < a.max_rounds):
             o, scoring, cli, acceptall, sizes = draw(rng)
             seqs, names, sz = data(rng, sizes)
             block = rng.choice([1, 5, 16, 1000])

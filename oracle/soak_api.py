@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="")
+    ap.add_argument("--max-rounds", type=int, default=0, help="stop after this many rounds (0: run for --seconds): a deterministic set of rounds for a given seed")
     a = ap.parse_args()
     if not os.path.exists(DRIVER):
         raise SystemExit("oracle/_ref/api_driver_vsx missing: make -C oracle ref_full ref_api")
@@ -47,7 +48,7 @@ def main():
     failing = []
     env = dict(os.environ, VSX_ADAPTER_TRACE="1")
     with tempfile.TemporaryDirectory(prefix="vsxsoakapi_") as tmp:
-        while time.time() < t_end:
+        while time.time() < t_end and (a.max_rounds <= 0 or rounds < a.max_rounds):
             if rounds % 3 == 2:
                 o, scoring, cli, by_size, round_size = soak_cluster.draw(rng)
                 seqs, names, sz, order = soak_cluster.data(rng, by_size)

@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="")
+    ap.add_argument("--max-rounds", type=int, default=0, help="stop after this many rounds (0: run for --seconds): a deterministic set of rounds for a given seed")
     ap.add_argument("--only-round", type=int, default=-1, help="replay the draws, run just this round and print its whole diff")
     a = ap.parse_args()
     if not refcli.available():
@@ -138,7 +139,7 @@ def main():
     failing = []
     with tempfile.TemporaryDirectory(prefix="vsxsoak_") as tmp:
         dbf, qf, uf = (os.path.join(tmp, x) for x in ("db.fa", "q.fa", "u.tsv"))
-        while time.time() < t_end:
+        while time.time() < t_end and (a.max_rounds <= 0 or rounds < a.max_rounds):
             o, scoring, cli, sizes, use_self = draw_options(rng)
             db, qs, tn, qn, tsize, qsize = draw_data(rng, sizes, use_self)
             if a.only_round >= 0 and rounds != a.only_round:

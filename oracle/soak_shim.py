@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="")
+    ap.add_argument("--max-rounds", type=int, default=0, help="stop after this many rounds (0: run for --seconds): a deterministic set of rounds for a given seed")
     a = ap.parse_args()
     if not (refcli.available() and os.path.exists(VSX_BIN)):
         raise SystemExit("oracle/_ref/vsearch_ref / vsearch_vsx missing: make -C oracle ref_full ref_shim")
@@ -106,7 +107,7 @@ def main():
     rounds = bad = files_ok = 0
     by_cmd, failing = {}, []
     with tempfile.TemporaryDirectory(prefix="vsxsoaks_") as tmp:
-        while time.time() < t_end:
+        while time.time() < t_end and (a.max_rounds <= 0 or rounds < a.max_rounds):
             cmd, argv_of, files = draw(rng, tmp)
             threads = rng.choice(["1", "1", "3"])
             res = {}
