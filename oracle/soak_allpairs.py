@@ -58,6 +58,9 @@ def draw(rng):
                                 ("minsizeratio", "--minsizeratio", [0.2, 0.5]), ("maxsizeratio", "--maxsizeratio", [0.5, 2.0])):
             if rng.random() < 0.35:
                 put(key, rng.choice(vals), flag)
+    if rng.random() < 0.12:        # --self: pairs whose labels coincide are skipped (the data below then repeats some labels)
+        o["self_"] = 1
+        cli.append("--self")
     scoring = None
     if rng.random() < 0.4:
         match, mism = rng.randint(1, 5), -rng.randint(1, 8)
@@ -68,7 +71,7 @@ def draw(rng):
     return o, scoring, cli, acceptall, sizes
 
 
-def data(rng, sizes):
+def data(rng, sizes, dup_labels=False):
     seqs = M._masked_families(rng, rng.randint(3, 10), rng.randint(2, 8), rng.choice([100, 220, 330]), rng.choice([0.02, 0.06, 0.15]), rng.random() < 0.3)
     seqs += [common.rnd_seq(rng, rng.randint(40, 300)) for _ in range(rng.randint(0, 8))]
     seqs += [seqs[rng.randrange(len(seqs))] for _ in range(rng.randint(0, 3))]
@@ -77,6 +80,11 @@ def data(rng, sizes):
     rng.shuffle(seqs)
     sz = [rng.choice([1, 1, 2, 3, 8, 30]) for _ in seqs] if sizes else None
     names = [f"t{i}" + (f";size={sz[i]}" if sizes else "") for i in range(len(seqs))]
+    if dup_labels:
+        for k in range(1, len(names), 4):
+            names[k] = names[k - 1]
+            if sizes:
+                sz[k] = sz[k - 1]
     return seqs, names, sz
 
 
@@ -98,7 +106,7 @@ def main():
         fa, uo = os.path.join(tmp, "a.fa"), os.path.join(tmp, "u.tsv")
         while time.time() < t_end and (a.max_rounds <= 0 or rounds < a.max_rounds):
             o, scoring, cli, acceptall, sizes = draw(rng)
-            seqs, names, sz = data(rng, sizes)
+            seqs, names, sz = data(rng, sizes, bool(o.get("self_")))
             block = rng.choice([1, 5, 16, 1000])
             refcli.write_fasta(fa, names, seqs)
             p = subprocess.run([refcli.REF_BIN, "--allpairs_global", fa, "--qmask", "none", "--threads", "1", "--userout", uo, "--userfields", "+".join(FIELDS),
@@ -110,7 +118,7 @@ def main():
                 continue
             exp = open(uo).read().splitlines()
             with (Aligner(scoring=scoring) if scoring else Aligner()) as al:
-                ss = SearchSession(al, seqs, sizes=sz, labels=names if sizes else None, **o)
+                ss = SearchSession(al, seqs, sizes=sz, labels=names if (sizes or o.get("self_")) else None, **o)
                 hits = []
                 for first in range(0, len(seqs), block):
                     hits += ss.allpairs(first, min(block, len(seqs) - first), acceptall=acceptall)

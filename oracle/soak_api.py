@@ -51,7 +51,9 @@ def main():
         while time.time() < t_end and (a.max_rounds <= 0 or rounds < a.max_rounds):
             if rounds % 3 == 2:
                 o, scoring, cli, by_size, round_size = soak_cluster.draw(rng)
-                seqs, names, sz, order = soak_cluster.data(rng, by_size)
+                seqs, names, sz, order = soak_cluster.data(rng, bool(by_size))
+                if by_size == "unoise":          # the library API has no unoise entry point: draw again
+                    continue
                 refcli.write_fasta(tmp + "/c.fa", names, seqs)         # the driver sorts by length itself (Database::sortbylength)
                 kv = [f"{k}={v}" for k, v in o.items() if k not in ("id", "maxaccepts", "maxrejects", "soft_mask")] + scoring_kv(scoring)
                 if by_size:

@@ -36,6 +36,15 @@ def draw(rng):
         cli.extend([flag, repr(val) if isinstance(val, float) else str(val)])
 
     by_size = rng.random() < 0.35
+    unoise = by_size and rng.random() < 0.3        # --cluster_unoise: abundance order, the skew rule instead of --id, weak_id forced to 0.90
+    if unoise:
+        alpha = rng.choice([1.0, 2.0, 3.0])
+        o.update(id=0.0, maxaccepts=1, maxrejects=32, cluster_unoise=1, unoise_alpha=alpha)
+        cli += ["--minsize", "1", "--sizein", "--unoise_alpha", repr(alpha)]
+        mask = rng.choice(MASKS)
+        o["soft_mask"] = MASKS.index(mask)
+        cli += ["--qmask", mask]
+        return o, None, cli, "unoise", rng.choice([3, 16, 50, 100000])
     put("id", rng.choice([0.8, 0.9, 0.95, 0.97, 0.99]), "--id")
     put("maxaccepts", rng.choice([1, 1, 2, 3]), "--maxaccepts")
     put("maxrejects", rng.choice([2, 8, 8, 16, 32]), "--maxrejects")
@@ -131,13 +140,14 @@ def main():
         fa, uc = os.path.join(tmp, "c.fa"), os.path.join(tmp, "c.uc")
         while time.time() < t_end and (a.max_rounds <= 0 or rounds < a.max_rounds):
             o, scoring, cli, by_size, round_size = draw(rng)
-            seqs, names, sz, order = data(rng, by_size)
+            unoise = by_size == "unoise"
+            seqs, names, sz, order = data(rng, bool(by_size))
             refcli.write_fasta(fa, names, seqs)
             # the CIGAR consumer too (msa.cpp): star MSA, consensus and profile of every cluster, on the device, in half of the
             # cluster_fast rounds without masking (masking changes the case of the printed rows)
             want_msa = (not by_size) and o["soft_mask"] == 0 and rng.random() < 0.5
             msa_args = ["--msaout", tmp + "/m.msa", "--consout", tmp + "/m.cons", "--profile", tmp + "/m.prof"] if want_msa else []
-            p = subprocess.run([refcli.REF_BIN, "--cluster_size" if by_size else "--cluster_fast", fa, "--threads", "1", "--uc", uc, "--quiet"] + cli + msa_args,
+            p = subprocess.run([refcli.REF_BIN, "--cluster_unoise" if unoise else ("--cluster_size" if by_size else "--cluster_fast"), fa, "--threads", "1", "--uc", uc, "--quiet"] + cli + msa_args,
                                capture_output=True, text=True)
             rounds += 1
             if p.returncode != 0:
@@ -149,7 +159,7 @@ def main():
             ssz = [sz[i] for i in order] if by_size else None
             with (Aligner(scoring=scoring) if scoring else Aligner()) as al:
                 ss = SearchSession(al, sseqs, sizes=ssz, labels=snames if by_size else None, **o)
-                got = ss.uc_lines(snames, round=round_size, sizes=ssz, command="cluster_size" if by_size else "cluster_fast")
+                got = ss.uc_lines(snames, round=round_size, sizes=ssz, command="cluster_unoise" if unoise else ("cluster_size" if by_size else "cluster_fast"))
                 if want_msa:
                     got_msa = msa_files(ss, al, sseqs, snames, round_size)
                     exp_msa = tuple(open(tmp + x).read().splitlines() for x in ("/m.msa", "/m.cons", "/m.prof"))

@@ -376,13 +376,14 @@ def test_soak_harnesses_draw_valid_reference_commands(tmp_path):
         assert p.returncode == 0, (cli, p.stderr[-500:])
         lines += len(open(tmp + "/u.tsv").read().splitlines())
         o, sc, cli, by_size, rs = soak_cluster.draw(rng)
-        seqs, names, sz, order = soak_cluster.data(rng, by_size)
+        seqs, names, sz, order = soak_cluster.data(rng, bool(by_size))
         refcli.write_fasta(tmp + "/c.fa", names, seqs)
-        p = subprocess.run([refcli.REF_BIN, "--cluster_size" if by_size else "--cluster_fast", tmp + "/c.fa", "--threads", "1", "--uc", tmp + "/c.uc",
+        command = "--cluster_unoise" if by_size == "unoise" else ("--cluster_size" if by_size else "--cluster_fast")
+        p = subprocess.run([refcli.REF_BIN, command, tmp + "/c.fa", "--threads", "1", "--uc", tmp + "/c.uc",
                             "--quiet"] + cli, capture_output=True, text=True)
         assert p.returncode == 0, (cli, p.stderr[-500:])
         o, sc, cli, aa, sizes = soak_allpairs.draw(rng)
-        seqs, names, sz = soak_allpairs.data(rng, sizes)
+        seqs, names, sz = soak_allpairs.data(rng, sizes, bool(o.get("self_")))
         refcli.write_fasta(tmp + "/a.fa", names, seqs)
         p = subprocess.run([refcli.REF_BIN, "--allpairs_global", tmp + "/a.fa", "--qmask", "none", "--threads", "1", "--userout", tmp + "/ua.tsv",
                             "--userfields", "+".join(soak_allpairs.FIELDS), "--quiet"] + cli, capture_output=True, text=True)
