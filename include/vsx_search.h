@@ -142,6 +142,11 @@ void vsx_hits_free(vsx_hits * h);
    soft_mask = 2 applies to the queries; exported for callers that prepare their own text. */
 int vsx_dust_mask(char * blob, uint64_t n, const uint64_t * offsets, const uint32_t * lengths, int32_t threads);
 
+/* Sign of (value - ratio * reference) as the abundance filters compare it (--minsizeratio / --maxsizeratio / abskew;
+   core/searchcore.cpp:480-537): the rounded double product while both abundances are below 2^53, exact integer arithmetic on
+   the double's stored value beyond.  Host only; exported so that callers and tests can pin the boundary behaviour. */
+int vsx_abundance_ratio_cmp(int64_t value, double ratio, int64_t reference);
+
 /* allpairs_global (commands/allpairs_global.cpp:394-527): database sequences [first, first+count) as
    queries, each against every LATER sequence (unaligned filters applied unless acceptall); kept hits are
    those accepted (or all with acceptall), ordered id desc, target asc.  vsx_hit.query is the database

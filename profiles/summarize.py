@@ -81,6 +81,10 @@ def sq_block(needle):
     return out
 
 
+WORKLOAD = {"queries": 100000, "qlen": 250, "db": 1000000, "dlen": 1000, "cands": 8}
+if os.environ.get("VSX_SUMMARY_WORKLOAD"):
+    q_, d_, db_ = (int(x) for x in os.environ["VSX_SUMMARY_WORKLOAD"].split(","))
+    WORKLOAD = {"queries": 100000, "qlen": q_, "db": db_, "dlen": d_, "cands": 8}
 fwd, tb = kernel_block("vsx_forward_kernel"), kernel_block("vsx_traceback_ck_kernel")
 if fwd is not None:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -101,7 +105,7 @@ if fwd is not None:
                 "GRBM_GUI_ACTIVE": sq.get("GRBM_GUI_ACTIVE"),
                 "active_inst_valu_over_busy": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_BUSY_CYCLES"]}
     doc = {"kernel_source_sha": sha, "kernel_sources": list(getattr(bench, "KERNEL_SOURCES", [])) if sha else None,
-           "workload": {"queries": 100000, "qlen": 250, "db": 1000000, "dlen": 1000, "cands": 8},
+           "workload": WORKLOAD,
            "forward": dict(fwd, kernel="vsx_forward_kernel", sq=sq), "traceback": dict(tb or {}, kernel="vsx_traceback_ck_kernel",
                                                                                      sq=sq_block("vsx_traceback_ck_kernel")),
            "valu_issue": valu,

@@ -265,7 +265,8 @@ def test_device_ranking_equals_host_sort(gpu_required, keep_weak):
     rng = random.Random(7)
     db, fam = common.family_db(rng, 12, 10, 260, div=0.06)
     db += [common.rnd_seq(rng, 250) for _ in range(20)]
-    db.append("")                                                   # an empty target: undecided (sentinel) pairs
+    db.append(common.rnd_seq(rng, 40000))                           # 250 nt against 40 kb: the 16-bit DP overflows AT RUN TIME (:1774-1786)
+    db.append("")                                                   # an empty target: sentinel pairs answered before the launch
     n = len(db)
     flt = dict(iddef=2, id=0.85, weak_id=0.7)
     qi, ti = np.triu_indices(n, 1)
@@ -287,5 +288,9 @@ def test_device_ranking_equals_host_sort(gpu_required, keep_weak):
         assert int(rk["verdict"][j]) == int(full.verdict[k])
     order = sorted(keep, key=lambda k: (int(qi[k]), -float(rk["id"][pos[k]]), k))
     assert rk["pair"].tolist() == order
+    # undecided = every pair the 16-bit aligner refused, whether the planner saw it coming (empty target) or the DP overflowed
+    # on the GPU (the 40 kb target): the caller's linear-memory fallback decides those (searchcore.cpp:806-832)
     und = sorted(int(k) for k in range(len(qi)) if full.verdict[k] == 0)
-    assert sorted(rk["undecided"].tolist()) == und and len(und) == n - 1
+    assert sorted(rk["undecided"].tolist()) == und and len(und) == (n - 1) + (n - 2)
+    overflowed = [k for k in und if int(ti[k]) == n - 2]
+    assert len(overflowed) == n - 2 and all(full.row(k)[0] == 32767 and full.row(k)[5] == "" for k in overflowed)

@@ -148,6 +148,30 @@ def test_allpairs_global_matches_reference_cli(gpu_required, tmp_path, name, acc
     assert got == exp, _first_diff(got, exp)
 
 
+def test_allpairs_runtime_overflow_pairs_take_the_fallback(gpu_required, tmp_path):
+    """A pair whose 16-bit DP overflows ON THE GPU (a 250-nt fragment against its 40-kb source: the terminal gap alone costs
+    more than SHRT_MIN, align_simd.cpp:1774-1786) must still be reported: the ranked device path lists it as undecided and
+    vsx_allpairs_rows recovers it through the linear-memory fallback, as the reference does (searchcore.cpp:806-832).
+    ADVICE r02 (high): such pairs used to vanish from the ranked path."""
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing")
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(77)
+    long_a = common.rnd_seq(rng, 40000)
+    frags = [common.mutate(rng, long_a[o:o + 250], 0.03) for o in (100, 9000, 20000, 39700)]
+    db, fam = common.family_db(rng, 3, 5, 300, div=0.08)
+    db = frags[:2] + db + [long_a] + frags[2:]
+    exp = run_reference_allpairs(str(tmp_path), db, ["--id", "0.8"])
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.8)
+        hits = ss.allpairs(0, len(db), acceptall=False)
+        names = [f"t{i}" for i in range(len(db))]
+        got = ss.userout(db, qnames=names, tnames=names, fields=FIELDS, hits=hits)
+    li = db.index(long_a)
+    assert sum(1 for l in exp if f"t{li}" in l.split("\t")[:2]) == 4          # the four fragment-vs-source hits exist in the reference
+    assert got == exp, _first_diff(got, exp)
+
+
 def run_reference_cluster(tmp, seqs, names, extra, threads=1):
     f_in, f_uc = os.path.join(tmp, "c.fa"), os.path.join(tmp, "c.uc")
     with open(f_in, "w") as f:

@@ -396,3 +396,41 @@ def test_soak_harnesses_draw_valid_reference_commands(tmp_path):
         finally:
             ref.close()
     assert lines > 100
+
+
+def test_abundance_ratio_compare_is_exact_beyond_2_53():
+    """abundance filters (--minsizeratio / --maxsizeratio, core/searchcore.cpp:480-537): below 2^53 the ROUNDED double product
+    decides (historical boundary behaviour), beyond it the comparison is exact on the double's stored value.  Checked against
+    Python's exact rationals / its own double arithmetic; no GPU involved."""
+    import ctypes as C
+    import math
+    import random
+    from fractions import Fraction
+    from vsearch_amd import _lib
+    lib = _lib.load()
+    rng = random.Random(53)
+
+    def expect(v, ratio, ref):
+        if ref <= 0 or ratio <= 0.0:
+            return 1 if v > 0 else 0
+        if math.isinf(ratio) or math.isnan(ratio):
+            return -1
+        if v < (1 << 53) and ref < (1 << 53):
+            prod = ratio * float(ref)
+            return -1 if float(v) < prod else (1 if float(v) > prod else 0)
+        d = Fraction(v) - Fraction(ratio) * ref
+        return -1 if d < 0 else (1 if d > 0 else 0)
+
+    ratios = [0.0, -1.0, 1.0, 0.5, 2.0, 1 / 9, 1 / 3, 16.0, 1e-300, 5e-324, 1e300, 1.7976931348623157e308, float("inf"), 3.0000000000000004,
+              2.0 ** -60, 2.0 ** 60, 2.0 ** -1074, 0.9999999999999999]
+    big = [0, 1, 2, 9, (1 << 53) - 1, 1 << 53, (1 << 53) + 1, (1 << 62) + 12345, (1 << 63) - 1, 3 * (1 << 60) + 7, 9 * ((1 << 53) + 1)]
+    n = 0
+    for ratio in ratios + [rng.uniform(0, 4) for _ in range(200)] + [2.0 ** rng.randint(-80, 80) * rng.uniform(1, 2) for _ in range(200)]:
+        for _ in range(40):
+            ref = rng.choice(big + [rng.randrange(1, 1 << rng.randint(1, 63)), 0, -3])
+            v = rng.choice(big + [rng.randrange(0, 1 << rng.randint(1, 63))])
+            if ref > 0 and rng.random() < 0.3 and 0 < ratio < 1e18:
+                v = min((1 << 63) - 1, max(0, int(Fraction(ratio) * ref) + rng.randint(-1, 1)))      # straddle the boundary
+            assert lib.vsx_abundance_ratio_cmp(v, ratio, ref) == expect(v, ratio, ref), (v, ratio, ref)
+            n += 1
+    assert n > 15000

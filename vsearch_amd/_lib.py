@@ -26,7 +26,7 @@ SYMBOLS = [
 SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
                   "vsx_search_batch_meta", "vsx_searcher_set_meta",
                   "vsx_hits_free", "vsx_search_candidates", "vsx_search_candidates_batch", "vsx_candidates_free", "vsx_lma_align", "vsx_allpairs_block", "vsx_allpairs_rows", "vsx_cluster_fast", "vsx_cluster_out_free", "vsx_msa", "vsx_msa_out_free",
-                  "vsx_msa_device", "vsx_msa_device_batch", "vsx_dust_mask"]
+                  "vsx_msa_device", "vsx_msa_device_batch", "vsx_dust_mask", "vsx_abundance_ratio_cmp"]
 
 
 class Candidates(C.Structure):
@@ -194,6 +194,8 @@ def load():
     lib.vsx_allpairs_block.argtypes = [vp, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(Hits)]
     lib.vsx_allpairs_rows.argtypes = [vp, C.c_int32, vp, C.c_uint64, C.POINTER(Hits)]
     lib.vsx_dust_mask.argtypes = [vp, C.c_uint64, vp, vp, C.c_int32]
+    lib.vsx_abundance_ratio_cmp.argtypes = [C.c_int64, C.c_double, C.c_int64]
+    lib.vsx_abundance_ratio_cmp.restype = C.c_int
     lib.vsx_cluster_fast.argtypes = [vp, C.c_uint64, C.POINTER(ClusterOut)]
     lib.vsx_cluster_out_free.argtypes = [C.POINTER(ClusterOut)]
     lib.vsx_cluster_out_free.restype = None

@@ -120,8 +120,13 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // computed at all: 7 instead of 9 packed instructions per lane-row.  Borders: Htop*(j) = Htop(j) + (j-1)g, Hleft* alike,
 // H*(-1,-1) = -2g; the score is un-tilted in the epilogue; checkpoints hold tilted values (the traceback recomputes with the
 // same primed constants).
+// occupancy floor of the DP kernel (waves per SIMD the register allocator must make room for): 4 up to R = 16 (128 VGPRs, a few
+// spills: measured better than 3 without), 2 beyond R = 24 (256 VGPRs); A/B builds override VSX_FWD_WAVES
+#ifndef VSX_FWD_WAVES
+#define VSX_FWD_WAVES(R_, TILT_) ((R_) <= 16 ? 4 : ((R_) > 24 ? 2 : 1))
+#endif
 template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R <= 16 ? 4 : (R > 24 ? 2 : 1), 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VSX_FWD_WAVES(R, TILT), 8)))
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
                    u32 * __restrict__ dir, uint2 * strip, VsxSlotOut * __restrict__ slot_out)

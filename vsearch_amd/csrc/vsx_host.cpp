@@ -1487,16 +1487,30 @@ static int fetch_ranked_core(vsx_plan * pl, uint64_t first, const uint32_t * qke
   HIPCHK(d_id.alloc(&ctx->pool, n));
   HIPCHK(d_qstart.alloc(&ctx->pool, G + 1));
   HIPCHK(d_seg.alloc(&ctx->pool, G + 1));
+  PoolBuf<uint32_t> d_refused;                 // [0] = count, then the GPU pairs whose 16-bit DP overflowed at run time
+  const uint32_t ngpu = (uint32_t) pl->pair_ids.size();
+  HIPCHK(d_refused.alloc(&ctx->pool, (size_t) ngpu + 1));
   HIPCHK(hipMemcpyAsync(d_qstart.p, qstart.data(), (G + 1) * 4, hipMemcpyHostToDevice, st));
   size_t tb = 0;
   HIPCHK(vsx_rank_flag_scan(pl->filter, S.keep_weak, pl->d_out.p, pl->d_pair_ids.p, pl->d_pair_slot.p, pl->d_tasks.p, (uint32_t) pl->pair_ids.size(),
-                            (uint32_t) n, pl->d_runs.p, pl->runs_capacity, d_flag.p, d_pos.p, d_id.p, nullptr, &tb, st));
+                            (uint32_t) n, pl->d_runs.p, pl->runs_capacity, d_flag.p, d_pos.p, d_id.p, d_refused.p, nullptr, &tb, st));
   HIPCHK(d_temp.alloc(&ctx->pool, tb + 16));
   HIPCHK(vsx_rank_flag_scan(pl->filter, S.keep_weak, pl->d_out.p, pl->d_pair_ids.p, pl->d_pair_slot.p, pl->d_tasks.p, (uint32_t) pl->pair_ids.size(),
-                            (uint32_t) n, pl->d_runs.p, pl->runs_capacity, d_flag.p, d_pos.p, d_id.p, d_temp.p, &tb, st));
-  uint32_t kept = 0;
+                            (uint32_t) n, pl->d_runs.p, pl->runs_capacity, d_flag.p, d_pos.p, d_id.p, d_refused.p, d_temp.p, &tb, st));
+  uint32_t kept = 0, n_refused = 0;
   HIPCHK(hipMemcpyAsync(&kept, d_pos.p + n, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&n_refused, d_refused.p, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if (n_refused)
+    {
+      // the contract of vsx_ranked (include/vsx.h): a pair the 16-bit aligner refused -- before the launch (host_pairs above) or
+      // by the overflow rule inside it -- is `undecided`, never silently dropped; the caller's fallback aligns and filters it
+      if (n_refused > ngpu) return fail(VSX_EHIP, "vsx_align_pairs_ranked: refused-pair list is corrupt");
+      std::vector<uint32_t> rf(n_refused);
+      HIPCHK(hipMemcpy(rf.data(), d_refused.p + 1, (size_t) n_refused * 4, hipMemcpyDeviceToHost));
+      std::sort(rf.begin(), rf.end());         // the device appends in arbitrary order
+      for (uint32_t k : rf) S.undecided.push_back((uint32_t) (first + k));
+    }
 
   const uint64_t k1 = std::max<uint32_t>(kept, 1);
   // compact output arrays in one block: pair u32, id f64, text_off u64, 5 x 16 bit, verdict u8 (16-byte aligned sections)

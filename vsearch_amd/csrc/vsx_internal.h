@@ -125,6 +125,7 @@ extern "C" {
 hipError_t vsx_rank_flag_scan(VsxFilterDev F, int keep_weak, const VsxPairOut * d_out, const uint32_t * d_pair_ids,
                               const uint32_t * d_pair_slot, const VsxTask * d_tasks, uint32_t ngpu_pairs, uint32_t n_pairs,
                               const uint32_t * d_runs, uint64_t runs_capacity, uint32_t * d_flag, uint32_t * d_pos, double * d_id,
+                              uint32_t * d_refused /* [0] = count, then the pairs the DP refused at run time */,
                               void * d_temp, size_t * temp_bytes, hipStream_t st);
 // ... then compaction, per-query stable sort by identity (descending) and the gather of the kept pairs' fields
 hipError_t vsx_rank_sort_gather(const uint32_t * d_flag, const uint32_t * d_pos, const double * d_id, uint32_t n_pairs, uint32_t kept,

@@ -3,18 +3,34 @@
 // In the reference the CALLER owns this step: LinearMemoryAligner::align + alignstats
 // (src/core/linmemalign.cpp:311-808, call sites core/searchcore.cpp:806-832, commands/allpairs_global.cpp:447-473).
 // It stays on the host CPU here as well (rare path, int64 arithmetic, linear memory).
-// This is a restatement of the reference's divide-and-conquer (Hirschberg / Myers-Miller with 12
-// position-specific gap penalties); every tie-break of the reference is kept so that CIGARs are identical:
-//   * midpoint row I = a_len / 2; forward pass over the upper half, reverse pass over the lower half
-//   * join type 0 (diagonal at the break) beats type 1 (gap in b across the break) on a strictly larger score;
-//     equal scores: the smaller column wins, type 0 on equal columns
-//   * within a type the FIRST maximal column wins
-//   * a_len == 1: candidates in the order "D then I", "I then D", then the substitution columns left to right,
-//     replaced only on a strictly larger score
+//
+// What has to be reproduced is the reference's OUTPUT (the CIGAR it picks among co-optimal alignments), so this file is
+// written against the following specification of that choice, not against the reference's code:
+//
+//   S1  divide and conquer on the query: a piece of q rows is cut after row floor(q / 2); the upper part is scored top-down,
+//       the lower part bottom-up, both over all columns of the piece (linear memory: two score vectors per direction);
+//   S2  two ways to cross the cut at column c:  THROUGH (the two halves simply meet at c) and HANGING (a gap in the target
+//       spans the cut: the rows on both sides of the cut are deleted, and the opening penalty both halves charged is
+//       refunded once).  Per way the FIRST column attaining the maximum counts.  THROUGH wins on a strictly larger score;
+//       on equal scores the way with the smaller column wins, THROUGH on equal columns;
+//   S3  a piece keeps six facts: whether it touches the head / tail of the query, the head / tail of the target (terminal
+//       gap penalties apply there), and whether a target gap is already open on its left / right side (then the opening
+//       penalty of a gap starting at that side is waived);
+//   S4  gaps in the query INSIDE a sweep are always priced as interior gaps; only the sweep's starting row (an all-gap
+//       prefix) uses the terminal penalties of S3.  Gaps in the target use the terminal penalties only in the column
+//       farthest from the sweep's start, and in column 0;
+//   S5  a piece of ONE query row is solved by enumeration, in this order and replaced only by a strictly better score:
+//       "delete the row, then insert all columns", "insert all columns, then delete the row" (whose score is charged ON TOP
+//       of the first candidate's -- a quirk of the reference that decides ties and is therefore kept), then "substitute at
+//       column c" for c = 0, 1, ...;
+//   S6  empty pieces: no columns -> delete the rows; no rows -> insert the columns.
+//
+// The recursion is an explicit work stack (no call depth proportional to log(query length) x stack frame), the two sweeps
+// are ONE routine run in two orientations, and the statistics are computed by an own CIGAR tokenizer.
+// Pinned by tests/golden/lma_golden.json and a live fuzz against the reference's class (tests/test_host_cpu.py).
 #include "../../include/vsx_search.h"
 
 #include <algorithm>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -23,229 +39,248 @@
 
 namespace {
 
-inline unsigned map4(unsigned char c)
-{
-  switch (c)
-    {
-    case 'A': case 'a': return 1;  case 'B': case 'b': return 14; case 'C': case 'c': return 2;  case 'D': case 'd': return 13;
-    case 'G': case 'g': return 4;  case 'H': case 'h': return 11; case 'K': case 'k': return 12; case 'M': case 'm': return 3;
-    case 'N': case 'n': return 15; case 'R': case 'r': return 5;  case 'S': case 's': return 6;
-    case 'T': case 't': case 'U': case 'u': return 8;
-    case 'V': case 'v': return 7;  case 'W': case 'w': return 9;  case 'Y': case 'y': return 10;
-    default: return 0;
-    }
-}
+constexpr int64_t kNever = std::numeric_limits<int64_t>::min();
 
-constexpr int64_t NEG = std::numeric_limits<int64_t>::min();
-
-struct Lma {
-  int64_t goql, gotl, goqi, goti, goqr, gotr, geql, getl, geqi, geti, geqr, getr;
-  bool nmm;
-  int64_t S[16][16];
-  const char * a = nullptr;      // query
-  const char * b = nullptr;      // target
-  std::vector<int64_t> HH, EE, XX, YY;
-  std::string cigar;
-  char op = 0;
-  int64_t run = 0;
-
-  explicit Lma(const vsx_scoring & sc)
-    : goql(sc.gap_open_query_left), gotl(sc.gap_open_target_left), goqi(sc.gap_open_query_interior),
-      goti(sc.gap_open_target_interior), goqr(sc.gap_open_query_right), gotr(sc.gap_open_target_right),
-      geql(sc.gap_ext_query_left), getl(sc.gap_ext_target_left), geqi(sc.gap_ext_query_interior),
-      geti(sc.gap_ext_target_interior), geqr(sc.gap_ext_query_right), getr(sc.gap_ext_target_right),
-      nmm(sc.n_mismatch != 0)
+// 4-bit IUPAC set of a nucleotide symbol (utils/maps.cpp:75-117); 0 = not a nucleotide code
+struct SymbolSets {
+  unsigned char set[256];
+  SymbolSets()
   {
-    // scorematrix_fill, linmemalign.cpp:189-222
-    auto amb = [](unsigned x) { return !(x == 1 || x == 2 || x == 4 || x == 8); };
-    for (unsigned r = 0; r < 16; ++r)
-      for (unsigned c = 0; c < 16; ++c)
-        S[r][c] = (amb(r) || amb(c)) ? 0 : (r == c ? sc.match : sc.mismatch);
-    if (nmm)
-      for (unsigned k = 0; k < 16; ++k) { S[k][15] = sc.mismatch; S[15][k] = sc.mismatch; }
-  }
-
-  int64_t sub(char x, char y) const { return S[map4((unsigned char) y)][map4((unsigned char) x)]; }
-
-  void flush()
-  {
-    if (run <= 0) return;
-    if (run > 1) cigar += std::to_string(run);
-    cigar.push_back(op);
-  }
-  void add(char o, int64_t n)
-  {
-    if (op == o) { run += n; return; }
-    flush();
-    op = o;
-    run = n;
-  }
-
-  void diff(int64_t a0, int64_t b0, int64_t al, int64_t bl, bool gap_b_left, bool gap_b_right,
-            bool a_left, bool a_right, bool b_left, bool b_right)
-  {
-    if (bl == 0) { if (al > 0) add('D', al); return; }
-    if (al == 0) { add('I', bl); return; }
-    if (al == 1)
+    std::memset(set, 0, sizeof set);
+    const char * letters = "ACMGRSVTWYHKDBN";            // the set value of letters[k] is k + 1 (A=1, C=2, G=4, T=8 and unions)
+    for (int k = 0; letters[k]; ++k)
       {
-        // one query symbol against bl target symbols (linmemalign.cpp:338-451)
-        int64_t score = 0;
-        if (!gap_b_left) score -= b_left ? gotl : goti;
-        score -= b_left ? getl : geti;
-        score -= a_right ? goqr + bl * geqr : goqi + bl * geqi;
-        int64_t best_score = score;
-        int64_t best = -1;                                   // "D then I"
-        // NB: the reference keeps accumulating into the same variable for the second candidate
-        score -= a_left ? goql + bl * geql : goqi + bl * geqi;
-        if (!gap_b_right) score -= b_right ? gotr : goti;
-        score -= b_right ? getr : geti;
-        if (score > best_score) { best_score = score; best = bl; }   // "I then D"
-        for (int64_t i = 0; i < bl; ++i)
+        set[(unsigned char) letters[k]] = (unsigned char) (k + 1);
+        set[(unsigned char) (letters[k] | 0x20)] = (unsigned char) (k + 1);
+      }
+    set[(unsigned char) 'U'] = set[(unsigned char) 'u'] = 8;
+  }
+};
+const SymbolSets kSets;
+
+enum Zone { HEAD = 0, INNER = 1, TAIL = 2 };
+
+// facts a piece carries (S3)
+enum : unsigned {
+  Q_HEAD = 1u, Q_TAIL = 2u, T_HEAD = 4u, T_TAIL = 8u,       // the piece touches that end of the whole problem
+  OPEN_L = 16u, OPEN_R = 32u                                // a target gap is already open on that side of the piece
+};
+
+struct Piece { int64_t q0, t0, qn, tn; unsigned facts; };
+
+// the CIGAR under construction: equal neighbouring operations merge, a count of 1 is not written
+class OpWriter {
+public:
+  void put(char op, int64_t n)
+  {
+    if (n <= 0) return;
+    if (op == last_) { count_ += n; return; }
+    close();
+    last_ = op;
+    count_ = n;
+  }
+  std::string finish() { close(); last_ = 0; count_ = 0; return std::move(text_); }
+private:
+  void close()
+  {
+    if (!last_) return;
+    if (count_ > 1) text_ += std::to_string(count_);
+    text_.push_back(last_);
+  }
+  std::string text_;
+  char last_ = 0;
+  int64_t count_ = 0;
+};
+
+class LinearAligner {
+public:
+  explicit LinearAligner(const vsx_scoring & sc) : count_n_as_mismatch_(sc.n_mismatch != 0)
+  {
+    q_open_[HEAD] = sc.gap_open_query_left;  q_open_[INNER] = sc.gap_open_query_interior;  q_open_[TAIL] = sc.gap_open_query_right;
+    q_ext_[HEAD] = sc.gap_ext_query_left;    q_ext_[INNER] = sc.gap_ext_query_interior;    q_ext_[TAIL] = sc.gap_ext_query_right;
+    t_open_[HEAD] = sc.gap_open_target_left; t_open_[INNER] = sc.gap_open_target_interior; t_open_[TAIL] = sc.gap_open_target_right;
+    t_ext_[HEAD] = sc.gap_ext_target_left;   t_ext_[INNER] = sc.gap_ext_target_interior;   t_ext_[TAIL] = sc.gap_ext_target_right;
+    // substitution scores by symbol set (linmemalign.cpp:189-222): unambiguous symbols score match / mismatch, anything
+    // ambiguous scores 0, unless N-as-mismatch is on, which overrides every pairing with set 15
+    for (unsigned x = 0; x < 16; ++x)
+      for (unsigned y = 0; y < 16; ++y)
+        {
+          const bool plain = (x && !(x & (x - 1))) && (y && !(y & (y - 1)));
+          pair_score_[x][y] = plain ? (x == y ? sc.match : sc.mismatch) : 0;
+          if (count_n_as_mismatch_ && (x == 15 || y == 15)) pair_score_[x][y] = sc.mismatch;
+        }
+  }
+
+  std::string align(const char * query, int64_t qlen, const char * target, int64_t tlen)
+  {
+    query_ = query; target_ = target;
+    for (auto * v : {&down_.reach, &down_.hang, &up_.reach, &up_.hang}) v->assign((size_t) tlen + 1, 0);
+    OpWriter out;
+    // pending work, last in first out: a piece to solve, or (qn < 0) an operation to write when its turn comes
+    std::vector<Piece> todo;
+    todo.push_back(Piece {0, 0, qlen, tlen, Q_HEAD | Q_TAIL | T_HEAD | T_TAIL});
+    while (!todo.empty())
+      {
+        const Piece p = todo.back();
+        todo.pop_back();
+        if (p.qn < 0) { out.put((char) p.q0, p.t0); continue; }                  // a deferred operation
+        if (p.tn == 0) { out.put('D', p.qn); continue; }                         // S6
+        if (p.qn == 0) { out.put('I', p.tn); continue; }
+        if (p.qn == 1) { single_row(p, out); continue; }                         // S5
+        const Cut c = best_cut(p);
+        const int64_t upper_rows = p.qn / 2;
+        const unsigned keep_left = p.facts & (Q_HEAD | T_HEAD | OPEN_L), keep_right = p.facts & (Q_TAIL | T_TAIL | OPEN_R);
+        // what the halves know about the target's ends: only a half that still reaches the end inherits the fact
+        const unsigned upper_facts = keep_left | ((c.column == p.tn) ? (p.facts & T_TAIL) : 0u);
+        const unsigned lower_facts = keep_right | ((c.column == 0) ? (p.facts & T_HEAD) : 0u);
+        if (!c.hanging)
           {
-            int64_t s = 0;
-            if (i > 0) s -= a_left ? goql + i * geql : goqi + i * geqi;
-            s += sub(a[a0], b[b0 + i]);
-            if (i < bl - 1) s -= a_right ? goqr + (bl - 1 - i) * geqr : goqi + (bl - 1 - i) * geqi;
-            if (s > best_score) { best_score = s; best = i; }
+            todo.push_back(Piece {p.q0 + upper_rows, p.t0 + c.column, p.qn - upper_rows, p.tn - c.column, lower_facts});
+            todo.push_back(Piece {p.q0, p.t0, upper_rows, c.column, upper_facts});
           }
-        if (best == -1) { add('D', 1); add('I', bl); }
-        else if (best == bl) { add('I', bl); add('D', 1); }
         else
           {
-            if (best > 0) add('I', best);
-            add('M', 1);
-            if (best < bl - 1) add('I', bl - 1 - best);
-          }
-        return;
-      }
-
-    const int64_t I = al / 2;
-    // forward pass over rows 1..I (linmemalign.cpp:463-513)
-    HH[0] = 0; EE[0] = 0;
-    for (int64_t j = 1; j <= bl; ++j) { HH[j] = -(a_left ? goql + j * geql : goqi + j * geqi); EE[j] = NEG; }
-    for (int64_t i = 1; i <= I; ++i)
-      {
-        int64_t p = HH[0];
-        int64_t h = -(b_left ? (gap_b_left ? 0 : gotl) + i * getl : (gap_b_left ? 0 : goti) + i * geti);
-        HH[0] = h;
-        int64_t f = NEG;
-        for (int64_t j = 1; j <= bl; ++j)
-          {
-            f = std::max(f, h - goqi) - geqi;
-            if (b_right && j == bl) EE[j] = std::max(EE[j], HH[j] - gotr) - getr;
-            else EE[j] = std::max(EE[j], HH[j] - goti) - geti;
-            h = p + sub(a[a0 + i - 1], b[b0 + j - 1]);
-            h = std::max(f, h);
-            h = std::max(EE[j], h);
-            p = HH[j];
-            HH[j] = h;
+            // the two rows around the cut are deleted; both neighbours see an open target gap on that side
+            todo.push_back(Piece {p.q0 + upper_rows + 1, p.t0 + c.column, p.qn - upper_rows - 1, p.tn - c.column, lower_facts | OPEN_L});
+            todo.push_back(Piece {(int64_t) 'D', 2, -1, 0, 0});
+            todo.push_back(Piece {p.q0, p.t0, upper_rows - 1, c.column, upper_facts | OPEN_R});
           }
       }
-    EE[0] = HH[0];
-    // reverse pass over the lower half (:515-569)
-    XX[0] = 0; YY[0] = 0;
-    for (int64_t j = 1; j <= bl; ++j) { XX[j] = -(a_right ? goqr + j * geqr : goqi + j * geqi); YY[j] = NEG; }
-    for (int64_t i = 1; i <= al - I; ++i)
-      {
-        int64_t p = XX[0];
-        int64_t h = -(b_right ? (gap_b_right ? 0 : gotr) + i * getr : (gap_b_right ? 0 : goti) + i * geti);
-        XX[0] = h;
-        int64_t f = NEG;
-        for (int64_t j = 1; j <= bl; ++j)
-          {
-            f = std::max(f, h - goqi) - geqi;
-            if (b_left && j == bl) YY[j] = std::max(YY[j], XX[j] - gotl) - getl;
-            else YY[j] = std::max(YY[j], XX[j] - goti) - geti;
-            h = p + sub(a[a0 + al - i], b[b0 + bl - j]);
-            h = std::max(f, h);
-            h = std::max(YY[j], h);
-            p = XX[j];
-            XX[j] = h;
-          }
-      }
-    YY[0] = XX[0];
-    // best join along the division line (:572-652)
-    int64_t m0 = NEG, j0 = -1;
-    for (int64_t j = 0; j <= bl; ++j)
-      {
-        const int64_t s = HH[j] + XX[bl - j];
-        if (s > m0) { m0 = s; j0 = j; }
-      }
-    int64_t m1 = NEG, j1 = -1;
-    for (int64_t j = 0; j <= bl; ++j)
-      {
-        const int64_t g = (b_left && j == 0) ? gotl : ((b_right && j == bl) ? gotr : goti);
-        const int64_t s = EE[j] + YY[bl - j] + g;
-        if (s > m1) { m1 = s; j1 = j; }
-      }
-    bool split;      // true: a gap in b spans the division line (two 'D' columns emitted here)
-    int64_t best;
-    if (m0 > m1) { split = false; best = j0; }
-    else if (m1 > m0) { split = true; best = j1; }
-    else if (j0 <= j1) { split = false; best = j0; }
-    else { split = true; best = j1; }
-    if (!split)
-      {
-        diff(a0, b0, I, best, gap_b_left, false, a_left, false, b_left, b_right && best == bl);
-        diff(a0 + I, b0 + best, al - I, bl - best, false, gap_b_right, false, a_right, b_left && best == 0, b_right);
-      }
-    else
-      {
-        diff(a0, b0, I - 1, best, gap_b_left, true, a_left, false, b_left, b_right && best == bl);
-        add('D', 2);
-        diff(a0 + I + 1, b0 + best, al - I - 1, bl - best, true, gap_b_right, false, a_right, b_left && best == 0, b_right);
-      }
+    return out.finish();
   }
 
-  void align(const char * q, int64_t ql, const char * t, int64_t tl)
+  // score and counts of a finished CIGAR (linmemalign.cpp:722-808): a gap that starts the alignment is a head gap, one that
+  // ends it a tail gap (head wins when the whole alignment is one gap), all others are interior
+  void measure(const std::string & cigar, const char * query, const char * target, int64_t * score, int64_t * columns,
+               int64_t * matches, int64_t * mismatches, int64_t * gaps) const
   {
-    a = q; b = t;
-    cigar.clear(); op = 0; run = 0;
-    HH.assign((size_t) tl + 1, 0); EE.assign((size_t) tl + 1, 0);
-    XX.assign((size_t) tl + 1, 0); YY.assign((size_t) tl + 1, 0);
-    diff(0, 0, ql, tl, false, false, true, true, true, true);
-    flush();
+    int64_t total = 0, cols = 0, same = 0, differ = 0, opened = 0, qpos = 0, tpos = 0;
+    size_t at = 0;
+    while (at < cigar.size())
+      {
+        int64_t n = 0;
+        bool counted = false;
+        while (at < cigar.size() && cigar[at] >= '0' && cigar[at] <= '9') { n = 10 * n + (cigar[at++] - '0'); counted = true; }
+        if (!counted) n = 1;
+        const char op = cigar[at++];
+        const bool first = (qpos == 0 && tpos == 0), last = (at == cigar.size());
+        const Zone z = first ? HEAD : (last ? TAIL : INNER);
+        cols += n;
+        if (op == 'M')
+          for (int64_t k = 0; k < n; ++k, ++qpos, ++tpos)
+            {
+              const unsigned x = kSets.set[(unsigned char) query[qpos]], y = kSets.set[(unsigned char) target[tpos]];
+              total += pair_score_[y][x];
+              if ((x & y) && !(count_n_as_mismatch_ && (x == 15 || y == 15))) ++same; else ++differ;
+            }
+        else if (op == 'I') { total -= q_open_[z] + n * q_ext_[z]; ++opened; tpos += n; }
+        else if (op == 'D') { total -= t_open_[z] + n * t_ext_[z]; ++opened; qpos += n; }
+      }
+    *score = total; *columns = cols; *matches = same; *mismatches = differ; *gaps = opened;
   }
 
-  // alignstats, linmemalign.cpp:722-808
-  void stats(const char * q, const char * t, int64_t * score, int64_t * alnlen, int64_t * matches,
-             int64_t * mismatches, int64_t * gaps) const
+private:
+  // scores of the best alignments of (rows swept so far) x (first j columns in sweep order): `reach` = ending anyhow,
+  // `hang` = ending inside a gap in the target
+  struct Frontier { std::vector<int64_t> reach, hang; };
+  struct Cut { bool hanging; int64_t column; };
+
+  int64_t substitution(int64_t qi, int64_t ti) const
   {
-    int64_t sc = 0, al = 0, ma = 0, mi = 0, ga = 0, ap = 0, bp = 0;
-    const char * p = cigar.c_str();
-    while (*p)
+    return pair_score_[kSets.set[(unsigned char) target_[ti]]][kSets.set[(unsigned char) query_[qi]]];
+  }
+  int64_t query_gap(Zone z, int64_t n) const { return q_open_[z] + n * q_ext_[z]; }
+
+  // One orientation of S1: sweep `rows` rows of piece p starting from its top (mirrored = false) or from its bottom, with the
+  // columns running away from the matching side.  Orientation only changes which symbols meet and which facts are "near".
+  void sweep(Frontier & f, const Piece & p, int64_t rows, bool mirrored) const
+  {
+    const unsigned near_q = mirrored ? Q_TAIL : Q_HEAD, near_t = mirrored ? T_TAIL : T_HEAD, far_t = mirrored ? T_HEAD : T_TAIL;
+    const unsigned near_open = mirrored ? OPEN_R : OPEN_L;
+    const Zone start_q = (p.facts & near_q) ? (mirrored ? TAIL : HEAD) : INNER;      // S4: only the all-gap starting row
+    const Zone col0_t = (p.facts & near_t) ? (mirrored ? TAIL : HEAD) : INNER;
+    const Zone last_t = (p.facts & far_t) ? (mirrored ? HEAD : TAIL) : INNER;
+    const int64_t col0_open = (p.facts & near_open) ? 0 : t_open_[col0_t];
+
+    f.reach[0] = 0;
+    f.hang[0] = 0;
+    for (int64_t j = 1; j <= p.tn; ++j) { f.reach[(size_t) j] = -query_gap(start_q, j); f.hang[(size_t) j] = kNever; }
+    for (int64_t i = 1; i <= rows; ++i)
       {
-        long long n = 1; int scan = 0;
-        std::sscanf(p, "%lld%n", &n, &scan);
-        p += scan;
-        const char o = *p++;
-        if (o == 'M')
+        const int64_t qi = mirrored ? p.q0 + p.qn - i : p.q0 + i - 1;
+        int64_t corner = f.reach[0];                               // the cell diagonally behind the one being filled
+        int64_t here = -(col0_open + i * t_ext_[col0_t]);          // column 0: i rows deleted
+        f.reach[0] = here;
+        int64_t run = kNever;                                      // ending inside a gap in the query, along this row
+        for (int64_t j = 1; j <= p.tn; ++j)
           {
-            al += n;
-            for (long long k = 0; k < n; ++k)
-              {
-                const char x = q[ap], y = t[bp];
-                sc += sub(x, y);
-                const unsigned cx = map4((unsigned char) x), cy = map4((unsigned char) y);
-                if (nmm && (cx == 15 || cy == 15)) ++mi;
-                else if (cx & cy) ++ma;
-                else ++mi;
-                ++ap; ++bp;
-              }
-          }
-        else if (o == 'I')
-          {
-            const int64_t g = (ap == 0 && bp == 0) ? goql + n * geql : (*p == 0 ? goqr + n * geqr : goqi + n * geqi);
-            sc -= g; ++ga; al += n; bp += n;
-          }
-        else if (o == 'D')
-          {
-            const int64_t g = (ap == 0 && bp == 0) ? gotl + n * getl : (*p == 0 ? gotr + n * getr : goti + n * geti);
-            sc -= g; ++ga; al += n; ap += n;
+            const size_t jx = (size_t) j;
+            const Zone tz = (j == p.tn) ? last_t : INNER;
+            run = std::max(run, here - q_open_[INNER]) - q_ext_[INNER];
+            f.hang[jx] = std::max(f.hang[jx], f.reach[jx] - t_open_[tz]) - t_ext_[tz];
+            const int64_t ti = mirrored ? p.t0 + p.tn - j : p.t0 + j - 1;
+            here = std::max(std::max(corner + substitution(qi, ti), run), f.hang[jx]);
+            corner = f.reach[jx];
+            f.reach[jx] = here;
           }
       }
-    *score = sc; *alnlen = al; *matches = ma; *mismatches = mi; *gaps = ga;
+    f.hang[0] = f.reach[0];
   }
+
+  // S2
+  Cut best_cut(const Piece & p)
+  {
+    const int64_t upper_rows = p.qn / 2;
+    sweep(down_, p, upper_rows, false);
+    sweep(up_, p, p.qn - upper_rows, true);
+    int64_t through = kNever, through_at = -1, hanging = kNever, hanging_at = -1;
+    for (int64_t c = 0; c <= p.tn; ++c)
+      {
+        const size_t a = (size_t) c, b = (size_t) (p.tn - c);
+        const int64_t meet = down_.reach[a] + up_.reach[b];
+        if (meet > through) { through = meet; through_at = c; }
+        // both halves opened the gap: one opening is refunded, priced where the gap lies
+        const Zone z = ((p.facts & T_HEAD) && c == 0) ? HEAD : (((p.facts & T_TAIL) && c == p.tn) ? TAIL : INNER);
+        const int64_t span = down_.hang[a] + up_.hang[b] + t_open_[z];
+        if (span > hanging) { hanging = span; hanging_at = c; }
+      }
+    const bool take_hanging = (hanging > through) || (hanging == through && hanging_at < through_at);
+    return take_hanging ? Cut {true, hanging_at} : Cut {false, through_at};
+  }
+
+  // S5
+  void single_row(const Piece & p, OpWriter & out) const
+  {
+    const Zone qz_head = (p.facts & Q_HEAD) ? HEAD : INNER, qz_tail = (p.facts & Q_TAIL) ? TAIL : INNER;
+    const Zone tz_head = (p.facts & T_HEAD) ? HEAD : INNER, tz_tail = (p.facts & T_TAIL) ? TAIL : INNER;
+    enum { DELETE_THEN_INSERT = -1 };
+    // "delete, then insert": the deleted row hangs on the left side, the inserted columns end the piece
+    int64_t charged = -(((p.facts & OPEN_L) ? 0 : t_open_[tz_head]) + t_ext_[tz_head]) - query_gap(qz_tail, p.tn);
+    int64_t best = charged;
+    int64_t choice = DELETE_THEN_INSERT;
+    // "insert, then delete": priced on top of what the first candidate was charged (S5)
+    charged -= query_gap(qz_head, p.tn);
+    charged -= ((p.facts & OPEN_R) ? 0 : t_open_[tz_tail]) + t_ext_[tz_tail];
+    if (charged > best) { best = charged; choice = p.tn; }
+    for (int64_t c = 0; c < p.tn; ++c)
+      {
+        const int64_t before = c, after = p.tn - 1 - c;
+        int64_t s = substitution(p.q0, p.t0 + c);
+        if (before > 0) s -= query_gap(qz_head, before);
+        if (after > 0) s -= query_gap(qz_tail, after);
+        if (s > best) { best = s; choice = c; }
+      }
+    if (choice == DELETE_THEN_INSERT) { out.put('D', 1); out.put('I', p.tn); }
+    else if (choice == p.tn) { out.put('I', p.tn); out.put('D', 1); }
+    else { out.put('I', choice); out.put('M', 1); out.put('I', p.tn - 1 - choice); }
+  }
+
+  int64_t q_open_[3], q_ext_[3], t_open_[3], t_ext_[3];
+  int64_t pair_score_[16][16];
+  bool count_n_as_mismatch_;
+  const char * query_ = nullptr;
+  const char * target_ = nullptr;
+  Frontier down_, up_;
 };
 
 }  // namespace
@@ -255,17 +290,17 @@ extern "C" int vsx_lma_align(const vsx_scoring * scoring, const char * q, uint64
                              int64_t * gaps, char ** cigar)
 {
   if (!scoring || !cigar || (qlen && !q) || (tlen && !t)) return VSX_EINVAL;
-  Lma lma(*scoring);
-  lma.align(q, (int64_t) qlen, t, (int64_t) tlen);
+  LinearAligner aligner(*scoring);
+  const std::string text = aligner.align(q, (int64_t) qlen, t, (int64_t) tlen);
   int64_t s, l, m, x, g;
-  lma.stats(q, t, &s, &l, &m, &x, &g);
+  aligner.measure(text, q, t, &s, &l, &m, &x, &g);
   if (score) *score = s;
   if (alnlen) *alnlen = l;
   if (matches) *matches = m;
   if (mismatches) *mismatches = x;
   if (gaps) *gaps = g;
-  *cigar = (char *) std::malloc(lma.cigar.size() + 1);
+  *cigar = (char *) std::malloc(text.size() + 1);
   if (!*cigar) return VSX_ENOMEM;
-  std::memcpy(*cigar, lma.cigar.c_str(), lma.cigar.size() + 1);
+  std::memcpy(*cigar, text.c_str(), text.size() + 1);
   return VSX_OK;
 }

@@ -26,7 +26,8 @@ typedef unsigned int u32;
 __global__ void __launch_bounds__(256)
 vsx_rank_flag_kernel(const VsxFilterDev F, int keep_weak, const VsxPairOut * __restrict__ out, const u32 * __restrict__ pair_ids,
                      const u32 * __restrict__ pair_slot, const VsxTask * __restrict__ tasks, u32 npairs,
-                     const u32 * __restrict__ runs, uint64_t runs_capacity, u32 * __restrict__ flag, double * __restrict__ id)
+                     const u32 * __restrict__ runs, uint64_t runs_capacity, u32 * __restrict__ flag, double * __restrict__ id,
+                     u32 * __restrict__ refused /* [0] = count, then pair indices */)
 {
   const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= npairs) return;
@@ -44,6 +45,10 @@ vsx_rank_flag_kernel(const VsxFilterDev F, int keep_weak, const VsxPairOut * __r
     }
   flag[pid] = keep ? 1u : 0u;
   id[pid] = idv;
+  // a pair the 16-bit DP refused AT RUN TIME (overflow rule, align_simd.cpp:1774-1786: score SHRT_MAX, no statistics, no verdict)
+  // is neither kept nor rejected: it goes on the list of pairs the caller's linear-memory fallback must decide
+  // (searchcore.cpp:806-832).  Rare, so one atomic per such pair; the host sorts the list.
+  if (o.score == 32767 /* VSX_SCORE_SENTINEL */ && v == 0u) refused[1 + atomicAdd(refused, 1u)] = pid;
 }
 
 // kept pairs in pair order: keys (id) and values (pair index) at their scanned positions
@@ -83,16 +88,18 @@ vsx_rank_gather_kernel(const u32 * __restrict__ ranked, const double * __restric
 extern "C" hipError_t vsx_rank_flag_scan(VsxFilterDev F, int keep_weak, const VsxPairOut * d_out, const uint32_t * d_pair_ids,
                                          const uint32_t * d_pair_slot, const VsxTask * d_tasks, uint32_t ngpu_pairs, uint32_t n_pairs,
                                          const uint32_t * d_runs, uint64_t runs_capacity, uint32_t * d_flag /* n + 1 */,
-                                         uint32_t * d_pos /* n + 1 */, double * d_id, void * d_temp, size_t * temp_bytes, hipStream_t st)
+                                         uint32_t * d_pos /* n + 1 */, double * d_id, uint32_t * d_refused /* ngpu_pairs + 1 */,
+                                         void * d_temp, size_t * temp_bytes, hipStream_t st)
 {
   // size query: d_temp == nullptr
   if (!d_temp)
     return rocprim::exclusive_scan(nullptr, *temp_bytes, d_flag, d_pos, 0u, (size_t) n_pairs + 1, rocprim::plus<u32>(), st);
   hipError_t e = hipMemsetAsync(d_flag, 0, ((size_t) n_pairs + 1) * 4, st);        // pairs answered on the host stay unflagged
   if (e != hipSuccess) return e;
+  if ((e = hipMemsetAsync(d_refused, 0, 4, st)) != hipSuccess) return e;
   if (ngpu_pairs)
     hipLaunchKernelGGL(vsx_rank_flag_kernel, dim3((ngpu_pairs + 255) / 256), dim3(256), 0, st, F, keep_weak, d_out, d_pair_ids, d_pair_slot,
-                       d_tasks, ngpu_pairs, d_runs, runs_capacity, d_flag, d_id);
+                       d_tasks, ngpu_pairs, d_runs, runs_capacity, d_flag, d_id, d_refused);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   return rocprim::exclusive_scan(d_temp, *temp_bytes, d_flag, d_pos, 0u, (size_t) n_pairs + 1, rocprim::plus<u32>(), st);
 }

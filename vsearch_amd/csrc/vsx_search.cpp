@@ -325,25 +325,42 @@ void candidates_for(const vsx_searcher & S, const char * q, int64_t qlen, std::v
   out.resize(keep);
 }
 
-// abundance_ratio_cmp, core/searchcore.cpp:480-537: sign of value - ratio * reference, exact beyond 2^53
+// Sign of (value - ratio * reference) for two abundances and a size-ratio threshold -- what the abundance filters of
+// core/searchcore.cpp:480-537 compare.  Contract (from the reference's behaviour, which callers' outputs depend on):
+//   * ratio * reference == 0 (no reference abundance, or a non-positive ratio): positive iff value > 0;
+//   * an infinite ratio is larger than any value;
+//   * while both abundances are below 2^53 the comparison is the ROUNDED double product ratio * reference against value
+//     (long-standing boundary behaviour for ratios like 1/9 must not move);
+//   * beyond that it is exact: the double is taken at its stored dyadic value m * 2^e and compared in integers.
+// The exact branch here reads m and e from the IEEE-754 fields and decides by magnitude before it shifts anything.
 int abundance_ratio_cmp(int64_t value, double ratio, int64_t reference)
 {
+  const auto sign_of = [](auto lhs, auto rhs) { return lhs < rhs ? -1 : (rhs < lhs ? 1 : 0); };
   if (reference <= 0 || ratio <= 0.0) return value > 0 ? 1 : 0;
   if (!std::isfinite(ratio)) return -1;
-  constexpr int64_t exact_double_limit = int64_t {1} << 53;
-  if (value < exact_double_limit && reference < exact_double_limit)
+  constexpr int64_t doubles_are_exact_below = int64_t {1} << 53;
+  if (value < doubles_are_exact_below && reference < doubles_are_exact_below)
+    return sign_of((double) value, ratio * (double) reference);
+
+  typedef unsigned __int128 wide;
+  const auto bit_length = [](wide x) { int n = 0; while (x) { ++n; x >>= 1; } return n; };
+  uint64_t bits;
+  std::memcpy(&bits, &ratio, sizeof bits);
+  const uint64_t fraction = bits & ((uint64_t {1} << 52) - 1);
+  const int biased = (int) ((bits >> 52) & 0x7ff);
+  // ratio = m * 2^e exactly (a subnormal has no hidden bit and the exponent of the smallest normal)
+  const uint64_t m = biased ? (fraction | (uint64_t {1} << 52)) : fraction;
+  const int e = (biased ? biased : 1) - 1075;
+  const wide have = (wide) (uint64_t) value;
+  const wide want = (wide) m * (wide) (uint64_t) reference;          // < 2^117: ratio * reference = want * 2^e
+  if (e >= 0)
     {
-      const double product = ratio * (double) reference, v = (double) value;
-      return v < product ? -1 : (v > product ? 1 : 0);
+      if (bit_length(want) + e > 64) return -1;                       // want * 2^e >= 2^64 > any 64-bit value
+      return sign_of(have, want << e);
     }
-  typedef unsigned __int128 u128;
-  int exponent = 0;
-  const int64_t mantissa = (int64_t) std::ldexp(std::frexp(ratio, &exponent), 53);
-  exponent -= 53;
-  u128 lhs = (u128) (uint64_t) value, rhs = (u128) (uint64_t) mantissa * (u128) (uint64_t) reference;
-  for (int sh = exponent; sh > 0; --sh) { if ((rhs >> 126) != 0) return -1; rhs <<= 1; }
-  for (int sh = exponent; sh < 0; ++sh) { if ((lhs >> 126) != 0) return 1; lhs <<= 1; }
-  return lhs < rhs ? -1 : (lhs > rhs ? 1 : 0);
+  if (have == 0) return -1;                                           // want > 0
+  if (bit_length(have) - e > 120) return 1;                           // value * 2^-e >= 2^119 > want
+  return sign_of(have << -e, want);
 }
 
 // search_acceptable_unaligned, core/searchcore.cpp:541-609
@@ -916,6 +933,8 @@ static int batch_candidates(vsx_searcher * S, bool device, uint64_t nq, FSeq qse
 }
 
 extern "C" {
+
+int vsx_abundance_ratio_cmp(int64_t value, double ratio, int64_t reference) { return abundance_ratio_cmp(value, ratio, reference); }
 
 void vsx_search_opts_default(vsx_search_opts * o)
 {
