@@ -121,9 +121,11 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // H*(-1,-1) = -2g; the score is un-tilted in the epilogue; checkpoints hold tilted values (the traceback recomputes with the
 // same primed constants).
 // occupancy floor of the DP kernel (waves per SIMD the register allocator must make room for): 4 up to R = 16 (128 VGPRs, a few
-// spills: measured better than 3 without), 2 beyond R = 24 (256 VGPRs); A/B builds override VSX_FWD_WAVES
+// spills: measured better than 3 without), 3 up to R = 24 (168 VGPRs; r03: the allocator left to itself took 244 = 2 waves,
+// 300 x 300: 12.23 -> 11.17 ms, 360 x 360: 15.9 -> 15.0 ms; 4 waves at R = 18 / 20: 12.7 ms), 2 beyond (256 VGPRs; 3 there
+// spills into the loop: 500 x 500 25.5 -> 30.8 ms) -- profiles/r03/r03c_occupancy_ab.txt.  A/B builds override VSX_FWD_WAVES
 #ifndef VSX_FWD_WAVES
-#define VSX_FWD_WAVES(R_, TILT_) ((R_) <= 16 ? 4 : ((R_) > 24 ? 2 : 1))
+#define VSX_FWD_WAVES(R_, TILT_) ((R_) <= 16 ? 4 : ((R_) <= 24 ? 3 : 2))
 #endif
 template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VSX_FWD_WAVES(R, TILT), 8)))

@@ -179,8 +179,10 @@ hipError_t vsx_kmer_launch_case_bits(const uint8_t * d_ascii, uint64_t nbytes, u
 // vsx_mask.hip: DUST intervals of every sequence OR-ed into the case bitmap (dword-aligned, zero-padded to a dword)
 hipError_t vsx_launch_dust(const uint8_t * d_codes, const uint64_t * d_off, const uint32_t * d_len, uint64_t nseq, uint8_t * d_bits,
                            hipStream_t st);
-hipError_t vsx_kmer_launch_count(const uint32_t * postings, const uint64_t * bucket_start, uint32_t ntiles,
-                                 uint32_t nseq, uint32_t nslots, const uint64_t * qk_start, const uint32_t * qk,
+// bits = 8 | 16: counter width of the kernel (queries with <= 255 unique words take 8); slots [slot_base, slot_base + nslots) of the
+// batch (query = qlist ? qlist[slot] : slot); rec / qcount point at the FIRST of these slots
+hipError_t vsx_kmer_launch_count(int bits, const uint32_t * postings, const uint64_t * bucket_start, uint32_t ntiles,
+                                 uint32_t nseq, uint32_t nslots, uint32_t slot_base, const uint64_t * qk_start, const uint32_t * qk,
                                  const uint32_t * minmatch, const uint32_t * qlist, void * rec, uint32_t cap,
                                  uint32_t * qcount, hipStream_t st);
 hipError_t vsx_kmer_launch_select(const void * rec, uint32_t cap, const uint32_t * qcount, uint32_t nslots,

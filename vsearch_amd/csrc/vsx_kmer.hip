@@ -6,12 +6,14 @@
 // kernels.  No MFMA: this is a sparse count, not a contraction.
 //
 //   index   = postings grouped by (word, TILE of 2^15 consecutive sequence numbers): a CSR over 4^w x ntiles buckets of
-//             16-BIT tile-local sequence indices, two per dword (an odd bucket ends in the 0xFFFF sentinel) -- half the
-//             bytes of sequence numbers, and the count kernel is bound by exactly this stream.
+//             16-BIT tile-local sequence indices in 16-byte units of eight (a bucket's last unit is padded with the index of
+//             a spare counter, so the count kernel never tests for a sentinel) -- half the bytes of sequence numbers, and the
+//             count kernel is bound by exactly this stream.
 //             Built on the device from the 4-bit codes in two sweeps (count, fill); the order inside a bucket is
 //             arbitrary (counting commutes), so no sort is needed.
-//   count   = one 1024-thread block per (query, tile): 2^15 16-bit counters live in 64 KB of LDS; the query's unique words
-//             select one bucket each, whose postings are streamed (coalesced) into ds_add_u32 on the packed halves;
+//   count   = one block per (query, tile): 2^15 counters live in LDS -- 8 bits each (32 KB, 512 threads, four blocks per CU) for
+//             queries with at most 255 unique words, 16 bits (64 KB, 1024 threads) otherwise; the query's unique words
+//             select one bucket each, whose postings are streamed (coalesced 16-byte loads) into ds_add_u32 on the packed fields;
 //             a final LDS sweep appends (sequence, count) for count >= minmatches to the QUERY's own record region
 //             (one counter per query: a single global cursor serialises at ~40 ns per atomic and cost 7x the counting).
 //   select  = one wave per query: threshold c* = the largest count with at least `tophits` records at or above it
@@ -22,6 +24,7 @@
 //   Counts are exact integers, the host applies the reference's total order (count desc, length asc, seqno asc) and the
 //   heap size, so candidate lists are bit-identical to the host restatement in vsx_search.cpp.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "vsx_internal.h"
 
 typedef unsigned int u32;
@@ -117,146 +120,245 @@ vsx_kmer_sweep_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict
             {
               const size_t b = (size_t) word * ntiles + tile;
               const u32 slot = atomicAdd(&bucket_count[b], 1u);
-              if (FILL) postings[2 * bucket_start[b] + slot] = (uint16_t) (seq & (KM_TILE - 1));   // bucket_start counts dwords
+              if (FILL) postings[8 * bucket_start[b] + slot] = (uint16_t) (seq & (KM_TILE - 1));   // bucket_start counts 16-byte units
             }
         }
     }
   // leave the bitmap clean for nobody (one sequence per wave): nothing to do
 }
 
-// counters of one (query, tile) in LDS; see the header comment
-#define KM_UNROLL 8                    // independent postings loads per lane and trip
-#define KM_COUNT_THREADS 1024          // 16 waves share one 64 KB counter tile: two blocks = 32 waves per CU keep the postings stream deep
-__global__ void __launch_bounds__(KM_COUNT_THREADS)
-vsx_kmer_count_kernel(const u32 * __restrict__ postings, const u64 * __restrict__ bucket_start, u32 ntiles, u32 nseq,
+// ---- counting: the counters of one (query, tile) live in LDS; see the header comment -------------------------------------
+// Postings format (r03): a bucket is a whole number of 16-BYTE units (bucket_start counts uint4), i.e. 8 tile-local
+// indices per unit; the last unit of a bucket is padded with KM_PAD = 0x8000 -- the index of a SPARE counter one past the tile,
+// so the hot loop carries no sentinel test: every posting is one unconditional ds_add_u32.
+// Two counter widths, chosen per query by the host:
+//   BITS = 8  (queries with <= 255 unique words, i.e. every BASELINE read length): four counters per dword, 32 KB per tile,
+//             512 threads -> FOUR blocks per CU (32 waves): the latency phases of one block (bucket table look-up, the final
+//             sweep) hide under the streaming of the others.  A count never exceeds the number of words, so bytes cannot carry;
+//   BITS = 16 (longer queries): two counters per dword, 64 KB, 1024 threads, two blocks per CU.
+// r03 measurements that led here (profiles/r03/r03_ubench_lds.txt): random-address ds_add_u32 sustains 8.1 ops per clock and CU
+// (13 conflict-free), the r02 kernel reached 3.2 -- it was bound by the per-posting VALU work around the sentinel tests and by
+// two fat blocks per CU taking turns, not by the LDS.
+#define KM_PAD 0x8000u
+#define KM_LOADS 4                     // independent 16-byte loads per lane and trip (32 postings)
+template <int BITS>
+__global__ void __launch_bounds__(BITS == 8 ? 512 : 1024) __attribute__((amdgpu_waves_per_eu(8, 8)))     // 64 VGPRs: 32 waves per CU in both widths
+vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restrict__ bucket_start, u32 ntiles, u32 nseq,
                       const u64 * __restrict__ qk_start, const u32 * __restrict__ qk, const u32 * __restrict__ minmatch,
-                      const u32 * __restrict__ qlist, uint2 * __restrict__ rec, u32 cap, u32 * __restrict__ qcount)
+                      const u32 * __restrict__ qlist, u32 slot_base, uint2 * __restrict__ rec, u32 cap, u32 * __restrict__ qcount, int probe)
 {
-  __shared__ u32 cnt[KM_TILE / 2];                      // two 16-bit counters per dword: 64 KB
-  __shared__ u64 rs[256];                                // first posting of each selected bucket
-  __shared__ u32 pre[257];                               // exclusive prefix sum of the bucket sizes; pre[ne ..] = total
-  const int tid = (int) threadIdx.x, lane = tid & 63;
-  const u32 slot = blockIdx.x, tile = blockIdx.y;
-  const u32 q = qlist ? qlist[slot] : slot;             // second pass: only the queries whose region overflowed
+  // probe (VSX_KMER_PROBE, measurements only -- results are wrong): bit 0 = no LDS atomics (the loads are still consumed),
+  // bit 1 = no postings loads (addresses synthesised), bit 2 = no final sweep
+  constexpr int THREADS = (BITS == 8) ? 512 : 1024;
+  constexpr int WAVES = THREADS / 64;
+  constexpr int PER = 32 / BITS;                                  // counters per dword
+  constexpr int NDW = (int) (KM_TILE / PER);                      // dwords of real counters
+  __shared__ __attribute__((aligned(16))) u32 cnt[NDW + 4];       // + the spare dword the pad index lands in
+  __shared__ u64 rs[256];                                         // first unit of each selected bucket
+  __shared__ u32 pre[256];                                        // ... and its size in units
+  __shared__ u32 wave_hits[WAVES];
+  const int tid = (int) threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 slot = blockIdx.x + slot_base, tile = blockIdx.y;
+  const u32 q = qlist ? qlist[slot] : slot;
   const u32 mm = minmatch[q];
-  if (mm == 0xffffffffu) return;                         // this query is answered on the host (minmatches == 0, > 32767 words)
+  if (mm == 0xffffffffu) return;                                  // this query is answered on the host (minmatches == 0, > 32767 words)
   const u32 base = tile << KM_TILE_SHIFT;
   {
     uint4 * c4 = reinterpret_cast<uint4 *>(cnt);
-    for (int x = tid; x < (int) (KM_TILE / 8); x += KM_COUNT_THREADS) c4[x] = make_uint4(0, 0, 0, 0);
+    for (int x = tid; x < (NDW + 4) / 4; x += THREADS) c4[x] = make_uint4(0, 0, 0, 0);
   }
   const u64 k0 = qk_start[q];
   const int nk = (int) (qk_start[q + 1] - k0);
+  auto bump = [&](u32 x) __attribute__((always_inline)) {
+    // counter x: dword x / PER, field x % PER
+    if (BITS == 8) atomicAdd(&cnt[x >> 2], 1u << ((x & 3u) << 3));
+    else atomicAdd(&cnt[x >> 1], 1u << ((x & 1u) << 4));
+  };
   for (int chunk = 0; chunk < nk; chunk += 256)
     {
       __syncthreads();
-      // the buckets of up to 256 words, flattened: 256 threads fetch one range each, wave 0 scans the sizes (4 per lane)
+      // the bucket ranges of up to 256 words: 256 threads fetch one range each
       if (tid < 256)
         {
           u32 n = 0;
+          u64 first = 0;
           if (chunk + tid < nk)
             {
               const size_t b = (size_t) qk[k0 + chunk + tid] * ntiles + tile;
-              const u64 first = bucket_start[b];
-              rs[tid] = first;
+              first = bucket_start[b];
               n = (u32) (bucket_start[b + 1] - first);
             }
+          rs[tid] = first;
           pre[tid] = n;
         }
       __syncthreads();
-      if (tid < 64)
+      // Wave w takes the buckets w, w + WAVES, ...: lane j keeps the range of the wave's j-th bucket in registers, and the loop
+      // below broadcasts it with v_readlane -- the streaming loop touches the LDS with ds_add_u32 ONLY.  (r03: the flattened
+      // equal split of r02 looked its bucket up in LDS for every load; each look-up waits for lgkmcnt(0), i.e. for all the
+      // atomics queued before it, so a wave's atomics and its next loads took turns instead of overlapping: 192 ms where the
+      // LDS atomics alone need 115 and the postings stream 80.)
+      constexpr int BPW = 256 / WAVES;                            // buckets per wave and chunk
+      u32 my_n = 0, my_lo = 0, my_hi = 0;
+      if (lane < BPW)
         {
-          u32 sz[4], run = 0;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { sz[u] = run; run += pre[4 * tid + u]; }     // exclusive within the lane
-          u32 incl = run;
-#pragma unroll
-          for (int d = 1; d < 64; d <<= 1)
-            {
-              const u32 up = (u32) __shfl_up((int) incl, d, 64);
-              if (tid >= d) incl += up;
-            }
-          const u32 excl = incl - run;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) pre[4 * tid + u] = excl + sz[u];
-          if (tid == 63) pre[256] = incl;
+          const int bidx = wave + WAVES * lane;
+          my_n = pre[bidx];
+          const u64 f = rs[bidx];
+          my_lo = (u32) f; my_hi = (u32) (f >> 32);
         }
-      __syncthreads();
-      const u32 total = pre[256];
-      // each wave streams one contiguous sixteenth of the flattened postings: the bucket of a lane's index is found by
-      // binary search once, afterwards it only ever steps forward; four independent loads in flight per lane
-      const u32 per_wave = (total + KM_COUNT_THREADS / 64 - 1) / (KM_COUNT_THREADS / 64);
-      const u32 wbeg = ((u32) (tid >> 6) * per_wave < total) ? (u32) (tid >> 6) * per_wave : total;
-      const u32 wend = (wbeg + per_wave < total) ? wbeg + per_wave : total;
-      if (wbeg + (u32) lane < wend)
-        {
-          int e = 0;
+      int nb = 0;                                                   // buckets of this wave that exist in this chunk
+      {
+        const int left = nk - chunk - wave;                         // words chunk + wave, chunk + wave + WAVES, ...
+        nb = left <= 0 ? 0 : (left + WAVES - 1) / WAVES;
+        if (nb > BPW) nb = BPW;
+      }
+      const uint4 pad4 = make_uint4(KM_PAD * 0x10001u, KM_PAD * 0x10001u, KM_PAD * 0x10001u, KM_PAD * 0x10001u);
+      u32 sink = 0;
+      auto consume = [&](const uint4 & v) __attribute__((always_inline)) {
+        const u32 w4[4] = {v.x, v.y, v.z, v.w};
+        if (probe & 1) sink ^= w4[0] + w4[1] + w4[2] + w4[3];
+        else
           {
-            const u32 i = wbeg + (u32) lane;
 #pragma unroll
-            for (int bstep = 128; bstep >= 1; bstep >>= 1)
-              if (pre[e + bstep] <= i) e += bstep;              // entries past the last word hold `total`
+            for (int d = 0; d < 4; ++d) { bump(w4[d] & 0xffffu); bump(w4[d] >> 16); }
           }
-          u32 lo = pre[e], hi = pre[e + 1];
-          u64 r0 = rs[e];
-          // software pipeline: the loads of trip k + 1 are issued before the LDS atomics of trip k
-          auto fetch = [&](u32 i0, u32 (&s)[KM_UNROLL]) {
+      };
+      // first 64 units of KM_LOADS buckets per trip (a bucket of the bench shape has ~61 units); the loads of trip t + 1 are
+      // issued before the atomics of trip t.  Longer buckets: their remaining units follow in a tail loop.
+      auto fetch = [&](int j0, uint4 (&s4)[KM_LOADS], bool (&on)[KM_LOADS]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < KM_UNROLL; ++u)
+        for (int u = 0; u < KM_LOADS; ++u)
+          {
+            on[u] = false;
+            if (j0 + u < nb)
               {
-                const u32 i = i0 + 64u * (u32) u;
-                s[u] = 0xffffffffu;
-                if (i < wend)
+                const u32 n = (u32) __builtin_amdgcn_readlane((int) my_n, j0 + u);
+                const u64 r0 = (u64) (u32) __builtin_amdgcn_readlane((int) my_lo, j0 + u) | ((u64) (u32) __builtin_amdgcn_readlane((int) my_hi, j0 + u) << 32);
+                on[u] = (u32) lane < n;
+                if (on[u])
                   {
-                    while (i >= hi) { ++e; lo = hi; hi = pre[e + 1]; r0 = rs[e]; }
-                    s[u] = postings[r0 + (i - lo)];               // two tile-local indices
+                    if (probe & 2) { const u32 z = (((u32) r0 + (u32) lane) * 2654435761u) & 0x7fff7fffu; s4[u] = make_uint4(z, (z ^ 0x01230456u) & 0x7fff7fffu, (z ^ 0x10002000u) & 0x7fff7fffu, (z ^ 0x5a5a2b2bu) & 0x7fff7fffu); }
+                    else s4[u] = postings[r0 + (u32) lane];
                   }
               }
-          };
-          u32 cur[KM_UNROLL], nxt[KM_UNROLL];
-          u32 i0 = wbeg + (u32) lane;
-          fetch(i0, cur);
-          for (;;)
+          }
+      };
+      uint4 cur[KM_LOADS], nxt[KM_LOADS];
+      bool con[KM_LOADS], non[KM_LOADS];
+      fetch(0, cur, con);
+      for (int j0 = 0; j0 < nb; j0 += KM_LOADS)
+        {
+          const bool more = j0 + KM_LOADS < nb;
+          if (more) fetch(j0 + KM_LOADS, nxt, non);
+#pragma unroll
+          for (int u = 0; u < KM_LOADS; ++u)
+            if (con[u]) consume(cur[u]);
+          // tails of this trip's buckets (rare for sizes around one wave-load; wave-uniform trip counts)
+#pragma unroll
+          for (int u = 0; u < KM_LOADS; ++u)
+            if (j0 + u < nb)
+              {
+                const u32 n = (u32) __builtin_amdgcn_readlane((int) my_n, j0 + u);
+                if (n > 64u)
+                  {
+                    const u64 r0 = (u64) (u32) __builtin_amdgcn_readlane((int) my_lo, j0 + u) | ((u64) (u32) __builtin_amdgcn_readlane((int) my_hi, j0 + u) << 32);
+                    for (u32 i = 64u + (u32) lane; i < n; i += 64u)
+                      {
+                        if (probe & 2) { const u32 z = (((u32) r0 + i) * 2654435761u) & 0x7fff7fffu; consume(make_uint4(z, z, z, z)); }
+                        else consume(postings[r0 + i]);
+                      }
+                  }
+              }
+          if (more)
             {
-              i0 += 64 * KM_UNROLL;
-              const bool more = i0 < wend;
-              if (more) fetch(i0, nxt);
 #pragma unroll
-              for (int u = 0; u < KM_UNROLL; ++u)
-                {
-                  const u32 x0 = cur[u] & 0xffffu, x1 = cur[u] >> 16;
-                  if (x0 != 0xffffu) atomicAdd(&cnt[x0 >> 1], 1u << ((x0 & 1u) * 16));
-                  if (x1 != 0xffffu) atomicAdd(&cnt[x1 >> 1], 1u << ((x1 & 1u) * 16));
-                }
-              if (!more) break;
-#pragma unroll
-              for (int u = 0; u < KM_UNROLL; ++u) cur[u] = nxt[u];
+              for (int u = 0; u < KM_LOADS; ++u) { cur[u] = nxt[u]; con[u] = non[u]; }
             }
         }
+      if ((probe & 1) && sink == 0x9e3779b9u) cnt[NDW] = sink;       // keeps the probe's loads alive
+      (void) pad4;
     }
   __syncthreads();
+  if (probe & 4) return;
+  // ---- sweep: counters >= mm -> (sequence, count) records in the query's region.  Hits are rare (a fraction of a per cent of
+  // the counters), so a lane first tests whole dwords (SWAR for the byte counters), the block allocates ONE range in the region
+  // (a wave-level prefix sum, one atomic per block) and the few hits are written in a second pass over the same dwords.
   const u32 top = (nseq - base < KM_TILE) ? nseq - base : KM_TILE;
-  for (u32 x = (u32) tid; x < KM_TILE / 2; x += KM_COUNT_THREADS)     // same trip count for every lane: the ballots below are wave-wide
-    {
-      const u32 v = cnt[x];
+  constexpr int DW_PER_THREAD = NDW / THREADS;                    // 16 in both configurations
+  static_assert(DW_PER_THREAD * THREADS == NDW && DW_PER_THREAD % 4 == 0, "the sweep reads whole uint4s");
+  // a thread owns DW_PER_THREAD consecutive dwords (conflict-free 16-byte LDS reads: consecutive lanes, consecutive uint4 groups)
+  auto field = [&](u32 v, int h) -> u32 { return (BITS == 8) ? ((v >> (8 * h)) & 0xffu) : ((v >> (16 * h)) & 0xffffu); };
+  auto any_hit = [&](u32 v) -> bool {
+    if (BITS == 16) return ((v & 0xffffu) >= mm) || ((v >> 16) >= mm);
+    if (mm > 255u) return false;
+    if (mm == 0u) return true;
+    // bytes >= mm, for 1 <= mm <= 255: split at 128 so that the per-byte addition cannot carry into the next byte
+    const u32 hi7 = v & 0x80808080u, lo7 = v & 0x7f7f7f7fu;
+    if (mm <= 128u) return (hi7 | ((lo7 + (128u - mm) * 0x01010101u) & 0x80808080u)) != 0u;
+    return (hi7 & (lo7 + (256u - mm) * 0x01010101u)) != 0u;
+  };
+  u32 mine = 0;
+  const uint4 * c4 = reinterpret_cast<const uint4 *>(cnt);
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+  for (int g4 = 0; g4 < DW_PER_THREAD / 4; ++g4)
+    {
+      const uint4 v4 = c4[g4 * THREADS + tid];
+      const u32 vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        if (any_hit(vv[d]))
+          {
+            const u32 dw = (u32) (g4 * THREADS + tid) * 4u + (u32) d;
+#pragma unroll
+            for (int h = 0; h < PER; ++h)
+              if (field(vv[d], h) >= mm && dw * PER + (u32) h < top) ++mine;
+          }
+    }
+  // block-wide exclusive prefix of `mine`
+  u32 incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+    {
+      const u32 up = (u32) __shfl_up((int) incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+  if (lane == 63) wave_hits[wave] = incl;
+  __syncthreads();
+  if (tid == 0)
+    {
+      u32 tot = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < WAVES; ++w2) { const u32 t = wave_hits[w2]; wave_hits[w2] = tot; tot += t; }
+      const u32 first = tot ? atomicAdd(&qcount[slot - slot_base], tot) : 0u;
+#pragma unroll
+      for (int w2 = 0; w2 < WAVES; ++w2) wave_hits[w2] += first;
+    }
+  __syncthreads();
+  if (mine)
+    {
+      u32 pos = wave_hits[wave] + incl - mine;
+#pragma unroll
+      for (int g4 = 0; g4 < DW_PER_THREAD / 4; ++g4)
         {
-          const u32 c = h ? (v >> 16) : (v & 0xffffu);
-          const u32 sidx = 2 * x + h;
-          const bool hit = (c >= mm) && (sidx < top);
-          const u64 ballot = __ballot(hit);
-          if (ballot)
-            {
-              u32 first = 0;
-              if (lane == 0) first = atomicAdd(&qcount[slot], (u32) __popcll(ballot));
-              first = (u32) __shfl((int) first, 0, 64);
-              if (hit)
-                {
-                  const u32 pos = first + (u32) __popcll(ballot & ((1ull << lane) - 1ull));
-                  if (pos < cap) rec[(size_t) slot * cap + pos] = make_uint2(base + sidx, c);
-                }
-            }
+          const uint4 v4 = c4[g4 * THREADS + tid];
+          const u32 vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+          for (int d = 0; d < 4; ++d)
+            if (any_hit(vv[d]))
+              {
+                const u32 dw = (u32) (g4 * THREADS + tid) * 4u + (u32) d;
+#pragma unroll
+                for (int h = 0; h < PER; ++h)
+                  {
+                    const u32 c = field(vv[d], h);
+                    const u32 sidx = dw * PER + (u32) h;
+                    if (c >= mm && sidx < top)
+                      {
+                        if (pos < cap) rec[(size_t) (slot - slot_base) * cap + pos] = make_uint2(base + sidx, c);
+                        ++pos;
+                      }
+                  }
+              }
         }
     }
 }
@@ -334,14 +436,21 @@ extern "C" hipError_t vsx_kmer_launch_case_bits(const uint8_t * d_ascii, uint64_
   return hipGetLastError();
 }
 
-extern "C" hipError_t vsx_kmer_launch_count(const uint32_t * postings, const uint64_t * bucket_start, uint32_t ntiles,
-                                            uint32_t nseq, uint32_t nslots, const uint64_t * qk_start, const uint32_t * qk,
+extern "C" hipError_t vsx_kmer_launch_count(int bits, const uint32_t * postings, const uint64_t * bucket_start, uint32_t ntiles,
+                                            uint32_t nseq, uint32_t nslots, uint32_t slot_base, const uint64_t * qk_start, const uint32_t * qk,
                                             const uint32_t * minmatch, const uint32_t * qlist, void * rec, uint32_t cap,
                                             uint32_t * qcount, hipStream_t st)
 {
+  // slots [slot_base, slot_base + nslots) of the batch; rec / qcount are the arrays of the WHOLE batch (the kernel indexes them
+  // by slot - slot_base, so the caller passes them offset by slot_base)
   if (nslots == 0 || nseq == 0) return hipSuccess;
-  hipLaunchKernelGGL(vsx_kmer_count_kernel, dim3(nslots, ntiles), dim3(KM_COUNT_THREADS), 0, st, postings,
-                     (const u64 *) bucket_start, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, (uint2 *) rec, cap, qcount);
+  static const int probe = std::getenv("VSX_KMER_PROBE") ? std::atoi(std::getenv("VSX_KMER_PROBE")) : 0;
+  if (bits == 8)
+    hipLaunchKernelGGL(vsx_kmer_count_kernel<8>, dim3(nslots, ntiles), dim3(512), 0, st, (const uint4 *) postings,
+                       (const u64 *) bucket_start, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base, (uint2 *) rec, cap, qcount, probe);
+  else
+    hipLaunchKernelGGL(vsx_kmer_count_kernel<16>, dim3(nslots, ntiles), dim3(1024), 0, st, (const uint4 *) postings,
+                       (const u64 *) bucket_start, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base, (uint2 *) rec, cap, qcount, probe);
   return hipGetLastError();
 }
 

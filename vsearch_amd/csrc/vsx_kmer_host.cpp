@@ -173,7 +173,8 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   std::vector<uint64_t> & start = ix->h_start;
   start.resize(ix->nbuckets + 1);
   uint64_t acc = 0;
-  // a bucket holds 16-bit tile-local indices, two per dword: start[] counts DWORDS, odd buckets end in a 0xFFFF sentinel
+  // a bucket holds 16-bit tile-local indices in 16-byte units of eight: start[] counts UNITS, the last unit of a bucket is padded
+  // with 0x8000 = the spare counter past the tile (vsx_kmer.hip KM_PAD): the count kernel streams units without any sentinel test
   uint64_t entries = 0;
   {
     // buckets are word-major: b = word * ntiles + tile (nested loops: no division per bucket -- clustering rebuilds the index
@@ -186,7 +187,7 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
         for (uint64_t t = 0; t < nt; ++t, ++b)
           {
             start[b] = acc;
-            acc += (cnt[b] + 1u) / 2u;
+            acc += (cnt[b] + 7u) / 8u;
             tot += cnt[b];
           }
         ix->word_total[word] = tot;
@@ -194,8 +195,8 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
       }
   }
   start[ix->nbuckets] = acc;
-  KCHK(ix->d_post.ensure(acc));
-  if (acc) KCHK(hipMemsetAsync(ix->d_post.p, 0xff, acc * 4, ix->st));
+  KCHK(ix->d_post.ensure(acc * 4));                    // dwords
+  if (acc) KCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->d_post.p), (int) 0x80008000u, acc * 4, ix->st));
   KCHK(hipMemcpyAsync(ix->d_start.p, start.data(), (ix->nbuckets + 1) * 8, hipMemcpyHostToDevice, ix->st));
   KCHK(hipMemsetAsync(ix->d_count.p, 0, ix->nbuckets * 4, ix->st));
   KCHK(vsx_kmer_launch_sweep(1, codes, off, len, d_list, ix->nseq, w, ix->ntiles, ix->d_count.p, ix->d_start.p, ix->d_post.p, vsx_internal_seqset_lower(ix->db), ix->st));
@@ -205,7 +206,7 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   KCHK(hipEventElapsedTime(&ms, ix->e0, ix->e1));
   ix->stats.build_ms = ms;
   ix->stats.postings = entries;
-  ix->stats.index_bytes = acc * 4 + (ix->nbuckets + 1) * 8;
+  ix->stats.index_bytes = acc * 16 + (ix->nbuckets + 1) * 8;
   return VSX_OK;
 }
 
@@ -221,7 +222,8 @@ const VsxKmerStats * vsx_kmer_stats(const VsxKmerIndex * ix) { return ix ? &ix->
 namespace {
 
 // one counting + selection pass over `nslots` query slots (slot -> query through qlist, or identity); appends to recs
-int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, const uint32_t * d_qlist, const std::vector<uint32_t> * h_qlist, uint32_t cap,
+// Slots [0, n8) hold queries of the 8-bit counter class (<= 255 unique words), the rest take the 16-bit kernel.
+int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, uint32_t n8, const uint32_t * d_qlist, const std::vector<uint32_t> * h_qlist, uint32_t cap,
                uint32_t keep, VsxKmerResult & out, std::vector<uint32_t> & overflow, uint32_t & overflow_max, float & ms_total)
 {
   KCHK(sc->d_rec.ensure((size_t) nslots * cap));
@@ -230,8 +232,10 @@ int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, const uint3
   KCHK(sc->d_sel_off.ensure(nslots));
   KCHK(hipMemsetAsync(sc->d_qcount.p, 0, (size_t) nslots * 4, sc->st));
   KCHK(hipEventRecord(sc->e0, sc->st));
-  KCHK(vsx_kmer_launch_count(ix->d_post.p, ix->d_start.p, ix->ntiles, ix->nseq, nslots, sc->d_qk_start.p, sc->d_qk.p,
+  KCHK(vsx_kmer_launch_count(8, ix->d_post.p, ix->d_start.p, ix->ntiles, ix->nseq, n8, 0, sc->d_qk_start.p, sc->d_qk.p,
                              sc->d_minmatch.p, d_qlist, sc->d_rec.p, cap, sc->d_qcount.p, sc->st));
+  KCHK(vsx_kmer_launch_count(16, ix->d_post.p, ix->d_start.p, ix->ntiles, ix->nseq, nslots - n8, n8, sc->d_qk_start.p, sc->d_qk.p,
+                             sc->d_minmatch.p, d_qlist, sc->d_rec.p + (size_t) n8 * cap, cap, sc->d_qcount.p + n8, sc->st));
   uint64_t capacity = std::max<uint64_t>(sc->d_dense.n, std::max<uint64_t>(1u << 20, (uint64_t) nslots * 128));
   unsigned long long produced = 0;
   for (int attempt = 0; attempt < 2; ++attempt)
@@ -331,20 +335,57 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
   // words (chance runs of shared 11..13-mers), so 8 192 x 8 B = 64 KB per query; HBM is plentiful (100 k queries = 6.5 GB)
   uint32_t cap = cap_hint ? cap_hint : (nq <= (1u << 18) ? 8192 : 2048);
   if (const char * c = std::getenv("VSX_KMER_CAP")) cap = (uint32_t) std::max(1, std::atoi(c));      // tests: force the second pass
-  int rc = count_pass(ix, sc, (uint32_t) nq, nullptr, nullptr, cap, keep, out, overflow, overflow_max, ms);
+  // counter class per query: at most 255 unique words -> byte counters (a count never exceeds the number of words)
+  auto by_class = [&](const std::vector<uint32_t> * subset, std::vector<uint32_t> & ordered, uint32_t & n8) -> bool {
+    const uint64_t n = subset ? subset->size() : nq;
+    n8 = 0;
+    bool all8 = true;
+    for (uint64_t x = 0; x < n && all8; ++x)
+      {
+        const uint32_t q = subset ? (*subset)[x] : (uint32_t) x;
+        all8 = (qk_start[q + 1] - qk_start[q]) <= 255;
+      }
+    if (all8) { n8 = (uint32_t) n; return false; }              // no reordering needed
+    ordered.clear();
+    ordered.reserve(n);
+    for (int pass = 0; pass < 2; ++pass)
+      {
+        for (uint64_t x = 0; x < n; ++x)
+          {
+            const uint32_t q = subset ? (*subset)[x] : (uint32_t) x;
+            const bool small = (qk_start[q + 1] - qk_start[q]) <= 255;
+            if (small == (pass == 0)) ordered.push_back(q);
+          }
+        if (pass == 0) n8 = (uint32_t) ordered.size();
+      }
+    return true;
+  };
+  std::vector<uint32_t> ordered;
+  uint32_t n8 = 0;
+  Buf<uint32_t> d_order;
+  int rc;
+  if (by_class(nullptr, ordered, n8))
+    {
+      KCHK(d_order.alloc(ordered.size()));
+      KCHK(hipMemcpyAsync(d_order.p, ordered.data(), ordered.size() * 4, hipMemcpyHostToDevice, sc->st));
+      rc = count_pass(ix, sc, (uint32_t) nq, n8, d_order.p, &ordered, cap, keep, out, overflow, overflow_max, ms);
+    }
+  else rc = count_pass(ix, sc, (uint32_t) nq, n8, nullptr, nullptr, cap, keep, out, overflow, overflow_max, ms);
   if (rc != VSX_OK) return rc;
-  if (std::getenv("VSX_KMER_DEBUG")) std::fprintf(stderr, "kmer: %zu of %llu queries overflowed cap %u (max %u records), %.1f ms\n", overflow.size(), (unsigned long long) nq, cap, overflow_max, ms);
+  if (std::getenv("VSX_KMER_DEBUG")) std::fprintf(stderr, "kmer: %zu of %llu queries overflowed cap %u (max %u records), %u in the 8-bit class, %.1f ms\n", overflow.size(), (unsigned long long) nq, cap, overflow_max, n8, ms);
   if (!overflow.empty())
     {
       // queries with more than `cap` sequences at or above their threshold (low-complexity words): a second pass over
       // just these, with regions of the size the first pass measured
+      std::vector<uint32_t> list;
+      uint32_t m8 = 0;
+      if (!by_class(&overflow, list, m8)) list = overflow;
       Buf<uint32_t> d_qlist;
-      KCHK(d_qlist.alloc(overflow.size()));
-      KCHK(hipMemcpyAsync(d_qlist.p, overflow.data(), overflow.size() * 4, hipMemcpyHostToDevice, sc->st));
+      KCHK(d_qlist.alloc(list.size()));
+      KCHK(hipMemcpyAsync(d_qlist.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, sc->st));
       std::vector<uint32_t> again;
       uint32_t again_max = 0;
-      const std::vector<uint32_t> list = overflow;
-      rc = count_pass(ix, sc, (uint32_t) list.size(), d_qlist.p, &list, overflow_max, keep, out, again, again_max, ms);
+      rc = count_pass(ix, sc, (uint32_t) list.size(), m8, d_qlist.p, &list, overflow_max, keep, out, again, again_max, ms);
       if (rc != VSX_OK) return rc;
       if (!again.empty()) { vsx_internal_set_error("vsx_kmer_count_batch: record region overflow in the second pass"); return VSX_EHIP; }
     }
