@@ -179,13 +179,17 @@ hipError_t vsx_kmer_launch_case_bits(const uint8_t * d_ascii, uint64_t nbytes, u
 // vsx_mask.hip: DUST intervals of every sequence OR-ed into the case bitmap (dword-aligned, zero-padded to a dword)
 hipError_t vsx_launch_dust(const uint8_t * d_codes, const uint64_t * d_off, const uint32_t * d_len, uint64_t nseq, uint8_t * d_bits,
                            hipStream_t st);
+// bucket ranges of the 8-bit class in the order the count kernel's waves read them: ranges[(tile * nslots + slot) * 256 + ..] (uint2)
+hipError_t vsx_kmer_launch_ranges(const uint64_t * bucket_start, uint32_t ntiles, const uint64_t * qk_start, const uint32_t * qk,
+                                  const uint32_t * minmatch, const uint32_t * qlist, uint32_t nslots, void * ranges, hipStream_t st);
 // bits = 8 | 16: counter width of the kernel (queries with <= 255 unique words take 8); slots [slot_base, slot_base + nslots) of the
-// batch (query = qlist ? qlist[slot] : slot); rec / qcount point at the FIRST of these slots
-hipError_t vsx_kmer_launch_count(int bits, const uint32_t * postings, const uint64_t * bucket_start, uint32_t ntiles,
-                                 uint32_t nseq, uint32_t nslots, uint32_t slot_base, const uint64_t * qk_start, const uint32_t * qk,
-                                 const uint32_t * minmatch, const uint32_t * qlist, void * rec, uint32_t cap,
-                                 uint32_t * qcount, hipStream_t st);
-hipError_t vsx_kmer_launch_select(const void * rec, uint32_t cap, const uint32_t * qcount, uint32_t nslots,
+// batch (query = qlist ? qlist[slot] : slot); ranges (8-bit class, may be NULL) / rec / tile_count belong to THESE slots:
+// (slot, tile) owns rec[(slot * ntiles + tile) * subcap ..) and tile_count[slot * ntiles + tile]
+hipError_t vsx_kmer_launch_count(int bits, const uint32_t * postings, const uint64_t * bucket_start, const void * ranges,
+                                 uint32_t ntiles, uint32_t nseq, uint32_t nslots, uint32_t slot_base, const uint64_t * qk_start,
+                                 const uint32_t * qk, const uint32_t * minmatch, const uint32_t * qlist, void * rec, uint32_t subcap,
+                                 uint32_t * tile_count, hipStream_t st);
+hipError_t vsx_kmer_launch_select(const void * rec, uint32_t subcap, uint32_t ntiles, const uint32_t * tile_count, uint32_t nslots,
                                   uint32_t keep, void * dense, unsigned long long * cursor, uint64_t capacity,
                                   void * sel_m_n, uint64_t * sel_off, hipStream_t st);
 uint32_t vsx_kmer_tile_shift(void);

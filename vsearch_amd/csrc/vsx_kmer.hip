@@ -14,10 +14,11 @@
 //   count   = one block per (query, tile): 2^15 counters live in LDS -- 8 bits each (32 KB, 512 threads, four blocks per CU) for
 //             queries with at most 255 unique words, 16 bits (64 KB, 1024 threads) otherwise; the query's unique words
 //             select one bucket each, whose postings are streamed (coalesced 16-byte loads) into ds_add_u32 on the packed fields;
-//             a final LDS sweep appends (sequence, count) for count >= minmatches to the QUERY's own record region
-//             (one counter per query: a single global cursor serialises at ~40 ns per atomic and cost 7x the counting).
+//             a final LDS sweep writes (sequence, count) for count >= minmatches to the (query, tile)'s own record sub-region
+//             (no atomics: a single global cursor serialised at ~40 ns per atomic and cost 7x the counting, and even one
+//             atomic with return per block is a latency the block cannot hide).
 //   select  = one wave per query: threshold c* = the largest count with at least `tophits` records at or above it
-//             (15 counting passes over the <= cap records); records >= c* -- a superset of the heap's content under any
+//             (one histogram pass over the records); records >= c* -- a superset of the heap's content under any
 //             tie-break -- go to a dense buffer for the host.
 //             Blocks are ordered tile-major (blockIdx.x = query), so the postings of one tile (index bytes / ntiles) are
 //             re-read from L2 / Infinity Cache by all queries before the next tile is touched.
@@ -133,19 +134,56 @@ vsx_kmer_sweep_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict
 // so the hot loop carries no sentinel test: every posting is one unconditional ds_add_u32.
 // Two counter widths, chosen per query by the host:
 //   BITS = 8  (queries with <= 255 unique words, i.e. every BASELINE read length): four counters per dword, 32 KB per tile,
-//             512 threads -> FOUR blocks per CU (32 waves): the latency phases of one block (bucket table look-up, the final
-//             sweep) hide under the streaming of the others.  A count never exceeds the number of words, so bytes cannot carry;
+//             512 threads -> FOUR blocks per CU (32 waves).  A count never exceeds the number of words, so bytes cannot carry;
 //   BITS = 16 (longer queries): two counters per dword, 64 KB, 1024 threads, two blocks per CU.
-// r03 measurements that led here (profiles/r03/r03_ubench_lds.txt): random-address ds_add_u32 sustains 8.1 ops per clock and CU
-// (13 conflict-free), the r02 kernel reached 3.2 -- it was bound by the per-posting VALU work around the sentinel tests and by
-// two fat blocks per CU taking turns, not by the LDS.
+// r03 measurements that shaped it (profiles/r03/r03_ubench_lds.txt, r03e_kmer_probe.txt; 100 k x 250 bp vs 1 M x 1 kbp):
+//   * random-address ds_add_u32 sustains 8.1 ops per clock and CU (13 conflict-free); the r02 kernel reached 3.2;
+//   * r02's flattened equal split looked its bucket up in LDS for every load; a look-up waits for lgkmcnt(0), i.e. for all the
+//     atomics queued before it, so a wave's atomics and its next loads took turns: 192 ms.  Per-wave buckets whose ranges are
+//     broadcast with v_readlane (no LDS read in the streaming loop): 142 ms;
+//   * of those 142 ms, 73 remained with neither loads nor atomics: a block's fixed latency chain -- query -> its words -> their
+//     bucket ranges (three dependent global loads), barriers, and a global atomic with return in the sweep.  Now a pre-pass
+//     (vsx_kmer_ranges_kernel) writes the ranges of every (query, tile) in the order the waves want them, so a block starts with
+//     ONE coalesced load, and every (query, tile) owns a sub-region of the record buffer, so the sweep needs no atomic.
 #define KM_PAD 0x8000u
 #define KM_LOADS 4                     // independent 16-byte loads per lane and trip (32 postings)
-template <int BITS>
+
+// Bucket ranges of the 8-bit class, one block per query slot, thread i = the query's i-th word.  R[(tile * nslots + slot) * 256 +
+// (i % 8) * 32 + i / 8] = (first unit, units): wave w of the count kernel reads entries w * 32 .. w * 32 + 31 -- its buckets w,
+// w + 8, ... -- with one coalesced load.  The ranges of one word over all tiles are contiguous in bucket_start (word-major).
+__global__ void __launch_bounds__(256)
+vsx_kmer_ranges_kernel(const u64 * __restrict__ bucket_start, u32 ntiles, const u64 * __restrict__ qk_start, const u32 * __restrict__ qk,
+                       const u32 * __restrict__ minmatch, const u32 * __restrict__ qlist, u32 nslots, uint2 * __restrict__ R)
+{
+  const u32 slot = blockIdx.x, i = threadIdx.x;
+  const u32 q = qlist ? qlist[slot] : slot;
+  const u64 k0 = qk_start[q];
+  const u32 nk = (minmatch[q] == 0xffffffffu) ? 0u : (u32) (qk_start[q + 1] - k0);
+  const u32 p = (i & 7u) * 32u + (i >> 3);
+  if (i < nk)
+    {
+      const u64 * __restrict__ row = bucket_start + (size_t) qk[k0 + i] * ntiles;
+      u64 first = row[0];
+      for (u32 t = 0; t < ntiles; ++t)
+        {
+          const u64 next = row[t + 1];
+          R[((size_t) t * nslots + slot) * 256 + p] = make_uint2((u32) first, (u32) (next - first));
+          first = next;
+        }
+    }
+  else
+    for (u32 t = 0; t < ntiles; ++t) R[((size_t) t * nslots + slot) * 256 + p] = make_uint2(0u, 0u);
+}
+
+// PRE = the ranges come from vsx_kmer_ranges_kernel (8-bit class); otherwise the block looks them up itself, 256 words at a time.
+// Records: (query slot, tile) owns rec[(slot * ntiles + tile) * subcap ..) and tile_count[slot * ntiles + tile] (the number of
+// counters at or above the threshold, also when it exceeds subcap: the host then repeats the slot with larger sub-regions).
+template <int BITS, bool PRE>
 __global__ void __launch_bounds__(BITS == 8 ? 512 : 1024) __attribute__((amdgpu_waves_per_eu(8, 8)))     // 64 VGPRs: 32 waves per CU in both widths
-vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restrict__ bucket_start, u32 ntiles, u32 nseq,
-                      const u64 * __restrict__ qk_start, const u32 * __restrict__ qk, const u32 * __restrict__ minmatch,
-                      const u32 * __restrict__ qlist, u32 slot_base, uint2 * __restrict__ rec, u32 cap, u32 * __restrict__ qcount, int probe)
+vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restrict__ bucket_start, const uint2 * __restrict__ R,
+                      u32 ntiles, u32 nseq, const u64 * __restrict__ qk_start, const u32 * __restrict__ qk, const u32 * __restrict__ minmatch,
+                      const u32 * __restrict__ qlist, u32 slot_base, u32 nslots, uint2 * __restrict__ rec, u32 subcap,
+                      u32 * __restrict__ tile_count, int probe)
 {
   // probe (VSX_KMER_PROBE, measurements only -- results are wrong): bit 0 = no LDS atomics (the loads are still consumed),
   // bit 1 = no postings loads (addresses synthesised), bit 2 = no final sweep
@@ -153,22 +191,31 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
   constexpr int WAVES = THREADS / 64;
   constexpr int PER = 32 / BITS;                                  // counters per dword
   constexpr int NDW = (int) (KM_TILE / PER);                      // dwords of real counters
+  constexpr int BPW = 256 / WAVES;                                // buckets per wave and chunk of 256 words
+  static_assert(!PRE || BITS == 8, "the range table is laid out for 8 waves");
   __shared__ __attribute__((aligned(16))) u32 cnt[NDW + 4];       // + the spare dword the pad index lands in
-  __shared__ u64 rs[256];                                         // first unit of each selected bucket
-  __shared__ u32 pre[256];                                        // ... and its size in units
+  __shared__ uint2 rng[PRE ? 1 : 256];                            // !PRE: (first unit, units) of each selected bucket
   __shared__ u32 wave_hits[WAVES];
   const int tid = (int) threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const u32 slot = blockIdx.x + slot_base, tile = blockIdx.y;
+  const u32 srel = blockIdx.x, slot = srel + slot_base, tile = blockIdx.y;        // srel indexes R / rec / tile_count
   const u32 q = qlist ? qlist[slot] : slot;
   const u32 mm = minmatch[q];
-  if (mm == 0xffffffffu) return;                                  // this query is answered on the host (minmatches == 0, > 32767 words)
+  const size_t region = (size_t) srel * ntiles + tile;
+  if (mm == 0xffffffffu)                                          // this query is answered on the host (minmatches == 0, > 32767 words)
+    {
+      if (tid == 0) tile_count[region] = 0;
+      return;
+    }
+  // the wave's bucket ranges: lane j holds bucket wave + WAVES * j of the chunk (PRE: straight from the table)
+  uint2 mine_rng = make_uint2(0u, 0u);
+  if (PRE && lane < BPW) mine_rng = R[((size_t) tile * nslots + srel) * 256 + (u32) (wave * BPW + lane)];
   const u32 base = tile << KM_TILE_SHIFT;
   {
     uint4 * c4 = reinterpret_cast<uint4 *>(cnt);
     for (int x = tid; x < (NDW + 4) / 4; x += THREADS) c4[x] = make_uint4(0, 0, 0, 0);
   }
-  const u64 k0 = qk_start[q];
-  const int nk = (int) (qk_start[q + 1] - k0);
+  const u64 k0 = PRE ? 0 : qk_start[q];
+  const int nk = PRE ? 256 : (int) (qk_start[q + 1] - k0);        // PRE: absent words have empty ranges
   auto bump = [&](u32 x) __attribute__((always_inline)) {
     // counter x: dword x / PER, field x % PER
     if (BITS == 8) atomicAdd(&cnt[x >> 2], 1u << ((x & 3u) << 3));
@@ -176,43 +223,25 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
   };
   for (int chunk = 0; chunk < nk; chunk += 256)
     {
-      __syncthreads();
-      // the bucket ranges of up to 256 words: 256 threads fetch one range each
-      if (tid < 256)
+      __syncthreads();                                              // counters cleared / previous chunk's ranges consumed
+      if (!PRE)
         {
-          u32 n = 0;
-          u64 first = 0;
-          if (chunk + tid < nk)
+          if (tid < 256)
             {
-              const size_t b = (size_t) qk[k0 + chunk + tid] * ntiles + tile;
-              first = bucket_start[b];
-              n = (u32) (bucket_start[b + 1] - first);
+              uint2 r = make_uint2(0u, 0u);
+              if (chunk + tid < nk)
+                {
+                  const size_t b = (size_t) qk[k0 + chunk + tid] * ntiles + tile;
+                  const u64 first = bucket_start[b];
+                  r = make_uint2((u32) first, (u32) (bucket_start[b + 1] - first));
+                }
+              rng[tid] = r;
             }
-          rs[tid] = first;
-          pre[tid] = n;
+          __syncthreads();
+          mine_rng = (lane < BPW) ? rng[wave + WAVES * lane] : make_uint2(0u, 0u);
         }
-      __syncthreads();
-      // Wave w takes the buckets w, w + WAVES, ...: lane j keeps the range of the wave's j-th bucket in registers, and the loop
-      // below broadcasts it with v_readlane -- the streaming loop touches the LDS with ds_add_u32 ONLY.  (r03: the flattened
-      // equal split of r02 looked its bucket up in LDS for every load; each look-up waits for lgkmcnt(0), i.e. for all the
-      // atomics queued before it, so a wave's atomics and its next loads took turns instead of overlapping: 192 ms where the
-      // LDS atomics alone need 115 and the postings stream 80.)
-      constexpr int BPW = 256 / WAVES;                            // buckets per wave and chunk
-      u32 my_n = 0, my_lo = 0, my_hi = 0;
-      if (lane < BPW)
-        {
-          const int bidx = wave + WAVES * lane;
-          my_n = pre[bidx];
-          const u64 f = rs[bidx];
-          my_lo = (u32) f; my_hi = (u32) (f >> 32);
-        }
-      int nb = 0;                                                   // buckets of this wave that exist in this chunk
-      {
-        const int left = nk - chunk - wave;                         // words chunk + wave, chunk + wave + WAVES, ...
-        nb = left <= 0 ? 0 : (left + WAVES - 1) / WAVES;
-        if (nb > BPW) nb = BPW;
-      }
-      const uint4 pad4 = make_uint4(KM_PAD * 0x10001u, KM_PAD * 0x10001u, KM_PAD * 0x10001u, KM_PAD * 0x10001u);
+      // Wave w takes the buckets w, w + WAVES, ...; the loop below broadcasts lane j's range with v_readlane -- the streaming
+      // loop touches the LDS with ds_add_u32 ONLY
       u32 sink = 0;
       auto consume = [&](const uint4 & v) __attribute__((always_inline)) {
         const u32 w4[4] = {v.x, v.y, v.z, v.w};
@@ -223,6 +252,10 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
             for (int d = 0; d < 4; ++d) { bump(w4[d] & 0xffffu); bump(w4[d] >> 16); }
           }
       };
+      auto unit = [&](u32 idx) __attribute__((always_inline)) -> uint4 {
+        if (probe & 2) { const u32 z = (idx * 2654435761u) & 0x7fff7fffu; return make_uint4(z, (z ^ 0x01230456u) & 0x7fff7fffu, (z ^ 0x10002000u) & 0x7fff7fffu, (z ^ 0x5a5a2b2bu) & 0x7fff7fffu); }
+        return postings[idx];
+      };
       // first 64 units of KM_LOADS buckets per trip (a bucket of the bench shape has ~61 units); the loads of trip t + 1 are
       // issued before the atomics of trip t.  Longer buckets: their remaining units follow in a tail loop.
       auto fetch = [&](int j0, uint4 (&s4)[KM_LOADS], bool (&on)[KM_LOADS]) __attribute__((always_inline)) {
@@ -230,25 +263,21 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
         for (int u = 0; u < KM_LOADS; ++u)
           {
             on[u] = false;
-            if (j0 + u < nb)
+            if (j0 + u < BPW)
               {
-                const u32 n = (u32) __builtin_amdgcn_readlane((int) my_n, j0 + u);
-                const u64 r0 = (u64) (u32) __builtin_amdgcn_readlane((int) my_lo, j0 + u) | ((u64) (u32) __builtin_amdgcn_readlane((int) my_hi, j0 + u) << 32);
+                const u32 n = (u32) __builtin_amdgcn_readlane((int) mine_rng.y, j0 + u);
+                const u32 r0 = (u32) __builtin_amdgcn_readlane((int) mine_rng.x, j0 + u);
                 on[u] = (u32) lane < n;
-                if (on[u])
-                  {
-                    if (probe & 2) { const u32 z = (((u32) r0 + (u32) lane) * 2654435761u) & 0x7fff7fffu; s4[u] = make_uint4(z, (z ^ 0x01230456u) & 0x7fff7fffu, (z ^ 0x10002000u) & 0x7fff7fffu, (z ^ 0x5a5a2b2bu) & 0x7fff7fffu); }
-                    else s4[u] = postings[r0 + (u32) lane];
-                  }
+                if (on[u]) s4[u] = unit(r0 + (u32) lane);
               }
           }
       };
       uint4 cur[KM_LOADS], nxt[KM_LOADS];
       bool con[KM_LOADS], non[KM_LOADS];
       fetch(0, cur, con);
-      for (int j0 = 0; j0 < nb; j0 += KM_LOADS)
+      for (int j0 = 0; j0 < BPW; j0 += KM_LOADS)
         {
-          const bool more = j0 + KM_LOADS < nb;
+          const bool more = j0 + KM_LOADS < BPW;
           if (more) fetch(j0 + KM_LOADS, nxt, non);
 #pragma unroll
           for (int u = 0; u < KM_LOADS; ++u)
@@ -256,17 +285,13 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
           // tails of this trip's buckets (rare for sizes around one wave-load; wave-uniform trip counts)
 #pragma unroll
           for (int u = 0; u < KM_LOADS; ++u)
-            if (j0 + u < nb)
+            if (j0 + u < BPW)
               {
-                const u32 n = (u32) __builtin_amdgcn_readlane((int) my_n, j0 + u);
+                const u32 n = (u32) __builtin_amdgcn_readlane((int) mine_rng.y, j0 + u);
                 if (n > 64u)
                   {
-                    const u64 r0 = (u64) (u32) __builtin_amdgcn_readlane((int) my_lo, j0 + u) | ((u64) (u32) __builtin_amdgcn_readlane((int) my_hi, j0 + u) << 32);
-                    for (u32 i = 64u + (u32) lane; i < n; i += 64u)
-                      {
-                        if (probe & 2) { const u32 z = (((u32) r0 + i) * 2654435761u) & 0x7fff7fffu; consume(make_uint4(z, z, z, z)); }
-                        else consume(postings[r0 + i]);
-                      }
+                    const u32 r0 = (u32) __builtin_amdgcn_readlane((int) mine_rng.x, j0 + u);
+                    for (u32 i = 64u + (u32) lane; i < n; i += 64u) consume(unit(r0 + i));
                   }
               }
           if (more)
@@ -276,22 +301,19 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
             }
         }
       if ((probe & 1) && sink == 0x9e3779b9u) cnt[NDW] = sink;       // keeps the probe's loads alive
-      (void) pad4;
     }
   __syncthreads();
-  if (probe & 4) return;
-  // ---- sweep: counters >= mm -> (sequence, count) records in the query's region.  Hits are rare (a fraction of a per cent of
-  // the counters), so a lane first tests whole dwords (SWAR for the byte counters), the block allocates ONE range in the region
-  // (a wave-level prefix sum, one atomic per block) and the few hits are written in a second pass over the same dwords.
+  if (probe & 4) { if (tid == 0) tile_count[region] = 0; return; }
+  // ---- sweep: counters >= mm -> (sequence, count) records in the (query, tile) sub-region.  Hits are rare (a fraction of a per
+  // cent of the counters), so a lane first tests whole dwords (SWAR for the byte counters); a wave-level prefix sum and one
+  // exchange through LDS give every lane its position -- no atomic, the sub-region belongs to this block.
   const u32 top = (nseq - base < KM_TILE) ? nseq - base : KM_TILE;
   constexpr int DW_PER_THREAD = NDW / THREADS;                    // 16 in both configurations
   static_assert(DW_PER_THREAD * THREADS == NDW && DW_PER_THREAD % 4 == 0, "the sweep reads whole uint4s");
-  // a thread owns DW_PER_THREAD consecutive dwords (conflict-free 16-byte LDS reads: consecutive lanes, consecutive uint4 groups)
   auto field = [&](u32 v, int h) -> u32 { return (BITS == 8) ? ((v >> (8 * h)) & 0xffu) : ((v >> (16 * h)) & 0xffffu); };
   auto any_hit = [&](u32 v) -> bool {
     if (BITS == 16) return ((v & 0xffffu) >= mm) || ((v >> 16) >= mm);
     if (mm > 255u) return false;
-    if (mm == 0u) return true;
     // bytes >= mm, for 1 <= mm <= 255: split at 128 so that the per-byte addition cannot carry into the next byte
     const u32 hi7 = v & 0x80808080u, lo7 = v & 0x7f7f7f7fu;
     if (mm <= 128u) return (hi7 | ((lo7 + (128u - mm) * 0x01010101u) & 0x80808080u)) != 0u;
@@ -299,7 +321,6 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
   };
   u32 mine = 0;
   const uint4 * c4 = reinterpret_cast<const uint4 *>(cnt);
-#pragma unroll
   for (int g4 = 0; g4 < DW_PER_THREAD / 4; ++g4)
     {
       const uint4 v4 = c4[g4 * THREADS + tid];
@@ -314,7 +335,6 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
               if (field(vv[d], h) >= mm && dw * PER + (u32) h < top) ++mine;
           }
     }
-  // block-wide exclusive prefix of `mine`
   u32 incl = mine;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1)
@@ -324,20 +344,14 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
     }
   if (lane == 63) wave_hits[wave] = incl;
   __syncthreads();
-  if (tid == 0)
-    {
-      u32 tot = 0;
+  u32 before = 0, total = 0;
 #pragma unroll
-      for (int w2 = 0; w2 < WAVES; ++w2) { const u32 t = wave_hits[w2]; wave_hits[w2] = tot; tot += t; }
-      const u32 first = tot ? atomicAdd(&qcount[slot - slot_base], tot) : 0u;
-#pragma unroll
-      for (int w2 = 0; w2 < WAVES; ++w2) wave_hits[w2] += first;
-    }
-  __syncthreads();
+  for (int w2 = 0; w2 < WAVES; ++w2) { const u32 t = wave_hits[w2]; before += (w2 < wave) ? t : 0u; total += t; }
+  if (tid == 0) tile_count[region] = total;
   if (mine)
     {
-      u32 pos = wave_hits[wave] + incl - mine;
-#pragma unroll
+      u32 pos = before + incl - mine;
+      uint2 * __restrict__ out = rec + region * subcap;
       for (int g4 = 0; g4 < DW_PER_THREAD / 4; ++g4)
         {
           const uint4 v4 = c4[g4 * THREADS + tid];
@@ -354,7 +368,7 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
                     const u32 sidx = dw * PER + (u32) h;
                     if (c >= mm && sidx < top)
                       {
-                        if (pos < cap) rec[(size_t) (slot - slot_base) * cap + pos] = make_uint2(base + sidx, c);
+                        if (pos < subcap) out[pos] = make_uint2(base + sidx, c);
                         ++pos;
                       }
                   }
@@ -363,51 +377,119 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
     }
 }
 
-// One wave per query slot: keep the records that can still reach the top `keep` (see the header comment).
-// sel[slot] = (offset into dense, number kept); a slot whose region overflowed (qcount > cap) is left for the second pass.
+// One wave per query slot: keep the records that can still reach the top `keep` (see the header comment).  The slot's records lie
+// in ntiles sub-regions; ONE pass builds a histogram of their counts (clamped at 255), its suffix sums give the threshold -- the
+// largest count with at least `keep` records at or above it -- and a second pass copies the records at or above the threshold to
+// the dense buffer.  sel_off_n[slot] = (kept, seen); a slot with a sub-region that overflowed is marked (0xffffffff, the largest
+// sub-region count) and left for the second pass.
 __global__ void __launch_bounds__(256)
-vsx_kmer_select_kernel(const uint2 * __restrict__ rec, u32 cap, const u32 * __restrict__ qcount, u32 nslots, u32 keep,
+vsx_kmer_select_kernel(const uint2 * __restrict__ rec, u32 subcap, u32 ntiles, const u32 * __restrict__ tile_count, u32 nslots, u32 keep,
                        uint2 * __restrict__ dense, u64 * cursor, u64 capacity, uint2 * __restrict__ sel_off_n, u64 * __restrict__ sel_off)
 {
-  const int lane = (int) (threadIdx.x & 63);
-  const u32 slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (slot >= nslots) return;
-  const u32 n = qcount[slot];
-  if (n > cap) { if (lane == 0) { sel_off[slot] = 0; sel_off_n[slot] = make_uint2(0xffffffffu, n); } return; }
-  const uint2 * __restrict__ r = rec + (size_t) slot * cap;
+  __shared__ u32 hist_all[4][256];
+  const int lane = (int) (threadIdx.x & 63), wv = (int) (threadIdx.x >> 6);
+  const u32 slot = blockIdx.x * 4 + (u32) wv;
+  if (slot >= nslots) return;                                      // (no barrier below: the four waves are independent)
+  u32 * hist = hist_all[wv];
+  const u32 * __restrict__ tc = tile_count + (size_t) slot * ntiles;
+  u32 n = 0, worst = 0;
+  for (u32 t = (u32) lane; t < ntiles; t += 64) { const u32 c = tc[t]; n += c; worst = c > worst ? c : worst; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+    {
+      n += (u32) __shfl_xor((int) n, m, 64);
+      const u32 o = (u32) __shfl_xor((int) worst, m, 64);
+      worst = o > worst ? o : worst;
+    }
+  if (worst > subcap) { if (lane == 0) { sel_off[slot] = 0; sel_off_n[slot] = make_uint2(0xffffffffu, worst); } return; }
+  const uint2 * __restrict__ r0 = rec + (size_t) slot * ntiles * subcap;
   u32 thr = 0;
   if (n > keep)
     {
-      // largest c with #(count >= c) >= keep: binary search on the 15-bit count
-      u32 lo = 0, hi = 32768;                            // invariant: #(>= lo) >= keep, #(>= hi) < keep
-      while (hi - lo > 1)
+      for (int x = lane; x < 256; x += 64) hist[x] = 0;
+      for (u32 t = 0; t < ntiles; ++t)
         {
-          const u32 mid = (lo + hi) >> 1;
-          u32 c = 0;
-          for (u32 x = (u32) lane; x < n; x += 64) c += (r[x].y >= mid) ? 1u : 0u;
-#pragma unroll
-          for (int m = 32; m >= 1; m >>= 1) c += (u32) __shfl_xor((int) c, m, 64);
-          if (c >= keep) lo = mid; else hi = mid;
+          const u32 nt = tc[t];
+          const uint2 * __restrict__ r = r0 + (size_t) t * subcap;
+          for (u32 x = (u32) lane; x < nt; x += 64) { const u32 c = r[x].y; atomicAdd(&hist[c < 255u ? c : 255u], 1u); }
         }
-      thr = lo;
-    }
-  u32 m = 0;
-  for (u32 x = (u32) lane; x < n; x += 64) m += (r[x].y >= thr) ? 1u : 0u;
+      // suffix sums: lane l owns bins 4 l .. 4 l + 3
+      u32 h4[4], own = 0;
 #pragma unroll
-  for (int k = 32; k >= 1; k >>= 1) m += (u32) __shfl_xor((int) m, k, 64);
+      for (int u = 0; u < 4; ++u) { h4[u] = hist[4 * lane + u]; own += h4[u]; }
+      u32 above = own;                                             // inclusive suffix over lanes l .. 63
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1)
+        {
+          const u32 dn = (u32) __shfl_down((int) above, d, 64);
+          if (lane + d < 64) above += dn;
+        }
+      above -= own;                                                // records in the bins of the lanes above this one
+      // the largest bin b with #(>= b) >= keep lies in exactly one lane
+      u32 cand = 0xffffffffu, run = above;
+#pragma unroll
+      for (int u = 3; u >= 0; --u)
+        {
+          run += h4[u];
+          if (cand == 0xffffffffu && run >= keep) cand = (u32) (4 * lane + u);
+        }
+      // the highest lane that found one wins
+      const u64 found = __ballot(cand != 0xffffffffu);
+      const int win = found ? 63 - __builtin_clzll(found) : 0;
+      thr = (u32) __shfl((int) cand, win, 64);
+      if (thr == 255u)
+        {
+          // more than `keep` records sit in the clamped bin (16-bit class only): exact threshold by bisection over those
+          u32 lo = 255, hi = 32768;                                // invariant: #(>= lo) >= keep, #(>= hi) < keep
+          while (hi - lo > 1)
+            {
+              const u32 mid = (lo + hi) >> 1;
+              u32 c = 0;
+              for (u32 t = 0; t < ntiles; ++t)
+                {
+                  const u32 nt = tc[t];
+                  const uint2 * __restrict__ r = r0 + (size_t) t * subcap;
+                  for (u32 x = (u32) lane; x < nt; x += 64) c += (r[x].y >= mid) ? 1u : 0u;
+                }
+#pragma unroll
+              for (int m = 32; m >= 1; m >>= 1) c += (u32) __shfl_xor((int) c, m, 64);
+              if (c >= keep) lo = mid; else hi = mid;
+            }
+          thr = lo;
+        }
+    }
+  // count, allocate, copy
+  u32 m = 0;
+  if (thr == 0) m = n;
+  else
+    {
+      for (u32 t = 0; t < ntiles; ++t)
+        {
+          const u32 nt = tc[t];
+          const uint2 * __restrict__ r = r0 + (size_t) t * subcap;
+          for (u32 x = (u32) lane; x < nt; x += 64) m += (r[x].y >= thr) ? 1u : 0u;
+        }
+#pragma unroll
+      for (int k = 32; k >= 1; k >>= 1) m += (u32) __shfl_xor((int) m, k, 64);
+    }
   u64 first = 0;
   if (lane == 0) first = atomicAdd(cursor, (u64) m);
   first = (u64) __shfl((long long) first, 0, 64);
   if (lane == 0) { sel_off[slot] = first; sel_off_n[slot] = make_uint2(m, n); }
   if (first + m > capacity) return;                      // the host re-runs the selection with the exact size
   u32 done = 0;
-  for (u32 x0 = 0; x0 < n; x0 += 64)
+  for (u32 t = 0; t < ntiles; ++t)
     {
-      const u32 x = x0 + (u32) lane;
-      const bool take = (x < n) && (r[x].y >= thr);
-      const u64 ballot = __ballot(take);
-      if (take) dense[first + done + (u32) __popcll(ballot & ((1ull << lane) - 1ull))] = r[x];
-      done += (u32) __popcll(ballot);
+      const u32 nt = tc[t];
+      const uint2 * __restrict__ r = r0 + (size_t) t * subcap;
+      for (u32 x0 = 0; x0 < nt; x0 += 64)
+        {
+          const u32 x = x0 + (u32) lane;
+          const bool take = (x < nt) && (r[x].y >= thr);
+          const u64 ballot = __ballot(take);
+          if (take) dense[first + done + (u32) __popcll(ballot & ((1ull << lane) - 1ull))] = r[x];
+          done += (u32) __popcll(ballot);
+        }
     }
 }
 
@@ -436,30 +518,44 @@ extern "C" hipError_t vsx_kmer_launch_case_bits(const uint8_t * d_ascii, uint64_
   return hipGetLastError();
 }
 
-extern "C" hipError_t vsx_kmer_launch_count(int bits, const uint32_t * postings, const uint64_t * bucket_start, uint32_t ntiles,
-                                            uint32_t nseq, uint32_t nslots, uint32_t slot_base, const uint64_t * qk_start, const uint32_t * qk,
-                                            const uint32_t * minmatch, const uint32_t * qlist, void * rec, uint32_t cap,
-                                            uint32_t * qcount, hipStream_t st)
+extern "C" hipError_t vsx_kmer_launch_ranges(const uint64_t * bucket_start, uint32_t ntiles, const uint64_t * qk_start, const uint32_t * qk,
+                                             const uint32_t * minmatch, const uint32_t * qlist, uint32_t nslots, void * ranges, hipStream_t st)
 {
-  // slots [slot_base, slot_base + nslots) of the batch; rec / qcount are the arrays of the WHOLE batch (the kernel indexes them
-  // by slot - slot_base, so the caller passes them offset by slot_base)
-  if (nslots == 0 || nseq == 0) return hipSuccess;
-  static const int probe = std::getenv("VSX_KMER_PROBE") ? std::atoi(std::getenv("VSX_KMER_PROBE")) : 0;
-  if (bits == 8)
-    hipLaunchKernelGGL(vsx_kmer_count_kernel<8>, dim3(nslots, ntiles), dim3(512), 0, st, (const uint4 *) postings,
-                       (const u64 *) bucket_start, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base, (uint2 *) rec, cap, qcount, probe);
-  else
-    hipLaunchKernelGGL(vsx_kmer_count_kernel<16>, dim3(nslots, ntiles), dim3(1024), 0, st, (const uint4 *) postings,
-                       (const u64 *) bucket_start, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base, (uint2 *) rec, cap, qcount, probe);
+  if (nslots == 0) return hipSuccess;
+  hipLaunchKernelGGL(vsx_kmer_ranges_kernel, dim3(nslots), dim3(256), 0, st, (const u64 *) bucket_start, ntiles, (const u64 *) qk_start, qk,
+                     minmatch, qlist, nslots, (uint2 *) ranges);
   return hipGetLastError();
 }
 
-extern "C" hipError_t vsx_kmer_launch_select(const void * rec, uint32_t cap, const uint32_t * qcount, uint32_t nslots,
+extern "C" hipError_t vsx_kmer_launch_count(int bits, const uint32_t * postings, const uint64_t * bucket_start, const void * ranges,
+                                            uint32_t ntiles, uint32_t nseq, uint32_t nslots, uint32_t slot_base, const uint64_t * qk_start,
+                                            const uint32_t * qk, const uint32_t * minmatch, const uint32_t * qlist, void * rec, uint32_t subcap,
+                                            uint32_t * tile_count, hipStream_t st)
+{
+  // slots [slot_base, slot_base + nslots) of the batch; ranges / rec / tile_count belong to THESE slots (indexed from 0)
+  if (nslots == 0 || nseq == 0) return hipSuccess;
+  static const int probe = std::getenv("VSX_KMER_PROBE") ? std::atoi(std::getenv("VSX_KMER_PROBE")) : 0;
+  if (bits == 8 && ranges)
+    hipLaunchKernelGGL((vsx_kmer_count_kernel<8, true>), dim3(nslots, ntiles), dim3(512), 0, st, (const uint4 *) postings,
+                       (const u64 *) bucket_start, (const uint2 *) ranges, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base,
+                       nslots, (uint2 *) rec, subcap, tile_count, probe);
+  else if (bits == 8)
+    hipLaunchKernelGGL((vsx_kmer_count_kernel<8, false>), dim3(nslots, ntiles), dim3(512), 0, st, (const uint4 *) postings,
+                       (const u64 *) bucket_start, (const uint2 *) nullptr, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base,
+                       nslots, (uint2 *) rec, subcap, tile_count, probe);
+  else
+    hipLaunchKernelGGL((vsx_kmer_count_kernel<16, false>), dim3(nslots, ntiles), dim3(1024), 0, st, (const uint4 *) postings,
+                       (const u64 *) bucket_start, (const uint2 *) nullptr, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base,
+                       nslots, (uint2 *) rec, subcap, tile_count, probe);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t vsx_kmer_launch_select(const void * rec, uint32_t subcap, uint32_t ntiles, const uint32_t * tile_count, uint32_t nslots,
                                              uint32_t keep, void * dense, unsigned long long * cursor, uint64_t capacity,
                                              void * sel_m_n, uint64_t * sel_off, hipStream_t st)
 {
   if (nslots == 0) return hipSuccess;
-  hipLaunchKernelGGL(vsx_kmer_select_kernel, dim3((nslots + 3) / 4), dim3(256), 0, st, (const uint2 *) rec, cap, qcount, nslots,
+  hipLaunchKernelGGL(vsx_kmer_select_kernel, dim3((nslots + 3) / 4), dim3(256), 0, st, (const uint2 *) rec, subcap, ntiles, tile_count, nslots,
                      keep, (uint2 *) dense, (u64 *) cursor, (u64) capacity, (uint2 *) sel_m_n, (u64 *) sel_off);
   return hipGetLastError();
 }

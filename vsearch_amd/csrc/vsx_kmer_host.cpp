@@ -53,7 +53,8 @@ struct KmerScratch {
   Buf<uint64_t> d_qk_start;
   Buf<uint32_t> d_qk, d_minmatch;
   Buf<uint64_t> d_rec, d_dense, d_sel_mn, d_sel_off;    // uint2 records (target, count); (kept, seen) per slot
-  Buf<uint32_t> d_qcount;
+  Buf<uint64_t> d_ranges;                                // uint2 (first unit, units) per (tile, slot, word): 8-bit class
+  Buf<uint32_t> d_tilecnt;                               // records per (slot, tile)
   Buf<unsigned long long> d_cursor;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   uint64_t records = 0;
@@ -207,6 +208,7 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   ix->stats.build_ms = ms;
   ix->stats.postings = entries;
   ix->stats.index_bytes = acc * 16 + (ix->nbuckets + 1) * 8;
+  if (acc >= (1ull << 32)) { vsx_internal_set_error("vsx_kmer_index_rebuild: more than 64 GB of postings (32-bit unit addresses)"); return VSX_EINVAL; }
   return VSX_OK;
 }
 
@@ -223,26 +225,31 @@ namespace {
 
 // one counting + selection pass over `nslots` query slots (slot -> query through qlist, or identity); appends to recs
 // Slots [0, n8) hold queries of the 8-bit counter class (<= 255 unique words), the rest take the 16-bit kernel.
-int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, uint32_t n8, const uint32_t * d_qlist, const std::vector<uint32_t> * h_qlist, uint32_t cap,
+// subcap = records per (slot, tile) sub-region.
+int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, uint32_t n8, const uint32_t * d_qlist, const std::vector<uint32_t> * h_qlist, uint32_t subcap,
                uint32_t keep, VsxKmerResult & out, std::vector<uint32_t> & overflow, uint32_t & overflow_max, float & ms_total)
 {
-  KCHK(sc->d_rec.ensure((size_t) nslots * cap));
-  KCHK(sc->d_qcount.ensure(nslots));
+  const uint32_t nt = ix->ntiles;
+  KCHK(sc->d_rec.ensure((size_t) nslots * nt * subcap));
+  KCHK(sc->d_tilecnt.ensure((size_t) nslots * nt));
   KCHK(sc->d_sel_mn.ensure(nslots));
   KCHK(sc->d_sel_off.ensure(nslots));
-  KCHK(hipMemsetAsync(sc->d_qcount.p, 0, (size_t) nslots * 4, sc->st));
+  static const bool no_pre = std::getenv("VSX_KMER_NO_RANGES") != nullptr;       // A/B: the blocks look their ranges up themselves
+  if (n8 && !no_pre) KCHK(sc->d_ranges.ensure((size_t) n8 * nt * 256));
   KCHK(hipEventRecord(sc->e0, sc->st));
-  KCHK(vsx_kmer_launch_count(8, ix->d_post.p, ix->d_start.p, ix->ntiles, ix->nseq, n8, 0, sc->d_qk_start.p, sc->d_qk.p,
-                             sc->d_minmatch.p, d_qlist, sc->d_rec.p, cap, sc->d_qcount.p, sc->st));
-  KCHK(vsx_kmer_launch_count(16, ix->d_post.p, ix->d_start.p, ix->ntiles, ix->nseq, nslots - n8, n8, sc->d_qk_start.p, sc->d_qk.p,
-                             sc->d_minmatch.p, d_qlist, sc->d_rec.p + (size_t) n8 * cap, cap, sc->d_qcount.p + n8, sc->st));
+  if (n8 && !no_pre)
+    KCHK(vsx_kmer_launch_ranges(ix->d_start.p, nt, sc->d_qk_start.p, sc->d_qk.p, sc->d_minmatch.p, d_qlist, n8, sc->d_ranges.p, sc->st));
+  KCHK(vsx_kmer_launch_count(8, ix->d_post.p, ix->d_start.p, (n8 && !no_pre) ? sc->d_ranges.p : nullptr, nt, ix->nseq, n8, 0, sc->d_qk_start.p, sc->d_qk.p,
+                             sc->d_minmatch.p, d_qlist, sc->d_rec.p, subcap, sc->d_tilecnt.p, sc->st));
+  KCHK(vsx_kmer_launch_count(16, ix->d_post.p, ix->d_start.p, nullptr, nt, ix->nseq, nslots - n8, n8, sc->d_qk_start.p, sc->d_qk.p,
+                             sc->d_minmatch.p, d_qlist, sc->d_rec.p + (size_t) n8 * nt * subcap, subcap, sc->d_tilecnt.p + (size_t) n8 * nt, sc->st));
   uint64_t capacity = std::max<uint64_t>(sc->d_dense.n, std::max<uint64_t>(1u << 20, (uint64_t) nslots * 128));
   unsigned long long produced = 0;
   for (int attempt = 0; attempt < 2; ++attempt)
     {
       KCHK(sc->d_dense.ensure(capacity));
       KCHK(hipMemsetAsync(sc->d_cursor.p, 0, sizeof(unsigned long long), sc->st));
-      KCHK(vsx_kmer_launch_select(sc->d_rec.p, cap, sc->d_qcount.p, nslots, keep, sc->d_dense.p, sc->d_cursor.p, sc->d_dense.n,
+      KCHK(vsx_kmer_launch_select(sc->d_rec.p, subcap, nt, sc->d_tilecnt.p, nslots, keep, sc->d_dense.p, sc->d_cursor.p, sc->d_dense.n,
                                   sc->d_sel_mn.p, sc->d_sel_off.p, sc->st));
       KCHK(hipEventRecord(sc->e1, sc->st));
       KCHK(hipMemcpyAsync(&produced, sc->d_cursor.p, sizeof produced, hipMemcpyDeviceToHost, sc->st));
@@ -333,8 +340,12 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
   uint32_t overflow_max = 0;
   // records per query region in the first pass: at 1 M x 1 kbp a 250-bp query has ~5 000 sequences with >= 12 shared
   // words (chance runs of shared 11..13-mers), so 8 192 x 8 B = 64 KB per query; HBM is plentiful (100 k queries = 6.5 GB)
+  // (r03) every (query, tile) owns a sub-region: 512 records where a tile is one of many (a 250-bp query finds ~160 per tile of
+  // 32 768 sequences), the whole 8 192 for single-tile databases (clustering rounds)
   uint32_t cap = cap_hint ? cap_hint : (nq <= (1u << 18) ? 8192 : 2048);
-  if (const char * c = std::getenv("VSX_KMER_CAP")) cap = (uint32_t) std::max(1, std::atoi(c));      // tests: force the second pass
+  bool forced = cap_hint != 0;
+  if (const char * c = std::getenv("VSX_KMER_CAP")) { cap = (uint32_t) std::max(1, std::atoi(c)); forced = true; }      // tests: force the second pass
+  cap = std::max<uint32_t>(1, forced ? cap / ix->ntiles : std::max<uint32_t>(512, cap / ix->ntiles));
   // counter class per query: at most 255 unique words -> byte counters (a count never exceeds the number of words)
   auto by_class = [&](const std::vector<uint32_t> * subset, std::vector<uint32_t> & ordered, uint32_t & n8) -> bool {
     const uint64_t n = subset ? subset->size() : nq;
