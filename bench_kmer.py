@@ -130,7 +130,7 @@ def main():
             out = {
                 "metric": "k-mer candidate lists per second (search_topscores: count + threshold, device kernel)",
                 "value": round(a.queries / (best["kernel_ms"] * 1e-3), 1), "unit": "queries/s",
-                "n_gpus": 1, "higher_is_better": True, "dtype": "u16 counters", "data": "synthetic",
+                "n_gpus": 1, "higher_is_better": True, "dtype": "u8 counters (u16 for queries with more than 255 words)", "data": "synthetic",
                 "config": {"workload": f"{a.queries} x {a.qlen} bp queries vs {a.db} x {a.dlen} bp family DB, wordlength 8, "
                                        "minwordmatches 12 (BASELINE config[1] shape)"},
                 "kernel_ms": round(best["kernel_ms"], 3),

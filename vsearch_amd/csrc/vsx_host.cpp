@@ -88,6 +88,8 @@ struct ScratchPool {
   std::vector<PoolBlock> free_blocks;
   std::mutex mu;
   bool enabled = true;
+  bool retired = false;                 // the owning context is gone (sequence sets may outlive it): nothing is kept any more
+  ~ScratchPool() { for (PoolBlock & b : free_blocks) (void) hipFree(b.p); }
   hipError_t get(size_t bytes, void ** out, size_t * got)
   {
     if (bytes == 0) bytes = 1;
@@ -115,6 +117,7 @@ struct ScratchPool {
     if (!p) return;
     if (!enabled) { (void) hipFree(p); return; }
     std::lock_guard<std::mutex> lk(mu);
+    if (retired) { (void) hipFree(p); return; }
     free_blocks.push_back(PoolBlock {p, bytes});
     while (free_blocks.size() > 64)                       // bound the number of idle blocks: drop the smallest
       {
@@ -137,6 +140,7 @@ struct ScratchPool {
     for (PoolBlock & b : free_blocks) (void) hipFree(b.p);
     free_blocks.clear();
   }
+  void retire() { trim(); std::lock_guard<std::mutex> lk(mu); retired = true; }
 };
 
 template <typename T>
@@ -146,14 +150,14 @@ struct PoolBuf {
   ScratchPool * pool = nullptr;
   ~PoolBuf() { release(); }
   void release() { if (p && pool) pool->put(p, bytes); else if (p) (void) hipFree(p); p = nullptr; n = 0; bytes = 0; }
-  hipError_t alloc(ScratchPool * pl, size_t count)
+  hipError_t alloc(ScratchPool * pl, size_t count)       // pl == nullptr: plain hipMalloc / hipFree
   {
     release();
     pool = pl;
     if (count == 0) count = 1;
     void * q = nullptr;
-    size_t got = 0;
-    hipError_t e = pl->get(count * sizeof(T), &q, &got);
+    size_t got = count * sizeof(T);
+    hipError_t e = pl ? pl->get(count * sizeof(T), &q, &got) : hipMalloc(&q, count * sizeof(T));
     if (e == hipSuccess) { p = static_cast<T *>(q); n = count; bytes = got; }
     return e;
   }
@@ -218,7 +222,8 @@ struct vsx_ctx {
   DevBuf<int16_t> d_htop, d_hleft, d_matrix;
   VsxDevParams Pt {};               // the same scoring in TILTED coordinates (VsxDevParams::tilt, vsx_forward_kernel TILT); Pt.tilt == 0: unavailable
   DevBuf<int16_t> d_htop_t, d_hleft_t, d_matrix_t;
-  ScratchPool pool;
+  std::shared_ptr<ScratchPool> pool_owner = std::make_shared<ScratchPool>();   // sequence sets hold a reference (they may outlive the context)
+  ScratchPool & pool = *pool_owner;
   // Two checkpoint blocks, used alternately by the plans of the context: the DP kernels of plan i+1 run while the traceback of
   // plan i still reads its block, so the launch tails of one fill with the other's waves (a pipeline of small plans lost 15 %
   // to tails when every plan waited for its predecessor's traceback: r02 timeline in DESIGN 5).  ev_tb[s] = "the last traceback
@@ -240,6 +245,7 @@ struct vsx_ctx {
   }
 };
 
+#define VSX_SEQSET_POOLED_BYTES (64ull << 20)
 struct vsx_seqset {
   vsx_ctx * ctx = nullptr;
   int device = 0;
@@ -247,13 +253,17 @@ struct vsx_seqset {
   uint64_t bytes = 0;
   std::vector<uint64_t> off;
   std::vector<uint32_t> len;
-  DevBuf<uint8_t> d_codes;          // VSX_CODE_SLACK bytes | codes | VSX_CODE_SLACK bytes: the traceback stages rows/columns with unaligned dword loads
+  // Device buffers of sets up to VSX_SEQSET_POOLED_BYTES come from the context's scratch pool and go back to it: a search creates
+  // one query set per window, and hipMalloc / hipFree synchronise the WHOLE device -- with the k-mer counting kernel of the next
+  // window running that was an 8-11 ms stall per window (r03 timeline); large sets (databases) use hipMalloc as before.
+  std::shared_ptr<ScratchPool> pool_ref;   // keeps the pool alive; declared BEFORE the buffers, so it is destroyed after them
+  PoolBuf<uint8_t> d_codes;         // VSX_CODE_SLACK bytes | codes | VSX_CODE_SLACK bytes: the traceback stages rows/columns with unaligned dword loads
   uint8_t * codes() const { return d_codes.p + VSX_CODE_SLACK; }
-  DevBuf<uint64_t> d_off;
-  DevBuf<uint32_t> d_len;
+  PoolBuf<uint64_t> d_off;
+  PoolBuf<uint32_t> d_len;
   // soft masking for the k-mer index only (vsx_internal_seqset_create_cased): one bit per blob byte, set where the symbol was
   // not an upper-case A C G T U.  The aligner never sees it: alignment is case-blind in the reference too (chrmap_4bit)
-  DevBuf<uint8_t> d_lower;
+  PoolBuf<uint8_t> d_lower;
   uint64_t lower_bytes = 0;
   // VSX_SCORE=arith only: per-sequence "contains a non-ACGT symbol", computed on first use (vsx_purity_kernel) under the lock
   mutable std::mutex impure_mu;
@@ -577,10 +587,15 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
     delete c;
   };
   hipError_t e;
-  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipStreamCreateWithFlags(&c->stream_dn, hipStreamNonBlocking)) != hipSuccess ||
+  // the aligner's streams get the HIGHEST priority the device offers: in a search its short plans share the GPU with the k-mer
+  // counting kernel of the next window (lowest priority, vsx_kmer_host.cpp), whose millions of 15-us blocks would otherwise keep
+  // every CU busy and hold each alignment stage back until the counting is over (r03 timeline: windows aligned 100 ms late)
+  int prio_low = 0, prio_high = 0;
+  (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+  if ((e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high)) != hipSuccess ||
+      (e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_high)) != hipSuccess ||
+      (e = hipStreamCreateWithPriority(&c->stream_up, hipStreamNonBlocking, prio_high)) != hipSuccess ||
+      (e = hipStreamCreateWithPriority(&c->stream_dn, hipStreamNonBlocking, prio_high)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_tb[0], hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_tb[1], hipEventDisableTiming)) != hipSuccess ||
       (e = c->d_htop.alloc(VSX_TABLE_LEN)) != hipSuccess || (e = c->d_hleft.alloc(VSX_TABLE_LEN)) != hipSuccess ||
@@ -651,7 +666,7 @@ void vsx_destroy(vsx_ctx * c)
   c->shared_dir[0].reset();
   c->shared_dir[1].reset();
   c->shared_slab.reset();
-  c->pool.trim();
+  c->pool.retire();
   delete c;
 }
 
@@ -684,12 +699,14 @@ static int seqset_common(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const voi
       s->bytes = code_bytes;
     }
   hipError_t e = hipSuccess;
-  DevBuf<uint8_t> staging;
+  ScratchPool * pl = (code_bytes <= VSX_SEQSET_POOLED_BYTES) ? &ctx->pool : nullptr;
+  if (pl) s->pool_ref = ctx->pool_owner;
+  PoolBuf<uint8_t> staging;
   const uint8_t * d_ascii = static_cast<const uint8_t *>(blob);
   do {
-    if ((e = s->d_codes.alloc(code_bytes + 2 * VSX_CODE_SLACK)) != hipSuccess) break;
-    if ((e = s->d_off.alloc(s->n)) != hipSuccess) break;
-    if ((e = s->d_len.alloc(s->n)) != hipSuccess) break;
+    if ((e = s->d_codes.alloc(pl, code_bytes + 2 * VSX_CODE_SLACK)) != hipSuccess) break;
+    if ((e = s->d_off.alloc(pl, s->n)) != hipSuccess) break;
+    if ((e = s->d_len.alloc(pl, s->n)) != hipSuccess) break;
     if (n)
       {
         if ((e = hipMemcpyAsync(s->d_off.p, s->off.data(), s->n * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
@@ -697,7 +714,7 @@ static int seqset_common(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const voi
       }
     if (!blob_on_device && blob_bytes)
       {
-        if ((e = staging.alloc(blob_bytes + 16)) != hipSuccess) break;
+        if ((e = staging.alloc(pl, blob_bytes + 16)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(staging.p, blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) break;
         d_ascii = staging.p;
       }
@@ -705,7 +722,7 @@ static int seqset_common(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const voi
     if (case_bits)
       {
         const uint64_t nb = (blob_bytes + 7) / 8 + 16;             // the sweep reads a dword at any byte of the map
-        if ((e = s->d_lower.alloc(nb)) != hipSuccess) break;
+        if ((e = s->d_lower.alloc(pl, nb)) != hipSuccess) break;
         if ((e = hipMemsetAsync(s->d_lower.p, 0, nb, ctx->stream)) != hipSuccess) break;
         if ((e = vsx_kmer_launch_case_bits(d_ascii, blob_bytes, s->d_lower.p, case_bits == 2, ctx->stream)) != hipSuccess) break;
         if (case_bits == 2 && (e = vsx_launch_dust(s->codes(), s->d_off.p, s->d_len.p, n, s->d_lower.p, ctx->stream)) != hipSuccess) break;

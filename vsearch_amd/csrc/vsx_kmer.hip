@@ -146,7 +146,9 @@ vsx_kmer_sweep_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict
 //     (vsx_kmer_ranges_kernel) writes the ranges of every (query, tile) in the order the waves want them, so a block starts with
 //     ONE coalesced load, and every (query, tile) owns a sub-region of the record buffer, so the sweep needs no atomic.
 #define KM_PAD 0x8000u
+#ifndef KM_LOADS
 #define KM_LOADS 4                     // independent 16-byte loads per lane and trip (32 postings)
+#endif
 
 // Bucket ranges of the 8-bit class, one block per query slot, thread i = the query's i-th word.  R[(tile * nslots + slot) * 256 +
 // (i % 8) * 32 + i / 8] = (first unit, units): wave w of the count kernel reads entries w * 32 .. w * 32 + 31 -- its buckets w,

@@ -313,7 +313,9 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
         if (ix->scratch.size() < VSX_KMER_SCRATCH_MAX)
           {
             std::unique_ptr<KmerScratch> p(new KmerScratch);
-            if (hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&p->e0) != hipSuccess ||
+            int prio_low = 0, prio_high = 0;               // counting runs BEHIND the aligner's plans (vsx_host.cpp vsx_create)
+            (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+            if (hipStreamCreateWithPriority(&p->st, hipStreamNonBlocking, prio_low) != hipSuccess || hipEventCreate(&p->e0) != hipSuccess ||
                 hipEventCreate(&p->e1) != hipSuccess || p->d_cursor.alloc(1) != hipSuccess)
               { (void) hipGetLastError(); vsx_internal_set_error("vsx_kmer_count_batch: scratch allocation failed"); return VSX_EHIP; }
             lease.sc = p.get();

@@ -1121,6 +1121,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
   for (uint64_t i = 0; i < nq; ++i)
     if (qoff[i] + qlen[i] > qbytes) return sfail(VSX_EINVAL, "vsx_search_batch: query exceeds the blob");
   const double t_begin = now_s();
+  static const bool timeline = std::getenv("VSX_DEBUG_TIMELINE") != nullptr;
   // Windows of queries; the k-mer stage of window i+1 (host word extraction, device counting, host ranking) runs on a
   // producer thread while this thread aligns window i (a query's hits do not depend on its window).  Large batches use
   // smaller windows so that the two stages overlap; VSX_SEARCH_PIPELINE=0 = one thread, as before.
@@ -1128,6 +1129,25 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
   static const uint64_t env_window = std::getenv("VSX_SEARCH_WINDOW") ? std::strtoull(std::getenv("VSX_SEARCH_WINDOW"), nullptr, 10) : 0;   // tests
   const bool piped = !pipe_off && (env_window ? nq > env_window : (S->o.window <= 0 && nq > 32768));
   const uint64_t window = env_window ? env_window : (S->o.window > 0 ? (uint64_t) S->o.window : (piped ? 16384 : 65536));
+  // window boundaries.  Piped: the first windows are small (the GPU starts after the first window's words: a quarter, then half
+  // a window), the last two shrink again (half, then a quarter: the last alignment stage is the only thing nothing overlaps)
+  std::vector<uint64_t> cut {0};
+  while (cut.back() < nq)
+    {
+      const uint64_t left = nq - cut.back();
+      uint64_t want = window;
+      if (piped && !env_window && S->o.window <= 0)
+        {
+          if (cut.size() == 1) want = window / 4;
+          else if (cut.size() == 2) want = window / 2;
+          else if (left <= window / 4) want = left;
+          else if (left <= window / 2 + window / 4) want = left - window / 4;
+          else if (left <= window + window / 2 + window / 4) want = std::min<uint64_t>(window, left - window / 2 - window / 4);
+        }
+      cut.push_back(cut.back() + std::min<uint64_t>(std::max<uint64_t>(want, 1), left));
+    }
+  const size_t n_windows = cut.size() - 1;
+  auto window_of = [&](uint64_t w0) -> size_t { return (size_t) (std::upper_bound(cut.begin(), cut.end(), w0) - cut.begin()) - 1; };
   std::vector<std::vector<Hit>> kept(nq);
   double t_kmer = 0, t_align = 0, t_adv = 0, t_rep = 0, t_qset = 0, t_join = 0;
   uint64_t pairs = 0, cells = 0, stages = 0, sentinels = 0;
@@ -1176,7 +1196,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
   auto prepare_words = [&](uint64_t w0) -> std::unique_ptr<Window> {
       std::unique_ptr<Window> W(new Window);
       W->w0 = w0;
-      const uint64_t wn = W->wn = std::min<uint64_t>(window, nq - w0);
+      const uint64_t wn = W->wn = cut[window_of(w0) + 1] - w0;
       // --strand both: state k < wn searches query w0 + k, state wn + k its reverse complement (search.cpp:200-214)
       const uint64_t ns = W->ns = both ? 2 * wn : wn;
       W->st.resize(ns);
@@ -1239,12 +1259,14 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
             }
         }
       w->t_kmer = now_s() - t0;
+      if (timeline) std::fprintf(stderr, "  [%7.1f ms] window %llu: words done (%.1f ms)\n", (now_s() - t_begin) * 1e3, (unsigned long long) window_of(w0), w->t_kmer * 1e3);
       return W;
   };
   // stage 1b: k-mer heuristic for the whole window: device counters (vsx_kmer.hip) or host threads
   auto prepare_rank = [&](Window & Wr) {
       Window * w = &Wr;
       const double t0 = now_s();
+      if (timeline) std::fprintf(stderr, "  [%7.1f ms] window %llu: rank begins\n", (t0 - t_begin) * 1e3, (unsigned long long) window_of(w->w0));
       std::vector<std::vector<Cand>> cands;
       auto seqf = [w](uint64_t k) { return w->wblob + w->lo[k]; };
       auto lenf = [w](uint64_t k) { return (int64_t) w->ln[k]; };
@@ -1254,6 +1276,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
         for (uint64_t k = 0; k < w->ns; ++k) w->st[k].cands = std::move(cands[k]);
       std::vector<std::vector<uint32_t>>().swap(w->words);
       w->t_kmer += now_s() - t0;
+      if (timeline) std::fprintf(stderr, "  [%7.1f ms] window %llu: rank done (%.1f ms)\n", (now_s() - t_begin) * 1e3, (unsigned long long) window_of(w->w0), (now_s() - t0) * 1e3);
   };
   auto prepare = [&](uint64_t w0) -> std::unique_ptr<Window> {
       std::unique_ptr<Window> W = prepare_words(w0);
@@ -1264,6 +1287,8 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
   std::mutex acc_mu;                            // two consumers add to the accounting
   auto consume = [&](Window & W, vsx_ctx * ctx) -> int {
       const uint64_t w0 = W.w0, wn = W.wn, ns = W.ns;
+      const double tc0 = now_s();
+      if (timeline) std::fprintf(stderr, "  [%7.1f ms] window %llu: align begins\n", (tc0 - t_begin) * 1e3, (unsigned long long) window_of(w0));
       auto seq_of = [&](uint64_t k) { return W.wblob + W.lo[k]; };
       std::vector<QState> & st = W.st;
       // the window's sequences as a device sequence set
@@ -1320,14 +1345,15 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
           std::stable_sort(dst.begin(), dst.end(), [](const Hit & a, const Hit & b) { return hit_compare_byid(a, b) < 0; });
         }
       { std::lock_guard<std::mutex> lk(acc_mu); t_join += now_s() - tj; }
+      if (timeline) std::fprintf(stderr, "  [%7.1f ms] window %llu: align done (%.1f ms)\n", (now_s() - t_begin) * 1e3, (unsigned long long) window_of(w0), (now_s() - tc0) * 1e3);
       return VSX_OK;
   };
 
   if (!piped)
     {
-      for (uint64_t w0 = 0; w0 < nq; w0 += window)
+      for (size_t wi = 0; wi < n_windows; ++wi)
         {
-          std::unique_ptr<Window> W = prepare(w0);
+          std::unique_ptr<Window> W = prepare(cut[wi]);
           t_kmer += W->t_kmer;
           if (W->krc != VSX_OK) { vsx_internal_set_error(W->err.c_str()); return W->krc; }
           const int crc = consume(*W, S->ctx);
@@ -1365,8 +1391,8 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       };
       Slot s1, s2;
       std::thread stage_words([&]() {
-        for (uint64_t w0 = 0; w0 < nq; w0 += window)
-          if (!s1.put(prepare_words(w0))) break;
+        for (size_t wi = 0; wi < n_windows; ++wi)
+          if (!s1.put(prepare_words(cut[wi]))) break;
         s1.finish();
       });
       // two rank workers: one window's host work (CSR, uploads, record download, ranking) runs under the other's counting
