@@ -157,6 +157,27 @@ int vsx_allpairs_block(vsx_searcher * s, int32_t acceptall, uint64_t first, uint
    hits.first has count + 1 entries (entry k = rows[k]); vsx_hit.query is the database sequence number. */
 int vsx_allpairs_rows(vsx_searcher * s, int32_t acceptall, const uint32_t * rows, uint64_t count, vsx_hits * out);
 
+/* ---- multi-device form: several GPUs of one node behind ONE handle (vsx_multi.cpp) ----------------------------------------
+   The reference is one process with a pool of worker threads over a shared database (commands/usearch_global.cpp:500-535,
+   core/search.cpp:397-508); here the pool is one aligner context + database replica + k-mer index per listed device and one
+   host thread per device.  vsx_multi_search_batch cuts the batch into contiguous blocks of queries (one per device), runs
+   vsx_search_batch_meta on each concurrently and merges the hit lists in the caller's query order: the result is what a single
+   vsx_search_batch_meta of all queries returns, hit for hit (the accounting fields are summed, the times are the slowest
+   device's).  vsx_multi_allpairs deals the rows first .. first + count - 1 of the triangular pair space out boustrophedon (balanced
+   pairs and cells) and merges per row: the result of vsx_allpairs_block(first, count).  Clustering does not shard (sequential
+   centroid dependency): use vsx_multi_searcher_replica(m, 0) with vsx_cluster_fast.  No collective is involved: the multi-PROCESS
+   form with an RCCL gather is vsearch_amd/sharding.py.  A device may be listed more than once (several replicas on one GPU). */
+typedef struct vsx_multi_searcher vsx_multi_searcher;
+int vsx_multi_searcher_create(vsx_multi_searcher ** out, const vsx_scoring * scoring, const int32_t * devices, int32_t n_devices,
+                              const vsx_search_opts * opts, uint64_t n, const char * blob, uint64_t blob_bytes,
+                              const uint64_t * offsets, const uint32_t * lengths, const vsx_seq_meta * meta /* may be NULL */);
+void vsx_multi_searcher_destroy(vsx_multi_searcher * m);
+int32_t vsx_multi_searcher_devices(const vsx_multi_searcher * m);
+vsx_searcher * vsx_multi_searcher_replica(vsx_multi_searcher * m, int32_t k);       /* owned by m */
+int vsx_multi_search_batch(vsx_multi_searcher * m, uint64_t n_queries, const char * qblob, uint64_t qblob_bytes,
+                           const uint64_t * qoffsets, const uint32_t * qlengths, const vsx_seq_meta * qmeta /* may be NULL */, vsx_hits * out);
+int vsx_multi_allpairs(vsx_multi_searcher * m, int32_t acceptall, uint64_t first, uint64_t count, vsx_hits * out);
+
 /* Candidate list of ONE query exactly as search_topscores + minheap_sort produce it (best first):
    fills up to `cap` (target, count) pairs, returns the number of candidates. For tests / tooling. */
 int64_t vsx_search_candidates(vsx_searcher * s, const char * q, uint32_t qlen,

@@ -80,3 +80,62 @@ def test_sharded_alignment_and_gather_world2(gpu_required, tmp_path):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert p.stdout.count("ok") == 2
+
+
+def _same_hits(a, b):
+    """(first, hits, cigar blob) of two runs: same lists, every field; CIGARs compared as text (blob offsets may differ)"""
+    import numpy as np
+    fa, ha, ca = a
+    fb, hb, cb = b
+    assert np.array_equal(fa, fb)
+    assert len(ha) == len(hb)
+    for name in ha.dtype.names:
+        if name in ("cigar_off", "pad"):
+            continue
+        assert np.array_equal(ha[name], hb[name]), name
+    for x in range(len(ha)):
+        oa, ob = int(ha["cigar_off"][x]), int(hb["cigar_off"][x])
+        assert ca[oa:ca.index(b"\0", oa)] == cb[ob:cb.index(b"\0", ob)], x
+
+
+@pytest.mark.parametrize("devices", [(0, 0), (0, 0, 0)])
+def test_multi_device_handle_equals_single_device(gpu_required, devices):
+    """vsx_multi_searcher (vsx_multi.cpp): one C handle over several device replicas -- here two / three replicas on ONE GPU -- must
+    return exactly what a single searcher returns: --usearch_global (contiguous query blocks merged in query order; plus strand
+    and both strands + DUST + abundances / labels) and --allpairs_global (rows dealt boustrophedon, merged per row).
+    VERDICT r02 'next' #5: the multi-device driver below the C-ABI."""
+    import random
+    from tests import common
+    from vsearch_amd import Aligner
+    from vsearch_amd.search import SearchSession, MultiSearchSession
+    rng = random.Random(303)
+    db, fam = common.family_db(rng, 10, 8, 330, div=0.06)
+    db += ["", "ACGTNNRYacgtu" * 9]
+    qs, src = common.queries_from_db(rng, db[:80], 53, 160)
+    qs += ["", common.rnd_seq(rng, 210, "ACGTRYN"), db[3]]
+    qsize = [rng.randint(1, 40) for _ in qs]
+    qlab = [f"q{i};size={s}" for i, s in enumerate(qsize)]
+    dsize = [rng.randint(1, 40) for _ in db]
+    dlab = [f"t{i}" for i in range(len(db))]
+    for kw in (dict(id=0.8, maxaccepts=3, maxrejects=8),
+               dict(id=0.8, maxaccepts=2, strand_both=1, soft_mask=2, minsizeratio=0.2, self_=1)):
+        with Aligner(device=0) as al:
+            one = SearchSession(al, db, sizes=dsize, labels=dlab, **kw)
+            exp = one.search_batch_raw(qs, sizes=qsize, labels=qlab)
+            exp_pairs = one.stats["pairs_aligned"]
+            exp_ap = None
+            if not kw.get("strand_both"):
+                f, h, c = [], [], b""
+                lib_hits = one.allpairs(0, 60)
+            one.close()
+        with MultiSearchSession(db, devices=devices, sizes=dsize, labels=dlab, **kw) as ms:
+            assert ms.n_devices == len(devices)
+            got = ms.search_batch_raw(qs, sizes=qsize, labels=qlab)
+            assert ms.stats["pairs_aligned"] == exp_pairs
+            _same_hits(got, exp)
+            assert len(got[1]) > 40
+            if not kw.get("strand_both"):
+                f, h, c = ms.allpairs_raw(0, 60)
+                got_lists = SearchSession.hits_as_lists(f, h, c)
+                assert got_lists == lib_hits
+                assert sum(len(x) for x in got_lists) > 100

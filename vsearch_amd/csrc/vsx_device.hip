@@ -913,8 +913,15 @@ struct __attribute__((aligned(4))) Trio { u32 x, y, z; };
 // a workgroup is TWO independent waves (no barrier after the table set-up) that share the score table, the symbols of a tile are
 // packed two to a byte, the boundary keeps only the 17 entries that are read and the tilted class stores its scores (0 .. 255) as
 // bytes: 13.0 KB of LDS per wave at R = 16 instead of 14.75 -> 12 waves per CU = the 3 per SIMD the 168 VGPRs allow.
+// occupancy floor of the traceback (latency bound, see below): 4 waves per SIMD (128 VGPRs) for the half-height tiles up to R = 24
+// and the short tiles up to R = 12, 3 (168) up to R = 16 and for the taller half-height tiles, 2 beyond.  r03 A/B
+// (profiles/r03/r03j_tb_occupancy_ab.txt): 150 x 300 2.71 -> 2.50 ms, 300 x 300 6.88 -> 6.61 ms; the LDS (11 KB per wave)
+// then caps the CU at 14 waves
+#ifndef VSX_TB_WAVES
+#define VSX_TB_WAVES(R_, MID_) ((MID_) ? ((R_) <= 24 ? 4 : 3) : ((R_) <= 12 ? 4 : ((R_) <= 16 ? 3 : 2)))
+#endif
 template <int R, bool FAST, bool CK8 = false, bool MID = false>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(MID ? 3 : ((R == 14 || R == 16) ? 3 : (R >= 28 ? 2 : 1)), 8)))      // R = 14, 16: <= 168 VGPRs, R >= 28: <= 256
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(VSX_TB_WAVES(R, MID), 8)))
 vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTask * __restrict__ tasks,
                         const u32 * __restrict__ pair_slot, const u32 * __restrict__ pair_ids, u32 npairs,
                         const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,

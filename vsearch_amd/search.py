@@ -339,3 +339,85 @@ def msa_batch(clusters_seqs, clusters_cigars, clusters_abundances=None, aligner=
         finally:
             lib.vsx_msa_out_free(C.byref(outs[k]))
     return res
+
+
+class MultiSearchSession:
+    """Several GPUs of one node behind one handle (include/vsx_search.h, multi-device form; vsx_multi.cpp): the reference's
+    worker pool over a shared database (commands/usearch_global.cpp:500-535) as one database replica + k-mer index + aligner
+    context per listed device.  search_batch_raw / allpairs_raw return what SearchSession.search_batch_raw returns for the same
+    call on ONE device -- hit for hit.  A device may be listed twice (two replicas on one GPU)."""
+
+    def __init__(self, db, devices=(0,), scoring=None, sizes=None, labels=None, **opts):
+        from .aligner import DEFAULT_SCORING
+        lib = _lib.load()
+        o = SearchOpts()
+        lib.vsx_search_opts_default(C.byref(o))
+        for k, v in opts.items():
+            k = "self" if k == "self_" else k
+            if not hasattr(o, k):
+                raise TypeError(f"unknown search option {k}")
+            setattr(o, k, v)
+        sc = scoring
+        if sc is None:
+            sc = _lib.Scoring()
+            for k, v in DEFAULT_SCORING.items():
+                setattr(sc, k, int(v))
+        self.db = list(db)
+        blob, off, lens = _blob(self.db)
+        dev = np.ascontiguousarray(devices, np.int32)
+        m, keep = _meta(sizes, labels, len(lens))
+        self.h = C.c_void_p()
+        check(lib.vsx_multi_searcher_create(C.byref(self.h), C.byref(sc), dev.ctypes.data_as(C.c_void_p), dev.size, C.byref(o), len(lens),
+                                            C.cast(C.c_char_p(blob), C.c_void_p), len(blob), off.ctypes.data_as(C.c_void_p),
+                                            lens.ctypes.data_as(C.c_void_p), C.byref(m) if keep else None),
+              "vsx_multi_searcher_create")
+        self.n_devices = int(lib.vsx_multi_searcher_devices(self.h))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            _lib.load().vsx_multi_searcher_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _raw(res):
+        lib = _lib.load()
+        try:
+            n, nh = int(res.n_queries), int(res.n_hits)
+            first = np.ctypeslib.as_array(res.first, shape=(n + 1,)).copy()
+            hits = np.ctypeslib.as_array(res.hit, shape=(max(nh, 1),))[:nh].copy()
+            cig = C.string_at(res.cigar_blob, int(res.cigar_bytes)) if res.cigar_bytes else b""
+            stats = {nm: getattr(res, nm) for nm in ("pairs_aligned", "cells_aligned", "stages", "sentinel_pairs")}
+            return first, hits, cig, stats
+        finally:
+            lib.vsx_hits_free(C.byref(res))
+
+    def search_batch_raw(self, queries, sizes=None, labels=None):
+        lib = _lib.load()
+        blob, off, lens = _blob(queries)
+        res = Hits()
+        m, keep = _meta(sizes, labels, len(lens))
+        check(lib.vsx_multi_search_batch(self.h, len(lens), C.cast(C.c_char_p(blob), C.c_void_p), len(blob), off.ctypes.data_as(C.c_void_p),
+                                         lens.ctypes.data_as(C.c_void_p), C.byref(m) if keep else None, C.byref(res)),
+              "vsx_multi_search_batch")
+        first, hits, cig, self.stats = self._raw(res)
+        return first, hits, cig
+
+    def allpairs_raw(self, first=0, count=None, acceptall=False):
+        lib = _lib.load()
+        count = len(self.db) - first if count is None else count
+        res = Hits()
+        check(lib.vsx_multi_allpairs(self.h, 1 if acceptall else 0, first, count, C.byref(res)), "vsx_multi_allpairs")
+        f, hits, cig, self.stats = self._raw(res)
+        return f, hits, cig
