@@ -17,8 +17,16 @@
 //     the batch boundaries -- that is what the reference's intra-batch fix-up guarantees) and serves every later range from
 //     that result; the caller's Dbindex is not grown.  A session that started with cluster_assign_single stays on the
 //     reference's code for its whole life.
-//   * --hardmask, opt_strand with clustering, and maxaccepts / maxrejects == 0 (unclamped in the library, search.cpp:521-529)
-//     take the reference's code.
+//   * --hardmask and opt_strand with clustering take the reference's code.  maxaccepts / maxrejects == 0 are NOT "unlimited" in the
+//     library (only the CLI rewrites them, search.cpp:521-529): search_onequery's loop condition accepts < maxaccepts /
+//     rejects < maxrejects (searchcore.cpp:915-918) is false at once, so search_batch reports no hit for any query -- answered
+//     here directly; clustering with such a configuration takes the reference's code.
+//   * a RUNTIME failure of the fast path (no device, out of memory, a libvsx error) is logged and the call is answered by the
+//     reference's code; nothing aborts the embedding process.
+//   * devices: VSX_DEVICES=0,1,2,... (one database replica per device, queries sharded over them: include/vsx_search.h multi-device
+//     form), else VSX_DEVICE=n, else device 0.  Clustering runs on the first device.
+//   * the Database must not be modified while a session uses it; a cheap fingerprint (lengths, abundances, sampled sequence
+//     bytes) catches in-place changes between calls (dust_all / hardmask_all after the first batch) and rebuilds the searcher.
 #include "vsearch_api.h"
 
 #include "vsx.h"
@@ -45,10 +53,31 @@ void vsxref_cluster_session_cleanup(struct cluster_session_s *);
 
 namespace {
 
-void die(char const * where)
+// a failure of the fast path is reported and the caller falls back to the reference's code (never abort the embedder)
+bool complain(char const * where)
 {
-  std::fprintf(stderr, "libvsx adapter: %s: %s\n", where, vsx_last_error());
-  std::abort();
+  std::fprintf(stderr, "libvsx adapter: %s failed: %s -- answering with the reference's code\n", where, vsx_last_error());
+  return false;
+}
+
+// VSX_DEVICES=0,1,2 | VSX_DEVICE=n | 0
+std::vector<int32_t> wanted_devices()
+{
+  std::vector<int32_t> d;
+  if (char const * list = std::getenv("VSX_DEVICES"))
+    {
+      char const * p = list;
+      while (*p)
+        {
+          char * end = nullptr;
+          long const v = std::strtol(p, &end, 10);
+          if (end == p) break;
+          d.push_back((int32_t) v);
+          p = (*end == ',') ? end + 1 : end;
+        }
+    }
+  if (d.empty()) d.push_back(std::getenv("VSX_DEVICE") ? (int32_t) std::atoi(std::getenv("VSX_DEVICE")) : 0);
+  return d;
 }
 
 // VSX_ADAPTER_TRACE=1: say on stderr which code answered (tests assert that the fast path really ran)
@@ -119,38 +148,54 @@ vsx_search_opts opts_of(struct Parameters const & p, bool clustering)
 bool covered(struct Parameters const & p, bool clustering)
 {
   if (p.opt_hardmask) return false;
-  if (p.opt_maxaccepts == 0 || p.opt_maxrejects == 0) return false;
+  if (clustering && (p.opt_maxaccepts == 0 || p.opt_maxrejects == 0)) return false;
   if (clustering && p.opt_strand) return false;
   return true;
 }
 
 // A searcher over the caller's Database, rebuilt when the Database or the configuration changed
 struct Fast {
-  vsx_ctx * ctx = nullptr;
-  vsx_searcher * S = nullptr;
+  vsx_multi_searcher * M = nullptr;             // one replica per device; replica 0 serves clustering
   struct Database const * db = nullptr;
-  uint64_t count = 0, last_len = 0;
-  char const * first = nullptr, * last = nullptr;
+  uint64_t count = 0, mark = 0;
   vsx_search_opts o {};
   vsx_scoring sc {};
-  void drop()
-  {
-    vsx_searcher_destroy(S); S = nullptr;
-    vsx_destroy(ctx); ctx = nullptr;
-  }
-  void ensure(struct Parameters const & p, struct Database const & d, bool clustering)
+  void drop() { vsx_multi_searcher_destroy(M); M = nullptr; }
+  vsx_searcher * first() { return vsx_multi_searcher_replica(M, 0); }
+  // lengths, abundances, header and sequence bytes of a spread of at most 256 sequences, and the totals: cheap enough for every
+  // call, and an in-place re-masking or re-annotation of the Database changes it
+  static uint64_t fingerprint(struct Database const & d)
   {
     uint64_t const n = d.getsequencecount();
-    char const * const f0 = n ? d.getsequence(0) : nullptr;
-    char const * const fl = n ? d.getsequence(n - 1) : nullptr;
-    uint64_t const ll = n ? d.getsequencelen(n - 1) : 0;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](void const * p, size_t bytes) {
+      auto const * c = static_cast<unsigned char const *>(p);
+      for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    };
+    uint64_t total = 0, sizes = 0;
+    for (uint64_t i = 0; i < n; ++i) { total += d.getsequencelen(i); sizes += (uint64_t) d.getabundance(i); }
+    mix(&n, sizeof n); mix(&total, sizeof total); mix(&sizes, sizeof sizes);
+    uint64_t const step = n > 256 ? n / 256 : 1;
+    for (uint64_t i = 0; i < n; i += step)
+      {
+        uint64_t const len = d.getsequencelen(i);
+        mix(&len, sizeof len);
+        mix(d.getsequence(i), (size_t) len);
+        mix(d.getheader(i), (size_t) d.getheaderlen(i));
+      }
+    if (n) { uint64_t const len = d.getsequencelen(n - 1); mix(d.getsequence(n - 1), (size_t) len); }
+    return h;
+  }
+  bool ensure(struct Parameters const & p, struct Database const & d, bool clustering)
+  {
+    uint64_t const n = d.getsequencecount();
     vsx_search_opts const want = opts_of(p, clustering);
     vsx_scoring const wsc = scoring_of(p);
-    if (S != nullptr && db == &d && count == n && first == f0 && last == fl && last_len == ll &&
+    uint64_t const fp = fingerprint(d);
+    if (M != nullptr && db == &d && count == n && mark == fp &&
         std::memcmp(&want, &o, sizeof o) == 0 && std::memcmp(&wsc, &sc, sizeof sc) == 0)
-      return;
+      return true;
     drop();
-    if (vsx_create(&ctx, &wsc, 0) != VSX_OK) die("vsx_create");
     std::vector<uint64_t> off(n), size(n);
     std::vector<uint32_t> len(n);
     std::vector<char const *> label(n);
@@ -163,10 +208,13 @@ struct Fast {
         size[i] = d.getabundance(i);
         label[i] = d.getheader(i);
       }
-    if (vsx_searcher_create(ctx, &S, &want, n, blob.data(), total, off.data(), len.data()) != VSX_OK) die("vsx_searcher_create");
     vsx_seq_meta const meta = {size.data(), label.data()};
-    if (vsx_searcher_set_meta(S, &meta) != VSX_OK) die("vsx_searcher_set_meta");
-    db = &d; count = n; first = f0; last = fl; last_len = ll; o = want; sc = wsc;
+    std::vector<int32_t> dev = wanted_devices();
+    if (clustering) dev.resize(1);               // cluster_* does not shard (sequential centroid dependency)
+    if (vsx_multi_searcher_create(&M, &wsc, dev.data(), (int32_t) dev.size(), &want, n, blob.data(), total, off.data(), len.data(), &meta) != VSX_OK)
+      { M = nullptr; return complain("vsx_multi_searcher_create"); }
+    db = &d; count = n; mark = fp; o = want; sc = wsc;
+    return true;
   }
   ~Fast() { drop(); }
 };
@@ -187,8 +235,20 @@ auto search_batch(struct Parameters const & parameters, struct Dbindex const & d
                           max_results_per_query, result_counts);
       return;
     }
-  trace("search_batch -> vsx_search_batch_meta", query_count);
-  g_search.ensure(parameters, db, false);
+  if (parameters.opt_maxaccepts == 0 || parameters.opt_maxrejects == 0)
+    {
+      // the library does not rewrite 0 into "unlimited" (search.cpp:521-529): the candidate loop of search_onequery never runs
+      trace("search_batch -> no candidates are examined (maxaccepts / maxrejects == 0)", query_count);
+      for (int k = 0; k < query_count; ++k) result_counts[k] = 0;
+      return;
+    }
+  auto reference = [&]() {
+    trace("search_batch -> reference code (fast path failed)", query_count);
+    vsxref_search_batch(parameters, dbindex, db, query_seqs, query_heads, query_lens, query_sizes, query_count, results,
+                        max_results_per_query, result_counts);
+  };
+  if (!g_search.ensure(parameters, db, false)) { reference(); return; }
+  trace("search_batch -> vsx_multi_search_batch", query_count);
   uint64_t const n = (uint64_t) query_count;
   std::vector<uint64_t> off(n), size(n);
   std::vector<uint32_t> len(n);
@@ -202,7 +262,12 @@ auto search_batch(struct Parameters const & parameters, struct Dbindex const & d
     }
   vsx_seq_meta const qmeta = {size.data(), query_heads};
   vsx_hits H;
-  if (vsx_search_batch_meta(g_search.S, n, blob.data(), total, off.data(), len.data(), &qmeta, &H) != VSX_OK) die("vsx_search_batch_meta");
+  if (vsx_multi_search_batch(g_search.M, n, blob.data(), total, off.data(), len.data(), &qmeta, &H) != VSX_OK)
+    {
+      complain("vsx_multi_search_batch");
+      reference();
+      return;
+    }
   // search_joinhits order (accepted / weak hits of both strands, best first), the first max_results of it (search.cpp:463-488)
   for (uint64_t k = 0; k < n; ++k)
     {
@@ -244,11 +309,12 @@ struct FastCluster {
 
 FastCluster * mine(struct cluster_session_s * cs) { return reinterpret_cast<FastCluster *>(cs); }
 
-void run_fast(FastCluster & c)
+bool run_fast(FastCluster & c)
 {
-  c.fast.ensure(*c.parameters, *c.db, true);
-  if (vsx_cluster_fast(c.fast.S, 0, &c.out) != VSX_OK) die("vsx_cluster_fast");
+  if (!c.fast.ensure(*c.parameters, *c.db, true)) return false;
+  if (vsx_cluster_fast(c.fast.first(), 0, &c.out) != VSX_OK) return complain("vsx_cluster_fast");
   c.have = true;
+  return true;
 }
 
 // cluster_assign_single's result record (core/cluster.cpp:1719-1750) for sequence s
@@ -312,7 +378,18 @@ auto cluster_assign_batch(struct cluster_session_s * cs, int start_seqno, int co
   FastCluster & c = *mine(cs);
   if (c.mode == FastCluster::undecided) c.mode = covered(*c.parameters, true) ? FastCluster::fast_path : FastCluster::reference_code;
   if (c.mode == FastCluster::reference_code) { vsxref_cluster_assign_batch(c.ref, start_seqno, count, results); return; }
-  if (!c.have) { trace("cluster_assign_batch -> vsx_cluster_fast", (long) c.db->getsequencecount()); run_fast(c); }
+  if (!c.have)
+    {
+      trace("cluster_assign_batch -> vsx_cluster_fast", (long) c.db->getsequencecount());
+      if (!run_fast(c))
+        {
+          // nothing has been answered from the fast path yet (this is the session's first batch): the reference's session, which
+          // cluster_session_init prepared alongside, takes over for the rest of the session
+          c.mode = FastCluster::reference_code;
+          vsxref_cluster_assign_batch(c.ref, start_seqno, count, results);
+          return;
+        }
+    }
   for (int k = 0; k < count; ++k) materialise(c, (uint64_t) (start_seqno + k), results[k]);
 }
 

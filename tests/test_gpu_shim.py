@@ -178,8 +178,8 @@ def _api_data(tmp):
     return ex
 
 
-def _api_run(argv, cwd):
-    env = dict(os.environ, VSX_ADAPTER_TRACE="1")
+def _api_run(argv, cwd, **extra_env):
+    env = dict(os.environ, VSX_ADAPTER_TRACE="1", **extra_env)
     return subprocess.run(argv, capture_output=True, text=True, timeout=600, cwd=cwd, env=env)
 
 
@@ -189,7 +189,7 @@ def test_reference_example_search_on_the_fast_path(api_binaries, tmp_path):
     ex = _api_data(str(tmp_path))
     p = _api_run([API_SEARCH], str(tmp_path))
     assert p.returncode == 0, p.stderr[-2000:]
-    assert "search_batch -> vsx_search_batch_meta" in p.stderr, p.stderr[-2000:]
+    assert "search_batch -> vsx_multi_search_batch" in p.stderr, p.stderr[-2000:]
     assert "PASS: batch search matches sequential search" in p.stderr
     got = sorted(tuple(l.split("\t")) for l in p.stdout.splitlines())
     exp = sorted((e["query"], e["target"], e["id"]) for e in ex["expected_search"])
@@ -224,7 +224,7 @@ def test_library_search_batch_equals_sequential_reference(api_binaries, tmp_path
     M._write(str(tmp_path / "q.fa"), [f"q{i}" for i in range(len(qs))], qs)
     p = _api_run([API_DRIVER, "search", str(tmp_path / "db.fa"), str(tmp_path / "q.fa"), "0.8", "3", "8", str(strand), qmask, dbmask], str(tmp_path))
     assert p.returncode == 0, (p.stdout, p.stderr[-3000:])
-    assert "search_batch -> vsx_search_batch_meta" in p.stderr
+    assert "search_batch -> vsx_multi_search_batch" in p.stderr
     n_hits = int(p.stdout.split(" queries, ")[1].split(" hits")[0])
     assert n_hits > 500 and p.stdout.strip().endswith(" 0 differences"), p.stdout
     if strand:
@@ -245,3 +245,36 @@ def test_library_cluster_batch_equals_sequential_reference(api_binaries, tmp_pat
     assert "cluster_assign_batch -> vsx_cluster_fast" in p.stderr
     assert p.stdout.strip().endswith(" 0 differences"), p.stdout
     assert int(p.stdout.split(" clusters, ")[1].split(" members")[0]) > 100
+
+
+def test_library_search_batch_on_two_replicas(api_binaries, tmp_path):
+    """VSX_DEVICES=0,0: the adapter's searcher is a vsx_multi_searcher with two database replicas (here on one GPU); the queries
+    are sharded over them and the merged result must still equal the reference's sequential search field by field"""
+    from tests import test_gpu_mask as M
+    rng = random.Random(77)
+    db = M._masked_families(rng, 50, 5, 400, 0.05, False)
+    qs = M._queries(rng, db, 301, 200, 0.04, False)
+    M._write(str(tmp_path / "db.fa"), [f"t{i}" for i in range(len(db))], db)
+    M._write(str(tmp_path / "q.fa"), [f"q{i}" for i in range(len(qs))], qs)
+    p = _api_run([API_DRIVER, "search", str(tmp_path / "db.fa"), str(tmp_path / "q.fa"), "0.8", "3", "8", "1", "dust", "dust"], str(tmp_path),
+                 VSX_DEVICES="0,0")
+    assert p.returncode == 0, (p.stdout, p.stderr[-3000:])
+    assert "search_batch -> vsx_multi_search_batch" in p.stderr
+    assert int(p.stdout.split(" queries, ")[1].split(" hits")[0]) > 300 and p.stdout.strip().endswith(" 0 differences"), p.stdout
+
+
+def test_library_zero_accepts_examines_no_candidate(api_binaries, tmp_path):
+    """maxaccepts == 0 is not 'unlimited' in the library (search.cpp:521-529 does not rewrite it): the reference's candidate loop
+    never runs (searchcore.cpp:915-918).  The adapter answers that directly; the driver compares with the reference's sequential
+    search, which must also report nothing"""
+    from tests import test_gpu_mask as M
+    rng = random.Random(78)
+    db = M._masked_families(rng, 10, 4, 300, 0.05, False)
+    qs = M._queries(rng, db, 40, 200, 0.04, False)
+    M._write(str(tmp_path / "db.fa"), [f"t{i}" for i in range(len(db))], db)
+    M._write(str(tmp_path / "q.fa"), [f"q{i}" for i in range(len(qs))], qs)
+    for ma, mr in (("0", "8"), ("2", "0")):
+        p = _api_run([API_DRIVER, "search", str(tmp_path / "db.fa"), str(tmp_path / "q.fa"), "0.8", ma, mr, "0", "none", "none"], str(tmp_path))
+        assert p.returncode == 0, (p.stdout, p.stderr[-3000:])
+        assert "no candidates are examined" in p.stderr
+        assert " 0 hits" in p.stdout and p.stdout.strip().endswith(" 0 differences"), p.stdout

@@ -434,3 +434,27 @@ def test_abundance_ratio_compare_is_exact_beyond_2_53():
             assert lib.vsx_abundance_ratio_cmp(v, ratio, ref) == expect(v, ratio, ref), (v, ratio, ref)
             n += 1
     assert n > 15000
+
+
+def test_api_adapter_falls_back_to_reference_code_without_a_device(tmp_path):
+    """a runtime failure of the fast path -- here: no GPU in this process (ROCR_VISIBLE_DEVICES empty) -- must not
+    abort the embedding process; the adapter logs it and answers with the reference's own code.  The reference's api example then
+    still prints its in-tree golden TSV and passes its own batch == sequential assertion."""
+    import subprocess
+    from tests import common
+    exe = os.path.join(ROOT, "oracle", "_ref", "example_search_vsx")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/example_search_vsx not built here (make -C oracle ref_full ref_api)")
+    ex = common.load_api_examples()
+    os.makedirs(tmp_path / "data", exist_ok=True)
+    with open(tmp_path / "data" / "chimera_ref.fasta", "w") as f:
+        f.write("".join(f">{n}\n{s}\n" for n, s in ex["refs"].items()))
+    with open(tmp_path / "data" / "chimera_queries.fasta", "w") as f:
+        f.write("".join(f">{n}\n{s}\n" for n, s in ex["queries"].items()))
+    env = dict(os.environ, VSX_ADAPTER_TRACE="1", ROCR_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "answering with the reference's code" in p.stderr and "search_batch -> reference code (fast path failed)" in p.stderr, p.stderr[-2000:]
+    assert "PASS: batch search matches sequential search" in p.stderr
+    got = sorted(tuple(l.split("\t")) for l in p.stdout.splitlines())
+    assert got == sorted((e["query"], e["target"], e["id"]) for e in ex["expected_search"])
