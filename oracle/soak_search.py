@@ -30,6 +30,9 @@ FIELDS = ["query", "target", "id", "alnlen", "mism", "opens", "exts", "raw", "ca
 MASKS = ["none", "soft", "dust"]
 
 
+WORDLENGTHS = None            # --wordlengths LO..HI: every round draws its word length from this range
+
+
 def draw_options(rng):
     """-> (SearchSession kwargs, scoring tuple or None, CLI argv)"""
     o, cli = {}, []
@@ -41,8 +44,10 @@ def draw_options(rng):
     put("id", rng.choice([0.5, 0.7, 0.8, 0.9, 0.95, 0.97]), "--id")
     put("maxaccepts", rng.choice([0, 1, 1, 2, 3, 5]), "--maxaccepts")
     put("maxrejects", rng.choice([0, 2, 8, 16, 32]), "--maxrejects")
-    if rng.random() < 0.5:
-        put("wordlength", rng.choice([3, 4, 5, 6, 7, 8, 8, 9, 10, 12]), "--wordlength")      # > 8: the host restatement of the k-mer stage
+    if WORDLENGTHS is not None:
+        put("wordlength", rng.randint(*WORDLENGTHS), "--wordlength")
+    elif rng.random() < 0.5:
+        put("wordlength", rng.choice([3, 4, 5, 6, 7, 8, 8, 9, 10, 12]), "--wordlength")      # > 8: tagged postings on the device (r03; the host restatement before)
     if rng.random() < 0.2:
         put("minwordmatches", rng.choice([0, 3, 8, 20]), "--minwordmatches")
     if rng.random() < 0.5:
@@ -129,7 +134,12 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--max-rounds", type=int, default=0, help="stop after this many rounds (0: run for --seconds): a deterministic set of rounds for a given seed")
     ap.add_argument("--only-round", type=int, default=-1, help="replay the draws, run just this round and print its whole diff")
+    ap.add_argument("--wordlengths", default="", help="LO..HI: draw every round's --wordlength from this range (e.g. 9..15: the tagged device index)")
     a = ap.parse_args()
+    if a.wordlengths:
+        global WORDLENGTHS
+        lo, hi = a.wordlengths.split("..")
+        WORDLENGTHS = (int(lo), int(hi))
     if not refcli.available():
         raise SystemExit("oracle/_ref/vsearch_ref missing: make -C oracle ref_full")
     from vsearch_amd import Aligner, SearchSession

@@ -295,6 +295,12 @@ def _kmer_case(rng, n_fam, per_fam, L, nq, qlen, iupac=0.0, **opts):
     dict(seed=4, n_fam=12, per_fam=6, L=250, nq=25, qlen=120, wordlength=3, minwordmatches=2),
     dict(seed=5, n_fam=15, per_fam=8, L=300, nq=30, qlen=100, maxaccepts=3, maxrejects=5),
     dict(seed=6, n_fam=6, per_fam=6, L=200, nq=10, qlen=80, minwordmatches=0),            # every sequence qualifies: host path
+    # word lengths 9..15 (r03): tagged postings -- buckets by a word's last eight symbols, the rest rides along as a tag
+    dict(seed=7, n_fam=14, per_fam=8, L=300, nq=30, qlen=150, wordlength=9),
+    dict(seed=8, n_fam=14, per_fam=8, L=300, nq=30, qlen=150, wordlength=10, iupac=0.01),
+    dict(seed=9, n_fam=14, per_fam=8, L=300, nq=30, qlen=150, wordlength=12, minwordmatches=3),
+    dict(seed=10, n_fam=14, per_fam=8, L=300, nq=30, qlen=150, wordlength=13, minwordmatches=2),   # (the host checker needs 8 B x 4^w: 15 is left to the CLI test below)
+    dict(seed=11, n_fam=8, per_fam=5, L=420, nq=20, qlen=400, wordlength=11, minwordmatches=4),   # > 255 words: 16-bit counters
 ])
 def test_device_kmer_candidates_equal_host(gpu_required, case):
     from vsearch_amd import Aligner, SearchSession
@@ -327,6 +333,47 @@ def test_device_kmer_multi_tile(gpu_required):
     assert host == dev
     assert all(len(h) >= 50 for h in host)
     assert any(t >= 65536 for h in host for t, _ in h) and any(t < 32768 for h in host for t, _ in h)
+
+
+@pytest.mark.gpu
+def test_device_kmer_long_words_multi_tile_and_repeats(gpu_required):
+    """tagged index (word length 12) over more than 2^15 sequences, with sequences that repeat their words many times (a word counts
+    once per sequence: unique_count, core/unique.cpp:155-352 -- the build dedups by sorting each tile's keys) and lower-case
+    (soft-masked) stretches"""
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(78)
+    anc = [common.rnd_seq(rng, 130) for _ in range(500)]
+    db = [common.mutate(rng, anc[i % 500], 0.04) for i in range(40_000)]
+    rep = common.rnd_seq(rng, 40)
+    db[5] = rep * 6                                       # every word of `rep` six times
+    db[33000] = rep * 3 + common.rnd_seq(rng, 50)
+    db[100] = db[100][:40] + db[100][40:90].lower() + db[100][90:]
+    qs = [common.mutate(rng, db[i], 0.02) for i in (0, 5, 100, 32767, 32768, 33000, 39999)] + [rep * 2]
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.5, maxaccepts=2, maxrejects=100, wordlength=12, minwordmatches=3, soft_mask=1)
+        host = ss.candidates_batch(qs, device=False)
+        dev = ss.candidates_batch(qs, device=True)
+    assert host == dev
+    assert any(t >= 32768 for h in host for t, _ in h) and any(t < 32768 for h in host for t, _ in h)
+    assert len(host[-1]) >= 2 and {5, 33000} <= {t for t, _ in host[-1]}
+
+
+@pytest.mark.parametrize("wl", [9, 12, 15])
+def test_usearch_global_long_words_match_reference_cli(gpu_required, tmp_path, wl):
+    """--wordlength 9..15 end to end against the reference CLI (the device k-mer path serves them now: VERDICT r02 missing #2)"""
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing")
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(90 + wl)
+    db, fam = common.family_db(rng, 12, 8, 350, div=0.06)
+    db += [common.rnd_seq(rng, 300) for _ in range(10)]
+    qs, src = common.queries_from_db(rng, db, 40, 180)
+    exp = run_reference(str(tmp_path), db, qs, ["--id", "0.8", "--maxaccepts", "3", "--wordlength", str(wl)])
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.8, maxaccepts=3, wordlength=wl)
+        got = ss.userout(qs, fields=FIELDS)
+    assert len(exp) > 30
+    assert got == exp, _first_diff(got, exp)
 
 
 @pytest.mark.gpu

@@ -483,6 +483,8 @@ int vsx_internal_pool_selftest(int regions, int width)
 }
 int vsx_internal_device(const vsx_ctx * ctx) { return ctx->device; }
 hipStream_t vsx_internal_stream(const vsx_ctx * ctx) { return ctx->stream; }
+// host copies of the set's lengths (the k-mer index build of long words lays its key slots out by their running sum)
+const uint32_t * vsx_internal_seqset_host_lengths(const vsx_seqset * s) { return s ? s->len.data() : nullptr; }
 void vsx_internal_seqset_device(const vsx_seqset * s, const uint8_t ** codes, const uint64_t ** off, const uint32_t ** len, uint64_t * n)
 {
   *codes = s->codes(); *off = s->d_off.p; *len = s->d_len.p; *n = s->n;

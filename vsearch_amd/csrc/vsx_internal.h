@@ -185,10 +185,15 @@ hipError_t vsx_kmer_launch_ranges(const uint64_t * bucket_start, uint32_t ntiles
 // bits = 8 | 16: counter width of the kernel (queries with <= 255 unique words take 8); slots [slot_base, slot_base + nslots) of the
 // batch (query = qlist ? qlist[slot] : slot); ranges (8-bit class, may be NULL) / rec / tile_count belong to THESE slots:
 // (slot, tile) owns rec[(slot * ntiles + tile) * subcap ..) and tile_count[slot * ntiles + tile]
-hipError_t vsx_kmer_launch_count(int bits, const uint32_t * postings, const uint64_t * bucket_start, const void * ranges,
+// tagged != 0: the index of a word length 9..15 (postings = tag << 16 | sequence, buckets by the word's low 16 bits)
+hipError_t vsx_kmer_launch_count(int bits, int tagged, const uint32_t * postings, const uint64_t * bucket_start, const void * ranges,
                                  uint32_t ntiles, uint32_t nseq, uint32_t nslots, uint32_t slot_base, const uint64_t * qk_start,
                                  const uint32_t * qk, const uint32_t * minmatch, const uint32_t * qlist, void * rec, uint32_t subcap,
                                  uint32_t * tile_count, hipStream_t st);
+hipError_t vsx_kmer_tagged_tile(int fill, const uint8_t * codes, const uint64_t * off, const uint32_t * len, uint32_t first_seq,
+                                uint32_t nseq_tile, int w, const uint8_t * lower_bits, const uint64_t * slot_of /* running sum of the lengths */, uint64_t n_slots,
+                                uint64_t * keys_a, uint64_t * keys_b, void * temp, size_t * temp_bytes, uint32_t tile, uint32_t ntiles,
+                                uint32_t * bucket_count, const uint64_t * bucket_start, uint32_t * postings, hipStream_t st);
 hipError_t vsx_kmer_launch_select(const void * rec, uint32_t subcap, uint32_t ntiles, const uint32_t * tile_count, uint32_t nslots,
                                   uint32_t keep, void * dense, unsigned long long * cursor, uint64_t capacity,
                                   void * sel_m_n, uint64_t * sel_off, hipStream_t st);

@@ -26,6 +26,7 @@
 //   heap size, so candidate lists are bit-identical to the host restatement in vsx_search.cpp.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <rocprim/device/device_radix_sort.hpp>
 #include "vsx_internal.h"
 
 typedef unsigned int u32;
@@ -128,6 +129,80 @@ vsx_kmer_sweep_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict
   // leave the bitmap clean for nobody (one sequence per wave): nothing to do
 }
 
+// ---- word lengths 9..15 (r03): TAGGED postings -------------------------------------------------------------------------------
+// A bucket table over 4^w words stops being affordable at w = 12 (4.2 GB for 31 tiles) and impossible at 15.  The index of a
+// longer word length keeps the 4^8 x ntiles table: a word goes to the bucket of its LAST EIGHT symbols (its low 16 bits) and its
+// posting carries the remaining symbols as a tag -- one dword (tag << 16 | tile-local sequence), four per 16-byte unit, pad
+// 0xFFFF8000 (a tag no word has).  The count kernel streams the bucket of a query word's low 16 bits and bumps the counter only
+// where the tag equals the word's high part: exact counts, the same kernel structure, twice the bytes of the w = 8 index per
+// posting.  Build: per tile, every position's (bucket, tag, sequence) key -> radix sort (rocPRIM: a library sort of ~32 M keys,
+// off the search path) -> adjacent equal keys are the repeats of a word inside one sequence (unique_count, core/unique.cpp:155-352)
+// -> first of each run counted / scattered.  Two passes (count, fill) like the short-word sweep.
+typedef unsigned long long u64k;
+#define KM_TAG_BUCKET_BITS 16
+__device__ __forceinline__ bool long_word_at(const uint8_t * __restrict__ s, int p, int w, u32 & word,
+                                             const uint8_t * __restrict__ lower, u64 base)
+{
+  u32 v = 0;
+  bool ok = true;
+  for (int x = 0; x < w; ++x)
+    {
+      const u32 c = s[p + x];
+      ok = ok && (c == 1u || c == 2u || c == 4u || c == 8u);
+      v = (v << 2) | ((c >> 1) - (c >> 3));
+    }
+  word = v;
+  if (lower)
+    {
+      const u64 i = base + (u64) p;
+      const uint8_t * b = lower + (i >> 3);
+      const u32 b0 = *reinterpret_cast<const u32_una *>(b);
+      const u32 wnd = (b0 >> (u32) (i & 7)) & 0xffffffu;        // 24 bits >= the 15 of a word, whatever the phase
+      ok = ok && ((wnd & ((1u << w) - 1u)) == 0u);
+    }
+  return ok;
+}
+
+// one wave per sequence of the tile: key of every position -> keys[position in the tile's blob range]; invalid positions hold ~0
+__global__ void __launch_bounds__(256)
+vsx_kmer_keys_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict__ off, const u32 * __restrict__ len, u32 first_seq,
+                     u32 nseq_tile, int w, const uint8_t * __restrict__ lower, const u64 * __restrict__ slot_of, u64k * __restrict__ keys)
+{
+  const int lane = (int) (threadIdx.x & 63);
+  const u32 local = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (local >= nseq_tile) return;
+  const u32 sid = first_seq + local;
+  const u64 base = off[sid];
+  const uint8_t * __restrict__ s = codes + base;
+  const int L = (int) len[sid];
+  u64k * __restrict__ out = keys + (slot_of[sid] - slot_of[first_seq]);        // slot_of = running sum of the lengths: any blob layout works
+  for (int p0 = 0; p0 < L; p0 += 64)
+    {
+      const int p = p0 + lane;
+      if (p >= L) break;
+      u32 word = 0;
+      u64k key = ~0ull;
+      if (p + w <= L && long_word_at(s, p, w, word, lower, base))
+        key = ((u64k) (word & 0xffffu) << 32) | ((u64k) (word >> KM_TAG_BUCKET_BITS) << 16) | (u64k) local;      // bucket | tag | tile-local sequence
+      out[p] = key;
+    }
+}
+
+// sorted keys: the first of each run of equal keys is one (word, sequence) pair
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+vsx_kmer_runs_kernel(const u64k * __restrict__ keys, u64 n, u32 tile, u32 ntiles, u32 * __restrict__ bucket_count,
+                     const u64 * __restrict__ bucket_start, u32 * __restrict__ postings)
+{
+  const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64k k = keys[i];
+  if (k == ~0ull || (i > 0 && keys[i - 1] == k)) return;
+  const size_t b = (size_t) (k >> 32) * ntiles + tile;
+  const u32 slot = atomicAdd(&bucket_count[b], 1u);
+  if (FILL) postings[4 * bucket_start[b] + slot] = (u32) (k & 0xffffffffu);       // tag << 16 | sequence; bucket_start counts 16-byte units
+}
+
 // ---- counting: the counters of one (query, tile) live in LDS; see the header comment -------------------------------------
 // Postings format (r03): a bucket is a whole number of 16-BYTE units (bucket_start counts uint4), i.e. 8 tile-local
 // indices per unit; the last unit of a bucket is padded with KM_PAD = 0x8000 -- the index of a SPARE counter one past the tile,
@@ -180,7 +255,8 @@ vsx_kmer_ranges_kernel(const u64 * __restrict__ bucket_start, u32 ntiles, const 
 // PRE = the ranges come from vsx_kmer_ranges_kernel (8-bit class); otherwise the block looks them up itself, 256 words at a time.
 // Records: (query slot, tile) owns rec[(slot * ntiles + tile) * subcap ..) and tile_count[slot * ntiles + tile] (the number of
 // counters at or above the threshold, also when it exceeds subcap: the host then repeats the slot with larger sub-regions).
-template <int BITS, bool PRE>
+// TAG = tagged postings (word lengths 9..15, see above): one dword per posting, counted where its tag equals the query word's
+template <int BITS, bool PRE, bool TAG = false>
 __global__ void __launch_bounds__(BITS == 8 ? 512 : 1024) __attribute__((amdgpu_waves_per_eu(8, 8)))     // 64 VGPRs: 32 waves per CU in both widths
 vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restrict__ bucket_start, const uint2 * __restrict__ R,
                       u32 ntiles, u32 nseq, const u64 * __restrict__ qk_start, const u32 * __restrict__ qk, const u32 * __restrict__ minmatch,
@@ -195,8 +271,10 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
   constexpr int NDW = (int) (KM_TILE / PER);                      // dwords of real counters
   constexpr int BPW = 256 / WAVES;                                // buckets per wave and chunk of 256 words
   static_assert(!PRE || BITS == 8, "the range table is laid out for 8 waves");
+  static_assert(!(PRE && TAG), "tagged indexes look their ranges up in the block");
   __shared__ __attribute__((aligned(16))) u32 cnt[NDW + 4];       // + the spare dword the pad index lands in
   __shared__ uint2 rng[PRE ? 1 : 256];                            // !PRE: (first unit, units) of each selected bucket
+  __shared__ u32 tagL[TAG ? 256 : 1];                             // TAG: the high part of each selected word
   __shared__ u32 wave_hits[WAVES];
   const int tid = (int) threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 srel = blockIdx.x, slot = srel + slot_base, tile = blockIdx.y;        // srel indexes R / rec / tile_count
@@ -210,6 +288,7 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
     }
   // the wave's bucket ranges: lane j holds bucket wave + WAVES * j of the chunk (PRE: straight from the table)
   uint2 mine_rng = make_uint2(0u, 0u);
+  u32 mine_tag = 0;
   if (PRE && lane < BPW) mine_rng = R[((size_t) tile * nslots + srel) * 256 + (u32) (wave * BPW + lane)];
   const u32 base = tile << KM_TILE_SHIFT;
   {
@@ -231,23 +310,33 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
           if (tid < 256)
             {
               uint2 r = make_uint2(0u, 0u);
+              u32 tg = 0;
               if (chunk + tid < nk)
                 {
-                  const size_t b = (size_t) qk[k0 + chunk + tid] * ntiles + tile;
+                  const u32 word = qk[k0 + chunk + tid];
+                  const size_t b = (size_t) (TAG ? (word & 0xffffu) : word) * ntiles + tile;
                   const u64 first = bucket_start[b];
                   r = make_uint2((u32) first, (u32) (bucket_start[b + 1] - first));
+                  tg = word >> KM_TAG_BUCKET_BITS;
                 }
               rng[tid] = r;
+              if (TAG) tagL[tid] = tg;
             }
           __syncthreads();
           mine_rng = (lane < BPW) ? rng[wave + WAVES * lane] : make_uint2(0u, 0u);
+          if (TAG) mine_tag = (lane < BPW) ? tagL[wave + WAVES * lane] : 0u;
         }
       // Wave w takes the buckets w, w + WAVES, ...; the loop below broadcasts lane j's range with v_readlane -- the streaming
       // loop touches the LDS with ds_add_u32 ONLY
       u32 sink = 0;
-      auto consume = [&](const uint4 & v) __attribute__((always_inline)) {
+      auto consume = [&](const uint4 & v, u32 tag) __attribute__((always_inline)) {
         const u32 w4[4] = {v.x, v.y, v.z, v.w};
         if (probe & 1) sink ^= w4[0] + w4[1] + w4[2] + w4[3];
+        else if (TAG)
+          {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) if ((w4[d] >> 16) == tag) bump(w4[d] & 0xffffu);
+          }
         else
           {
 #pragma unroll
@@ -283,7 +372,7 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
           if (more) fetch(j0 + KM_LOADS, nxt, non);
 #pragma unroll
           for (int u = 0; u < KM_LOADS; ++u)
-            if (con[u]) consume(cur[u]);
+            if (con[u]) consume(cur[u], TAG && j0 + u < BPW ? (u32) __builtin_amdgcn_readlane((int) mine_tag, j0 + u) : 0u);
           // tails of this trip's buckets (rare for sizes around one wave-load; wave-uniform trip counts)
 #pragma unroll
           for (int u = 0; u < KM_LOADS; ++u)
@@ -293,7 +382,8 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
                 if (n > 64u)
                   {
                     const u32 r0 = (u32) __builtin_amdgcn_readlane((int) mine_rng.x, j0 + u);
-                    for (u32 i = 64u + (u32) lane; i < n; i += 64u) consume(unit(r0 + i));
+                    const u32 tg = TAG ? (u32) __builtin_amdgcn_readlane((int) mine_tag, j0 + u) : 0u;
+                    for (u32 i = 64u + (u32) lane; i < n; i += 64u) consume(unit(r0 + i), tg);
                   }
               }
           if (more)
@@ -529,7 +619,7 @@ extern "C" hipError_t vsx_kmer_launch_ranges(const uint64_t * bucket_start, uint
   return hipGetLastError();
 }
 
-extern "C" hipError_t vsx_kmer_launch_count(int bits, const uint32_t * postings, const uint64_t * bucket_start, const void * ranges,
+extern "C" hipError_t vsx_kmer_launch_count(int bits, int tagged, const uint32_t * postings, const uint64_t * bucket_start, const void * ranges,
                                             uint32_t ntiles, uint32_t nseq, uint32_t nslots, uint32_t slot_base, const uint64_t * qk_start,
                                             const uint32_t * qk, const uint32_t * minmatch, const uint32_t * qlist, void * rec, uint32_t subcap,
                                             uint32_t * tile_count, hipStream_t st)
@@ -537,18 +627,39 @@ extern "C" hipError_t vsx_kmer_launch_count(int bits, const uint32_t * postings,
   // slots [slot_base, slot_base + nslots) of the batch; ranges / rec / tile_count belong to THESE slots (indexed from 0)
   if (nslots == 0 || nseq == 0) return hipSuccess;
   static const int probe = std::getenv("VSX_KMER_PROBE") ? std::atoi(std::getenv("VSX_KMER_PROBE")) : 0;
-  if (bits == 8 && ranges)
-    hipLaunchKernelGGL((vsx_kmer_count_kernel<8, true>), dim3(nslots, ntiles), dim3(512), 0, st, (const uint4 *) postings,
-                       (const u64 *) bucket_start, (const uint2 *) ranges, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base,
-                       nslots, (uint2 *) rec, subcap, tile_count, probe);
-  else if (bits == 8)
-    hipLaunchKernelGGL((vsx_kmer_count_kernel<8, false>), dim3(nslots, ntiles), dim3(512), 0, st, (const uint4 *) postings,
-                       (const u64 *) bucket_start, (const uint2 *) nullptr, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base,
-                       nslots, (uint2 *) rec, subcap, tile_count, probe);
+#define KM_ARGS (const uint4 *) postings, (const u64 *) bucket_start, (const uint2 *) ranges, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base, \
+                nslots, (uint2 *) rec, subcap, tile_count, probe
+  if (tagged && bits == 8) hipLaunchKernelGGL((vsx_kmer_count_kernel<8, false, true>), dim3(nslots, ntiles), dim3(512), 0, st, KM_ARGS);
+  else if (tagged) hipLaunchKernelGGL((vsx_kmer_count_kernel<16, false, true>), dim3(nslots, ntiles), dim3(1024), 0, st, KM_ARGS);
+  else if (bits == 8 && ranges) hipLaunchKernelGGL((vsx_kmer_count_kernel<8, true>), dim3(nslots, ntiles), dim3(512), 0, st, KM_ARGS);
+  else if (bits == 8) hipLaunchKernelGGL((vsx_kmer_count_kernel<8, false>), dim3(nslots, ntiles), dim3(512), 0, st, KM_ARGS);
+  else hipLaunchKernelGGL((vsx_kmer_count_kernel<16, false>), dim3(nslots, ntiles), dim3(1024), 0, st, KM_ARGS);
+#undef KM_ARGS
+  return hipGetLastError();
+}
+
+// One tile of a tagged index build (word lengths 9..15): keys of the tile's positions -> sorted -> runs counted (fill == 0) or
+// scattered (fill != 0).  temp == nullptr: only *temp_bytes (the sort's scratch for n_slots keys) is set.
+extern "C" hipError_t vsx_kmer_tagged_tile(int fill, const uint8_t * codes, const uint64_t * off, const uint32_t * len, uint32_t first_seq,
+                                           uint32_t nseq_tile, int w, const uint8_t * lower_bits, const uint64_t * slot_of, uint64_t n_slots,
+                                           uint64_t * keys_a, uint64_t * keys_b, void * temp, size_t * temp_bytes, uint32_t tile, uint32_t ntiles,
+                                           uint32_t * bucket_count, const uint64_t * bucket_start, uint32_t * postings, hipStream_t st)
+{
+  if (!temp)
+    return rocprim::radix_sort_keys(nullptr, *temp_bytes, (u64k *) keys_a, (u64k *) keys_b, (size_t) n_slots, 0, 48, st);
+  if (n_slots == 0 || nseq_tile == 0) return hipSuccess;
+  hipLaunchKernelGGL(vsx_kmer_keys_kernel, dim3((nseq_tile + 3) / 4), dim3(256), 0, st, codes, (const u64 *) off, len, first_seq, nseq_tile, w,
+                     lower_bits, (const u64 *) slot_of, (u64k *) keys_a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if ((e = rocprim::radix_sort_keys(temp, *temp_bytes, (u64k *) keys_a, (u64k *) keys_b, (size_t) n_slots, 0, 48, st)) != hipSuccess) return e;
+  const dim3 grid((unsigned) ((n_slots + 255) / 256));
+  if (fill)
+    hipLaunchKernelGGL(vsx_kmer_runs_kernel<true>, grid, dim3(256), 0, st, (const u64k *) keys_b, (u64) n_slots, tile, ntiles, bucket_count,
+                       (const u64 *) bucket_start, postings);
   else
-    hipLaunchKernelGGL((vsx_kmer_count_kernel<16, false>), dim3(nslots, ntiles), dim3(1024), 0, st, (const uint4 *) postings,
-                       (const u64 *) bucket_start, (const uint2 *) nullptr, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base,
-                       nslots, (uint2 *) rec, subcap, tile_count, probe);
+    hipLaunchKernelGGL(vsx_kmer_runs_kernel<false>, grid, dim3(256), 0, st, (const u64k *) keys_b, (u64) n_slots, tile, ntiles, bucket_count,
+                       (const u64 *) bucket_start, postings);
   return hipGetLastError();
 }
 

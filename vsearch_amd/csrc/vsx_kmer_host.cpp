@@ -19,6 +19,7 @@ extern "C" void vsx_internal_seqset_device(const vsx_seqset * s, const uint8_t *
                                            const uint32_t ** len, uint64_t * n);
 // the set's case bitmap (soft masking) or NULL: an index over a set that has one leaves out every word over a lower-case symbol
 extern "C" const uint8_t * vsx_internal_seqset_lower(const vsx_seqset * s);
+extern "C" const uint32_t * vsx_internal_seqset_host_lengths(const vsx_seqset * s);
 
 namespace {
 
@@ -73,6 +74,7 @@ struct VsxKmerIndex {
   int device = 0;
   hipStream_t st = nullptr;
   int w = 8;
+  bool tagged = false;            // word lengths 9..15: buckets by the word's low 16 bits, postings carry the rest as a tag (vsx_kmer.hip)
   uint32_t nseq = 0, ntiles = 0;
   uint64_t nbuckets = 0;
   Buf<uint64_t> d_start;          // nbuckets + 1
@@ -108,9 +110,10 @@ int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIn
 {
   if (!ctx || !db || !out) { vsx_internal_set_error("vsx_kmer_index_create: null argument"); return VSX_EINVAL; }
   *out = nullptr;
-  if (w < 3 || w > 8) { vsx_internal_set_error("vsx_kmer_index_create: device index supports word lengths 3..8"); return VSX_EINVAL; }
+  if (w < 3 || w > 15) { vsx_internal_set_error("vsx_kmer_index_create: device index supports word lengths 3..15"); return VSX_EINVAL; }
   std::unique_ptr<VsxKmerIndex> ix(new VsxKmerIndex);
   ix->ctx = ctx; ix->db = db; ix->device = vsx_internal_device(ctx); ix->st = vsx_internal_stream(ctx); ix->w = w;
+  ix->tagged = w > 8;
   ix->make_stream();
   KCHK(hipSetDevice(ix->device));
   KCHK(hipEventCreate(&ix->e0));
@@ -148,10 +151,12 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   KCHK(hipSetDevice(ix->device));
   const int w = ix->w;
   const uint32_t shift = vsx_kmer_tile_shift();
+  if (ix->tagged && list) { vsx_internal_set_error("vsx_kmer_index_rebuild: subset indexes exist for word lengths 3..8 only"); return VSX_EINVAL; }
+  const uint64_t nwords = ix->tagged ? (1ull << 16) : (1ull << (2 * w));          // rows of the bucket table
   ix->nseq = (uint32_t) n;
   ix->ntiles = std::max<uint32_t>(1, (uint32_t) ((n + (1ull << shift) - 1) >> shift));
-  ix->nbuckets = (1ull << (2 * w)) * ix->ntiles;
-  ix->word_total.assign(1ull << (2 * w), 0);
+  ix->nbuckets = nwords * ix->ntiles;
+  ix->word_total.assign(nwords, 0);
   ix->stats.postings = 0;
   if (n == 0) return VSX_OK;
   const uint32_t * d_list = nullptr;
@@ -165,6 +170,43 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   KCHK(ix->d_start.ensure(ix->nbuckets + 1));
   KCHK(hipEventRecord(ix->e0, ix->st));
   KCHK(hipMemsetAsync(ix->d_count.p, 0, ix->nbuckets * 4, ix->st));
+  // tagged build (word lengths 9..15): per tile keys -> sort -> runs; scratch for the largest tile
+  Buf<uint64_t> d_slot, d_keys_a, d_keys_b;
+  Buf<uint8_t> d_sort_temp;
+  std::vector<uint64_t> slot_of;
+  size_t sort_bytes = 0;
+  auto tagged_pass = [&](int fill) -> int {
+    for (uint32_t t = 0; t < ix->ntiles; ++t)
+      {
+        const uint64_t first = (uint64_t) t << shift, last = std::min<uint64_t>(n, first + (1ull << shift));
+        KCHK(vsx_kmer_tagged_tile(fill, codes, off, len, (uint32_t) first, (uint32_t) (last - first), w, vsx_internal_seqset_lower(ix->db), d_slot.p,
+                                  slot_of[last] - slot_of[first], d_keys_a.p, d_keys_b.p, d_sort_temp.p, &sort_bytes, t, ix->ntiles, ix->d_count.p,
+                                  ix->d_start.p, ix->d_post.p, ix->st));
+      }
+    return VSX_OK;
+  };
+  if (ix->tagged)
+    {
+      const uint32_t * hl = vsx_internal_seqset_host_lengths(ix->db);
+      slot_of.assign(n + 1, 0);
+      uint64_t widest = 0;
+      for (uint64_t i = 0; i < n; ++i) slot_of[i + 1] = slot_of[i] + hl[i];
+      for (uint32_t t = 0; t < ix->ntiles; ++t)
+        {
+          const uint64_t first = (uint64_t) t << shift, last = std::min<uint64_t>(n, first + (1ull << shift));
+          widest = std::max(widest, slot_of[last] - slot_of[first]);
+        }
+      KCHK(d_slot.alloc(n + 1));
+      KCHK(hipMemcpyAsync(d_slot.p, slot_of.data(), (n + 1) * 8, hipMemcpyHostToDevice, ix->st));
+      KCHK(d_keys_a.alloc(std::max<uint64_t>(widest, 1)));
+      KCHK(d_keys_b.alloc(std::max<uint64_t>(widest, 1)));
+      KCHK(vsx_kmer_tagged_tile(0, nullptr, nullptr, nullptr, 0, 0, w, nullptr, nullptr, widest, d_keys_a.p, d_keys_b.p, nullptr, &sort_bytes, 0, ix->ntiles,
+                                nullptr, nullptr, nullptr, ix->st));
+      KCHK(d_sort_temp.alloc(sort_bytes + 16));
+      const int prc = tagged_pass(0);
+      if (prc != VSX_OK) return prc;
+    }
+  else
   KCHK(vsx_kmer_launch_sweep(0, codes, off, len, d_list, ix->nseq, w, ix->ntiles, ix->d_count.p, nullptr, nullptr, vsx_internal_seqset_lower(ix->db), ix->st));
   // bucket table: exclusive prefix sum on the host (4^w x ntiles entries: 8 MB for 1 M sequences, w = 8)
   std::vector<uint32_t> & cnt = ix->h_count;
@@ -174,13 +216,15 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   std::vector<uint64_t> & start = ix->h_start;
   start.resize(ix->nbuckets + 1);
   uint64_t acc = 0;
-  // a bucket holds 16-bit tile-local indices in 16-byte units of eight: start[] counts UNITS, the last unit of a bucket is padded
-  // with 0x8000 = the spare counter past the tile (vsx_kmer.hip KM_PAD): the count kernel streams units without any sentinel test
+  // a bucket holds 16-bit tile-local indices in 16-byte units of eight (tagged: dwords tag << 16 | index, units of four):
+  // start[] counts UNITS, the last unit of a bucket is padded with 0x8000 = the spare counter past the tile (vsx_kmer.hip KM_PAD;
+  // tagged: 0xFFFF8000, a tag no word has): the count kernel streams units without any sentinel test
+  const uint32_t per_unit = ix->tagged ? 4u : 8u;
   uint64_t entries = 0;
   {
     // buckets are word-major: b = word * ntiles + tile (nested loops: no division per bucket -- clustering rebuilds the index
     // once per round)
-    const uint64_t nwords = 1ull << (2 * w), nt = ix->ntiles;
+    const uint64_t nt = ix->ntiles;
     uint64_t b = 0;
     for (uint64_t word = 0; word < nwords; ++word)
       {
@@ -188,7 +232,7 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
         for (uint64_t t = 0; t < nt; ++t, ++b)
           {
             start[b] = acc;
-            acc += (cnt[b] + 7u) / 8u;
+            acc += (cnt[b] + per_unit - 1) / per_unit;
             tot += cnt[b];
           }
         ix->word_total[word] = tot;
@@ -196,10 +240,17 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
       }
   }
   start[ix->nbuckets] = acc;
+  if (acc >= (1ull << 32)) { vsx_internal_set_error("vsx_kmer_index_rebuild: more than 64 GB of postings (32-bit unit addresses)"); return VSX_EINVAL; }
   KCHK(ix->d_post.ensure(acc * 4));                    // dwords
-  if (acc) KCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->d_post.p), (int) 0x80008000u, acc * 4, ix->st));
+  if (acc) KCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->d_post.p), (int) (ix->tagged ? 0xFFFF8000u : 0x80008000u), acc * 4, ix->st));
   KCHK(hipMemcpyAsync(ix->d_start.p, start.data(), (ix->nbuckets + 1) * 8, hipMemcpyHostToDevice, ix->st));
   KCHK(hipMemsetAsync(ix->d_count.p, 0, ix->nbuckets * 4, ix->st));
+  if (ix->tagged)
+    {
+      const int prc = tagged_pass(1);
+      if (prc != VSX_OK) return prc;
+    }
+  else
   KCHK(vsx_kmer_launch_sweep(1, codes, off, len, d_list, ix->nseq, w, ix->ntiles, ix->d_count.p, ix->d_start.p, ix->d_post.p, vsx_internal_seqset_lower(ix->db), ix->st));
   KCHK(hipEventRecord(ix->e1, ix->st));
   KCHK(hipStreamSynchronize(ix->st));
@@ -208,7 +259,6 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   ix->stats.build_ms = ms;
   ix->stats.postings = entries;
   ix->stats.index_bytes = acc * 16 + (ix->nbuckets + 1) * 8;
-  if (acc >= (1ull << 32)) { vsx_internal_set_error("vsx_kmer_index_rebuild: more than 64 GB of postings (32-bit unit addresses)"); return VSX_EINVAL; }
   return VSX_OK;
 }
 
@@ -234,14 +284,16 @@ int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, uint32_t n8
   KCHK(sc->d_tilecnt.ensure((size_t) nslots * nt));
   KCHK(sc->d_sel_mn.ensure(nslots));
   KCHK(sc->d_sel_off.ensure(nslots));
-  static const bool no_pre = std::getenv("VSX_KMER_NO_RANGES") != nullptr;       // A/B: the blocks look their ranges up themselves
+  static const bool no_pre_env = std::getenv("VSX_KMER_NO_RANGES") != nullptr;   // A/B: the blocks look their ranges up themselves
+  const bool no_pre = no_pre_env || ix->tagged;                                   // tagged indexes (word lengths 9..15) always do
+  const int tg = ix->tagged ? 1 : 0;
   if (n8 && !no_pre) KCHK(sc->d_ranges.ensure((size_t) n8 * nt * 256));
   KCHK(hipEventRecord(sc->e0, sc->st));
   if (n8 && !no_pre)
     KCHK(vsx_kmer_launch_ranges(ix->d_start.p, nt, sc->d_qk_start.p, sc->d_qk.p, sc->d_minmatch.p, d_qlist, n8, sc->d_ranges.p, sc->st));
-  KCHK(vsx_kmer_launch_count(8, ix->d_post.p, ix->d_start.p, (n8 && !no_pre) ? sc->d_ranges.p : nullptr, nt, ix->nseq, n8, 0, sc->d_qk_start.p, sc->d_qk.p,
+  KCHK(vsx_kmer_launch_count(8, tg, ix->d_post.p, ix->d_start.p, (n8 && !no_pre) ? sc->d_ranges.p : nullptr, nt, ix->nseq, n8, 0, sc->d_qk_start.p, sc->d_qk.p,
                              sc->d_minmatch.p, d_qlist, sc->d_rec.p, subcap, sc->d_tilecnt.p, sc->st));
-  KCHK(vsx_kmer_launch_count(16, ix->d_post.p, ix->d_start.p, nullptr, nt, ix->nseq, nslots - n8, n8, sc->d_qk_start.p, sc->d_qk.p,
+  KCHK(vsx_kmer_launch_count(16, tg, ix->d_post.p, ix->d_start.p, nullptr, nt, ix->nseq, nslots - n8, n8, sc->d_qk_start.p, sc->d_qk.p,
                              sc->d_minmatch.p, d_qlist, sc->d_rec.p + (size_t) n8 * nt * subcap, subcap, sc->d_tilecnt.p + (size_t) n8 * nt, sc->st));
   uint64_t capacity = std::max<uint64_t>(sc->d_dense.n, std::max<uint64_t>(1u << 20, (uint64_t) nslots * 128));
   unsigned long long produced = 0;
@@ -329,7 +381,7 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
   KmerScratch * sc = lease.sc;
   const uint64_t nk = qk_start[nq];
   uint64_t increments = 0;
-  for (uint64_t x = 0; x < nk; ++x) increments += ix->word_total[qk[x]];
+  for (uint64_t x = 0; x < nk; ++x) increments += ix->word_total[ix->tagged ? (qk[x] & 0xffffu) : qk[x]];        // postings streamed
   sc->records = 0;
   KCHK(sc->d_qk_start.ensure(nq + 1));
   KCHK(sc->d_qk.ensure(nk));

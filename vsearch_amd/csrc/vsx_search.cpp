@@ -732,13 +732,15 @@ static void build_index(vsx_searcher * S)
   S->indexed = true;
 }
 
-// The device path covers what the tiled 16-bit counters can hold: word lengths 3..8, hard masking (words are derived from
-// the 4-bit codes), at least one sequence.  VSX_KMER=host forces the host threads.
+// The device path covers every word length the reference accepts (3..15, cli.cc:2934,4198; dbindex.cpp:176-177): 3..8 with one
+// bucket per word, 9..15 with tagged postings (vsx_kmer.hip); at least one sequence.  VSX_KMER=host forces the host threads.
 static bool device_kmer_ok(const vsx_searcher & S)
 {
   static const bool forced_host = std::getenv("VSX_KMER") && std::strcmp(std::getenv("VSX_KMER"), "host") == 0;
-  return !forced_host && S.w >= 3 && S.w <= 8 && !S.len.empty();
+  return !forced_host && S.w >= 3 && S.w <= 15 && !S.len.empty();
 }
+// clustering rebuilds SUBSET indexes (centroids, round members) every round: those exist for the one-bucket-per-word form only
+static bool device_kmer_subsets_ok(const vsx_searcher & S) { return device_kmer_ok(S) && S.w <= 8; }
 
 struct KmerAcct { double kernel_ms = 0, build_ms = 0; uint64_t streamed = 0, postings = 0; };
 
@@ -1064,7 +1066,7 @@ int vsx_search_candidates_batch(vsx_searcher * S, int32_t device, uint64_t nq, c
   for (uint64_t i = 0; i < nq; ++i)
     if (qoff[i] + qlen[i] > qbytes) return sfail(VSX_EINVAL, "vsx_search_candidates_batch: query exceeds the blob");
   if (device && !device_kmer_ok(*S))
-    return sfail(VSX_EINVAL, "vsx_search_candidates_batch: the device path needs wordlength 3..8 and a non-empty database");
+    return sfail(VSX_EINVAL, "vsx_search_candidates_batch: the device path needs wordlength 3..15 and a non-empty database");
   const double t0 = now_s();
   std::vector<std::vector<Cand>> cands;
   KmerAcct acct;
@@ -1739,7 +1741,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
 
   // device k-mer counting (vsx_kmer.hip): one index over the centroids, rebuilt when a round added some, and one over the
   // members of the current round (the intra-round shared-word counts of evaluate_extra_hits)
-  const bool dev_kmer = device_kmer_ok(*S);
+  const bool dev_kmer = device_kmer_subsets_ok(*S);
   struct IxDel { void operator()(VsxKmerIndex * p) const { vsx_kmer_index_destroy(p); } };
   // The centroid index grows by up to `round` sequences per round (Dbindex::add_sequence, cluster.cpp:1009).  Rebuilding it
   // every round cost 15 % of a 1 M-sequence run and grows quadratically; instead a MAIN index is rebuilt only when the DELTA
