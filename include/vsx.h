@@ -113,6 +113,7 @@ typedef struct vsx_plan_info {
   uint64_t tasks_tracked;   /* ... in the TRACK class (overflow rule evaluated, saturating arithmetic)      */
   uint32_t rows_dominant;   /* query rows per lane (R) of the launch with the most tasks                   */
   uint32_t chunks;          /* checkpoint-buffer chunks the plan runs in                                    */
+  uint64_t tasks_max3;      /* ... of the tilted ones in the MAX3 sub-class (15-bit range, v_pk_maximum3_f16)       */
 } vsx_plan_info;
 
 const char * vsx_version_string(void);

@@ -153,16 +153,28 @@ class Reference:
         return tuple(x.value for x in v) + (s,)
 
     def time_groups(self, qblob, qoff, qlen, tblob, toff, tlen, gq, goff, tidx, threads=1):
-        """Time the reference SSE2 search16 over query groups -> (seconds, cells, checksum)."""
+        """Time the reference SSE2 search16 over query groups -> (seconds, cells, checksum); self.last_digest = the
+        order-independent hash over every field of every pair incl. the CIGAR text (ref_driver.cc pair_digest)."""
         qoff = np.ascontiguousarray(qoff, np.uint64); qlen = np.ascontiguousarray(qlen, np.uint32)
         toff = np.ascontiguousarray(toff, np.uint64); tlen = np.ascontiguousarray(tlen, np.uint32)
         gq = np.ascontiguousarray(gq, np.uint32); goff = np.ascontiguousarray(goff, np.uint64)
         tidx = np.ascontiguousarray(tidx, np.uint32)
         p = lambda x: x.ctypes.data_as(C.c_void_p)
-        cells = C.c_uint64(); chk = C.c_int64()
+        cells = C.c_uint64(); chk = C.c_int64(); dig = C.c_uint64()
         secs = self.lib.vsref_time_groups(
             _P(self.P), int(self.nmm), C.c_char_p(bytes(qblob)), p(qoff), p(qlen),
             C.c_char_p(bytes(tblob)), p(toff), p(tlen), C.c_uint32(len(tlen)),
             C.c_uint32(len(gq)), p(gq), p(goff), p(tidx), C.c_int(threads),
-            C.byref(cells), C.byref(chk))
+            C.byref(cells), C.byref(chk), C.byref(dig))
+        self.last_digest = int(dig.value)
         return float(secs), int(cells.value), int(chk.value)
+
+    def digest_results(self, first_pair, score, aligned, matches, mismatches, gaps, cigar_blob_ptr, cigar_off):
+        """the same hash over a result block as libvsx hands it out (raw arrays + CIGAR blob pointer + offsets)"""
+        n = len(score)
+        a = lambda x, t: np.ascontiguousarray(x, t)
+        sc, al, ma, mi, ga, of = a(score, np.int16), a(aligned, np.uint16), a(matches, np.uint16), a(mismatches, np.uint16), a(gaps, np.uint16), a(cigar_off, np.uint64)
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        self.lib.vsref_digest_results.restype = C.c_uint64
+        self.lib.vsref_digest_results.argtypes = [C.c_uint64, C.c_uint64] + [C.c_void_p] * 7
+        return int(self.lib.vsref_digest_results(n, first_pair, p(sc), p(al), p(ma), p(mi), p(ga), cigar_blob_ptr, p(of)))

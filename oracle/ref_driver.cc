@@ -32,6 +32,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <cstring>
 #include <limits>
 #include <thread>
 #include <vector>
@@ -200,16 +201,41 @@ void vsref_lma(void * ctx, const char * q, int qlen, const char * t, int tlen,
 
   Sequences are given as one ASCII blob + offsets/lengths.  Groups: query g has
   targets tidx[goff[g] .. goff[g+1]).  Returns wall seconds; *cells receives
-  sum(Q*D) over all pairs, *checksum a simple sum of scores (defeats DCE and
-  lets the caller cross-check against the GPU path).
+  sum(Q*D) over all pairs, *checksum a simple sum of scores (defeats DCE),
+  *digest an order-independent hash of EVERY field of every pair -- pair number,
+  score, aligned, matches, mismatches, gaps and the CIGAR text -- that the caller
+  compares with vsref_digest_results() over the GPU path's results for the same pairs.
 */
+static inline uint64_t pair_digest(uint64_t pair, int16_t score, uint16_t aligned, uint16_t matches, uint16_t mismatches,
+                                   uint16_t gaps, char const * cigar)
+{
+  uint64_t h = 14695981039346656037ull;
+  auto mix = [&h](void const * p, size_t n) {
+    auto const * c = static_cast<unsigned char const *>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+  };
+  mix(&pair, 8); mix(&score, 2); mix(&aligned, 2); mix(&matches, 2); mix(&mismatches, 2); mix(&gaps, 2);
+  if (cigar != nullptr) mix(cigar, std::strlen(cigar));
+  return h;
+}
+
+/* the same digest over result arrays as libvsx hands them out (pairs first_pair .. first_pair + n - 1; cigar k at blob + off[k]) */
+uint64_t vsref_digest_results(uint64_t n, uint64_t first_pair, const int16_t * score, const uint16_t * aligned, const uint16_t * matches,
+                              const uint16_t * mismatches, const uint16_t * gaps, const char * blob, const uint64_t * off)
+{
+  uint64_t d = 0;
+  for (uint64_t k = 0; k < n; ++k)
+    d += pair_digest(first_pair + k, score[k], aligned[k], matches[k], mismatches[k], gaps[k], blob + off[k]);
+  return d;
+}
+
 double vsref_time_groups(const int64_t * P, int n_mismatch,
                          const char * qblob, const uint64_t * qoff, const uint32_t * qlen,
                          const char * tblob, const uint64_t * toff, const uint32_t * tlen,
                          uint32_t n_targets_total,
                          uint32_t n_groups, const uint32_t * gq, const uint64_t * goff,
                          const uint32_t * tidx, int threads,
-                         uint64_t * cells, int64_t * checksum)
+                         uint64_t * cells, int64_t * checksum, uint64_t * digest)
 {
   /* one shared read-only Database holding every target (as the reference does) */
   Database db;
@@ -223,6 +249,7 @@ double vsref_time_groups(const int64_t * P, int n_mismatch,
   std::atomic<uint32_t> next {0};
   std::atomic<uint64_t> tot_cells {0};
   std::atomic<int64_t> tot_sum {0};
+  std::atomic<uint64_t> tot_digest {0};
   std::atomic<int> ready {0};
   std::atomic<bool> go {false};
   bool const nmm = (n_mismatch != 0);
@@ -230,7 +257,7 @@ double vsref_time_groups(const int64_t * P, int n_mismatch,
 
   auto run_group = [&](s16info_s * s, uint32_t gi, std::vector<char> & qbuf, std::vector<int16_t> & sc,
                        std::vector<uint16_t> & a, std::vector<uint16_t> & m, std::vector<uint16_t> & mm,
-                       std::vector<uint16_t> & g, std::vector<char *> & cg, uint64_t & my_cells, int64_t & my_sum) {
+                       std::vector<uint16_t> & g, std::vector<char *> & cg, uint64_t & my_cells, int64_t & my_sum, uint64_t & my_digest) {
     uint32_t const qi = gq[gi];
     uint64_t const b = goff[gi];
     uint64_t const e = goff[gi + 1];
@@ -244,6 +271,7 @@ double vsref_time_groups(const int64_t * P, int n_mismatch,
       {
         my_cells += static_cast<uint64_t>(qlen[qi]) * tlen[tidx[b + k]];
         my_sum += sc[k] + a[k] + m[k];
+        my_digest += pair_digest(b + k, sc[k], a[k], m[k], mm[k], g[k], cg[k]);
         std::free(cg[k]);
       }
   };
@@ -254,13 +282,13 @@ double vsref_time_groups(const int64_t * P, int n_mismatch,
     std::vector<int16_t> sc;
     std::vector<uint16_t> a, m, mm, g;
     std::vector<char *> cg;
-    uint64_t my_cells = 0;
+    uint64_t my_cells = 0, my_digest = 0;
     int64_t my_sum = 0;
     if (n_groups > 0)
       {
         /* untimed warm-up: sizes this thread's direction/cigar buffers (first-touch page faults) */
-        uint64_t wc = 0; int64_t ws = 0;
-        run_group(s, 0, qbuf, sc, a, m, mm, g, cg, wc, ws);
+        uint64_t wc = 0, wd = 0; int64_t ws = 0;
+        run_group(s, 0, qbuf, sc, a, m, mm, g, cg, wc, ws, wd);
       }
     ready.fetch_add(1);
     while (!go.load(std::memory_order_acquire)) { std::this_thread::yield(); }
@@ -268,11 +296,12 @@ double vsref_time_groups(const int64_t * P, int n_mismatch,
       {
         uint32_t const gi = next.fetch_add(1);
         if (gi >= n_groups) { break; }
-        run_group(s, gi, qbuf, sc, a, m, mm, g, cg, my_cells, my_sum);
+        run_group(s, gi, qbuf, sc, a, m, mm, g, cg, my_cells, my_sum, my_digest);
       }
     search16_exit(s);
     tot_cells += my_cells;
     tot_sum += my_sum;
+    tot_digest += my_digest;
   };
 
   std::vector<std::thread> pool;
@@ -284,6 +313,7 @@ double vsref_time_groups(const int64_t * P, int n_mismatch,
   auto const t1 = std::chrono::steady_clock::now();
   *cells = tot_cells.load();
   *checksum = tot_sum.load();
+  if (digest != nullptr) { *digest = tot_digest.load(); }
   return std::chrono::duration<double>(t1 - t0).count();
 }
 

@@ -70,6 +70,10 @@
 #define I_MOVDPP(x)   "v_mov_b32_dpp " #x ", %16 row_ror:15 row_mask:0xf bank_mask:0xf\n"
 #define I_ADDDPP(x)   "v_add_u32_dpp " #x ", %16, " #x " row_shr:1 row_mask:0xf bank_mask:0xf\n"
 #define I_MOV64(x)    "v_mov_b64 %18, %19\n"
+#define I_PKMAX3F(x)  "v_pk_maximum3_f16 " #x ", " #x ", %16, %17\n"
+#define I_PKMAXU(x)   "v_pk_max_u16 " #x ", " #x ", %16\n"
+#define I_MIXAM(x)    "v_add_u32 " #x ", " #x ", %16\n" "v_pk_max_u16 " #x ", " #x ", %17\n"
+#define I_MIXAM3(x)   "v_add_u32 " #x ", " #x ", %16\n" "v_pk_maximum3_f16 " #x ", " #x ", %16, %17\n"
 
 #define DEFK(NAME, INS) \
   __global__ void __launch_bounds__(256) NAME(int iters, int * out, int seed) { \
@@ -134,6 +138,65 @@ DEFK(k2_addsdwa, I_ADDSDWA)
 DEFK(k2_max16sdwa, I_MAX16SDWA)
 DEFK(k2_movdpp, I_MOVDPP)
 DEFK(k2_adddpp, I_ADDDPP)
+DEFK(k3_pkmax3f, I_PKMAX3F)
+DEFK(k3_pkmaxu, I_PKMAXU)
+DEFK(k3_mix_add_max, I_MIXAM)
+DEFK(k3_mix_add_max3, I_MIXAM3)
+
+// The DP kernel's tilted interior ROW BODY with its real dependences (vsx_device.hip, 7 instructions per lane-row: v_perm_b32,
+// v_add_u32, 2 x v_pk_max_u16, v_sub_u32, 2 x v_pk_max_u16; F chains from row to row, E / H stay per row), 16 rows per step.
+// UB_ROWBODY=1 ./ubench_valu prints the issue cycles per instruction of THIS mix at 1..4 waves per SIMD: the number bench.py
+// multiplies SQ_INSTS_VALU with (VERDICT r02 'next' 7b: calibrate instead of assuming 3.33).
+template <int MODE>      // 0: the kernel's row body (F chains through 4 instructions per row); 1: F' = max(F, max(h0, E) - go) (1 per row, one more sub);
+                         // 2: no chain at all (every row takes a constant F): the mix's pure issue rate
+__global__ void __launch_bounds__(256) k_rowbody(int iters, int * out, int seed)
+{
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  auto pmaxu = [](unsigned a, unsigned b) -> unsigned {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+  };
+  unsigned H[16], E[16], pa[4], pb[4];
+  for (int i = 0; i < 16; ++i) { H[i] = 0x80008000u + (unsigned) (i * 77 + (int) threadIdx.x); E[i] = 0x80008000u - (unsigned) (i * 13 + seed); }
+  for (int i = 0; i < 4; ++i) { pa[i] = 0x06000600u + (unsigned) seed * (unsigned) i; pb[i] = 0x00060006u + (unsigned) i; }
+  unsigned F = 0x80008000u, diag = 0x80008000u;
+  const unsigned go = 0x00120012u;
+  for (int it = 0; it < iters; ++it)
+    {
+      unsigned Hd = diag;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        {
+          const unsigned V = __builtin_amdgcn_perm(pb[r >> 2], pa[r >> 2], 0x0C040C00u + 0x00010001u * (unsigned) (r & 3));
+          const unsigned h0 = Hd + V;
+          if (MODE == 1)
+            {
+              const unsigned m = pmaxu(h0, E[r]);
+              const unsigned mg = m - go;
+              const unsigned h2 = pmaxu(m, F);
+              F = pmaxu(F, mg);
+              Hd = H[r];
+              H[r] = h2;
+              E[r] = pmaxu(E[r], h2 - go);
+            }
+          else
+            {
+              const unsigned Fin = (MODE == 2) ? go + (unsigned) r : F;
+              const unsigned h1 = pmaxu(h0, Fin);
+              const unsigned h2 = pmaxu(h1, E[r]);
+              Hd = H[r];
+              H[r] = h2;
+              const unsigned he = h2 - go;
+              if (MODE == 2) F ^= pmaxu(Fin, he); else F = pmaxu(F, he);
+              E[r] = pmaxu(E[r], he);
+            }
+        }
+      diag = H[15] + (unsigned) it;
+      pa[it & 3] ^= F;           // keeps the profile registers loop-variant (the real kernel reloads them every step)
+    }
+  unsigned acc = F;
+  for (int i = 0; i < 16; ++i) acc ^= H[i] ^ E[i];
+  if (acc == 0x12345678u) out[0] = (int) acc;
+}
 
 typedef void (*kfn)(int, int *, int);
 
@@ -158,11 +221,41 @@ static void run(const char * name, kfn k, int waves_per_simd)
   CK(hipFree(out));
 }
 
+static void run_rowbody(int waves_per_simd, int mode)
+{
+  int * out; CK(hipMalloc(&out, 4));
+  const int iters = 20000;
+  const int blocks = 256 * waves_per_simd;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto launch = [&](int n) {
+    if (mode == 0) hipLaunchKernelGGL(k_rowbody<0>, dim3(blocks), dim3(256), 0, 0, n, out, 1);
+    if (mode == 1) hipLaunchKernelGGL(k_rowbody<1>, dim3(blocks), dim3(256), 0, 0, n, out, 1);
+    if (mode == 2) hipLaunchKernelGGL(k_rowbody<2>, dim3(blocks), dim3(256), 0, 0, n, out, 1);
+  };
+  launch(10);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  launch(iters);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const int per_row = (mode == 1) ? 8 : ((mode == 2) ? 8 : 7);
+  const double wave_instr_per_simd = (double) iters * 16 * per_row * waves_per_simd;
+  const double cycles = ms * 1e-3 * 2.4e9;
+  const char * what[] = {"kernel row body, F chain of 4 per row (perm, add, 2 max, sub, 2 max)", "F chain of 1 per row (perm, add, max, sub, 2 max, sub, max)",
+                         "no chain (+1 xor per row)"};
+  printf("%-70s x 16 rows  w/simd=%d %8.3f ms  %.3f cycles per instruction  %.1f cycles per lane-row\n",
+         what[mode], waves_per_simd, ms, cycles / wave_instr_per_simd, per_row * cycles / wave_instr_per_simd);
+  CK(hipFree(out));
+}
+
 int main()
 {
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
   printf("device %s  CUs %d  clock %d kHz  arch %s\n", p.name, p.multiProcessorCount, p.clockRate, p.gcnArchName);
+  if (getenv("UB_ROWBODY")) { for (int m = 0; m < 3; ++m) for (int w = 1; w <= 8; w *= 2) run_rowbody(w, m); run_rowbody(3, 0); return 0; }
 #define R(NAME) run(#NAME, NAME, 4);
+  if (getenv("UB_MAX3")) { R(k3_pkmaxu) R(k3_pkmax3f) R(k_add32) R(k3_mix_add_max) R(k3_mix_add_max3) return 0; }
   if (getenv("UB_NEW")) { R(k2_sub32) R(k2_subrev32) R(k2_min32) R(k2_maxu32) R(k2_ashr32) R(k2_and32) R(k2_or32) R(k2_lshl32) R(k2_addco) R(k2_addc) R(k2_min16) R(k2_addu16) R(k2_subu16) R(k2_cmp32) R(k2_lshladd) R(k2_madu24) R(k2_mulu24) R(k2_subi32c) R(k2_med3) R(k2_bfe) R(k2_addsdwa) R(k2_max16sdwa) R(k2_movdpp) R(k2_adddpp) return 0; }
   R(k_pk_add) R(k_pk_sub) R(k_pk_max) R(k_pk_min) R(k_pk_lshr) R(k_pk_ashr) R(k_pk_mad) R(k_pk_mul)
   R(k_xor) R(k_andor) R(k_lshr) R(k_bfi) R(k_lshlor) R(k_add32) R(k_add3) R(k_max32) R(k_max3_32)

@@ -127,7 +127,21 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 #ifndef VSX_FWD_WAVES
 #define VSX_FWD_WAVES(R_, TILT_) ((R_) <= 16 ? 4 : ((R_) <= 24 ? 3 : 2))
 #endif
-template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false>
+// MAX3 (r03, a sub-class of TILT for tasks whose tilted range fits 15 bits): the values are biased by 0x3E00 instead of 0x8000, i.e.
+// every H / E / F lies in [0, 0x7BFF] -- the bit patterns of the non-negative, finite fp16 numbers, whose IEEE order IS the
+// order of the patterns read as integers.  H = max(h0, F, E) is then ONE instruction for both halves, v_pk_maximum3_f16 (new on
+// gfx950), instead of two v_pk_max_u16: 6 instead of 7 instructions per lane-row, and every VALU instruction of this mix costs
+// the same ~4 issue cycles (profiles/r03/r03_ubench_rowbody.txt), so that is one seventh of the recurrence's issue time.
+// Exactness on the hardware (denormal patterns included, no flush): vsearch_amd/csrc/ubench_max3.hip, 3 x 4 M random triples.
+// Adds and subtractions stay integer ops on the patterns.  The checkpoints are stored re-biased to 0x8000, so the traceback
+// does not know the class exists.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+DEV u32 pk_max3_bits(u32 a, u32 b, u32 c)            // IEEE maximum of three: the compiler selects v_pk_maximum3_f16 (no inline asm: free register choice)
+{
+  const f16x2 x = __builtin_bit_cast(f16x2, a), y = __builtin_bit_cast(f16x2, b), z = __builtin_bit_cast(f16x2, c);
+  return __builtin_bit_cast(u32, __builtin_elementwise_maximum(__builtin_elementwise_maximum(x, y), z));
+}
+template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false, bool MAX3 = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VSX_FWD_WAVES(R, TILT), 8)))
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
@@ -148,7 +162,11 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   // intermediate inside (0, 65535)): the primed scores and the interior QR' = go are non-negative, so H + S' and H - go are
   // ONE 32-bit v_add_u32 / v_sub_u32 for both halves (2 cycles instead of the 4 of v_pk_add/sub_i16: no carry or borrow can
   // cross the halves); maxima are v_pk_max_u16, the remaining (possibly negative) penalties subtract with v_pk_sub_u16.
-  constexpr u32 BIAS = TILT ? 0x80008000u : 0u;
+  static_assert(!MAX3 || TILT, "the MAX3 arithmetic is a sub-class of TILT");
+  constexpr u32 BIAS16 = MAX3 ? 0x3E00u : (TILT ? 0x8000u : 0u);
+  constexpr u32 BIAS = BIAS16 * 0x10001u;
+  constexpr u32 CK_REBIAS = MAX3 ? (0x8000u - 0x3E00u) * 0x10001u : 0u;      // stored checkpoints are always biased by 0x8000
+  auto bpack = [](int v) -> u32 { return pack16(v + (int) BIAS16); };        // a border value -> both halves, biased
   auto vadd = [](u32 a, u32 b) -> u32 { return TILT ? a + b : sadd(a, b); };       // b >= 0 per half
   auto vsubk = [](u32 a, u32 b) -> u32 { return TILT ? a - b : ssub(a, b); };      // b >= 0 per half, a >= b per half
   auto vsub = [](u32 a, u32 b) -> u32 { return TILT ? psubw(a, b) : ssub(a, b); };
@@ -160,6 +178,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   constexpr bool MIDCK = VSX_MID(R, TILT);          // second row checkpoint after row R/2 - 1, column checkpoints per half
   constexpr int RT = MIDCK ? R / 2 : R;
   constexpr bool CKST = TILT && (VSX_CKT != 0);     // LDS-transposed checkpoint stores (A/B build)
+  static_assert(!(MAX3 && CKST), "the transposed A/B layout predates the MAX3 class");
   constexpr bool QPL = TILT && (VSX_QPL != 0);      // byte profile, read one step ahead
   constexpr bool QP8 = CKST || QPL;
   constexpr int RP = (R + 3) & ~3;
@@ -262,19 +281,19 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           if (i < 0) i = 0;
           const u32 a = qq[i];
           ac[r] = a | (a << 16);
-          u32 hl = pack16(P.hleft[i]) ^ BIAS;
+          u32 hl = bpack(P.hleft[i]);
           u32 e0 = vsub(hl, (i < Q - 1) ? P.qrq_i_pk : P.qrq_r_pk);
           if (dummy)
             {
               const int sh = (r - pad - 1) * tl;                                     // tilt of (i, -1), i = r - pad
-              hl = pack16(((r == pad - 1) ? 0 : -P.top_open) + sh) ^ BIAS;           // Htop(-1) = 0 for the first real row's diagonal
-              e0 = vsub(pack16(-P.top_open - P.top_step + sh) ^ BIAS, P.qrq_i_pk);   // <= Htop(0), stays below the chain
+              hl = bpack(((r == pad - 1) ? 0 : -P.top_open) + sh);           // Htop(-1) = 0 for the first real row's diagonal
+              e0 = vsub(bpack(-P.top_open - P.top_step + sh), P.qrq_i_pk);   // <= Htop(0), stays below the chain
             }
           hprev[r] = hl;
           hnext[r] = hl;     // a lane that has not started yet must find its border state in either array
           E[r] = e0;
         }
-      u32 diag = (first ? pack16(((TOPPAD && pad > 0) ? -P.top_open : 0) - (pad + 2) * tl) : pack16(P.hleft[i0 - 1])) ^ BIAS;   // H(i0-1, -1); Htop(-1) = 0 (:1895)
+      u32 diag = first ? bpack(((TOPPAD && pad > 0) ? -P.top_open : 0) - (pad + 2) * tl) : bpack(P.hleft[i0 - 1]);   // H(i0-1, -1); Htop(-1) = 0 (:1895)
       // query-gap penalties of row R-1: only the globally last row uses the right-end pair (:836-897)
       const bool lastpos = (L == total_lanes - 1);
       const u32 qrq_last = lastpos ? P.qrq_r_pk : P.qrq_i_pk;
@@ -321,7 +340,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               f_rt = rA | (rB << 16);
               if (s == 0)
                 {
-                  f_H = pack16(rawH - pad * tl) ^ BIAS;     // H(-1, j) = Htop(j) (tilted: it enters at row -pad - 1)
+                  f_H = bpack(rawH - pad * tl);             // H(-1, j) = Htop(j) (tilted: it enters at row -pad - 1)
                   f_F = vsub(f_H, f_qrt);              // f = v_sub(f, QR_t) at block entry (:830-833)
                 }
               else
@@ -481,8 +500,9 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   else V = a_pk_mad(a_pk_minu(ac[r] ^ code, 0x00010001u), nd, P.match_pk);
                   // onestep (:765-780)
                   const u32 h0 = vadd(Hd, V);
-                  const u32 h1 = vmax(h0, F);
-                  h2 = vmax(h1, E[r]);
+                  // (row R-1 keeps the two-step maximum: the leave-column tracking needs h1 = max(h0, F) on its own)
+                  const u32 h1 = (MAX3 && r < R - 1) ? 0u : vmax(h0, F);
+                  h2 = (MAX3 && r < R - 1) ? pk_max3_bits(h0, F, E[r]) : vmax(h1, E[r]);
                   if (TRACK) { smn = pmin(smn, h2); smx = pmax(smx, h2); }
                   Hd = hin[r];
                   hout[r] = h2;
@@ -590,11 +610,11 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                     {
                       // bytes 0 / 2 of the two wrapped differences = the signed 8-bit H - F of the lo / hi target, steps t-1 and t
                       const u32 dpk = __builtin_amdgcn_perm(psubw(outH, outF), psubw(pendH, pendF), 0x06040200u);
-                      __builtin_nontemporal_store((u32x3) {pendH, outH, dpk}, reinterpret_cast<u32x3 *>(rck_base + (size_t) (t >> 1) * 192));
+                      __builtin_nontemporal_store((u32x3) {pendH + CK_REBIAS, outH + CK_REBIAS, dpk}, reinterpret_cast<u32x3 *>(rck_base + (size_t) (t >> 1) * 192));
                       if (MIDCK)
                         {
                           const u32 dpm = __builtin_amdgcn_perm(psubw(curMH, curMF), psubw(pendMH, pendMF), 0x06040200u);
-                          __builtin_nontemporal_store((u32x3) {pendMH, curMH, dpm}, reinterpret_cast<u32x3 *>(mck_base + (size_t) (t >> 1) * 192));
+                          __builtin_nontemporal_store((u32x3) {pendMH + CK_REBIAS, curMH + CK_REBIAS, dpm}, reinterpret_cast<u32x3 *>(mck_base + (size_t) (t >> 1) * 192));
                         }
                     }
                   else
@@ -616,7 +636,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                     if (MIDCK)
                       {
                         const int hh = z / ZH, zz = z % ZH, r00 = hh * RT;
-                        if (zz < RT) return hout[r00 + zz];
+                        if (zz < RT) return hout[r00 + zz] + CK_REBIAS;
                         if (zz < NFH)
                           {
                             const int r0 = r00 + 2 * (zz - RT), r1 = (r0 + 1 < r00 + RT) ? r0 + 1 : r0;
@@ -624,7 +644,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                           }
                         return 0u;
                       }
-                    if (z < R) return hout[z];
+                    if (z < R) return hout[z] + CK_REBIAS;
                     if (z < NF)
                       {
                         const int r0 = 2 * (z - R), r1 = r0 + 1 < R ? r0 + 1 : r0;
@@ -734,7 +754,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       const int mnA = (int16_t) (hmin & 0xffff), mnB = (int16_t) (hmin >> 16);
       const int mxA = (int16_t) (hmax & 0xffff), mxB = (int16_t) (hmax >> 16);
       VsxSlotOut oA, oB;
-      score ^= BIAS;
+      score = psubw(score, BIAS);                 // (for the 0x8000 bias the same as the former xor)
       oA.score = (int16_t) ((int) (int16_t) (score & 0xffff) - (DA > 0 ? (Q + DA - 2) * tl : 0));     // H = H* - (i + j) g
       oB.score = (int16_t) ((int) (int16_t) (score >> 16) - (DB > 0 ? (Q + DB - 2) * tl : 0));
       oA.leave = (uint16_t) (leave & 0xffff); oB.leave = (uint16_t) (leave >> 16); oA.pad = 0; oB.pad = 0;
@@ -1549,7 +1569,12 @@ static hipError_t launch_fwd2(int generic, int track, const VsxDevParams & P, co
     {
       if (!(CK && generic && !track)) return hipErrorInvalidValue;
       if constexpr (CK)
-        hipLaunchKernelGGL((vsx_forward_kernel<R, true, false, true, true>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+        {
+          if (P.max3 && !VSX_CKT)
+            hipLaunchKernelGGL((vsx_forward_kernel<R, true, false, true, true, (VSX_CKT == 0)>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+          else
+            hipLaunchKernelGGL((vsx_forward_kernel<R, true, false, true, true>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+        }
     }
   else if (generic && track)
     hipLaunchKernelGGL((vsx_forward_kernel<R, true, true, CK>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);

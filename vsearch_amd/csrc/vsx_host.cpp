@@ -842,15 +842,21 @@ static bool no_overflow_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
 
 // The TILT class (vsx_forward_kernel): every value is shifted by (i + j) g with -R - 2 <= i < Q, -1 <= j < Dp + 16 and g <= B,
 // scores grow by 2g: the interval of no_overflow_possible() widened by that shift must still fit.
-static bool tilt_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
+// Returns 0 (not admitted), 1 (TILT: values biased by 0x8000 into unsigned 16 bits) or 2 (the MAX3 sub-class: the same bound
+// must hold for HALF the range -- values biased by 0x3E00 have to stay inside [0, 0x7BFF], the finite non-negative fp16 patterns,
+// for v_pk_maximum3_f16 to be an integer maximum; vsx_forward_kernel MAX3).  VSX_MAX3=0 switches the sub-class off (A/B, tests).
+static int tilt_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
 {
-  if (ctx->Pt.tilt == 0) return false;
+  if (ctx->Pt.tilt == 0) return 0;
+  static const bool max3_off = std::getenv("VSX_MAX3") && std::strcmp(std::getenv("VSX_MAX3"), "0") == 0;
   int64_t B = std::max<int64_t>(std::llabs(ctx->P.match), std::llabs(ctx->P.mismatch));
   int64_t G = 0;
   for (int k = 0; k < 12; ++k)
     if (k < 6) G = std::max<int64_t>(G, ctx->pen[k]); else B = std::max<int64_t>(B, ctx->pen[k]);
   const int64_t Dp = (D + 3) & ~3ll;
-  return 4 * G + 2 * (Q + Dp + 64) * B < 32000;
+  const int64_t reach = 4 * G + 2 * (Q + Dp + 64) * B;          // |value| of anything the kernel forms stays below this
+  if (reach < 15800 && !max3_off && !VSX_CKT) return 2;         // 0x3E00 = 15872 each way inside [0, 0x7BFF]
+  return reach < 32000 ? 1 : 0;
 }
 
 static int pick_rows(int Q)
@@ -1008,7 +1014,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
                 dmax = std::max(dmax, targets->len[tidx[pt.pair[sidx]]]);
               }
             pt.track = (!ctx->tb_packed && no_overflow_possible(ctx, queries->len[q], dmax)) ? 0 : 1;
-            pt.tilt = (pt.track == 0 && generic && ctx->ckpt && tilt_possible(ctx, queries->len[q], dmax)) ? 1 : 0;
+            pt.tilt = (pt.track == 0 && generic && ctx->ckpt) ? tilt_possible(ctx, queries->len[q], dmax) : 0;
             outp.push_back(pt);
           }
       }
@@ -1248,9 +1254,13 @@ int vsx_plan_run(vsx_plan * pl)
       else if (ctx->ev_tb_used[slot]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_tb[slot], 0));
       HIPCHK(hipEventRecord(c.e0, st));
       for (const Launch & L : c.launches)
-        HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, L.tilt ? ctx->Pt : ctx->P, pl->d_tasks.p + L.first, L.count,
-                                  pl->Q->codes(), pl->T->codes(), dir, pl->d_strip.p,
-                                  pl->d_slot.p + (size_t) L.first * VSX_TASK_SLOTS, st));
+        {
+          VsxDevParams Pf = L.tilt ? ctx->Pt : ctx->P;
+          Pf.max3 = (L.tilt == 2) ? 1 : 0;
+          HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, Pf, pl->d_tasks.p + L.first, L.count,
+                                    pl->Q->codes(), pl->T->codes(), dir, pl->d_strip.p,
+                                    pl->d_slot.p + (size_t) L.first * VSX_TASK_SLOTS, st));
+        }
       HIPCHK(hipEventRecord(c.e1, st));
       HIPCHK(hipStreamWaitEvent(st2, c.e1, 0));
       HIPCHK(hipEventRecord(c.e1b, st2));
@@ -1319,6 +1329,7 @@ int vsx_plan_describe(const vsx_plan * pl, vsx_plan_info * info)
     for (const Launch & L : c.launches)
       {
         if (L.tilt) info->tasks_tilted += L.count;
+        if (L.tilt == 2) info->tasks_max3 += L.count;
         if (L.track) info->tasks_tracked += L.count;
         if (L.count > best) { best = L.count; info->rows_dominant = (uint32_t) L.rows; }
       }

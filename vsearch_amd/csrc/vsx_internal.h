@@ -53,6 +53,7 @@ struct VsxDevParams {
   int32_t  tilt;                  // g > 0: TILTED coordinates X* = X + (i + j) g (vsx_forward_kernel TILT): every penalty above is
                                   // the original minus g, matrix = original + 2g, htop[j] / hleft[i] = original + (j - 1) g / (i - 1) g;
                                   // top_open / top_step stay the originals.  0: plain coordinates
+  int32_t  max3;                  // TILT only: 1 = the MAX3 sub-class (values biased into [0, 0x7BFF]: H = max(h0, F, E) is ONE v_pk_maximum3_f16)
   const int16_t * htop;           // H(-1, j), j >= 0: top border chain (:1895-1910, :2043-2051)
   const int16_t * hleft;          // H(i, -1), i >= 0: left border chain (:844-859, :881-887)
   const int16_t * matrix;         // 16x16 score matrix S[target code][query code] (:1319-1342)
