@@ -123,6 +123,13 @@ def parse():
     ap.add_argument("--ref-search-queries", type=int, default=4096,
                     help="queries the reference CLI searches against the full DB (0 = skip; its index build takes ~1 min)")
     ap.add_argument("--dir-budget-gb", type=float, default=0.0)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank plays its own --queries queries (per-GPU work fixed); strong: the job of --queries "
+                         "queries is cut into one contiguous block per rank (total work fixed)")
+    ap.add_argument("--gather", choices=["async", "sync"], default="async",
+                    help="N > 1: the final gather of hit records + CIGAR run words per step -- async: one fixed-capacity non-blocking "
+                         "collective that overlaps the next step's kernels (sharding.FixedGather); sync: counts first, then padded payload")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: the one-GPU tests)")
     return ap.parse_args()
 
 
@@ -136,27 +143,40 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()         # (several ranks may share a GPU: the one-GPU tests)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)     # RCCL
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # RCCL
+        else:
+            dist.init_process_group("gloo")
 
     from vsearch_amd import Aligner, SequenceSet, sharding, workload
 
     # ---- synthetic inputs, generated in HBM.  Weak scaling: the job has world x a.queries queries, rank r owns the
     # contiguous block sharding.shard_queries() gives it (generated here from its own seed) and a replica of the DB
     t0 = time.time()
-    q_lo, q_hi = sharding.shard_queries(world * a.queries, world, rank)
     db_ascii, db_off, db_len, fam = workload.make_family_db(a.db, a.dlen, seed=17, device=dev)
-    q_ascii, q_off, q_len, src = workload.make_queries(db_ascii, db_off, db_len, q_hi - q_lo, a.qlen,
-                                                       seed=11 + 1000 * rank, device=dev)
-    qidx, tidx = workload.family_candidates(src, fam, per_query=a.cands, seed=5 + rank)
+    strong = a.scaling == "strong" and world > 1
+    if strong:
+        # the whole job is generated identically on every rank (same seeds); a rank keeps the pairs of its block of queries
+        q_ascii, q_off, q_len, src = workload.make_queries(db_ascii, db_off, db_len, a.queries, a.qlen, seed=11, device=dev)
+        qidx, tidx = workload.family_candidates(src, fam, per_query=a.cands, seed=5)
+        q_lo, q_hi = sharding.shard_queries(a.queries, world, rank)
+        keep = (qidx >= q_lo) & (qidx < q_hi)
+        qidx, tidx = qidx[keep], tidx[keep]
+    else:
+        q_lo, q_hi = sharding.shard_queries(world * a.queries, world, rank)
+        q_ascii, q_off, q_len, src = workload.make_queries(db_ascii, db_off, db_len, q_hi - q_lo, a.qlen,
+                                                           seed=11 + 1000 * rank, device=dev)
+        qidx, tidx = workload.family_candidates(src, fam, per_query=a.cands, seed=5 + rank)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
 
-    al = Aligner(device=local_rank)
+    al = Aligner(device=dev_index)
     T = SequenceSet(al, blob=db_ascii.numel(), offsets=db_off, lengths=db_len, device_ptr=db_ascii.data_ptr())
     Q = SequenceSet(al, blob=q_ascii.numel(), offsets=q_off, lengths=q_len, device_ptr=q_ascii.data_ptr())
     t0 = time.time()
@@ -166,16 +186,38 @@ def main():
     cells = int((q_len[qidx].astype(np.int64) * db_len[tidx].astype(np.int64)).sum())
     scratch = {}
     gathered = None
+    fixed = sharding.FixedGather(dist, dst=0) if (world > 1 and a.gather == "async") else None
+    pending = None
+    gloo = world > 1 and a.backend == "gloo"
 
     def step():
-        nonlocal gathered
+        nonlocal gathered, pending
         plan.run()
         tm = plan.sync()
         if world > 1:
-            # the only collective on the path: final gather of the hit records and the CIGAR run words over RCCL/xGMI
-            # (the same function the world-2 tests drive: vsearch_amd/sharding.py)
-            gathered = sharding.export_and_gather(plan, n_pairs, dist, dev, scratch, dst=0)      # to rank 0, which would write the output
+            # the only collective on the path: final gather of the hit records and the CIGAR run words over RCCL/xGMI, to rank 0 (which
+            # would write the output) -- the functions the world-2 tests drive (vsearch_amd/sharding.py).  async: the collective of this
+            # step is posted and the PREVIOUS step's is collected, so it travels while the next step's kernels run
+            rec, runs = sharding.export_records(plan, n_pairs, dev, scratch, host=gloo)
+            if fixed is not None:
+                try:
+                    ticket = fixed.post(rec, runs)
+                except OverflowError:                      # (a step larger than the fixed capacity: this one goes the synchronous way)
+                    ticket = None
+                if pending is not None:
+                    gathered = fixed.collect(pending)
+                pending = ticket
+                if ticket is None:
+                    gathered = sharding.gather_results(rec, runs, dist, dst=0)
+            else:
+                gathered = sharding.gather_results(rec, runs, dist, dst=0)
         return tm
+
+    def drain():
+        nonlocal gathered, pending
+        if pending is not None:
+            gathered = fixed.collect(pending)
+            pending = None
 
     def barrier():
         torch.cuda.synchronize()
@@ -185,6 +227,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    drain()
     barrier()
     t0 = time.perf_counter()
     fwd_ms = tb_ms = tot_ms = 0.0
@@ -196,12 +239,18 @@ def main():
         tb_ms += tm.traceback_ms
         tot_ms += tm.total_ms
         fwd_launches += tm.forward_launches
+    drain()                                                # the last step's gather belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    job_cells, job_pairs = cells, n_pairs
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = torch.device("cpu") if gloo else dev
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        tot = torch.tensor([cells, n_pairs], dtype=torch.int64, device=cdev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)           # what ALL ranks processed per step
+        job_cells, job_pairs = int(tot[0]), int(tot[1])
 
     if rank != 0:
         if world > 1:
@@ -215,9 +264,9 @@ def main():
         rec_all, runs_all, counts = gathered
         mine = sharding.decode_records(rec_all[:n_pairs])
         own = sharding.decode_records(scratch["rec"])
-        other = sharding.decode_records(rec_all[n_pairs:2 * n_pairs])
+        other = sharding.decode_records(rec_all[counts[0]:counts[0] + counts[1]])
         n_runs0 = int(own["nruns"].sum())
-        gather_check = bool(counts == [n_pairs] * world and np.array_equal(mine["score"], own["score"])
+        gather_check = bool(counts[0] == n_pairs and sum(counts) == job_pairs and np.array_equal(mine["score"], own["score"])
                             and np.array_equal(mine["run_off"], own["run_off"])
                             and int(other["run_off"][other["nruns"] > 0].min()) >= n_runs0
                             and int(runs_all.numel()) >= n_runs0 + int(other["nruns"].sum()))
@@ -227,7 +276,7 @@ def main():
     res = plan.fetch()
     t_fetch = time.perf_counter() - t0
 
-    total_cells = cells * world * a.steps
+    total_cells = job_cells * a.steps
     value = total_cells / elapsed / 1e9
     ms_per_step = elapsed / a.steps * 1e3
     fwd_avg_ms = fwd_ms / max(1, fwd_launches)
@@ -243,10 +292,10 @@ def main():
         "metric": "GCUPS (useful DP cells/s of the search16 global-alignment path: DP + traceback + CIGAR)",
         "value": round(value, 2),
         "unit": "GCUPS",
-        "pairs_per_s": round(n_pairs * world * a.steps / elapsed, 1),
+        "pairs_per_s": round(job_pairs * a.steps / elapsed, 1),
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "int16", "data": "synthetic",
         "config": {
             "workload": f"usearch_global candidate batch: {a.queries} x {a.qlen} bp queries vs {a.db} x {a.dlen} bp "
@@ -254,7 +303,8 @@ def main():
                         "--id 0.9 shape, default scoring (BASELINE config[1])",
             "candidates": "synthetic for `value`: source member + 7 same-family members (what the k-mer stage yields on this DB); "
                           "search_end_to_end runs the real device k-mer stage (vsx_kmer.hip) in front of the aligner",
-            "parallelism": f"query-sharded x{world} (sharding.shard_queries), DB replicated, one gather of records + CIGAR runs per step"
+            "parallelism": (f"query-sharded x{world} (sharding.shard_queries, {'strong: one job of ' + str(a.queries) + ' queries cut into blocks' if strong else 'weak: ' + str(a.queries) + ' queries per rank'}), "
+                            f"DB replicated, one {a.gather} gather of records + CIGAR runs per step over {a.backend}")
                            if world > 1 else "single GPU",
             "cells_per_step_per_gpu": cells,
         },

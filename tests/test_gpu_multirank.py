@@ -139,3 +139,26 @@ def test_multi_device_handle_equals_single_device(gpu_required, devices):
                 got_lists = SearchSession.hits_as_lists(f, h, c)
                 assert got_lists == lib_hits
                 assert sum(len(x) for x in got_lists) > 100
+
+
+@pytest.mark.parametrize("mode,gather", [("strong", "async"), ("weak", "async"), ("strong", "sync")])
+def test_bench_two_ranks_on_one_gpu(gpu_required, mode, gather):
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per 'GPU' -- here both on device 0, gloo
+    instead of RCCL): --scaling strong cuts ONE job of --queries queries into two blocks, weak gives every rank its own; the final
+    gather is the asynchronous fixed-capacity collective (sharding.FixedGather) or the synchronous one.  Rank 0's line must carry the
+    whole job's pairs and a passing gather_check (its own block back unchanged, the other rank's run offsets rebased past it)."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    nq = 6000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+           "--scaling", mode, "--gather", gather, "--queries", str(nq), "--db", "20000", "--dlen", "600", "--qlen", "200"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, p.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == mode and d["gather_check"] is True
+    pairs_per_step = d["pairs_per_s"] * d["ms_per_step"] * 1e-3
+    expect = nq * 8 * (1 if mode == "strong" else 2)
+    assert abs(pairs_per_step - expect) < 0.01 * expect, (pairs_per_step, expect)

@@ -145,6 +145,32 @@ if rank == 0:
     assert torch.equal(r0, rec_all) and torch.equal(u0, runs_all)
 else:
     assert r0 is None and u0 is None
+# the ASYNCHRONOUS fixed-capacity form (sharding.FixedGather): three steps in flight back to back -- the same payload, a shorter
+# one, the same again -- posted before any is collected; every collected step must equal the synchronous gather of that step
+for dst in (0, None):
+    fg = sharding.FixedGather(dist, dst=dst)
+    steps = [(rec, runs), (rec[: len(rec) // 2], runs[: max(0, int(off[len(rec) // 2]) if len(rec) // 2 in off else 0)]), (rec, runs)]
+    # (the half step keeps whole records; their run offsets still point inside its own, shorter, run buffer or are unused)
+    tickets = []
+    for k, (rc_, rn_) in enumerate(steps):
+        tickets.append(fg.post(torch.from_numpy(np.ascontiguousarray(rc_)), torch.from_numpy(np.ascontiguousarray(rn_).view(np.int32))))
+        if k >= 1:                                   # at most two in flight (two send buffers)
+            got = fg.collect(tickets[k - 1])
+            exp = sharding.gather_results(torch.from_numpy(np.ascontiguousarray(steps[k - 1][0])), torch.from_numpy(np.ascontiguousarray(steps[k - 1][1]).view(np.int32)), dist, dst=dst)
+            if dst is None or rank == dst:
+                assert torch.equal(got[0], exp[0]) and torch.equal(got[1], exp[1]) and got[2] == exp[2], (dst, k)
+            else:
+                assert got == (None, None, None)
+    got = fg.collect(tickets[-1])
+    if dst is None or rank == dst:
+        assert torch.equal(got[0], rec_all) and torch.equal(got[1], runs_all) and got[2] == counts
+    # a step beyond the fixed capacity is refused loudly
+    big = np.concatenate([rec] * 3)
+    try:
+        fg.post(torch.from_numpy(big), torch.from_numpy(np.concatenate([runs] * 3).view(np.int32)))
+        raise SystemExit("FixedGather accepted a payload beyond its capacity")
+    except OverflowError:
+        pass
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
