@@ -205,7 +205,7 @@ void vsx_candidates_free(vsx_candidates * c);
 /* Greedy centroid clustering, --cluster_fast / --cluster_smallmem semantics (core/cluster.cpp:877-1125 with the
    intra-round fix-up evaluate_extra_hits :601-856): the searcher's sequences are processed IN THE GIVEN ORDER
    (sort them first: cluster_fast = length descending, core/db.cpp:433-450); each joins the cluster of its best
-   accepted centroid hit or founds a new cluster.  `round` sequences are searched per GPU stage (0 = 4096); the
+   accepted centroid hit or founds a new cluster.  `round` sequences are searched per GPU stage (0 = 16384); the
    result is independent of `round`.  hits.first[s]..first[s+1] holds the one hit of a member (target = its
    centroid) and is empty for centroids; clusterno[s] is the 0-based cluster number in creation order. */
 typedef struct vsx_cluster_out {

@@ -335,6 +335,33 @@ def test_device_kmer_multi_tile(gpu_required):
     assert any(t >= 65536 for h in host for t, _ in h) and any(t < 32768 for h in host for t, _ in h)
 
 
+def test_cluster_fast_members_without_words_take_the_host_index(gpu_required, tmp_path):
+    """Sequences the device counters cannot serve -- shorter than a word, or all N: min(minwordmatches, 0 words) = 0, every centroid
+    is a candidate (searchcore.cpp:283-288) -- are ranked on the host against the growing centroid index, which since r03 is only
+    caught up with the centroids when such a member turns up.  Several of them, spread over several rounds, among ordinary families:
+    --uc byte-identical to the reference CLI."""
+    if not os.path.exists(REF_BIN):
+        pytest.fail("oracle/_ref/vsearch_ref missing")
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(15)
+    seqs = []
+    for f in range(12):
+        anc = common.rnd_seq(rng, rng.randint(60, 90))
+        for _ in range(rng.randint(2, 6)):
+            seqs.append(common.mutate(rng, anc, 0.02))
+    seqs += ["ACGTAC", "ACGTACG", "N" * 40, "ACGTA", "NNNNACGTNNNN", "ACGTAC", "TTGCA"]
+    rng.shuffle(seqs)
+    names = [f"s{i:04d}" for i in range(len(seqs))]
+    order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), names[i]))
+    sseqs, snames = [seqs[i] for i in order], [names[i] for i in order]
+    exp = run_reference_cluster(str(tmp_path), seqs, names, ["--id", "0.9", "--minseqlength", "1"])
+    for round_size in (5, 1000):
+        with Aligner() as al:
+            ss = SearchSession(al, sseqs, id=0.9, maxrejects=8)
+            got = ss.uc_lines(snames, round=round_size)
+        assert got == exp, (round_size, _first_diff(got, exp))
+
+
 @pytest.mark.gpu
 def test_device_kmer_long_words_multi_tile_and_repeats(gpu_required):
     """tagged index (word length 12) over more than 2^15 sequences, with sequences that repeat their words many times (a word counts

@@ -41,7 +41,7 @@ void vsx_kmer_index_destroy(VsxKmerIndex * ix);
 // at once, further callers wait), NOT against vsx_kmer_index_rebuild.  stats_out: this call's kernel time / increments / records.
 int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_start, const uint32_t * qk,
                          const uint32_t * minmatch, uint32_t keep, VsxKmerResult & out, uint32_t cap_hint = 0,
-                         VsxKmerStats * stats_out = nullptr);
+                         VsxKmerStats * stats_out = nullptr, bool want_increments = false /* stats.increments costs a serial pass over qk */);
 const VsxKmerStats * vsx_kmer_stats(const VsxKmerIndex * ix);
 
 #endif

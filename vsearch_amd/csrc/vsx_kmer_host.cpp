@@ -344,7 +344,7 @@ struct ScratchLease {
 }  // namespace
 
 int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_start, const uint32_t * qk,
-                         const uint32_t * minmatch, uint32_t keep, VsxKmerResult & out, uint32_t cap_hint, VsxKmerStats * stats_out)
+                         const uint32_t * minmatch, uint32_t keep, VsxKmerResult & out, uint32_t cap_hint, VsxKmerStats * stats_out, bool want_increments)
 {
   out.rec.clear();
   out.off.assign(nq, 0);
@@ -381,7 +381,8 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
   KmerScratch * sc = lease.sc;
   const uint64_t nk = qk_start[nq];
   uint64_t increments = 0;
-  for (uint64_t x = 0; x < nk; ++x) increments += ix->word_total[ix->tagged ? (qk[x] & 0xffffu) : qk[x]];        // postings streamed
+  if (want_increments)
+    for (uint64_t x = 0; x < nk; ++x) increments += ix->word_total[ix->tagged ? (qk[x] & 0xffffu) : qk[x]];      // postings streamed
   sc->records = 0;
   KCHK(sc->d_qk_start.ensure(nq + 1));
   KCHK(sc->d_qk.ensure(nk));

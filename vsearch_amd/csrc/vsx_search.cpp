@@ -742,7 +742,7 @@ static bool device_kmer_ok(const vsx_searcher & S)
 // clustering rebuilds SUBSET indexes (centroids, round members) every round: those exist for the one-bucket-per-word form only
 static bool device_kmer_subsets_ok(const vsx_searcher & S) { return device_kmer_ok(S) && S.w <= 8; }
 
-struct KmerAcct { double kernel_ms = 0, build_ms = 0; uint64_t streamed = 0, postings = 0; };
+struct KmerAcct { double kernel_ms = 0, build_ms = 0; uint64_t streamed = 0, postings = 0; bool want_streamed = false; };      // want_streamed: count the postings a batch streams (a serial pass over its words: benches only)
 
 // Count the queries' words against a device index and rank: words[k] = unique words of query k; `map` translates index
 // positions to sequence numbers (subset index) or is null; keep = heap size.  cands[k] = (target, count, length) best first
@@ -764,12 +764,29 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
       qk_start[k + 1] = qk_start[k] + nk;
     }
   std::vector<uint32_t> qk(qk_start[nq]);
-  for (uint64_t k = 0; k < nq; ++k)
-    if (minmatch[k] != 0xffffffffu) std::copy(words[k].begin(), words[k].end(), qk.begin() + (int64_t) qk_start[k]);
+  const int nth = std::max(1, S->threads);
+  {
+    // the words of all queries back to back (threads: a round of clustering is 1.2 M words, a search window 4 M)
+    std::atomic<uint64_t> nextq {0};
+    auto fill = [&]() {
+      for (;;)
+        {
+          const uint64_t k0 = nextq.fetch_add(256);
+          if (k0 >= nq) break;
+          for (uint64_t k = k0; k < std::min(nq, k0 + 256); ++k)
+            if (minmatch[k] != 0xffffffffu) std::copy(words[k].begin(), words[k].end(), qk.begin() + (int64_t) qk_start[k]);
+        }
+    };
+    const int nfill = (int) std::min<uint64_t>((uint64_t) nth, std::max<uint64_t>(1, nq / 1024));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nfill; ++t) pool.emplace_back(fill);
+    fill();
+    for (auto & th : pool) th.join();
+  }
   // count on the device; the records come back grouped by query
   VsxKmerResult res;
   VsxKmerStats kst;
-  const int rc = vsx_kmer_count_batch(ix, nq, qk_start.data(), qk.data(), minmatch.data(), keep, res, cap_hint, &kst);
+  const int rc = vsx_kmer_count_batch(ix, nq, qk_start.data(), qk.data(), minmatch.data(), keep, res, cap_hint, &kst, acct.want_streamed);
   if (rc != VSX_OK) return rc;
   {
     static std::mutex acct_mu;                       // two windows' k-mer stages may finish at once
@@ -778,7 +795,6 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
     acct.streamed += kst.increments;
   }
   // per query: the heap's total order (count desc, length asc, seqno asc) and size
-  const int nth = std::max(1, S->threads);
   std::atomic<uint64_t> next {0};
   auto work = [&]() {
     for (;;)
@@ -1070,6 +1086,7 @@ int vsx_search_candidates_batch(vsx_searcher * S, int32_t device, uint64_t nq, c
   const double t0 = now_s();
   std::vector<std::vector<Cand>> cands;
   KmerAcct acct;
+  acct.want_streamed = true;                   // this entry reports postings_streamed (bench_kmer.py's roofline)
   std::string masked;
   if (S->qmode == 2 && qbytes)
     {
@@ -1716,7 +1733,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
   if (S->qmode != S->o.soft_mask) return sfail(VSX_EINVAL, "vsx_cluster_fast: clustering masks everything by soft_mask; qmask must be 0");
   const double t_begin = now_s();
   const uint64_t n = S->len.size();
-  if (round == 0) round = 4096;
+  if (round == 0) round = 16384;          // (r03: 4096 before; with the next round's main ranking prefetched, fewer and larger rounds win: 10.4 -> 8.5 s at 2 M sequences)
   const uint64_t nk = 1ull << (2 * S->w);
   IncIndex inc;
   inc.post.assign(nk, {});
@@ -1765,7 +1782,13 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
 
   // unique words of a round's members do not depend on any result: a helper computes them one round ahead (device k-mer path)
   std::vector<std::vector<uint32_t>> pre_kmers;
-  uint64_t pre_s0 = UINT64_MAX;
+  uint64_t pre_s0 = UINT64_MAX, pre_main_s0 = UINT64_MAX;
+  std::vector<std::vector<Cand>> pre_cands;              // the helper's ranking of the next round against the MAIN centroid index
+  std::vector<uint64_t> pre_fallback;
+  int pre_rc = VSX_OK;
+  std::string pre_err;
+  std::vector<uint32_t> main_list;                       // the centroids the main index stands for (a snapshot; see the helper below)
+  static const bool prefetch_main = !(std::getenv("VSX_CLUSTER_PREFETCH") && std::strcmp(std::getenv("VSX_CLUSTER_PREFETCH"), "0") == 0);
   std::thread pre_thread;
   std::vector<std::vector<uint64_t>> pre_seen;
   auto words_of_round = [&](uint64_t a0, std::vector<std::vector<uint32_t>> & dst, std::vector<std::vector<uint64_t>> & seen, int threads) {
@@ -1801,13 +1824,10 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       if (dev_kmer)
         {
           if (pre_thread.joinable()) pre_thread.join();
+          if (pre_rc != VSX_OK) { vsx_internal_set_error(pre_err.c_str()); return pre_rc; }
+          const bool have_main = (pre_main_s0 == s0);              // the helper already ranked this round against the main index
           if (pre_s0 == s0) kmers.swap(pre_kmers);
           else words_of_round(s0, kmers, main_seen, nth);
-          if (s0 + round < n)
-            {
-              pre_s0 = s0 + round;
-              pre_thread = std::thread([&, a0 = s0 + round]() { words_of_round(a0, pre_kmers, pre_seen, std::max(1, nth / 2)); });
-            }
           tm_words += now_s() - t0;
           const double tb0 = now_s();
           if (centroid_list.size() != delta_built)
@@ -1815,9 +1835,11 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
               const size_t total = centroid_list.size();
               if (total - main_n > main_n / 8 + 2 * round)
                 {
+                  if (have_main) return sfail(VSX_EHIP, "vsx_cluster_fast: the main index changed under a prefetched ranking");   // (excluded by the launch condition below)
                   const int irc = vsx_kmer_index_rebuild(cix.get(), centroid_list.data(), total);       // main: everything
                   if (irc != VSX_OK) return irc;
                   main_n = total;
+                  main_list.assign(centroid_list.begin(), centroid_list.end());
                   delta_list.clear();
                   static const uint32_t none = 0;                                                        // (a null list would mean "the whole set")
                   const int drc = vsx_kmer_index_rebuild(dix.get(), &none, 0);
@@ -1832,10 +1854,32 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
               delta_built = total;
             }
           tm_rebuild += now_s() - tb0;
+          // The helper of the NEXT round: its unique words, and -- when this round cannot trigger a rebuild of the main index even if
+          // every member founds a cluster -- its ranking against the main index (r03: that ranking is a third of the run and
+          // depends on nothing this round decides; only the small delta index has to wait for this round's centroids).  It reads
+          // main_list, a snapshot that changes only at a main rebuild, never the growing centroid_list.
+          if (s0 + round < n)
+            {
+              const uint64_t a0 = s0 + round;
+              const bool main_safe = prefetch_main && main_n > 0 && (centroid_list.size() + wn - main_n) <= main_n / 8 + 2 * round;
+              pre_s0 = a0;
+              pre_main_s0 = main_safe ? a0 : UINT64_MAX;
+              pre_thread = std::thread([&, a0, main_safe]() {
+                words_of_round(a0, pre_kmers, pre_seen, std::max(1, nth / 2));
+                if (!main_safe) return;
+                const uint64_t cnt = std::min<uint64_t>(round, n - a0);
+                pre_cands.assign(cnt, {});
+                pre_fallback.clear();
+                pre_rc = device_rank(S, cix.get(), &main_list, cnt, pre_kmers, (uint32_t) std::max<int64_t>(S->tophits, 1), 1024, true, pre_cands, pre_fallback, kacct);
+                if (pre_rc != VSX_OK) pre_err = vsx_last_error();
+              });
+            }
           const double tr0 = now_s();
           std::vector<std::vector<Cand>> cands(wn);
           const uint32_t keep_n = (uint32_t) std::max<int64_t>(S->tophits, 1);
-          int krc = device_rank(S, cix.get(), &centroid_list, wn, kmers, keep_n, 1024, true, cands, fallback, kacct);
+          int krc = VSX_OK;
+          if (have_main) { cands.swap(pre_cands); fallback.swap(pre_fallback); }
+          else krc = device_rank(S, cix.get(), &main_list, wn, kmers, keep_n, 1024, true, cands, fallback, kacct);
           if (krc != VSX_OK) return krc;
           if (!delta_list.empty())
             {
@@ -1868,6 +1912,20 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
             }
           tm_rank += now_s() - tr0;
           for (uint64_t k = 0; k < wn; ++k) st[k].cands = std::move(cands[k]);
+          if (!fallback.empty())
+            {
+              // the host's growing index is only read here, by the rare queries the device counters cannot serve: it catches up with
+              // the centroids founded since its last use (r03: filling it eagerly -- 290 push_backs per centroid -- was a third of the
+              // sequential reconcile phase of a 2 M-sequence run)
+              std::vector<uint32_t> km;
+              std::vector<uint64_t> seen(S->w < 10 ? (nk + 63) / 64 : 1, 0);
+              for (; inc.indexed < centroid_list.size(); ++inc.indexed)
+                {
+                  const uint32_t c = centroid_list[inc.indexed];
+                  unique_kmers(seq_of(c), S->len[c], S->w, S->o.soft_mask != 0, km, seen);
+                  for (uint32_t w2 : km) inc.post[w2].push_back(c);
+                }
+            }
           for (uint64_t k : fallback)
             {
               Scratch & sc = scratch[0];
@@ -2086,9 +2144,12 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
               extras.push_back((uint32_t) i);
               is_extra[i] = 1;
               S->is_centroid[seqno] = 1;
-              for (uint32_t km : kmers[i]) inc.post[km].push_back((uint32_t) seqno);    // Dbindex::add_sequence (:1009)
               centroid_list.push_back((uint32_t) seqno);
-              ++inc.indexed;
+              if (!dev_kmer)
+                {
+                  for (uint32_t km : kmers[i]) inc.post[km].push_back((uint32_t) seqno);    // Dbindex::add_sequence (:1009); device path: on demand
+                  ++inc.indexed;
+                }
             }
         }
       vsx_results_free(&spec);
