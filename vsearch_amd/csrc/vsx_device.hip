@@ -133,8 +133,8 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // gfx950), instead of two v_pk_max_u16: 6 instead of 7 instructions per lane-row, and every VALU instruction of this mix costs
 // the same ~4 issue cycles (profiles/r03/r03_ubench_rowbody.txt), so that is one seventh of the recurrence's issue time.
 // Exactness on the hardware (denormal patterns included, no flush): vsearch_amd/csrc/ubench_max3.hip, 3 x 4 M random triples.
-// Adds and subtractions stay integer ops on the patterns.  The checkpoints are stored re-biased to 0x8000, so the traceback
-// does not know the class exists.
+// Adds and subtractions stay integer ops on the patterns.  The checkpoints hold the 0x3E00-biased values as computed; the traceback
+// converts its border values with the same bias (VsxDevParams::max3).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 DEV u32 pk_max3_bits(u32 a, u32 b, u32 c)            // IEEE maximum of three: the compiler selects v_pk_maximum3_f16 (no inline asm: free register choice)
 {
@@ -165,7 +165,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   static_assert(!MAX3 || TILT, "the MAX3 arithmetic is a sub-class of TILT");
   constexpr u32 BIAS16 = MAX3 ? 0x3E00u : (TILT ? 0x8000u : 0u);
   constexpr u32 BIAS = BIAS16 * 0x10001u;
-  constexpr u32 CK_REBIAS = MAX3 ? (0x8000u - 0x3E00u) * 0x10001u : 0u;      // stored checkpoints are always biased by 0x8000
+  constexpr u32 CK_REBIAS = 0u;      // (first MAX3 build: stored checkpoints re-biased to 0x8000; the traceback takes the class's bias now)
   auto bpack = [](int v) -> u32 { return pack16(v + (int) BIAS16); };        // a border value -> both halves, biased
   auto vadd = [](u32 a, u32 b) -> u32 { return TILT ? a + b : sadd(a, b); };       // b >= 0 per half
   auto vsubk = [](u32 a, u32 b) -> u32 { return TILT ? a - b : ssub(a, b); };      // b >= 0 per half, a >= b per half
@@ -373,6 +373,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           load_profile(profA, sym);
         }
 
+      const uint4 * const feed4_g = FEED4 + g * 16;
+      const u32 * const feedf_g = FEEDF + g * 16;
       // one pipeline step; reads the left-neighbour row state from hin[] and writes hout[] (the caller ping-pongs the two
       // arrays over an even number of steps, so no per-step register copies remain)
       // INTERIOR (phase A of the strip, see the loops below): no lane of the wave has reached a last / padded column yet, so
@@ -419,14 +421,16 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           else if ((t & 15) == 0) build_feed(t >> 4);
 
           // ---- systolic shift (all lanes, full EXEC) ----
+          // feed reads: lane part (the group's 16-column row) hoisted, the step's part is uniform -- one v_add per address
           const int fo = QPL ? ((t >> 4) & 1) * 64 : 0;
-          const uint4 fv = FEED4[fo + g * 16 + (t & 15)];
-          const u32 fF = FEEDF[fo + g * 16 + (t & 15)];
+          const u32 fslot = (u32) (fo + (t & 15));
+          const uint4 fv = feed4_g[fslot];
+          const u32 fF = feedf_g[fslot];
           if (QPL)
             {
               // `sym` already holds this step's symbols; look one step ahead and request that step's profile rows now
               const int t1 = t + 1;
-              symn = dpp_shr1(FEED4[((t1 >> 4) & 1) * 64 + g * 16 + (t1 & 15)].x, sym);
+              symn = dpp_shr1(feed4_g[(u32) (((t1 >> 4) & 1) * 64 + (t1 & 15))].x, sym);
               load_profile(pn, symn);
             }
           else sym = dpp_shr1(fv.x, sym);
@@ -1007,6 +1011,11 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   const int g = (int) (sl >> 1);
   const bool hi = (sl & 1) != 0;
   const u32 half_sel = hi ? 0x07060302u : 0x05040100u;           // v_perm_b32(F, H, sel) = this pair's H | F << 16
+  // Border values (tables, corner seeds) enter the recompute through vin(): the FAST domain is the int16 value plus the class's bias --
+  // 0x8000, or 0x3E00 when the DP kernel ran its MAX3 arithmetic (VsxDevParams::max3): the checkpoints then hold 0x3E00-biased values
+  // as the DP kernel computes them (r03: re-biasing them at store time cost the DP kernel ~2 instructions per step)
+  const u32 fast_bias = (CK8 && P.max3) ? 0x3E00u : 0x8000u;
+  auto vin = [&](u32 lo16) -> u32 { return FAST ? ((lo16 + fast_bias) & 0xffffu) : A::in(lo16); };
   const u32 bias2 = (FAST && P.tilt == 0) ? 0x80008000u : 0u;      // checkpoints of the TILT class are stored biased
   const u32 ckb = (FAST && P.tilt == 0) ? 0x8000u : 0u;
   // penalties: FAST subtracts them in 32 bits, so they are sign-extended there (tilted penalties can be negative)
@@ -1168,8 +1177,8 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
               // corner H(slot RT - 1, -1): the left border of the row above the tile, as the DP kernel seeded it
               const int xs = RT - 1;
               int ii = i0 + xs; if (ii > Q - 1) ii = Q - 1;
-              u32 cv = A::in((u32) (uint16_t) P.hleft[ii < 0 ? 0 : ii]);
-              if (TOPPAD && L == 0 && xs < pad) cv = A::in((u32) (uint16_t) (((xs == pad - 1) ? 0 : -P.top_open) + (xs - pad - 1) * tl));
+              u32 cv = vin((u32) (uint16_t) P.hleft[ii < 0 ? 0 : ii]);
+              if (TOPPAD && L == 0 && xs < pad) cv = vin((u32) (uint16_t) (((xs == pad - 1) ? 0 : -P.top_open) + (xs - pad - 1) * tl));
               tbL[64 + tid] = cv;
             }
         }
@@ -1181,7 +1190,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
               int c = c0 - 1 + cc;
               if (c > jj) c = jj;
               const u32 corner = (u32) (uint16_t) (((TOPPAD && pad > 0) ? -P.top_open : 0) - (pad + 2) * tl);   // see the DP kernel's diag seed
-              tbL[(cc + 1) * 64 + tid] = (c < 0) ? A::in(corner) : A::in((u32) (uint16_t) (P.htop[c] - pad * tl));   // F is derived from H below
+              tbL[(cc + 1) * 64 + tid] = (c < 0) ? vin(corner) : vin((u32) (uint16_t) (P.htop[c] - pad * tl));   // F is derived from H below
             }
         }
       else
@@ -1193,7 +1202,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
           else
           stage_top(rowck + (size_t) VSX_CK_SLOT(CK8, g, lp) * (CK8 ? 3 : 4), VSX_ROWCK_PAIR_DW(CK8), (long) ((size_t) sp * steps) + (long) (c0 - 1 + lp),
                     (long) (rowsteps >> 1) - 1);
-          if (c0 == 0) tbL[64 + tid] = A::in((u32) (uint16_t) P.hleft[i0 - 1]);     // corner H(i0-1, -1)
+          if (c0 == 0) tbL[64 + tid] = vin((u32) (uint16_t) P.hleft[i0 - 1]);     // corner H(i0-1, -1)
         }
       stage_symbols(c0);
 
@@ -1211,7 +1220,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
             {
               int ii = i0 + r0h + x; if (ii > Q - 1) ii = Q - 1;
               if (ii < 0) ii = 0;
-              const u32 hl = A::in((u32) (uint16_t) P.hleft[ii]);
+              const u32 hl = vin((u32) (uint16_t) P.hleft[ii]);
               hp[x] = hl;
               ee[x] = A::sub(hl, (ii < Q - 1) ? qrq_i : pen_pk(P.qrq_r_pk));
             }
@@ -1223,8 +1232,8 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
                   {
                     const int xs = r0h + x;
                     const int sh = (xs - pad - 1) * tl;                 // tilt of (i, -1), i = xs - pad
-                    hp[x] = A::in((u32) (uint16_t) (((xs == pad - 1) ? 0 : -P.top_open) + sh));
-                    ee[x] = A::sub(A::in((u32) (uint16_t) (-P.top_open - P.top_step + sh)), qrq_i);
+                    hp[x] = vin((u32) (uint16_t) (((xs == pad - 1) ? 0 : -P.top_open) + sh));
+                    ee[x] = A::sub(vin((u32) (uint16_t) (-P.top_open - P.top_step + sh)), qrq_i);
                   }
             }
         }

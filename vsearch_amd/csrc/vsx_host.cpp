@@ -1267,10 +1267,14 @@ int vsx_plan_run(vsx_plan * pl)
       if (ctx->ckpt)
         {
           for (const Launch & L : c.launches)      // the recompute traceback is specialised on R like the DP kernel
-            HIPCHK(vsx_launch_traceback_ck(L.rows, (L.track == 0 && L.generic != 0) ? 1 : 0, L.tilt ? ctx->Pt : ctx->P, pl->filter, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
-                                           pl->d_pair_ids.p + L.pair_first, L.pair_count, pl->Q->codes(), pl->T->codes(),
-                                           dir, pl->d_slot.p, pl->d_slab.p, pl->d_slab_off.p + L.pair_first,
-                                           pl->d_runs.p, pl->runs_capacity, pl->d_cursor.p, pl->d_out.p, st2));
+            {
+              VsxDevParams Pb = L.tilt ? ctx->Pt : ctx->P;
+              Pb.max3 = (L.tilt == 2) ? 1 : 0;         // the checkpoints of the MAX3 class carry its bias
+              HIPCHK(vsx_launch_traceback_ck(L.rows, (L.track == 0 && L.generic != 0) ? 1 : 0, Pb, pl->filter, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
+                                             pl->d_pair_ids.p + L.pair_first, L.pair_count, pl->Q->codes(), pl->T->codes(),
+                                             dir, pl->d_slot.p, pl->d_slab.p, pl->d_slab_off.p + L.pair_first,
+                                             pl->d_runs.p, pl->runs_capacity, pl->d_cursor.p, pl->d_out.p, st2));
+            }
         }
       else
         HIPCHK(vsx_launch_traceback(ctx->P, pl->d_tasks.p, pl->d_pair_slot.p + c.pair_first, pl->d_pair_ids.p + c.pair_first,
