@@ -57,11 +57,12 @@ struct KmerScratch {
   Buf<uint64_t> d_ranges;                                // uint2 (first unit, units) per (tile, slot, word): 8-bit class
   Buf<uint32_t> d_tilecnt;                               // records per (slot, tile)
   Buf<unsigned long long> d_cursor;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e_turn = nullptr;   // timing; e_turn = this batch's counting kernels are done
   uint64_t records = 0;
   bool busy = false;
   ~KmerScratch()
   {
+    if (e_turn) (void) hipEventDestroy(e_turn);
     if (e0) (void) hipEventDestroy(e0);
     if (e1) (void) hipEventDestroy(e1);
     if (st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
@@ -85,6 +86,8 @@ struct VsxKmerIndex {
   std::vector<std::unique_ptr<KmerScratch>> scratch;
   std::mutex mu;
   std::condition_variable cv;
+  std::mutex turn_mu;                                    // count_pass: the counting kernels of concurrent batches run one after the other
+  hipEvent_t turn_ev = nullptr;                          // (borrowed from the scratch set that launched last)
   hipEvent_t e0 = nullptr, e1 = nullptr;                 // build timing
   VsxKmerStats stats;
   std::vector<uint64_t> word_total;   // postings per word over all tiles
@@ -291,10 +294,26 @@ int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, uint32_t n8
   KCHK(hipEventRecord(sc->e0, sc->st));
   if (n8 && !no_pre)
     KCHK(vsx_kmer_launch_ranges(ix->d_start.p, nt, sc->d_qk_start.p, sc->d_qk.p, sc->d_minmatch.p, d_qlist, n8, sc->d_ranges.p, sc->st));
+  // Counting kernels of concurrent batches take turns in arrival order: each fills the device on its own, so two at once only
+  // finish BOTH late (the search's windows then reach the aligner in pairs and its last stage starts later); uploads, ranges,
+  // selection and downloads of the other batch still overlap.  VSX_KMER_TURNS=0: free-running (A/B).
+  static const bool turns = !(std::getenv("VSX_KMER_TURNS") && std::strcmp(std::getenv("VSX_KMER_TURNS"), "0") == 0);
+  std::unique_lock<std::mutex> turn(ix->turn_mu, std::defer_lock);
+  if (turns)
+    {
+      turn.lock();
+      if (ix->turn_ev) KCHK(hipStreamWaitEvent(sc->st, ix->turn_ev, 0));
+    }
   KCHK(vsx_kmer_launch_count(8, tg, ix->d_post.p, ix->d_start.p, (n8 && !no_pre) ? sc->d_ranges.p : nullptr, nt, ix->nseq, n8, 0, sc->d_qk_start.p, sc->d_qk.p,
                              sc->d_minmatch.p, d_qlist, sc->d_rec.p, subcap, sc->d_tilecnt.p, sc->st));
   KCHK(vsx_kmer_launch_count(16, tg, ix->d_post.p, ix->d_start.p, nullptr, nt, ix->nseq, nslots - n8, n8, sc->d_qk_start.p, sc->d_qk.p,
                              sc->d_minmatch.p, d_qlist, sc->d_rec.p + (size_t) n8 * nt * subcap, subcap, sc->d_tilecnt.p + (size_t) n8 * nt, sc->st));
+  if (turns)
+    {
+      KCHK(hipEventRecord(sc->e_turn, sc->st));
+      ix->turn_ev = sc->e_turn;
+      turn.unlock();
+    }
   uint64_t capacity = std::max<uint64_t>(sc->d_dense.n, std::max<uint64_t>(1u << 20, (uint64_t) nslots * 128));
   unsigned long long produced = 0;
   for (int attempt = 0; attempt < 2; ++attempt)
@@ -334,7 +353,7 @@ int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, uint32_t n8
 
 }  // namespace
 
-#define VSX_KMER_SCRATCH_MAX 2
+#define VSX_KMER_SCRATCH_MAX 3
 
 namespace {
 struct ScratchLease {
@@ -368,7 +387,8 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
             int prio_low = 0, prio_high = 0;               // counting runs BEHIND the aligner's plans (vsx_host.cpp vsx_create)
             (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
             if (hipStreamCreateWithPriority(&p->st, hipStreamNonBlocking, prio_low) != hipSuccess || hipEventCreate(&p->e0) != hipSuccess ||
-                hipEventCreate(&p->e1) != hipSuccess || p->d_cursor.alloc(1) != hipSuccess)
+                hipEventCreate(&p->e1) != hipSuccess || hipEventCreateWithFlags(&p->e_turn, hipEventDisableTiming) != hipSuccess ||
+                p->d_cursor.alloc(1) != hipSuccess)
               { (void) hipGetLastError(); vsx_internal_set_error("vsx_kmer_count_batch: scratch allocation failed"); return VSX_EHIP; }
             lease.sc = p.get();
             ix->scratch.push_back(std::move(p));

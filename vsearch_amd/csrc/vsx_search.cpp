@@ -1151,11 +1151,25 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
   // window boundaries.  Piped: the first windows are small (the GPU starts after the first window's words: a quarter, then half
   // a window), the last two shrink again (half, then a quarter: the last alignment stage is the only thing nothing overlaps)
   std::vector<uint64_t> cut {0};
+  static const int env_taper = std::getenv("VSX_SEARCH_TAPER") ? std::atoi(std::getenv("VSX_SEARCH_TAPER")) : 0;      // A/B
+  const int taper = std::min(std::max(env_taper ? env_taper : 2, 1), 6);          // the tail: window / 2, / 4, ... / 2^taper
+  const bool graded = piped && !env_window && S->o.window <= 0;
+  uint64_t head_tail = window / 4 + window / 2;
+  for (int k = 1; k <= taper; ++k) head_tail += window >> k;
+  if (graded && nq > head_tail)
+    {
+      cut.push_back(window / 4);
+      cut.push_back(cut.back() + window / 2);
+      const uint64_t body = nq - head_tail;
+      for (uint64_t k = 0; k < body / window; ++k) cut.push_back(cut.back() + window);
+      if (body % window) cut.push_back(cut.back() + body % window);
+      for (int k = 1; k <= taper; ++k) cut.push_back(cut.back() + (window >> k));
+    }
   while (cut.back() < nq)
     {
       const uint64_t left = nq - cut.back();
       uint64_t want = window;
-      if (piped && !env_window && S->o.window <= 0)
+      if (graded)
         {
           if (cut.size() == 1) want = window / 4;
           else if (cut.size() == 2) want = window / 2;
@@ -1417,7 +1431,8 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       // two rank workers: one window's host work (CSR, uploads, record download, ranking) runs under the other's counting
       // kernel (vsx_kmer_count_batch leases a scratch set and a stream per call); windows may reach the aligner out of order,
       // a query's hits do not depend on it
-      const int n_rank = dev_kmer ? 2 : 1;
+      static const int env_rankers = std::getenv("VSX_SEARCH_RANKERS") ? std::atoi(std::getenv("VSX_SEARCH_RANKERS")) : 0;   // A/B
+      const int n_rank = dev_kmer ? std::min(std::max(env_rankers ? env_rankers : 2, 1), 4) : 1;
       std::atomic<int> rank_live {n_rank};
       auto rank_worker = [&]() {
         for (;;)
@@ -1431,8 +1446,8 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
         s1.abort();
         if (rank_live.fetch_sub(1) == 1) s2.finish();
       };
-      std::thread stage_rank(rank_worker), stage_rank2;
-      if (n_rank == 2) stage_rank2 = std::thread(rank_worker);
+      std::vector<std::thread> stage_rank;
+      for (int k = 0; k < n_rank; ++k) stage_rank.emplace_back(rank_worker);
       // two consumers, each with its own aligner context on the device (a window's plans, fetches and replays are a chain of
       // short round trips: ~20 ms of wall time for ~5 ms of kernels, so two windows in flight keep the stage off the critical
       // path); VSX_SEARCH_CONSUMERS=1 keeps one (A/B, tests).  Windows are independent: a query's hits live in its own slot.
@@ -1470,8 +1485,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       s2.abort();
       s1.abort();
       stage_words.join();
-      stage_rank.join();
-      if (stage_rank2.joinable()) stage_rank2.join();
+      for (std::thread & t : stage_rank) t.join();
       if (rc != VSX_OK) { vsx_internal_set_error(msg.c_str()); return rc; }
     }
 
