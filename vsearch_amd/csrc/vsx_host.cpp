@@ -211,6 +211,7 @@ struct vsx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // DP kernels, copies
   hipStream_t stream2 = nullptr;     // traceback kernels (overlap with the next chunk's DP)
+  hipStream_t stream_b = nullptr;    // DP kernels of every other pipelined slice (vsx_align_pairs): the next launch fills this one's tail
   hipStream_t stream_up = nullptr;   // plan uploads (a plan may be created while another one runs: vsx_align_pairs pipeline)
   hipStream_t stream_dn = nullptr;   // result downloads (vsx_plan_fetch of slice i-1 while slice i's kernels occupy `stream`)
   vsx_scoring sc {};
@@ -405,6 +406,7 @@ struct vsx_plan {
   PoolBuf<uint32_t> d_pair_slot, d_pair_ids;
   SharedBuf<uint32_t> d_dir[1], d_slab;         // stream-ordered scratch shared by the context's plans
   int dir_slot = 0;                             // which of the context's two checkpoint blocks
+  bool alt_fwd = false;                         // DP kernels on the context's second DP stream (pipelined slices, see vsx_align_pairs)
   PoolBuf<uint32_t> d_runs;
   PoolBuf<uint64_t> d_slab_off;
   PoolBuf<uint2> d_strip;
@@ -584,6 +586,7 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   auto cleanup = [&]() {
     if (c->stream) (void) hipStreamDestroy(c->stream);
     if (c->stream2) (void) hipStreamDestroy(c->stream2);
+    if (c->stream_b) (void) hipStreamDestroy(c->stream_b);
     if (c->stream_up) (void) hipStreamDestroy(c->stream_up);
     if (c->stream_dn) (void) hipStreamDestroy(c->stream_dn);
     delete c;
@@ -592,10 +595,18 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   // the aligner's streams get the HIGHEST priority the device offers: in a search its short plans share the GPU with the k-mer
   // counting kernel of the next window (lowest priority, vsx_kmer_host.cpp), whose millions of 15-us blocks would otherwise keep
   // every CU busy and hold each alignment stage back until the counting is over (r03 timeline: windows aligned 100 ms late)
+  // Between them the TRACEBACK stream ranks above the DP streams where the device has a level to spare: the DP kernel of slice
+  // i+2 waits for the traceback of slice i (two checkpoint blocks).  Same-box A/B of vsx_align_pairs (800 k pairs): 36.7-37.3 ms
+  // against 37.5-39.0 with equal priorities.  It does not cure the starvation itself: a traceback wave needs 168 VGPRs, a retiring
+  // DP wave frees 128, so while a DP launch still has workgroups to dispatch the traceback only gets whole-SIMD gaps (rocprofv3
+  // traces of one call: profiles/r03/r03v_e2e_trace*.csv).
   int prio_low = 0, prio_high = 0;
-  (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-  if ((e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high)) != hipSuccess ||
+  (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);            // numerically: high < low
+  static const bool flat_env = std::getenv("VSX_ALIGN_FLAT_PRIORITY") != nullptr;      // A/B
+  const int prio_dp = (!flat_env && prio_low - prio_high >= 2) ? prio_high + 1 : prio_high;
+  if ((e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_dp)) != hipSuccess ||
       (e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_high)) != hipSuccess ||
+      (e = hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, prio_dp)) != hipSuccess ||
       (e = hipStreamCreateWithPriority(&c->stream_up, hipStreamNonBlocking, prio_high)) != hipSuccess ||
       (e = hipStreamCreateWithPriority(&c->stream_dn, hipStreamNonBlocking, prio_high)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_tb[0], hipEventDisableTiming)) != hipSuccess ||
@@ -663,6 +674,7 @@ void vsx_destroy(vsx_ctx * c)
   (void) hipSetDevice(c->device);
   if (c->stream) { (void) hipStreamSynchronize(c->stream); (void) hipStreamDestroy(c->stream); }
   if (c->stream2) { (void) hipStreamSynchronize(c->stream2); (void) hipStreamDestroy(c->stream2); }
+  if (c->stream_b) { (void) hipStreamSynchronize(c->stream_b); (void) hipStreamDestroy(c->stream_b); }
   if (c->stream_up) { (void) hipStreamSynchronize(c->stream_up); (void) hipStreamDestroy(c->stream_up); }
   if (c->stream_dn) { (void) hipStreamSynchronize(c->stream_dn); (void) hipStreamDestroy(c->stream_dn); }
   c->shared_dir[0].reset();
@@ -1240,7 +1252,7 @@ int vsx_plan_run(vsx_plan * pl)
   if (!pl) return fail(VSX_EINVAL, "vsx_plan_run: null plan");
   vsx_ctx * ctx = pl->ctx;
   HIPCHK(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream, st2 = ctx->stream2;
+  hipStream_t st = pl->alt_fwd ? ctx->stream_b : ctx->stream, st2 = ctx->stream2;
   const int slot = pl->dir_slot;
   HIPCHK(hipMemsetAsync(pl->d_cursor.p, 0, 2 * sizeof(unsigned long long), st));
   HIPCHK(hipEventRecord(pl->ev_begin, st));
@@ -1845,6 +1857,11 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
         cv.wait(lk, [&] { return ready > i; });
       }
       if (plan_rc[i] != VSX_OK) { rc = plan_rc[i]; msg = plan_msg[i]; break; }
+      // odd slices launch their DP kernels on the second DP stream: a slice is ~3-6 rounds of resident waves, its last round drains
+      // for about half a wave's lifetime, and a launch on the same stream would wait for that (inputs are complete: plan_create
+      // has synchronised its uploads; the two checkpoint blocks alternate the same way)
+      static const bool alt_env = !(std::getenv("VSX_ALIGN_ALT_STREAM") && std::strcmp(std::getenv("VSX_ALIGN_ALT_STREAM"), "0") == 0);
+      plans[i]->alt_fwd = alt_env && (i & 1);
       rc = vsx_plan_run(plans[i]);                       // asynchronous: queued behind slice i-1 on the context's streams
       if (timing) std::fprintf(stderr, "  slice %zu: queued at %.1f ms\n", i, (now() - t_begin) * 1e3);
       if (rc != VSX_OK) { msg = vsx_last_error(); break; }
