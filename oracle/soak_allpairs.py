@@ -9,6 +9,7 @@ filters with --sizein, --self, a scoring set in the CLI's syntax; blocks of rand
 import argparse
 import json
 import os
+os.environ.setdefault("VSX_RANK_STRICT", "1")      # any device/host difference in identity or filter is an error here
 import random
 import subprocess
 import sys

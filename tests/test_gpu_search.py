@@ -596,3 +596,42 @@ def test_search_window_pipeline_equals_single_thread(gpu_required):
                         "-k", "usearch_global or strand_both or infinite_gap or candidate_order or sentinel_pairs"], env=e, capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert " passed" in p.stdout
+
+
+def test_dust_masking_refuses_overlapping_sequences(gpu_required):
+    """DUST rewrites the text in place: sequences that share bytes of the blob would get the union of their masks (the reference
+    masks every sequence on its own, mask.cpp:233-249), so the library refuses them -- database and raw queries alike."""
+    import ctypes as C
+    import numpy as np
+    from vsearch_amd import Aligner, _lib
+    lib = gpu_required
+    rng = random.Random(5)
+    blob = common.rnd_seq(rng, 400).encode()
+    off = np.array([0, 100, 150], dtype=np.uint64)          # the third starts inside the second
+    ln = np.array([100, 100, 200], dtype=np.uint32)
+    with Aligner() as al:
+        for soft_mask, want in ((2, _lib.VSX_EINVAL), (0, 0)):
+            o = _lib.SearchOpts()
+            lib.vsx_search_opts_default(C.byref(o))
+            o.soft_mask = soft_mask
+            o.id = 0.9
+            h = C.c_void_p()
+            rc = lib.vsx_searcher_create(al.h, C.byref(h), C.byref(o), 3, C.cast(C.c_char_p(blob), C.c_void_p), len(blob),
+                                         off.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p))
+            assert rc == want, (soft_mask, rc, lib.vsx_last_error())
+            if rc != 0:
+                assert b"overlap" in lib.vsx_last_error()
+            if rc == 0:
+                lib.vsx_searcher_destroy(h)
+        # disjoint but unordered offsets are fine
+        off2 = np.array([200, 0, 100], dtype=np.uint64)
+        ln2 = np.array([100, 100, 100], dtype=np.uint32)
+        o = _lib.SearchOpts()
+        lib.vsx_search_opts_default(C.byref(o))
+        o.soft_mask = 2
+        o.id = 0.9
+        h = C.c_void_p()
+        rc = lib.vsx_searcher_create(al.h, C.byref(h), C.byref(o), 3, C.cast(C.c_char_p(blob), C.c_void_p), len(blob),
+                                     off2.ctypes.data_as(C.c_void_p), ln2.ctypes.data_as(C.c_void_p))
+        assert rc == 0, lib.vsx_last_error()
+        lib.vsx_searcher_destroy(h)

@@ -826,9 +826,33 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
   return VSX_OK;
 }
 
+// DUST rewrites the text in place (host threads per sequence, atomicOr on the device): sequences that share bytes of the blob would
+// race and come out with the union of their masks, unlike the reference's per-sequence dust().  Offsets in ascending order (every
+// caller of ours) cost one sweep; anything else is sorted first.
+template <typename FOff, typename FLen>
+static bool sequences_disjoint(uint64_t n, FOff off, FLen len)
+{
+  bool ascending = true;
+  uint64_t end = 0;
+  for (uint64_t k = 0; k < n && ascending; ++k)
+    {
+      const uint64_t o = off(k), l = len(k);
+      if (l == 0) continue;
+      if (o < end) ascending = false;
+      end = o + l;
+    }
+  if (ascending) return true;
+  std::vector<std::pair<uint64_t, uint64_t>> iv;
+  iv.reserve(n);
+  for (uint64_t k = 0; k < n; ++k) if (len(k)) iv.emplace_back(off(k), off(k) + len(k));
+  std::sort(iv.begin(), iv.end());
+  for (size_t k = 1; k < iv.size(); ++k) if (iv[k].first < iv[k - 1].second) return false;
+  return true;
+}
+
 // DUST of raw queries (query masking mode 2): the reference masks every query -- and each strand of it separately -- in place before
 // anything else reads it (core/search.cpp:294-303, commands/usearch_global.cpp:386-392); text[off(k) .. + len(k)) for k < n.
-// The sequences must not overlap in the blob.
+// The sequences must not overlap in the blob (sequences_disjoint; the callers check).
 template <typename FOff, typename FLen>
 static void dust_states(const vsx_searcher * S, char * text, uint64_t n, FOff off, FLen len)
 {
@@ -1003,6 +1027,8 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
   if (S->o.soft_mask < 0 || S->o.soft_mask > 2) return sfail(VSX_EINVAL, "vsx_searcher_create: soft_mask must be 0 (none), 1 (soft) or 2 (dust)");
   if (S->o.qmask < 0 || S->o.qmask > 3) return sfail(VSX_EINVAL, "vsx_searcher_create: qmask must be 0 (as soft_mask), 1 (none), 2 (soft) or 3 (dust)");
   S->qmode = S->o.qmask ? S->o.qmask - 1 : S->o.soft_mask;
+  if (S->o.soft_mask == 2 && !sequences_disjoint(n, [&](uint64_t k) { return offsets[k]; }, [&](uint64_t k) { return (uint64_t) lengths[k]; }))
+    return sfail(VSX_EINVAL, "vsx_searcher_create: DUST masking (soft_mask 2) needs sequences that do not overlap in the blob");
   int rc = S->o.soft_mask ? vsx_internal_seqset_create_cased(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths, S->o.soft_mask)
                           : vsx_seqset_create(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths);
   if (rc != VSX_OK) return rc;
@@ -1090,6 +1116,8 @@ int vsx_search_candidates_batch(vsx_searcher * S, int32_t device, uint64_t nq, c
   std::string masked;
   if (S->qmode == 2 && qbytes)
     {
+      if (!sequences_disjoint(nq, [&](uint64_t k) { return qoff[k]; }, [&](uint64_t k) { return (uint64_t) qlen[k]; }))
+        return sfail(VSX_EINVAL, "vsx_search_candidates_batch: DUST query masking needs queries that do not overlap in the blob");
       masked.assign(qblob, qbytes);
       dust_states(S, &masked[0], nq, [&](uint64_t k) { return qoff[k]; }, [&](uint64_t k) { return qlen[k]; });
       qblob = masked.data();
@@ -1587,7 +1615,8 @@ int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows
       }
       const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, S->threads), count / 8));
       std::vector<int> err((size_t) nth, VSX_OK);
-      std::atomic<uint64_t> next {0};
+      std::atomic<uint64_t> next {0}, rank_drift {0};
+      static const bool rank_strict = std::getenv("VSX_RANK_STRICT") != nullptr;
       auto work = [&](int tid) {
         uint64_t dummy = 0;
         for (;;)
@@ -1598,15 +1627,32 @@ int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows
             const char * q = S->blob.data() + S->off[qi];
             const int64_t ql = S->len[qi];
             kept[k].reserve(hfirst[k + 1] - hfirst[k]);
+            bool resort = false;
             for (uint64_t j = hfirst[k]; j < hfirst[k + 1]; ++j)
               {
                 Hit h;
                 h.target = pt[rk.pair[j]];
                 const int frc = fill_hit(*S, [&]() { return q; }, ql, h, view, j, dummy);
                 if (frc != VSX_OK) { err[(size_t) tid] = frc; return; }
-                if (!acceptable_aligned(*S, ql, h, S->abundance(qi)) || h.id != rk.id[j]) { err[(size_t) tid] = VSX_EHIP; return; }
+                // The device's filter and identity are the same double expressions as the host's (vsx_rank.hip) and the soaks compare
+                // them bit for bit (VSX_RANK_STRICT=1 turns any difference into an error there).  In production a difference -- a host
+                // build with other floating-point flags, say -- must not fail the run: the host value stands, the group is re-ordered
+                // by it, a hit the host would not accept is dropped, and the count is reported once.
+                const bool ok = acceptable_aligned(*S, ql, h, S->abundance(qi));
+                if (!ok || h.id != rk.id[j])
+                  {
+                    if (rank_strict) { err[(size_t) tid] = VSX_EHIP; return; }
+                    rank_drift.fetch_add(1);
+                    resort = true;
+                    if (!ok) continue;
+                  }
                 kept[k].push_back(std::move(h));
               }
+            if (resort)
+              std::stable_sort(kept[k].begin(), kept[k].end(), [](const Hit & a, const Hit & b) {
+                if (a.id != b.id) return a.id > b.id;
+                return a.target < b.target;
+              });
           }
       };
       {
@@ -1622,6 +1668,13 @@ int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows
             return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "vsx_allpairs_rows: device and host accept filters disagree"
                                                                        : "vsx_allpairs_rows: fallback aligner failed");
           }
+      if (rank_drift.load())
+        {
+          static std::atomic<bool> told {false};
+          if (!told.exchange(true))
+            std::fprintf(stderr, "vsx_allpairs_rows: %llu hit(s) where the device's identity or filter differs from the host's; the host values stand\n",
+                         (unsigned long long) rank_drift.load());
+        }
       // pairs the 16-bit aligner refused: linear-memory fallback, host filter, ordered insertion (rare)
       for (uint64_t u = 0; u < rk.n_undecided; ++u)
         {
