@@ -197,6 +197,7 @@ typedef struct vsx_candidates {
   double     index_build_ms;   /* device index build, paid on first use */
   uint64_t   index_postings;   /* entries of the index */
   uint64_t   postings_streamed;/* counter increments of this call = postings read */
+  uint64_t   bytes_streamed;   /* bytes of postings the count kernel read (the index format decides: 2 per posting, 4 tagged, 16 per packed unit) */
 } vsx_candidates;
 int vsx_search_candidates_batch(vsx_searcher * s, int32_t device, uint64_t n, const char * qblob, uint64_t qbytes,
                                 const uint64_t * qoff, const uint32_t * qlen, vsx_candidates * out);

@@ -35,7 +35,8 @@ class Candidates(C.Structure):
     """vsx_candidates (include/vsx_search.h)"""
     _fields_ = [("n_queries", C.c_uint64), ("start", C.POINTER(C.c_uint64)), ("target", C.POINTER(C.c_uint32)),
                 ("count", C.POINTER(C.c_uint32)), ("seconds", C.c_double), ("kernel_ms", C.c_double),
-                ("index_build_ms", C.c_double), ("index_postings", C.c_uint64), ("postings_streamed", C.c_uint64)]
+                ("index_build_ms", C.c_double), ("index_postings", C.c_uint64), ("postings_streamed", C.c_uint64),
+                ("bytes_streamed", C.c_uint64)]
 
 
 class SearchOpts(C.Structure):

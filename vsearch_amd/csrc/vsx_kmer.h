@@ -21,6 +21,7 @@ struct VsxKmerStats {
   double count_ms = 0;            // last vsx_kmer_count_batch: kernel time (hipEvents)
   uint64_t postings = 0;          // entries in the index
   uint64_t increments = 0;        // last batch: counter updates = postings streamed
+  uint64_t streamed_bytes = 0;    // last batch: bytes of postings the count kernel read (2 per posting; tagged 4; packed 16 per unit of <= 15)
   uint64_t records = 0;           // last batch: candidates emitted
   uint64_t index_bytes = 0;
 };

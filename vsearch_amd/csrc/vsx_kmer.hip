@@ -469,6 +469,313 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
     }
 }
 
+// ---- PACKED postings (r03; word lengths 3..8, the whole-set index) --------------------------------------------------------------
+// The 16-bit format streams 2 bytes per posting and the count kernel is bound by exactly that stream (6.3 TB/s = what HBM
+// delivers).  Packed format: a bucket's tile-local counter indices SORTED, one 16-byte unit = a 16-bit first index + 14 one-byte
+// gaps = 15 postings (8.5 bits each).  Two things make every byte a plain increment -- no escape code, count field or predicate:
+//   * every 252nd counter of a tile (index = 251 mod 252: an odd index in the TOP byte of its dword) is a DUMMY that stands for no
+//     sequence.  A gap of more than 255 hops over dummies (one harmless increment each; a carry out of a top byte or top half
+//     leaves the dword), and the unused tail of a bucket's last unit is gaps of 0 on a dummy.  A tile therefore holds
+//     130 x 251 = 32 630 sequences; sequence s of the tile owns counter s + s / 251;
+//   * the sweep skips the dummies.
+// The units of one wave's buckets are dealt to its lanes as ONE run (lane = position in the concatenation mod 64): a bucket of
+// the bench shape has ~35 units, and a trip per bucket would leave half the lanes idle while costing the same instructions.
+// Build (per tile, like the tagged index): keys (word << 16 | counter index) of every position -> radix sort -> one thread per
+// word walks its run of distinct keys and counts / writes the units.
+#define KM_PK_PERIOD 252u
+#define KM_PK_REAL 251u
+#define KM_PK_TILE_SEQS (130u * KM_PK_REAL)
+#define KM_PK_SLOTS 15
+
+__global__ void __launch_bounds__(256)
+vsx_kmer_pk_keys_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict__ off, const u32 * __restrict__ len, u32 first_seq,
+                        u32 nseq_tile, int w, const uint8_t * __restrict__ lower, const u64 * __restrict__ slot_of, u32 * __restrict__ keys)
+{
+  const int lane = (int) (threadIdx.x & 63);
+  const u32 local = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (local >= nseq_tile) return;
+  const u32 sid = first_seq + local;
+  const u64 base = off[sid];
+  const uint8_t * __restrict__ s = codes + base;
+  const int L = (int) len[sid];
+  const u32 idx = local + local / KM_PK_REAL;
+  u32 * __restrict__ out = keys + (slot_of[sid] - slot_of[first_seq]);
+  for (int p0 = 0; p0 < L; p0 += 64)
+    {
+      const int p = p0 + lane;
+      if (p >= L) break;
+      u32 word = 0;
+      u32 key = 0xffffffffu;                                       // (no word has counter index 0xffff)
+      if (p + w <= L && word_at(s, p, w, word, lower, base)) key = (word << 16) | idx;
+      out[p] = key;
+    }
+}
+
+// One thread per word: its distinct keys in the sorted array -> units.  FILL = false: bucket_count[b] = units | postings << 16.
+template <bool FILL>
+__global__ void __launch_bounds__(64)
+vsx_kmer_pk_walk_kernel(const u32 * __restrict__ keys, u64 n, u32 tile, u32 ntiles, u32 nwords, u32 * __restrict__ bucket_count,
+                        const u64 * __restrict__ bucket_start, uint4 * __restrict__ postings)
+{
+  const u32 word = blockIdx.x * 64 + threadIdx.x;
+  if (word >= nwords) return;
+  // first key of the word
+  u64 lo = 0, hi = n;
+  const u32 want = word << 16;
+  while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+  const size_t b = (size_t) word * ntiles + tile;
+  uint4 * __restrict__ out = FILL ? postings + bucket_start[b] : nullptr;
+  u32 units = 0, real = 0, s = 0, acc = 0;
+  u32 wv[4] = {0, 0, 0, 0};
+  auto put = [&](u32 delta) {                                      // slot s (1 .. 14) of the open unit
+    const u32 bytepos = s + 1;                                     // bytes 0-1 hold the first index
+    wv[bytepos >> 2] |= delta << (8 * (bytepos & 3));
+    ++s;
+  };
+  auto close = [&]() {
+    if (FILL) out[units] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    ++units;
+    s = 0;
+    wv[0] = wv[1] = wv[2] = wv[3] = 0;
+  };
+  u32 prev = 0xffffffffu;
+  for (u64 i = lo; i < n; ++i)
+    {
+      const u32 k = keys[i];
+      if ((k >> 16) != word || k == 0xffffffffu) break;
+      if (k == prev) continue;                                      // the same word again in the same sequence (unique_count)
+      prev = k;
+      ++real;
+      const u32 idx = k & 0xffffu;
+      for (;;)
+        {
+          if (s == KM_PK_SLOTS) close();
+          if (s == 0) { wv[0] = idx; acc = idx; s = 1; break; }
+          if (idx - acc <= 255u) { put(idx - acc); acc = idx; break; }
+          const u32 d = KM_PK_REAL + KM_PK_PERIOD * ((acc + 4u) / KM_PK_PERIOD);       // the farthest dummy within 255
+          put(d - acc);
+          acc = d;
+        }
+    }
+  if (s > 0)
+    {
+      if (s < KM_PK_SLOTS && (acc % KM_PK_PERIOD) != KM_PK_REAL)
+        {
+          const u32 d = KM_PK_REAL + KM_PK_PERIOD * (acc / KM_PK_PERIOD);               // the dummy of acc's own period
+          put(d - acc);
+        }
+      close();                                                       // the remaining gaps are 0: they stay on the dummy
+    }
+  if (!FILL) bucket_count[b] = units | (real << 16);
+}
+
+// Counting on the packed index.  PRE as in vsx_kmer_count_kernel (the 8-bit class reads its ranges from the pre-pass table).
+// PROBE (timing only, results are wrong): the 16-bit index read as if it were packed, 9/16 of every bucket's units.
+template <int BITS, bool PRE, bool PROBE = false>
+__global__ void __launch_bounds__(BITS == 8 ? 512 : 1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+vsx_kmer_count_packed_kernel(const uint4 * __restrict__ postings, const u64 * __restrict__ bucket_start, const uint2 * __restrict__ R,
+                             u32 ntiles, u32 nseq, const u64 * __restrict__ qk_start, const u32 * __restrict__ qk, const u32 * __restrict__ minmatch,
+                             const u32 * __restrict__ qlist, u32 slot_base, u32 nslots, uint2 * __restrict__ rec, u32 subcap,
+                             u32 * __restrict__ tile_count, int probe)
+{
+  constexpr int THREADS = (BITS == 8) ? 512 : 1024;
+  constexpr int WAVES = THREADS / 64;
+  constexpr int PER = 32 / BITS;
+  constexpr int NDW = (int) (KM_TILE / PER);
+  constexpr int BPW = 256 / WAVES;
+  static_assert(!PRE || BITS == 8, "the range table is laid out for 8 waves");
+  __shared__ __attribute__((aligned(16))) u32 cnt[NDW + 4];
+  __shared__ uint2 rng[PRE ? 1 : 256];
+  __shared__ u32 wave_hits[WAVES];
+  const int tid = (int) threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 srel = blockIdx.x, slot = srel + slot_base, tile = blockIdx.y;
+  const u32 q = qlist ? qlist[slot] : slot;
+  const u32 mm = minmatch[q];
+  const size_t region = (size_t) srel * ntiles + tile;
+  if (mm == 0xffffffffu)
+    {
+      if (tid == 0) tile_count[region] = 0;
+      return;
+    }
+  uint2 mine = make_uint2(0u, 0u);
+  if (PRE && lane < BPW) mine = R[((size_t) tile * nslots + srel) * 256 + (u32) (wave * BPW + lane)];
+  {
+    uint4 * c4 = reinterpret_cast<uint4 *>(cnt);
+    for (int x = tid; x < (NDW + 4) / 4; x += THREADS) c4[x] = make_uint4(0, 0, 0, 0);
+  }
+  const u64 k0 = PRE ? 0 : qk_start[q];
+  const int nk = PRE ? 256 : (int) (qk_start[q + 1] - k0);
+  auto bump = [&](u32 x) __attribute__((always_inline)) {
+    if (BITS == 8) atomicAdd(&cnt[x >> 2], 1u << ((x & 3u) << 3));
+    else atomicAdd(&cnt[x >> 1], 1u << ((x & 1u) << 4));
+  };
+  u32 sink = 0;
+  auto consume = [&](const uint4 & v) __attribute__((always_inline)) {
+    if (probe & 1) { sink ^= v.x + v.y + v.z + v.w; return; }
+    u32 acc = v.x & 0xffffu;
+    if (PROBE) acc &= 0x7fffu;
+    bump(acc);
+    acc += (v.x >> 16) & 0xffu; if (PROBE) acc &= 0x7fffu; bump(acc);
+    acc += v.x >> 24; if (PROBE) acc &= 0x7fffu; bump(acc);
+    const u32 d3[3] = {v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        {
+          acc += (d3[e] >> (8 * b)) & 0xffu;
+          if (PROBE) acc &= 0x7fffu;
+          bump(acc);
+        }
+  };
+  for (int chunk = 0; chunk < nk; chunk += 256)
+    {
+      __syncthreads();                                              // counters cleared / previous chunk's ranges consumed
+      if (!PRE)
+        {
+          if (tid < 256)
+            {
+              uint2 r = make_uint2(0u, 0u);
+              if (chunk + tid < nk)
+                {
+                  const size_t b = (size_t) qk[k0 + chunk + tid] * ntiles + tile;
+                  const u64 first = bucket_start[b];
+                  r = make_uint2((u32) first, (u32) (bucket_start[b + 1] - first));
+                }
+              rng[tid] = r;
+            }
+          __syncthreads();
+          mine = (lane < BPW) ? rng[wave + WAVES * lane] : make_uint2(0u, 0u);
+        }
+      u32 n = mine.y;
+      if (PROBE) n = (n * 9u + 15u) >> 4;
+      // position of each of the wave's buckets in its run of units
+      u32 incl = n;
+#pragma unroll
+      for (int d = 1; d < BPW; d <<= 1)
+        {
+          const u32 up = (u32) __shfl_up((int) incl, d, 64);
+          if (lane >= d) incl += up;
+        }
+      const u32 cum = incl - n;
+      const u32 U = (u32) __builtin_amdgcn_readlane((int) incl, BPW - 1);
+      const u32 T = (U + 63u) >> 6;
+      // unit of this lane in trip t: the bucket whose run covers position 64 t + lane (a wave-uniform walk over the buckets the
+      // trip touches; jb = the first bucket that is not finished yet)
+      int jb = 0;
+      auto fetch = [&](u32 t, uint4 & v, bool & on) __attribute__((always_inline)) {
+        const u32 g = t * 64u + (u32) lane, lim = (t + 1u) * 64u;
+        u32 a = 0xffffffffu;
+        int j = __builtin_amdgcn_readfirstlane(jb);
+        while (j < BPW)
+          {
+            const u32 c = (u32) __builtin_amdgcn_readlane((int) cum, j);
+            if (c >= lim) break;
+            const u32 nn = (u32) __builtin_amdgcn_readlane((int) n, j);
+            const u32 r0 = (u32) __builtin_amdgcn_readlane((int) mine.x, j);
+            const u32 rel = g - c;
+            if (rel < nn) a = r0 + rel;
+            if (c + nn > lim) break;                                   // continues in the next trip
+            ++j;
+          }
+        jb = j;
+        on = a != 0xffffffffu;
+        if (on) v = postings[a];
+      };
+      // three trips in flight per lane
+      uint4 b0 = make_uint4(0, 0, 0, 0), b1 = b0, b2 = b0;
+      bool o0 = false, o1 = false, o2 = false;
+      if (T > 0) fetch(0, b0, o0);
+      if (T > 1) fetch(1, b1, o1);
+      for (u32 t = 0; t < T; t += 3)
+        {
+          if (t + 2 < T) fetch(t + 2, b2, o2); else o2 = false;
+          if (o0) consume(b0);
+          if (t + 1 >= T) break;
+          if (t + 3 < T) fetch(t + 3, b0, o0); else o0 = false;
+          if (o1) consume(b1);
+          if (t + 2 >= T) break;
+          if (t + 4 < T) fetch(t + 4, b1, o1); else o1 = false;
+          if (o2) consume(b2);
+        }
+    }
+  if ((probe & 1) && sink == 0x9e3779b9u) cnt[NDW] = sink;
+  __syncthreads();
+  if (probe & 4) { if (tid == 0) tile_count[region] = 0; return; }
+  // the dummies have collected the hops and the padding (~20 increments each): cleared here, or nearly every dword that holds one
+  // would look like a hit to the sweep's dword test (26 ms of 113 before this).  Dummy k = counter 251 + 252 k = the top byte of
+  // dword 62 + 63 k (8-bit counters) / the top half of dword 125 + 126 k (16-bit)
+  if (tid < 130) { if (BITS == 8) cnt[63 * tid + 62] &= 0x00ffffffu; else cnt[126 * tid + 125] &= 0x0000ffffu; }
+  __syncthreads();
+  // ---- sweep: counters >= mm -> (sequence, count) records in the (query, tile) sub-region, as in vsx_kmer_count_kernel.  Here the
+  // streaming part is short enough for the sweep to show (20 ms of 109 in its first form: ~0.5 % of the counters hit, so every wave
+  // iteration had SOME lane in the per-field path).  Now: one flag bit per hit counter by SWAR (5 instructions per dword, no
+  // branch), the hit count is a popcount, and the writing pass visits set bits only.  Counter x of the tile is sequence
+  // tile * 32 630 + x - x / 252; dummies are cleared, counters past the last sequence were never touched.
+  const u32 base = tile * KM_PK_TILE_SEQS;
+  constexpr int DW_PER_THREAD = NDW / THREADS;                      // 16 in both configurations
+  // flag = top bit of every field >= mm (1 <= mm; 8-bit class: a count never exceeds 255)
+  constexpr u32 TOPS = (BITS == 8) ? 0x80808080u : 0x80008000u, LOWS = ~TOPS, ONES = (BITS == 8) ? 0x01010101u : 0x00010001u;
+  constexpr u32 HALF = (BITS == 8) ? 128u : 32768u;
+  const bool never = (BITS == 8) ? (mm > 255u) : (mm > 65535u);
+  const bool low = mm <= HALF;
+  const u32 addk = (low ? HALF - mm : 2u * HALF - mm) * ONES;
+  auto flags = [&](u32 v) -> u32 {
+    const u32 t = (v & LOWS) + addk;                                 // per field: top bit set iff its low bits >= mm (resp. mm - HALF)
+    return low ? ((t | v) & TOPS) : (t & v & TOPS);
+  };
+  u32 ms[DW_PER_THREAD];
+  u32 found = 0;
+  const uint4 * c4 = reinterpret_cast<const uint4 *>(cnt);
+#pragma unroll
+  for (int g4 = 0; g4 < DW_PER_THREAD / 4; ++g4)
+    {
+      const uint4 v4 = c4[g4 * THREADS + tid];
+      const u32 vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        {
+          const u32 m = never ? 0u : flags(vv[d]);
+          ms[g4 * 4 + d] = m;
+          found += (u32) __builtin_popcount(m);
+        }
+    }
+  u32 inc2 = found;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+    {
+      const u32 up = (u32) __shfl_up((int) inc2, d, 64);
+      if (lane >= d) inc2 += up;
+    }
+  if (lane == 63) wave_hits[wave] = inc2;
+  __syncthreads();
+  u32 before = 0, total = 0;
+#pragma unroll
+  for (int w2 = 0; w2 < WAVES; ++w2) { const u32 t = wave_hits[w2]; before += (w2 < wave) ? t : 0u; total += t; }
+  if (tid == 0) tile_count[region] = total;
+  if (found)
+    {
+      u32 pos = before + inc2 - found;
+      uint2 * __restrict__ out = rec + region * subcap;
+#pragma unroll
+      for (int e = 0; e < DW_PER_THREAD; ++e)
+        {
+          u32 m = ms[e];
+          const u32 dw = (u32) ((e >> 2) * THREADS + tid) * 4u + (u32) (e & 3);
+          while (m)
+            {
+              const int bit = __builtin_ctz(m);                     // 7 / 15 / 23 / 31 (8-bit), 15 / 31 (16-bit)
+              m &= m - 1u;
+              const u32 h = (u32) bit / (u32) BITS;
+              const u32 x = dw * PER + h;
+              const u32 c = (cnt[dw] >> (BITS * h)) & ((BITS == 8) ? 0xffu : 0xffffu);
+              if (pos < subcap) out[pos] = make_uint2(base + x - x / KM_PK_PERIOD, c);
+              ++pos;
+            }
+        }
+    }
+}
+
 // One wave per query slot: keep the records that can still reach the top `keep` (see the header comment).  The slot's records lie
 // in ntiles sub-regions; ONE pass builds a histogram of their counts (clamped at 255), its suffix sums give the threshold -- the
 // largest count with at least `keep` records at or above it -- and a second pass copies the records at or above the threshold to
@@ -625,18 +932,54 @@ extern "C" hipError_t vsx_kmer_launch_count(int bits, int tagged, const uint32_t
                                             uint32_t * tile_count, hipStream_t st)
 {
   // slots [slot_base, slot_base + nslots) of the batch; ranges / rec / tile_count belong to THESE slots (indexed from 0)
+  // tagged: 0 = 16-bit postings, 1 = tagged postings (word lengths 9..15), 2 = packed postings
   if (nslots == 0 || nseq == 0) return hipSuccess;
   static const int probe = std::getenv("VSX_KMER_PROBE") ? std::atoi(std::getenv("VSX_KMER_PROBE")) : 0;
 #define KM_ARGS (const uint4 *) postings, (const u64 *) bucket_start, (const uint2 *) ranges, ntiles, nseq, (const u64 *) qk_start, qk, minmatch, qlist, slot_base, \
                 nslots, (uint2 *) rec, subcap, tile_count, probe
-  if (tagged && bits == 8) hipLaunchKernelGGL((vsx_kmer_count_kernel<8, false, true>), dim3(nslots, ntiles), dim3(512), 0, st, KM_ARGS);
+  if (tagged == 2 && bits == 8 && ranges) hipLaunchKernelGGL((vsx_kmer_count_packed_kernel<8, true>), dim3(nslots, ntiles), dim3(512), 0, st, KM_ARGS);
+  else if (tagged == 2 && bits == 8) hipLaunchKernelGGL((vsx_kmer_count_packed_kernel<8, false>), dim3(nslots, ntiles), dim3(512), 0, st, KM_ARGS);
+  else if (tagged == 2) hipLaunchKernelGGL((vsx_kmer_count_packed_kernel<16, false>), dim3(nslots, ntiles), dim3(1024), 0, st, KM_ARGS);
+  else if (tagged && bits == 8) hipLaunchKernelGGL((vsx_kmer_count_kernel<8, false, true>), dim3(nslots, ntiles), dim3(512), 0, st, KM_ARGS);
   else if (tagged) hipLaunchKernelGGL((vsx_kmer_count_kernel<16, false, true>), dim3(nslots, ntiles), dim3(1024), 0, st, KM_ARGS);
+  else if (bits == 8 && ranges && (probe & 8)) hipLaunchKernelGGL((vsx_kmer_count_packed_kernel<8, true, true>), dim3(nslots, ntiles), dim3(512), 0, st, KM_ARGS);
   else if (bits == 8 && ranges) hipLaunchKernelGGL((vsx_kmer_count_kernel<8, true>), dim3(nslots, ntiles), dim3(512), 0, st, KM_ARGS);
   else if (bits == 8) hipLaunchKernelGGL((vsx_kmer_count_kernel<8, false>), dim3(nslots, ntiles), dim3(512), 0, st, KM_ARGS);
   else hipLaunchKernelGGL((vsx_kmer_count_kernel<16, false>), dim3(nslots, ntiles), dim3(1024), 0, st, KM_ARGS);
 #undef KM_ARGS
   return hipGetLastError();
 }
+
+// One tile of a packed index build (word lengths 3..8): keys of the tile's positions -> sorted -> one thread per word counts
+// (fill == 0) or writes (fill != 0) its units.  temp == nullptr: only *temp_bytes (the sort's scratch for n_slots keys) is set.
+extern "C" hipError_t vsx_kmer_packed_tile(int fill, const uint8_t * codes, const uint64_t * off, const uint32_t * len, uint32_t first_seq,
+                                           uint32_t nseq_tile, int w, const uint8_t * lower_bits, const uint64_t * slot_of, uint64_t n_slots,
+                                           uint32_t * keys_a, uint32_t * keys_b, void * temp, size_t * temp_bytes, uint32_t tile, uint32_t ntiles,
+                                           uint32_t * bucket_count, const uint64_t * bucket_start, uint32_t * postings, hipStream_t st)
+{
+  if (!temp)
+    return rocprim::radix_sort_keys(nullptr, *temp_bytes, keys_a, keys_b, (size_t) n_slots, 0, 32, st);
+  if (nseq_tile == 0) return hipSuccess;
+  const u32 nwords = 1u << (2 * w);
+  if (n_slots)
+    {
+      hipLaunchKernelGGL(vsx_kmer_pk_keys_kernel, dim3((nseq_tile + 3) / 4), dim3(256), 0, st, codes, (const u64 *) off, len, first_seq, nseq_tile, w,
+                         lower_bits, (const u64 *) slot_of, keys_a);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      if ((e = rocprim::radix_sort_keys(temp, *temp_bytes, keys_a, keys_b, (size_t) n_slots, 0, 32, st)) != hipSuccess) return e;
+    }
+  const dim3 grid((nwords + 63) / 64);
+  if (fill)
+    hipLaunchKernelGGL(vsx_kmer_pk_walk_kernel<true>, grid, dim3(64), 0, st, (const u32 *) keys_b, (u64) n_slots, tile, ntiles, nwords, bucket_count,
+                       (const u64 *) bucket_start, (uint4 *) postings);
+  else
+    hipLaunchKernelGGL(vsx_kmer_pk_walk_kernel<false>, grid, dim3(64), 0, st, (const u32 *) keys_b, (u64) n_slots, tile, ntiles, nwords, bucket_count,
+                       (const u64 *) bucket_start, (uint4 *) postings);
+  return hipGetLastError();
+}
+
+extern "C" uint32_t vsx_kmer_packed_tile_seqs(void) { return KM_PK_TILE_SEQS; }
 
 // One tile of a tagged index build (word lengths 9..15): keys of the tile's positions -> sorted -> runs counted (fill == 0) or
 // scattered (fill != 0).  temp == nullptr: only *temp_bytes (the sort's scratch for n_slots keys) is set.

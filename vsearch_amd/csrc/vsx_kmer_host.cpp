@@ -21,6 +21,13 @@ extern "C" void vsx_internal_seqset_device(const vsx_seqset * s, const uint8_t *
 extern "C" const uint8_t * vsx_internal_seqset_lower(const vsx_seqset * s);
 extern "C" const uint32_t * vsx_internal_seqset_host_lengths(const vsx_seqset * s);
 
+// vsx_kmer.hip, packed postings (see there)
+extern "C" hipError_t vsx_kmer_packed_tile(int fill, const uint8_t * codes, const uint64_t * off, const uint32_t * len, uint32_t first_seq,
+                                           uint32_t nseq_tile, int w, const uint8_t * lower_bits, const uint64_t * slot_of, uint64_t n_slots,
+                                           uint32_t * keys_a, uint32_t * keys_b, void * temp, size_t * temp_bytes, uint32_t tile, uint32_t ntiles,
+                                           uint32_t * bucket_count, const uint64_t * bucket_start, uint32_t * postings, hipStream_t st);
+extern "C" uint32_t vsx_kmer_packed_tile_seqs(void);
+
 namespace {
 
 int kfail(int code, const char * what, hipError_t e)
@@ -76,6 +83,7 @@ struct VsxKmerIndex {
   hipStream_t st = nullptr;
   int w = 8;
   bool tagged = false;            // word lengths 9..15: buckets by the word's low 16 bits, postings carry the rest as a tag (vsx_kmer.hip)
+  bool packed = false;            // word lengths 3..8, whole-set index: sorted byte-gap postings, tiles of 32 630 sequences (vsx_kmer.hip)
   uint32_t nseq = 0, ntiles = 0;
   uint64_t nbuckets = 0;
   Buf<uint64_t> d_start;          // nbuckets + 1
@@ -91,6 +99,7 @@ struct VsxKmerIndex {
   hipEvent_t e0 = nullptr, e1 = nullptr;                 // build timing
   VsxKmerStats stats;
   std::vector<uint64_t> word_total;   // postings per word over all tiles
+  std::vector<uint64_t> word_units;   // packed: 16-byte units per word over all tiles
   bool own_stream = false;
   ~VsxKmerIndex()
   {
@@ -117,6 +126,9 @@ int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIn
   std::unique_ptr<VsxKmerIndex> ix(new VsxKmerIndex);
   ix->ctx = ctx; ix->db = db; ix->device = vsx_internal_device(ctx); ix->st = vsx_internal_stream(ctx); ix->w = w;
   ix->tagged = w > 8;
+  // the whole-set index of a short word length takes the packed format (VSX_KMER_PACKED=0: the 16-bit format, A/B and tests)
+  static const bool packed_off = std::getenv("VSX_KMER_PACKED") && std::strcmp(std::getenv("VSX_KMER_PACKED"), "0") == 0;
+  ix->packed = !ix->tagged && !packed_off;
   ix->make_stream();
   KCHK(hipSetDevice(ix->device));
   KCHK(hipEventCreate(&ix->e0));
@@ -155,9 +167,11 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   const int w = ix->w;
   const uint32_t shift = vsx_kmer_tile_shift();
   if (ix->tagged && list) { vsx_internal_set_error("vsx_kmer_index_rebuild: subset indexes exist for word lengths 3..8 only"); return VSX_EINVAL; }
+  if (list) ix->packed = false;                                                    // subset indexes (clustering) are rebuilt every round: two sweeps, no sort
   const uint64_t nwords = ix->tagged ? (1ull << 16) : (1ull << (2 * w));          // rows of the bucket table
+  const uint64_t tile_seqs = ix->packed ? vsx_kmer_packed_tile_seqs() : (1ull << shift);
   ix->nseq = (uint32_t) n;
-  ix->ntiles = std::max<uint32_t>(1, (uint32_t) ((n + (1ull << shift) - 1) >> shift));
+  ix->ntiles = std::max<uint32_t>(1, (uint32_t) ((n + tile_seqs - 1) / tile_seqs));
   ix->nbuckets = nwords * ix->ntiles;
   ix->word_total.assign(nwords, 0);
   ix->stats.postings = 0;
@@ -174,21 +188,28 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   KCHK(hipEventRecord(ix->e0, ix->st));
   KCHK(hipMemsetAsync(ix->d_count.p, 0, ix->nbuckets * 4, ix->st));
   // tagged build (word lengths 9..15): per tile keys -> sort -> runs; scratch for the largest tile
-  Buf<uint64_t> d_slot, d_keys_a, d_keys_b;
+  // (packed build, word lengths 3..8: the same per-tile scheme with 32-bit keys, vsx_kmer_packed_tile)
+  Buf<uint64_t> d_slot, d_keys_a, d_keys_b;                       // packed: the key buffers hold 32-bit keys (half used)
   Buf<uint8_t> d_sort_temp;
   std::vector<uint64_t> slot_of;
   size_t sort_bytes = 0;
+  const bool sorted_build = ix->tagged || ix->packed;
   auto tagged_pass = [&](int fill) -> int {
     for (uint32_t t = 0; t < ix->ntiles; ++t)
       {
-        const uint64_t first = (uint64_t) t << shift, last = std::min<uint64_t>(n, first + (1ull << shift));
+        const uint64_t first = (uint64_t) t * tile_seqs, last = std::min<uint64_t>(n, first + tile_seqs);
+        if (ix->packed)
+          KCHK(vsx_kmer_packed_tile(fill, codes, off, len, (uint32_t) first, (uint32_t) (last - first), w, vsx_internal_seqset_lower(ix->db), d_slot.p,
+                                    slot_of[last] - slot_of[first], reinterpret_cast<uint32_t *>(d_keys_a.p), reinterpret_cast<uint32_t *>(d_keys_b.p),
+                                    d_sort_temp.p, &sort_bytes, t, ix->ntiles, ix->d_count.p, ix->d_start.p, ix->d_post.p, ix->st));
+        else
         KCHK(vsx_kmer_tagged_tile(fill, codes, off, len, (uint32_t) first, (uint32_t) (last - first), w, vsx_internal_seqset_lower(ix->db), d_slot.p,
                                   slot_of[last] - slot_of[first], d_keys_a.p, d_keys_b.p, d_sort_temp.p, &sort_bytes, t, ix->ntiles, ix->d_count.p,
                                   ix->d_start.p, ix->d_post.p, ix->st));
       }
     return VSX_OK;
   };
-  if (ix->tagged)
+  if (sorted_build)
     {
       const uint32_t * hl = vsx_internal_seqset_host_lengths(ix->db);
       slot_of.assign(n + 1, 0);
@@ -196,13 +217,17 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
       for (uint64_t i = 0; i < n; ++i) slot_of[i + 1] = slot_of[i] + hl[i];
       for (uint32_t t = 0; t < ix->ntiles; ++t)
         {
-          const uint64_t first = (uint64_t) t << shift, last = std::min<uint64_t>(n, first + (1ull << shift));
+          const uint64_t first = (uint64_t) t * tile_seqs, last = std::min<uint64_t>(n, first + tile_seqs);
           widest = std::max(widest, slot_of[last] - slot_of[first]);
         }
       KCHK(d_slot.alloc(n + 1));
       KCHK(hipMemcpyAsync(d_slot.p, slot_of.data(), (n + 1) * 8, hipMemcpyHostToDevice, ix->st));
       KCHK(d_keys_a.alloc(std::max<uint64_t>(widest, 1)));
       KCHK(d_keys_b.alloc(std::max<uint64_t>(widest, 1)));
+      if (ix->packed)
+        KCHK(vsx_kmer_packed_tile(0, nullptr, nullptr, nullptr, 0, 0, w, nullptr, nullptr, widest, reinterpret_cast<uint32_t *>(d_keys_a.p),
+                                  reinterpret_cast<uint32_t *>(d_keys_b.p), nullptr, &sort_bytes, 0, ix->ntiles, nullptr, nullptr, nullptr, ix->st));
+      else
       KCHK(vsx_kmer_tagged_tile(0, nullptr, nullptr, nullptr, 0, 0, w, nullptr, nullptr, widest, d_keys_a.p, d_keys_b.p, nullptr, &sort_bytes, 0, ix->ntiles,
                                 nullptr, nullptr, nullptr, ix->st));
       KCHK(d_sort_temp.alloc(sort_bytes + 16));
@@ -222,8 +247,10 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
   // a bucket holds 16-bit tile-local indices in 16-byte units of eight (tagged: dwords tag << 16 | index, units of four):
   // start[] counts UNITS, the last unit of a bucket is padded with 0x8000 = the spare counter past the tile (vsx_kmer.hip KM_PAD;
   // tagged: 0xFFFF8000, a tag no word has): the count kernel streams units without any sentinel test
+  // (packed: the walk has already counted units, cnt = units | postings << 16)
   const uint32_t per_unit = ix->tagged ? 4u : 8u;
   uint64_t entries = 0;
+  if (ix->packed) ix->word_units.assign(nwords, 0);
   {
     // buckets are word-major: b = word * ntiles + tile (nested loops: no division per bucket -- clustering rebuilds the index
     // once per round)
@@ -231,24 +258,26 @@ int vsx_kmer_index_rebuild(VsxKmerIndex * ix, const uint32_t * list, uint64_t n_
     uint64_t b = 0;
     for (uint64_t word = 0; word < nwords; ++word)
       {
-        uint64_t tot = 0;
+        uint64_t tot = 0, units = 0;
         for (uint64_t t = 0; t < nt; ++t, ++b)
           {
             start[b] = acc;
-            acc += (cnt[b] + per_unit - 1) / per_unit;
-            tot += cnt[b];
+            if (ix->packed) { acc += cnt[b] & 0xffffu; units += cnt[b] & 0xffffu; tot += cnt[b] >> 16; }
+            else { acc += (cnt[b] + per_unit - 1) / per_unit; tot += cnt[b]; }
           }
         ix->word_total[word] = tot;
+        if (ix->packed) ix->word_units[word] = units;
         entries += tot;
       }
   }
   start[ix->nbuckets] = acc;
   if (acc >= (1ull << 32)) { vsx_internal_set_error("vsx_kmer_index_rebuild: more than 64 GB of postings (32-bit unit addresses)"); return VSX_EINVAL; }
   KCHK(ix->d_post.ensure(acc * 4));                    // dwords
-  if (acc) KCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->d_post.p), (int) (ix->tagged ? 0xFFFF8000u : 0x80008000u), acc * 4, ix->st));
+  if (acc && !ix->packed)                                  // (the packed walk writes whole units)
+    KCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->d_post.p), (int) (ix->tagged ? 0xFFFF8000u : 0x80008000u), acc * 4, ix->st));
   KCHK(hipMemcpyAsync(ix->d_start.p, start.data(), (ix->nbuckets + 1) * 8, hipMemcpyHostToDevice, ix->st));
   KCHK(hipMemsetAsync(ix->d_count.p, 0, ix->nbuckets * 4, ix->st));
-  if (ix->tagged)
+  if (sorted_build)
     {
       const int prc = tagged_pass(1);
       if (prc != VSX_OK) return prc;
@@ -289,7 +318,7 @@ int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, uint32_t n8
   KCHK(sc->d_sel_off.ensure(nslots));
   static const bool no_pre_env = std::getenv("VSX_KMER_NO_RANGES") != nullptr;   // A/B: the blocks look their ranges up themselves
   const bool no_pre = no_pre_env || ix->tagged;                                   // tagged indexes (word lengths 9..15) always do
-  const int tg = ix->tagged ? 1 : 0;
+  const int tg = ix->tagged ? 1 : (ix->packed ? 2 : 0);                           // the postings format (vsx_kmer_launch_count)
   if (n8 && !no_pre) KCHK(sc->d_ranges.ensure((size_t) n8 * nt * 256));
   KCHK(hipEventRecord(sc->e0, sc->st));
   if (n8 && !no_pre)
@@ -400,9 +429,13 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
   }
   KmerScratch * sc = lease.sc;
   const uint64_t nk = qk_start[nq];
-  uint64_t increments = 0;
+  uint64_t increments = 0, streamed_bytes = 0;
   if (want_increments)
-    for (uint64_t x = 0; x < nk; ++x) increments += ix->word_total[ix->tagged ? (qk[x] & 0xffffu) : qk[x]];      // postings streamed
+    {
+      for (uint64_t x = 0; x < nk; ++x) increments += ix->word_total[ix->tagged ? (qk[x] & 0xffffu) : qk[x]];      // postings streamed
+      if (ix->packed) for (uint64_t x = 0; x < nk; ++x) streamed_bytes += 16 * ix->word_units[qk[x]];
+      else streamed_bytes = increments * (ix->tagged ? 4 : 2);
+    }
   sc->records = 0;
   KCHK(sc->d_qk_start.ensure(nq + 1));
   KCHK(sc->d_qk.ensure(nk));
@@ -477,7 +510,7 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
     }
   {
     std::lock_guard<std::mutex> lk(ix->mu);
-    ix->stats.count_ms = ms; ix->stats.increments = increments; ix->stats.records = sc->records;
+    ix->stats.count_ms = ms; ix->stats.increments = increments; ix->stats.streamed_bytes = streamed_bytes; ix->stats.records = sc->records;
     if (stats_out) { *stats_out = ix->stats; }
   }
   return VSX_OK;

@@ -742,7 +742,7 @@ static bool device_kmer_ok(const vsx_searcher & S)
 // clustering rebuilds SUBSET indexes (centroids, round members) every round: those exist for the one-bucket-per-word form only
 static bool device_kmer_subsets_ok(const vsx_searcher & S) { return device_kmer_ok(S) && S.w <= 8; }
 
-struct KmerAcct { double kernel_ms = 0, build_ms = 0; uint64_t streamed = 0, postings = 0; bool want_streamed = false; };      // want_streamed: count the postings a batch streams (a serial pass over its words: benches only)
+struct KmerAcct { double kernel_ms = 0, build_ms = 0; uint64_t streamed = 0, streamed_bytes = 0, postings = 0; bool want_streamed = false; };      // want_streamed: count the postings a batch streams (a serial pass over its words: benches only)
 
 // Count the queries' words against a device index and rank: words[k] = unique words of query k; `map` translates index
 // positions to sequence numbers (subset index) or is null; keep = heap size.  cands[k] = (target, count, length) best first
@@ -793,6 +793,7 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
     std::lock_guard<std::mutex> lk(acct_mu);
     acct.kernel_ms += kst.count_ms;
     acct.streamed += kst.increments;
+    acct.streamed_bytes += kst.streamed_bytes;
   }
   // per query: the heap's total order (count desc, length asc, seqno asc) and size
   std::atomic<uint64_t> next {0};
@@ -1144,6 +1145,7 @@ int vsx_search_candidates_batch(vsx_searcher * S, int32_t device, uint64_t nq, c
   out->index_build_ms = acct.build_ms;
   out->index_postings = acct.postings;
   out->postings_streamed = acct.streamed;
+  out->bytes_streamed = acct.streamed_bytes;
   return VSX_OK;
 }
 

@@ -120,7 +120,7 @@ class SearchSession:
             tg = np.ctypeslib.as_array(res.target, shape=(max(tot, 1),))[:tot].copy()
             ct = np.ctypeslib.as_array(res.count, shape=(max(tot, 1),))[:tot].copy()
             self.kmer_stats = {k: getattr(res, k) for k in ("seconds", "kernel_ms", "index_build_ms", "index_postings",
-                                                            "postings_streamed")}
+                                                            "postings_streamed", "bytes_streamed")}
             return [list(zip(tg[start[k]:start[k + 1]].tolist(), ct[start[k]:start[k + 1]].tolist())) for k in range(n)]
         finally:
             lib.vsx_candidates_free(C.byref(res))
