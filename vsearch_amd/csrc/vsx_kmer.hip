@@ -476,8 +476,11 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
 //   * every 252nd counter of a tile (index = 251 mod 252: an odd index in the TOP byte of its dword) is a DUMMY that stands for no
 //     sequence.  A gap of more than 255 hops over dummies (one harmless increment each; a carry out of a top byte or top half
 //     leaves the dword), and the unused tail of a bucket's last unit is gaps of 0 on a dummy.  A tile therefore holds
-//     130 x 251 = 32 630 sequences; sequence s of the tile owns counter s + s / 251;
-//   * the sweep skips the dummies.
+//     130 x 251 = 32 630 sequences;
+//   * sequence s of the tile owns counter (s mod 130) * 252 + s / 130: NEIGHBOURS in the database sit 252 counters apart.  Related
+//     sequences are usually adjacent, so the postings of a word come in clusters with thousands of counters in between -- ten hops
+//     per cluster; transposed, the gaps of any word are spread evenly (bench database: 1.23 -> 1.1x bytes per posting);
+//   * the sweep clears the dummies before it looks for hits.
 // The units of one wave's buckets are dealt to its lanes as ONE run (lane = position in the concatenation mod 64): a bucket of
 // the bench shape has ~35 units, and a trip per bucket would leave half the lanes idle while costing the same instructions.
 // Build (per tile, like the tagged index): keys (word << 16 | counter index) of every position -> radix sort -> one thread per
@@ -498,7 +501,7 @@ vsx_kmer_pk_keys_kernel(const uint8_t * __restrict__ codes, const u64 * __restri
   const u64 base = off[sid];
   const uint8_t * __restrict__ s = codes + base;
   const int L = (int) len[sid];
-  const u32 idx = local + local / KM_PK_REAL;
+  const u32 idx = (local % 130u) * KM_PK_PERIOD + local / 130u;   // see the header comment: neighbours land 252 counters apart
   u32 * __restrict__ out = keys + (slot_of[sid] - slot_of[first_seq]);
   for (int p0 = 0; p0 < L; p0 += 64)
     {
@@ -707,12 +710,11 @@ vsx_kmer_count_packed_kernel(const uint4 * __restrict__ postings, const u64 * __
   // dword 62 + 63 k (8-bit counters) / the top half of dword 125 + 126 k (16-bit)
   if (tid < 130) { if (BITS == 8) cnt[63 * tid + 62] &= 0x00ffffffu; else cnt[126 * tid + 125] &= 0x0000ffffu; }
   __syncthreads();
-  // ---- sweep: counters >= mm -> (sequence, count) records in the (query, tile) sub-region, as in vsx_kmer_count_kernel.  Here the
+  // ---- sweep: counters >= mm -> (counter, count) records in the (query, tile) sub-region, as in vsx_kmer_count_kernel.  Here the
   // streaming part is short enough for the sweep to show (20 ms of 109 in its first form: ~0.5 % of the counters hit, so every wave
-  // iteration had SOME lane in the per-field path).  Now: one flag bit per hit counter by SWAR (5 instructions per dword, no
-  // branch), the hit count is a popcount, and the writing pass visits set bits only.  Counter x of the tile is sequence
-  // tile * 32 630 + x - x / 252; dummies are cleared, counters past the last sequence were never touched.
-  const u32 base = tile * KM_PK_TILE_SEQS;
+  // iteration had SOME lane in the per-field path).  Now: one flag bit per hit counter by SWAR (4 instructions per dword, no
+  // branch), the hit count is a popcount, and the writing pass visits set bits only -- four loop heads per thread.
+  // Dummies are cleared, counters of sequences past the last one were never touched.
   constexpr int DW_PER_THREAD = NDW / THREADS;                      // 16 in both configurations
   // flag = top bit of every field >= mm (1 <= mm; 8-bit class: a count never exceeds 255)
   constexpr u32 TOPS = (BITS == 8) ? 0x80808080u : 0x80008000u, LOWS = ~TOPS, ONES = (BITS == 8) ? 0x01010101u : 0x00010001u;
@@ -724,21 +726,17 @@ vsx_kmer_count_packed_kernel(const uint4 * __restrict__ postings, const u64 * __
     const u32 t = (v & LOWS) + addk;                                 // per field: top bit set iff its low bits >= mm (resp. mm - HALF)
     return low ? ((t | v) & TOPS) : (t & v & TOPS);
   };
-  u32 ms[DW_PER_THREAD];
+  // the flags of a uint4's fields share one dword: dword j's flags (bits BITS * h + BITS - 1) move right by j
+  u32 ms[DW_PER_THREAD / 4];
   u32 found = 0;
   const uint4 * c4 = reinterpret_cast<const uint4 *>(cnt);
 #pragma unroll
   for (int g4 = 0; g4 < DW_PER_THREAD / 4; ++g4)
     {
       const uint4 v4 = c4[g4 * THREADS + tid];
-      const u32 vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-        {
-          const u32 m = never ? 0u : flags(vv[d]);
-          ms[g4 * 4 + d] = m;
-          found += (u32) __builtin_popcount(m);
-        }
+      const u32 m = never ? 0u : (flags(v4.x) | (flags(v4.y) >> 1) | (flags(v4.z) >> 2) | (flags(v4.w) >> 3));
+      ms[g4] = m;
+      found += (u32) __builtin_popcount(m);
     }
   u32 inc2 = found;
 #pragma unroll
@@ -755,21 +753,23 @@ vsx_kmer_count_packed_kernel(const uint4 * __restrict__ postings, const u64 * __
   if (tid == 0) tile_count[region] = total;
   if (found)
     {
+      // records carry tile << 15 | counter index; the selection kernel turns the ones it keeps into sequence numbers
       u32 pos = before + inc2 - found;
       uint2 * __restrict__ out = rec + region * subcap;
+      const u32 tagx = tile << KM_TILE_SHIFT;
 #pragma unroll
-      for (int e = 0; e < DW_PER_THREAD; ++e)
+      for (int g4 = 0; g4 < DW_PER_THREAD / 4; ++g4)
         {
-          u32 m = ms[e];
-          const u32 dw = (u32) ((e >> 2) * THREADS + tid) * 4u + (u32) (e & 3);
+          u32 m = ms[g4];
+          const u32 x0 = (u32) (g4 * THREADS + tid) * 4u * PER;      // first counter of the uint4
           while (m)
             {
-              const int bit = __builtin_ctz(m);                     // 7 / 15 / 23 / 31 (8-bit), 15 / 31 (16-bit)
+              const u32 bit = (u32) __builtin_ctz(m);
               m &= m - 1u;
-              const u32 h = (u32) bit / (u32) BITS;
-              const u32 x = dw * PER + h;
-              const u32 c = (cnt[dw] >> (BITS * h)) & ((BITS == 8) ? 0xffu : 0xffffu);
-              if (pos < subcap) out[pos] = make_uint2(base + x - x / KM_PK_PERIOD, c);
+              const u32 j = (BITS - 1) - (bit & (BITS - 1)), h = bit / BITS;      // dword of the uint4, field of the dword
+              const u32 x = x0 + j * PER + h;
+              const u32 c = (BITS == 8) ? (u32) reinterpret_cast<const uint8_t *>(cnt)[x] : (u32) reinterpret_cast<const uint16_t *>(cnt)[x];
+              if (pos < subcap) out[pos] = make_uint2(tagx | x, c);
               ++pos;
             }
         }
@@ -783,8 +783,10 @@ vsx_kmer_count_packed_kernel(const uint4 * __restrict__ postings, const u64 * __
 // sub-region count) and left for the second pass.
 __global__ void __launch_bounds__(256)
 vsx_kmer_select_kernel(const uint2 * __restrict__ rec, u32 subcap, u32 ntiles, const u32 * __restrict__ tile_count, u32 nslots, u32 keep,
-                       uint2 * __restrict__ dense, u64 * cursor, u64 capacity, uint2 * __restrict__ sel_off_n, u64 * __restrict__ sel_off)
+                       uint2 * __restrict__ dense, u64 * cursor, u64 capacity, uint2 * __restrict__ sel_off_n, u64 * __restrict__ sel_off, int packed)
 {
+  // packed != 0: the records of the packed index hold tile << 15 | counter index; counter x of a tile is sequence
+  // tile * 32 630 + (x mod 252) * 130 + x / 252 (see the packed format above) -- converted here, for the kept records only
   __shared__ u32 hist_all[4][256];
   const int lane = (int) (threadIdx.x & 63), wv = (int) (threadIdx.x >> 6);
   const u32 slot = blockIdx.x * 4 + (u32) wv;
@@ -886,7 +888,16 @@ vsx_kmer_select_kernel(const uint2 * __restrict__ rec, u32 subcap, u32 ntiles, c
           const u32 x = x0 + (u32) lane;
           const bool take = (x < nt) && (r[x].y >= thr);
           const u64 ballot = __ballot(take);
-          if (take) dense[first + done + (u32) __popcll(ballot & ((1ull << lane) - 1ull))] = r[x];
+          if (take)
+            {
+              uint2 v = r[x];
+              if (packed)
+                {
+                  const u32 cx = v.x & (KM_TILE - 1u);
+                  v.x = (v.x >> KM_TILE_SHIFT) * KM_PK_TILE_SEQS + (cx % KM_PK_PERIOD) * 130u + cx / KM_PK_PERIOD;
+                }
+              dense[first + done + (u32) __popcll(ballot & ((1ull << lane) - 1ull))] = v;
+            }
           done += (u32) __popcll(ballot);
         }
     }
@@ -1012,7 +1023,17 @@ extern "C" hipError_t vsx_kmer_launch_select(const void * rec, uint32_t subcap, 
 {
   if (nslots == 0) return hipSuccess;
   hipLaunchKernelGGL(vsx_kmer_select_kernel, dim3((nslots + 3) / 4), dim3(256), 0, st, (const uint2 *) rec, subcap, ntiles, tile_count, nslots,
-                     keep, (uint2 *) dense, (u64 *) cursor, (u64) capacity, (uint2 *) sel_m_n, (u64 *) sel_off);
+                     keep, (uint2 *) dense, (u64 *) cursor, (u64) capacity, (uint2 *) sel_m_n, (u64 *) sel_off, 0);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t vsx_kmer_launch_select_packed(const void * rec, uint32_t subcap, uint32_t ntiles, const uint32_t * tile_count, uint32_t nslots,
+                                                    uint32_t keep, void * dense, unsigned long long * cursor, uint64_t capacity,
+                                                    void * sel_m_n, uint64_t * sel_off, hipStream_t st)
+{
+  if (nslots == 0) return hipSuccess;
+  hipLaunchKernelGGL(vsx_kmer_select_kernel, dim3((nslots + 3) / 4), dim3(256), 0, st, (const uint2 *) rec, subcap, ntiles, tile_count, nslots,
+                     keep, (uint2 *) dense, (u64 *) cursor, (u64) capacity, (uint2 *) sel_m_n, (u64 *) sel_off, 1);
   return hipGetLastError();
 }
 

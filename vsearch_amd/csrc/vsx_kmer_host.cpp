@@ -27,6 +27,9 @@ extern "C" hipError_t vsx_kmer_packed_tile(int fill, const uint8_t * codes, cons
                                            uint32_t * keys_a, uint32_t * keys_b, void * temp, size_t * temp_bytes, uint32_t tile, uint32_t ntiles,
                                            uint32_t * bucket_count, const uint64_t * bucket_start, uint32_t * postings, hipStream_t st);
 extern "C" uint32_t vsx_kmer_packed_tile_seqs(void);
+extern "C" hipError_t vsx_kmer_launch_select_packed(const void * rec, uint32_t subcap, uint32_t ntiles, const uint32_t * tile_count, uint32_t nslots,
+                                                    uint32_t keep, void * dense, unsigned long long * cursor, uint64_t capacity,
+                                                    void * sel_m_n, uint64_t * sel_off, hipStream_t st);
 
 namespace {
 
@@ -349,8 +352,8 @@ int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, uint32_t n8
     {
       KCHK(sc->d_dense.ensure(capacity));
       KCHK(hipMemsetAsync(sc->d_cursor.p, 0, sizeof(unsigned long long), sc->st));
-      KCHK(vsx_kmer_launch_select(sc->d_rec.p, subcap, nt, sc->d_tilecnt.p, nslots, keep, sc->d_dense.p, sc->d_cursor.p, sc->d_dense.n,
-                                  sc->d_sel_mn.p, sc->d_sel_off.p, sc->st));
+      KCHK((ix->packed ? vsx_kmer_launch_select_packed : vsx_kmer_launch_select)(sc->d_rec.p, subcap, nt, sc->d_tilecnt.p, nslots, keep, sc->d_dense.p,
+                                                                                  sc->d_cursor.p, sc->d_dense.n, sc->d_sel_mn.p, sc->d_sel_off.p, sc->st));
       KCHK(hipEventRecord(sc->e1, sc->st));
       KCHK(hipMemcpyAsync(&produced, sc->d_cursor.p, sizeof produced, hipMemcpyDeviceToHost, sc->st));
       KCHK(hipStreamSynchronize(sc->st));

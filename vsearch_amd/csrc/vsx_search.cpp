@@ -264,6 +264,7 @@ struct vsx_searcher {
   std::vector<uint32_t> len;
   vsx_seqset * dbset = nullptr;
   vsx_ctx * ctx2 = nullptr;          // a second aligner context of the same device (owned): the second consumer of the search pipeline
+  vsx_ctx * ctx3 = nullptr;          // ... and the third
   int w = 8;
   int qmode = 0;                     // masking of raw queries: opts.qmask - 1, or opts.soft_mask when qmask == 0
   std::vector<uint64_t> kstart;      // 4^w + 1
@@ -1083,6 +1084,7 @@ void vsx_searcher_destroy(vsx_searcher * s)
   vsx_kmer_index_destroy(s->kidx);
   vsx_seqset_destroy(s->dbset);
   vsx_destroy(s->ctx2);
+  vsx_destroy(s->ctx3);
   delete s;
 }
 
@@ -1458,11 +1460,11 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
           if (!s1.put(prepare_words(cut[wi]))) break;
         s1.finish();
       });
-      // two rank workers: one window's host work (CSR, uploads, record download, ranking) runs under the other's counting
+      // three rank workers (VSX_SEARCH_RANKERS): one window's host work (CSR, uploads, record download, ranking) runs under another's counting
       // kernel (vsx_kmer_count_batch leases a scratch set and a stream per call); windows may reach the aligner out of order,
       // a query's hits do not depend on it
       static const int env_rankers = std::getenv("VSX_SEARCH_RANKERS") ? std::atoi(std::getenv("VSX_SEARCH_RANKERS")) : 0;   // A/B
-      const int n_rank = dev_kmer ? std::min(std::max(env_rankers ? env_rankers : 2, 1), 4) : 1;
+      const int n_rank = dev_kmer ? std::min(std::max(env_rankers ? env_rankers : 3, 1), 4) : 1;
       std::atomic<int> rank_live {n_rank};
       auto rank_worker = [&]() {
         for (;;)
@@ -1481,11 +1483,14 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       // two consumers, each with its own aligner context on the device (a window's plans, fetches and replays are a chain of
       // short round trips: ~20 ms of wall time for ~5 ms of kernels, so two windows in flight keep the stage off the critical
       // path); VSX_SEARCH_CONSUMERS=1 keeps one (A/B, tests).  Windows are independent: a query's hits live in its own slot.
-      static const bool one_consumer = std::getenv("VSX_SEARCH_CONSUMERS") && std::atoi(std::getenv("VSX_SEARCH_CONSUMERS")) == 1;
-      if (!one_consumer && !S->ctx2)
+      // (r03: three -- a window's align stage is ~12 ms of latency for ~4 ms of kernels while the counting kernels share the device,
+      //  and the last window otherwise waits for one of two busy consumers: 147 -> 142 ms per 100 k queries)
+      static const int n_consumers = std::min(3, std::max(1, std::getenv("VSX_SEARCH_CONSUMERS") ? std::atoi(std::getenv("VSX_SEARCH_CONSUMERS")) : 3));
+      for (vsx_ctx ** extra : {&S->ctx2, &S->ctx3})
         {
-          const int crc = vsx_create(&S->ctx2, &S->scoring, vsx_internal_device(S->ctx));
-          if (crc != VSX_OK) S->ctx2 = nullptr;                    // (no second context: carry on with one consumer)
+          if ((extra == &S->ctx2 && n_consumers < 2) || (extra == &S->ctx3 && n_consumers < 3) || *extra) continue;
+          const int crc = vsx_create(extra, &S->scoring, vsx_internal_device(S->ctx));
+          if (crc != VSX_OK) *extra = nullptr;                     // (no further context: carry on with fewer consumers)
         }
       int rc = VSX_OK;
       std::string msg;
@@ -1508,10 +1513,12 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
           }
         s2.abort();
       };
-      std::thread consumer2;
-      if (!one_consumer && S->ctx2) consumer2 = std::thread(consumer, S->ctx2);
+      std::thread consumer2, consumer3;
+      if (n_consumers >= 2 && S->ctx2) consumer2 = std::thread(consumer, S->ctx2);
+      if (n_consumers >= 3 && S->ctx3) consumer3 = std::thread(consumer, S->ctx3);
       consumer(S->ctx);
       if (consumer2.joinable()) consumer2.join();
+      if (consumer3.joinable()) consumer3.join();
       s2.abort();
       s1.abort();
       stage_words.join();
