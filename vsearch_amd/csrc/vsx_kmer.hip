@@ -239,13 +239,17 @@ vsx_kmer_ranges_kernel(const u64 * __restrict__ bucket_start, u32 ntiles, const 
   const u32 p = (i & 7u) * 32u + (i >> 3);
   if (i < nk)
     {
+      // eight tiles per trip: the nine loads are independent (one after the other they were 31 dependent latencies per thread)
       const u64 * __restrict__ row = bucket_start + (size_t) qk[k0 + i] * ntiles;
-      u64 first = row[0];
-      for (u32 t = 0; t < ntiles; ++t)
+      for (u32 t0 = 0; t0 < ntiles; t0 += 8)
         {
-          const u64 next = row[t + 1];
-          R[((size_t) t * nslots + slot) * 256 + p] = make_uint2((u32) first, (u32) (next - first));
-          first = next;
+          u64 v[9];
+#pragma unroll
+          for (int x = 0; x < 9; ++x) v[x] = row[t0 + (u32) x <= ntiles ? t0 + (u32) x : ntiles];
+#pragma unroll
+          for (int x = 0; x < 8; ++x)
+            if (t0 + (u32) x < ntiles)
+              R[((size_t) (t0 + (u32) x) * nslots + slot) * 256 + p] = make_uint2((u32) v[x], (u32) (v[x + 1] - v[x]));
         }
     }
   else
@@ -805,6 +809,7 @@ vsx_kmer_select_kernel(const uint2 * __restrict__ rec, u32 subcap, u32 ntiles, c
   if (worst > subcap) { if (lane == 0) { sel_off[slot] = 0; sel_off_n[slot] = make_uint2(0xffffffffu, worst); } return; }
   const uint2 * __restrict__ r0 = rec + (size_t) slot * ntiles * subcap;
   u32 thr = 0;
+  u32 m = n;                                                       // records at or above the threshold (thr == 0: all of them)
   if (n > keep)
     {
       for (int x = lane; x < 256; x += 64) hist[x] = 0;
@@ -826,18 +831,19 @@ vsx_kmer_select_kernel(const uint2 * __restrict__ rec, u32 subcap, u32 ntiles, c
           if (lane + d < 64) above += dn;
         }
       above -= own;                                                // records in the bins of the lanes above this one
-      // the largest bin b with #(>= b) >= keep lies in exactly one lane
-      u32 cand = 0xffffffffu, run = above;
+      // the largest bin b with #(>= b) >= keep lies in exactly one lane; `at` = #(>= that bin)
+      u32 cand = 0xffffffffu, run = above, at = 0;
 #pragma unroll
       for (int u = 3; u >= 0; --u)
         {
           run += h4[u];
-          if (cand == 0xffffffffu && run >= keep) cand = (u32) (4 * lane + u);
+          if (cand == 0xffffffffu && run >= keep) { cand = (u32) (4 * lane + u); at = run; }
         }
       // the highest lane that found one wins
       const u64 found = __ballot(cand != 0xffffffffu);
       const int win = found ? 63 - __builtin_clzll(found) : 0;
       thr = (u32) __shfl((int) cand, win, 64);
+      m = (u32) __shfl((int) at, win, 64);                         // (the histogram already knows how many records pass)
       if (thr == 255u)
         {
           // more than `keep` records sit in the clamped bin (16-bit class only): exact threshold by bisection over those
@@ -853,25 +859,11 @@ vsx_kmer_select_kernel(const uint2 * __restrict__ rec, u32 subcap, u32 ntiles, c
                   for (u32 x = (u32) lane; x < nt; x += 64) c += (r[x].y >= mid) ? 1u : 0u;
                 }
 #pragma unroll
-              for (int m = 32; m >= 1; m >>= 1) c += (u32) __shfl_xor((int) c, m, 64);
-              if (c >= keep) lo = mid; else hi = mid;
+              for (int k = 32; k >= 1; k >>= 1) c += (u32) __shfl_xor((int) c, k, 64);
+              if (c >= keep) { lo = mid; m = c; } else hi = mid;
             }
           thr = lo;
         }
-    }
-  // count, allocate, copy
-  u32 m = 0;
-  if (thr == 0) m = n;
-  else
-    {
-      for (u32 t = 0; t < ntiles; ++t)
-        {
-          const u32 nt = tc[t];
-          const uint2 * __restrict__ r = r0 + (size_t) t * subcap;
-          for (u32 x = (u32) lane; x < nt; x += 64) m += (r[x].y >= thr) ? 1u : 0u;
-        }
-#pragma unroll
-      for (int k = 32; k >= 1; k >>= 1) m += (u32) __shfl_xor((int) m, k, 64);
     }
   u64 first = 0;
   if (lane == 0) first = atomicAdd(cursor, (u64) m);

@@ -87,6 +87,7 @@ struct VsxKmerIndex {
   int w = 8;
   bool tagged = false;            // word lengths 9..15: buckets by the word's low 16 bits, postings carry the rest as a tag (vsx_kmer.hip)
   bool packed = false;            // word lengths 3..8, whole-set index: sorted byte-gap postings, tiles of 32 630 sequences (vsx_kmer.hip)
+  bool prewarm = false;           // a search index: make the spare scratch sets behind the first batch (vsx_kmer_count_batch)
   uint32_t nseq = 0, ntiles = 0;
   uint64_t nbuckets = 0;
   Buf<uint64_t> d_start;          // nbuckets + 1
@@ -132,6 +133,7 @@ int vsx_kmer_index_create(vsx_ctx * ctx, const vsx_seqset * db, int w, VsxKmerIn
   // the whole-set index of a short word length takes the packed format (VSX_KMER_PACKED=0: the 16-bit format, A/B and tests)
   static const bool packed_off = std::getenv("VSX_KMER_PACKED") && std::strcmp(std::getenv("VSX_KMER_PACKED"), "0") == 0;
   ix->packed = !ix->tagged && !packed_off;
+  ix->prewarm = true;
   ix->make_stream();
   KCHK(hipSetDevice(ix->device));
   KCHK(hipEventCreate(&ix->e0));
@@ -388,6 +390,17 @@ int count_pass(VsxKmerIndex * ix, KmerScratch * sc, uint32_t nslots, uint32_t n8
 #define VSX_KMER_SCRATCH_MAX 3
 
 namespace {
+std::unique_ptr<KmerScratch> new_scratch()
+{
+  std::unique_ptr<KmerScratch> p(new KmerScratch);
+  int prio_low = 0, prio_high = 0;               // counting runs BEHIND the aligner's plans (vsx_host.cpp vsx_create)
+  (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+  if (hipStreamCreateWithPriority(&p->st, hipStreamNonBlocking, prio_low) != hipSuccess || hipEventCreate(&p->e0) != hipSuccess ||
+      hipEventCreate(&p->e1) != hipSuccess || hipEventCreateWithFlags(&p->e_turn, hipEventDisableTiming) != hipSuccess ||
+      p->d_cursor.alloc(1) != hipSuccess)
+    return nullptr;
+  return p;
+}
 struct ScratchLease {
   VsxKmerIndex * ix; KmerScratch * sc;
   ~ScratchLease() { if (sc) { { std::lock_guard<std::mutex> lk(ix->mu); sc->busy = false; } ix->cv.notify_all(); } }
@@ -415,13 +428,8 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
         if (lease.sc) break;
         if (ix->scratch.size() < VSX_KMER_SCRATCH_MAX)
           {
-            std::unique_ptr<KmerScratch> p(new KmerScratch);
-            int prio_low = 0, prio_high = 0;               // counting runs BEHIND the aligner's plans (vsx_host.cpp vsx_create)
-            (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-            if (hipStreamCreateWithPriority(&p->st, hipStreamNonBlocking, prio_low) != hipSuccess || hipEventCreate(&p->e0) != hipSuccess ||
-                hipEventCreate(&p->e1) != hipSuccess || hipEventCreateWithFlags(&p->e_turn, hipEventDisableTiming) != hipSuccess ||
-                p->d_cursor.alloc(1) != hipSuccess)
-              { (void) hipGetLastError(); vsx_internal_set_error("vsx_kmer_count_batch: scratch allocation failed"); return VSX_EHIP; }
+            std::unique_ptr<KmerScratch> p = new_scratch();
+            if (!p) { (void) hipGetLastError(); vsx_internal_set_error("vsx_kmer_count_batch: scratch allocation failed"); return VSX_EHIP; }
             lease.sc = p.get();
             ix->scratch.push_back(std::move(p));
             break;
@@ -510,6 +518,27 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
       rc = count_pass(ix, sc, (uint32_t) list.size(), m8, d_qlist.p, &list, overflow_max, keep, out, again, again_max, ms);
       if (rc != VSX_OK) return rc;
       if (!again.empty()) { vsx_internal_set_error("vsx_kmer_count_batch: record region overflow in the second pass"); return VSX_EHIP; }
+    }
+  // A search index (vsx_kmer_index_create) is counted against by up to three windows at once.  The further scratch sets are made
+  // HERE, behind the first batch and with its buffer sizes: created on demand, the first call that happens to overlap three
+  // windows paid ~0.4 s of hipMalloc in the middle of a warm search (one in seven calls of the bench took 0.55 s instead of 0.15)
+  if (ix->prewarm)
+    {
+      bool more = false;
+      { std::lock_guard<std::mutex> lk(ix->mu); more = ix->scratch.size() < VSX_KMER_SCRATCH_MAX; }
+      while (more)
+        {
+          std::unique_ptr<KmerScratch> p = new_scratch();
+          if (!p) { (void) hipGetLastError(); break; }
+          if (p->d_qk_start.ensure(sc->d_qk_start.n) != hipSuccess || p->d_qk.ensure(sc->d_qk.n) != hipSuccess || p->d_minmatch.ensure(sc->d_minmatch.n) != hipSuccess ||
+              p->d_rec.ensure(sc->d_rec.n) != hipSuccess || p->d_dense.ensure(sc->d_dense.n) != hipSuccess || p->d_sel_mn.ensure(sc->d_sel_mn.n) != hipSuccess ||
+              p->d_sel_off.ensure(sc->d_sel_off.n) != hipSuccess || p->d_ranges.ensure(sc->d_ranges.n) != hipSuccess || p->d_tilecnt.ensure(sc->d_tilecnt.n) != hipSuccess)
+            { (void) hipGetLastError(); break; }                   // (not enough memory for a spare set: the batches will share)
+          std::lock_guard<std::mutex> lk(ix->mu);
+          if (ix->scratch.size() < VSX_KMER_SCRATCH_MAX) ix->scratch.push_back(std::move(p));
+          more = ix->scratch.size() < VSX_KMER_SCRATCH_MAX;
+          ix->cv.notify_all();
+        }
     }
   {
     std::lock_guard<std::mutex> lk(ix->mu);
