@@ -176,13 +176,13 @@ struct SharedBlock {
 struct SharedSlot {
   std::mutex mu;
   std::shared_ptr<SharedBlock> cur;
-  hipError_t acquire(ScratchPool * pool, size_t bytes, std::shared_ptr<SharedBlock> & out)
+  hipError_t acquire(ScratchPool * pool, size_t bytes, std::shared_ptr<SharedBlock> & out, bool headroom = true)
   {
     std::lock_guard<std::mutex> lk(mu);
     if (cur && cur->bytes >= bytes) { out = cur; return hipSuccess; }
     auto b = std::make_shared<SharedBlock>();
     // a little headroom: the slices of a pipeline differ by a few per cent, and replacing a multi-GB block costs a hipMalloc
-    hipError_t e = pool->get(bytes + bytes / 8, &b->p, &b->bytes);
+    hipError_t e = pool->get(headroom ? bytes + bytes / 8 : bytes, &b->p, &b->bytes);
     if (e == hipErrorOutOfMemory) { (void) hipGetLastError(); e = pool->get(bytes, &b->p, &b->bytes); }
     if (e != hipSuccess) { b->p = nullptr; return e; }
     b->pool = pool;
@@ -484,6 +484,27 @@ int vsx_internal_pool_selftest(int regions, int width)
   return bad.load();
 }
 int vsx_internal_device(const vsx_ctx * ctx) { return ctx->device; }
+// The big stream-ordered scratch blocks of a context (two checkpoint blocks, the traceback slab): their sizes, and a reservation
+// of at least those sizes.  A search runs its windows on several contexts of one device; a context that meets its first full
+// window in the middle of a warm search would pay the multi-GB hipMalloc there (0.5-1 s in a 0.15 s call), so the searcher levels
+// the contexts after a call (vsx_search.cpp).
+void vsx_internal_scratch_sizes(vsx_ctx * ctx, uint64_t out[3])
+{
+  out[0] = ctx->shared_dir[0].bytes(); out[1] = ctx->shared_dir[1].bytes(); out[2] = ctx->shared_slab.bytes();
+}
+int vsx_internal_scratch_reserve(vsx_ctx * ctx, const uint64_t want[3])
+{
+  if (hipSetDevice(ctx->device) != hipSuccess) { (void) hipGetLastError(); return VSX_EHIP; }
+  SharedSlot * slot[3] = {&ctx->shared_dir[0], &ctx->shared_dir[1], &ctx->shared_slab};
+  for (int k = 0; k < 3; ++k)
+    if (want[k] > slot[k]->bytes())
+      {
+        std::shared_ptr<SharedBlock> hold;
+        const hipError_t e = slot[k]->acquire(&ctx->pool, (size_t) want[k], hold, false);     // (the size asked for already carries headroom)
+        if (e != hipSuccess) { (void) hipGetLastError(); return e == hipErrorOutOfMemory ? VSX_ENOMEM : VSX_EHIP; }
+      }
+  return VSX_OK;
+}
 hipStream_t vsx_internal_stream(const vsx_ctx * ctx) { return ctx->stream; }
 // host copies of the set's lengths (the k-mer index build of long words lays its key slots out by their running sum)
 const uint32_t * vsx_internal_seqset_host_lengths(const vsx_seqset * s) { return s ? s->len.data() : nullptr; }

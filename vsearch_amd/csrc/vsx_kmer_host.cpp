@@ -524,6 +524,28 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
   // windows paid ~0.4 s of hipMalloc in the middle of a warm search (one in seven calls of the bench took 0.55 s instead of 0.15)
   if (ix->prewarm)
     {
+      // ... and an idle set that has not met a batch of this size yet grows now rather than in the middle of a later call
+      auto grow_like = [&](KmerScratch * o) -> bool {
+        return o->d_qk_start.ensure(sc->d_qk_start.n) == hipSuccess && o->d_qk.ensure(sc->d_qk.n) == hipSuccess && o->d_minmatch.ensure(sc->d_minmatch.n) == hipSuccess &&
+               o->d_rec.ensure(sc->d_rec.n) == hipSuccess && o->d_dense.ensure(sc->d_dense.n) == hipSuccess && o->d_sel_mn.ensure(sc->d_sel_mn.n) == hipSuccess &&
+               o->d_sel_off.ensure(sc->d_sel_off.n) == hipSuccess && o->d_ranges.ensure(sc->d_ranges.n) == hipSuccess && o->d_tilecnt.ensure(sc->d_tilecnt.n) == hipSuccess;
+      };
+      for (;;)
+        {
+          KmerScratch * idle = nullptr;
+          {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            for (auto & q : ix->scratch)
+              if (!q->busy && q.get() != sc && (q->d_rec.n < sc->d_rec.n || q->d_qk.n < sc->d_qk.n || q->d_ranges.n < sc->d_ranges.n || q->d_dense.n < sc->d_dense.n))
+                { idle = q.get(); idle->busy = true; break; }
+          }
+          if (!idle) break;
+          const bool ok = grow_like(idle);
+          if (!ok) (void) hipGetLastError();
+          { std::lock_guard<std::mutex> lk(ix->mu); idle->busy = false; }
+          ix->cv.notify_all();
+          if (!ok) break;
+        }
       bool more = false;
       { std::lock_guard<std::mutex> lk(ix->mu); more = ix->scratch.size() < VSX_KMER_SCRATCH_MAX; }
       while (more)

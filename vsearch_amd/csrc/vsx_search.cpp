@@ -34,6 +34,8 @@
 extern "C" void vsx_internal_set_error(const char * msg);
 extern "C" const vsx_scoring * vsx_internal_scoring(const vsx_ctx * ctx);
 extern "C" int vsx_internal_device(const vsx_ctx * ctx);
+extern "C" void vsx_internal_scratch_sizes(vsx_ctx * ctx, uint64_t out[3]);
+extern "C" int vsx_internal_scratch_reserve(vsx_ctx * ctx, const uint64_t want[3]);
 extern "C" int vsx_internal_seqset_create_cased(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const char * blob, uint64_t blob_bytes,
                                                 const uint64_t * offsets, const uint32_t * lengths, int mode);
 extern "C" int vsx_internal_seqset_lower_download(const vsx_seqset * s, uint8_t * dst, uint64_t nbytes);
@@ -1524,6 +1526,16 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       stage_words.join();
       for (std::thread & t : stage_rank) t.join();
       if (rc != VSX_OK) { vsx_internal_set_error(msg.c_str()); return rc; }
+      // level the consumers' big scratch blocks: whichever context met the largest window sets the size for all, so none of them
+      // allocates gigabytes in the middle of a later, warm call (failure to reserve is not an error: that context grows on demand)
+      {
+        vsx_ctx * all[3] = {S->ctx, S->ctx2, S->ctx3};
+        uint64_t want[3] = {0, 0, 0};
+        for (vsx_ctx * c : all)
+          if (c) { uint64_t have[3]; vsx_internal_scratch_sizes(c, have); for (int k = 0; k < 3; ++k) want[k] = std::max(want[k], have[k]); }
+        want[0] = want[1] = std::max(want[0], want[1]);            // the two checkpoint blocks alternate
+        for (vsx_ctx * c : all) if (c) (void) vsx_internal_scratch_reserve(c, want);
+      }
     }
 
   // ---- marshal ----
