@@ -7,7 +7,9 @@ of its own:
   python bench_kmer.py [--db 1000000 --dlen 1000 --queries 100000 --qlen 250 --host-queries 1000]
 
 value      = candidate lists per second of the counting kernel (index resident, query words resident)
-roofline   = HBM: bytes of postings streamed (2 B per counter increment) / kernel time vs 8 TB/s
+roofline   = HBM: bytes of postings streamed (the index format decides: 16-byte units of <= 15 packed postings, 2 B per posting in
+             the 16-bit format) / kernel time vs 8 TB/s; `lds_atomics` = the second limit of the packed kernel: counter increments
+             per clock and CU against the rate a micro-benchmark sustains for random addresses (ubench_lds.hip: 8.1)
 cpu_baseline = the host path (vsx_search.cpp candidates_for, all usable cores) on the first --host-queries queries, whose
              lists are also compared with the device's (parity at full database size).
 """
@@ -139,9 +141,12 @@ def main():
                           "bytes": int(first["index_postings"]) * 2},
                 "increments_per_s": round(best["postings_streamed"] / (best["kernel_ms"] * 1e-3), 1),
                 "bytes_per_posting": round(bytes_streamed / max(1, best["postings_streamed"]), 3),
-                "roofline": {"kernel": "vsx_kmer_count_kernel", "bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0,
+                "roofline": {"kernel": "vsx_kmer_count_packed_kernel / vsx_kmer_count_kernel (VSX_KMER_PACKED=0)", "bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0,
                              "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": None,
                              "algorithmic_bytes_per_launch": int(bytes_streamed)},
+                "lds_atomics": {"per_clock_and_cu": round(best["postings_streamed"] / (best["kernel_ms"] * 1e-3) / (256 * 2.4e9), 2),
+                                "measured_random_address_rate": 8.1,
+                                "note": "increments only (hops and padding add ~4 %), over the whole timed region incl. the range pre-pass and the selection"},
                 "candidates_per_query": round(float(start[-1]) / a.queries, 2),
                 "source_member_leads": round(lead, 4),
                 "cpu_baseline": {"value": round(nh / hst["seconds"], 1), "unit": "queries/s", "cores": usable_cpus(),
