@@ -325,7 +325,8 @@ def test_device_kmer_multi_tile(gpu_required):
     rng = random.Random(77)
     anc = [common.rnd_seq(rng, 120) for _ in range(700)]
     db = [common.mutate(rng, anc[i % 700], 0.05) for i in range(70_000)]
-    qs = [common.mutate(rng, db[i], 0.02) for i in (0, 1, 32767, 32768, 40000, 65535, 65536, 69999)]
+    # (32 630 sequences per tile in the packed index, 2^15 in the 16-bit one: both kinds of boundary)
+    qs = [common.mutate(rng, db[i], 0.02) for i in (0, 1, 129, 130, 32629, 32630, 32631, 32767, 32768, 40000, 65259, 65260, 65535, 65536, 69999)]
     with Aligner() as al:
         ss = SearchSession(al, db, id=0.5, maxaccepts=2, maxrejects=200)
         host = ss.candidates_batch(qs, device=False)
@@ -333,6 +334,27 @@ def test_device_kmer_multi_tile(gpu_required):
     assert host == dev
     assert all(len(h) >= 50 for h in host)
     assert any(t >= 65536 for h in host for t, _ in h) and any(t < 32768 for h in host for t, _ in h)
+
+
+@pytest.mark.gpu
+def test_device_kmer_packed_index_on_clustered_and_sparse_postings(gpu_required):
+    """The packed index (sorted one-byte gaps, dummy counters for gaps above 255 and for the tail of a unit): families stored as
+    contiguous runs of the database (dense stretches of a word's postings, nothing in between) and words that occur in a handful
+    of far-apart sequences only (every gap needs hops) must count exactly like the host index."""
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(91)
+    anc = [common.rnd_seq(rng, 110) for _ in range(350)]
+    db = [common.mutate(rng, anc[i // 100], 0.03) for i in range(35_000)]          # 350 runs of 100 neighbours, two tiles
+    rare = common.rnd_seq(rng, 110)
+    for i in (5, 4000, 17000, 32629, 32630, 34999):                                  # six far-apart copies of one sequence
+        db[i] = common.mutate(rng, rare, 0.01)
+    qs = [common.mutate(rng, db[i], 0.02) for i in (0, 99, 100, 5, 17000, 32629, 32630, 34999, 20050)]
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.5, maxaccepts=2, maxrejects=150)
+        host = ss.candidates_batch(qs, device=False)
+        dev = ss.candidates_batch(qs, device=True)
+    assert host == dev
+    assert all(len(h) >= 6 for h in host)
 
 
 def test_cluster_fast_members_without_words_take_the_host_index(gpu_required, tmp_path):
