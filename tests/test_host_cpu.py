@@ -484,3 +484,82 @@ def test_api_adapter_falls_back_to_reference_code_without_a_device(tmp_path):
     assert "PASS: batch search matches sequential search" in p.stderr
     got = sorted(tuple(l.split("\t")) for l in p.stdout.splitlines())
     assert got == sorted((e["query"], e["target"], e["id"]) for e in ex["expected_search"])
+
+
+def test_packed_postings_format_counts_every_posting_once():
+    """The packed postings of the device k-mer index (vsx_kmer_pack.h: sorted counters as a 16-bit first value + 14 one-byte gaps
+    per unit, dummy counters for gaps above 255 and for the tail of a unit).  The encoder is the code the build kernel runs; the
+    decoder restates what the count kernel does with a unit (every byte one increment).  Any set of counters must come back as
+    exactly one increment each, with everything else landing on dummies."""
+    import ctypes as C
+    import random
+    from vsearch_amd import _lib
+    lib = _lib.load()
+    enc = lib.vsx_internal_kmer_pack_encode
+    enc.restype = C.c_int64
+    enc.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    cnt = lib.vsx_internal_kmer_pack_count
+    cnt.restype = None
+    cnt.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    c_of = lib.vsx_internal_kmer_pack_counter_of
+    c_of.restype = C.c_uint32
+    c_of.argtypes = [C.c_uint32]
+    s_of = lib.vsx_internal_kmer_pack_seq_of
+    s_of.restype = C.c_uint32
+    s_of.argtypes = [C.c_uint32]
+
+    # the sequence <-> counter map: a bijection of the tile's 32 630 sequences onto the non-dummy counters, neighbours 252 apart
+    seen = set()
+    for s in range(32630):
+        c = c_of(s)
+        assert c < 130 * 252 and c % 252 != 251 and s_of(c) == s
+        seen.add(c)
+    assert len(seen) == 32630
+    assert c_of(1) - c_of(0) == 252 and c_of(130) == 1
+
+    real = [c for c in range(130 * 252) if c % 252 != 251]
+    rng = random.Random(2024)
+
+    def check(counters):
+        counters = sorted(set(counters))
+        a = np.array(counters, dtype=np.uint32)
+        n_units = enc(a.ctypes.data, len(a), None, 0)
+        assert n_units >= (len(a) + 14) // 15 and (n_units > 0) == (len(a) > 0)
+        units = np.zeros(4 * max(1, n_units), dtype=np.uint32)
+        assert enc(a.ctypes.data, len(a), units.ctypes.data, n_units) == n_units
+        hits = np.zeros(32768, dtype=np.uint32)
+        cnt(units.ctypes.data, n_units, hits.ctypes.data)
+        want = np.zeros(32768, dtype=np.uint32)
+        want[a] = 1
+        dummies = np.arange(251, 130 * 252, 252)
+        got = hits.copy()
+        got[dummies] = 0
+        assert np.array_equal(got, want), (len(a), n_units)
+        assert hits[130 * 252:].sum() == 0
+        assert hits.sum() == 15 * n_units                         # every slot of every unit is an increment somewhere
+        return n_units
+
+    check([])
+    check([0])
+    check([32758])
+    check([0, 32758])                                             # one posting, 130 hops, one posting
+    check([5, 260, 261, 516, 517, 771])                           # gaps of exactly 255, 1, 255, 1, 254
+    check([5, 261, 517])                                          # gaps of 256: one hop each
+    check(list(range(0, 15)) + [300])                             # a full unit, then a new one
+    check(list(range(0, 16)))
+    check([c for c in real if c % 252 == 250])                    # the counter next to every dummy
+    check(real)                                                   # every sequence of the tile: 32 630 postings
+    for density in (1, 3, 15, 16, 40, 487, 5000):
+        for _ in range(6):
+            check(rng.sample(real, density))
+    # clustered: runs of neighbours far apart
+    for _ in range(6):
+        starts = rng.sample(range(0, len(real) - 60), 9)
+        check([real[s + k] for s in starts for k in range(rng.randrange(1, 50))])
+    # dense random buckets stay close to 15 postings per unit
+    dense = rng.sample(real, 4000)
+    assert check(dense) <= 4000 // 15 + 4000 // 40
+    # refused inputs: a dummy, unsorted, out of range
+    for bad in ([251], [7, 7], [9, 3], [130 * 252]):
+        a = np.array(bad, dtype=np.uint32)
+        assert enc(a.ctypes.data, len(a), None, 0) == -1

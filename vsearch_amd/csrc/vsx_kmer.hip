@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "vsx_internal.h"
+#include "vsx_kmer_pack.h"
 
 typedef unsigned int u32;
 typedef unsigned long long u64;
@@ -489,10 +490,7 @@ vsx_kmer_count_kernel(const uint4 * __restrict__ postings, const u64 * __restric
 // the bench shape has ~35 units, and a trip per bucket would leave half the lanes idle while costing the same instructions.
 // Build (per tile, like the tagged index): keys (word << 16 | counter index) of every position -> radix sort -> one thread per
 // word walks its run of distinct keys and counts / writes the units.
-#define KM_PK_PERIOD 252u
-#define KM_PK_REAL 251u
-#define KM_PK_TILE_SEQS (130u * KM_PK_REAL)
-#define KM_PK_SLOTS 15
+// (the format's constants, the counter <-> sequence maps and the encoder: vsx_kmer_pack.h, shared with a host entry for the CPU suite)
 
 __global__ void __launch_bounds__(256)
 vsx_kmer_pk_keys_kernel(const uint8_t * __restrict__ codes, const u64 * __restrict__ off, const u32 * __restrict__ len, u32 first_seq,
@@ -505,7 +503,7 @@ vsx_kmer_pk_keys_kernel(const uint8_t * __restrict__ codes, const u64 * __restri
   const u64 base = off[sid];
   const uint8_t * __restrict__ s = codes + base;
   const int L = (int) len[sid];
-  const u32 idx = (local % 130u) * KM_PK_PERIOD + local / 130u;   // see the header comment: neighbours land 252 counters apart
+  const u32 idx = km_pk_counter_of(local);                          // see the header comment: neighbours land 252 counters apart
   u32 * __restrict__ out = keys + (slot_of[sid] - slot_of[first_seq]);
   for (int p0 = 0; p0 < L; p0 += 64)
     {
@@ -531,20 +529,8 @@ vsx_kmer_pk_walk_kernel(const u32 * __restrict__ keys, u64 n, u32 tile, u32 ntil
   const u32 want = word << 16;
   while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
   const size_t b = (size_t) word * ntiles + tile;
-  uint4 * __restrict__ out = FILL ? postings + bucket_start[b] : nullptr;
-  u32 units = 0, real = 0, s = 0, acc = 0;
-  u32 wv[4] = {0, 0, 0, 0};
-  auto put = [&](u32 delta) {                                      // slot s (1 .. 14) of the open unit
-    const u32 bytepos = s + 1;                                     // bytes 0-1 hold the first index
-    wv[bytepos >> 2] |= delta << (8 * (bytepos & 3));
-    ++s;
-  };
-  auto close = [&]() {
-    if (FILL) out[units] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-    ++units;
-    s = 0;
-    wv[0] = wv[1] = wv[2] = wv[3] = 0;
-  };
+  KmPkEncoder enc(FILL ? reinterpret_cast<KmPkUnit *>(postings + bucket_start[b]) : nullptr);
+  u32 real = 0;
   u32 prev = 0xffffffffu;
   for (u64 i = lo; i < n; ++i)
     {
@@ -553,26 +539,10 @@ vsx_kmer_pk_walk_kernel(const u32 * __restrict__ keys, u64 n, u32 tile, u32 ntil
       if (k == prev) continue;                                      // the same word again in the same sequence (unique_count)
       prev = k;
       ++real;
-      const u32 idx = k & 0xffffu;
-      for (;;)
-        {
-          if (s == KM_PK_SLOTS) close();
-          if (s == 0) { wv[0] = idx; acc = idx; s = 1; break; }
-          if (idx - acc <= 255u) { put(idx - acc); acc = idx; break; }
-          const u32 d = KM_PK_REAL + KM_PK_PERIOD * ((acc + 4u) / KM_PK_PERIOD);       // the farthest dummy within 255
-          put(d - acc);
-          acc = d;
-        }
+      enc.push(k & 0xffffu);
     }
-  if (s > 0)
-    {
-      if (s < KM_PK_SLOTS && (acc % KM_PK_PERIOD) != KM_PK_REAL)
-        {
-          const u32 d = KM_PK_REAL + KM_PK_PERIOD * (acc / KM_PK_PERIOD);               // the dummy of acc's own period
-          put(d - acc);
-        }
-      close();                                                       // the remaining gaps are 0: they stay on the dummy
-    }
+  enc.finish();
+  const u32 units = enc.units;
   if (!FILL) bucket_count[b] = units | (real << 16);
 }
 
@@ -886,7 +856,7 @@ vsx_kmer_select_kernel(const uint2 * __restrict__ rec, u32 subcap, u32 ntiles, c
               if (packed)
                 {
                   const u32 cx = v.x & (KM_TILE - 1u);
-                  v.x = (v.x >> KM_TILE_SHIFT) * KM_PK_TILE_SEQS + (cx % KM_PK_PERIOD) * 130u + cx / KM_PK_PERIOD;
+                  v.x = (v.x >> KM_TILE_SHIFT) * KM_PK_TILE_SEQS + km_pk_seq_of(cx);
                 }
               dense[first + done + (u32) __popcll(ballot & ((1ull << lane) - 1ull))] = v;
             }

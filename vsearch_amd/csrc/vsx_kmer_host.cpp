@@ -27,6 +27,7 @@ extern "C" hipError_t vsx_kmer_packed_tile(int fill, const uint8_t * codes, cons
                                            uint32_t * keys_a, uint32_t * keys_b, void * temp, size_t * temp_bytes, uint32_t tile, uint32_t ntiles,
                                            uint32_t * bucket_count, const uint64_t * bucket_start, uint32_t * postings, hipStream_t st);
 extern "C" uint32_t vsx_kmer_packed_tile_seqs(void);
+#include "vsx_kmer_pack.h"
 extern "C" hipError_t vsx_kmer_launch_select_packed(const void * rec, uint32_t subcap, uint32_t ntiles, const uint32_t * tile_count, uint32_t nslots,
                                                     uint32_t keep, void * dense, unsigned long long * cursor, uint64_t capacity,
                                                     void * sel_m_n, uint64_t * sel_off, hipStream_t st);
@@ -569,3 +570,39 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
   }
   return VSX_OK;
 }
+
+// ---- the packed postings format on the host: what the CPU suite drives (tests/test_host_cpu.py) ------------------------------------
+// counters[n] ascending, none of them a dummy -> units (units_out may be NULL: only the count); returns the number of units, or
+// -1 for an input the format does not take
+extern "C" int64_t vsx_internal_kmer_pack_encode(const uint32_t * counters, uint64_t n, uint32_t * units_out, uint64_t units_cap)
+{
+  for (uint64_t k = 0; k < n; ++k)
+    if (counters[k] >= KM_PK_ROWS * KM_PK_PERIOD || km_pk_is_dummy(counters[k]) || (k && counters[k] <= counters[k - 1])) return -1;
+  KmPkEncoder count(nullptr);
+  for (uint64_t k = 0; k < n; ++k) count.push(counters[k]);
+  count.finish();
+  if (!units_out) return (int64_t) count.units;
+  if (count.units > units_cap) return -1;
+  KmPkEncoder enc(reinterpret_cast<KmPkUnit *>(units_out));
+  for (uint64_t k = 0; k < n; ++k) enc.push(counters[k]);
+  enc.finish();
+  return (int64_t) enc.units;
+}
+// what the count kernel does with a bucket: every byte of every unit is one increment; hits[counter] += 1 (hits has 32 768 entries)
+extern "C" void vsx_internal_kmer_pack_count(const uint32_t * units, uint64_t n_units, uint32_t * hits)
+{
+  for (uint64_t u = 0; u < n_units; ++u)
+    {
+      const uint32_t * w = units + 4 * u;
+      uint32_t acc = w[0] & 0xffffu;
+      ++hits[acc & 0x7fffu];
+      for (int slot = 1; slot < KM_PK_SLOTS; ++slot)
+        {
+          const int bytepos = slot + 1;
+          acc += (w[bytepos >> 2] >> (8 * (bytepos & 3))) & 0xffu;
+          ++hits[acc & 0x7fffu];
+        }
+    }
+}
+extern "C" uint32_t vsx_internal_kmer_pack_counter_of(uint32_t local_seq) { return km_pk_counter_of(local_seq); }
+extern "C" uint32_t vsx_internal_kmer_pack_seq_of(uint32_t counter) { return km_pk_seq_of(counter); }
