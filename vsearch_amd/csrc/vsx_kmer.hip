@@ -5,12 +5,14 @@
 // top-N heap) and the index it walks (core/dbindex.cpp:125-255, core/unique.cpp:155-352) by HBM/LDS-bound integer
 // kernels.  No MFMA: this is a sparse count, not a contraction.
 //
-//   index   = postings grouped by (word, TILE of 2^15 consecutive sequence numbers): a CSR over 4^w x ntiles buckets of
-//             16-BIT tile-local sequence indices in 16-byte units of eight (a bucket's last unit is padded with the index of
-//             a spare counter, so the count kernel never tests for a sentinel) -- half the bytes of sequence numbers, and the
-//             count kernel is bound by exactly this stream.
-//             Built on the device from the 4-bit codes in two sweeps (count, fill); the order inside a bucket is
-//             arbitrary (counting commutes), so no sort is needed.
+//   index   = postings grouped by (word, TILE of consecutive sequence numbers): a CSR over 4^w x ntiles buckets, in one of three
+//             formats (all in 16-byte units, so the count kernels stream whole units and never test for a sentinel):
+//             * PACKED (the whole-set index of a search, word lengths 3..8; "PACKED postings" below): sorted counter indices as a
+//               16-bit first value + 14 one-byte gaps per unit, tiles of 32 630 sequences -- 1.1 bytes per posting;
+//             * 16-BIT (subset indexes, rebuilt every clustering round): tile-local sequence indices, eight per unit, tiles of 2^15,
+//               the last unit of a bucket padded with the index of a spare counter; built in two sweeps (count, fill), the order
+//               inside a bucket arbitrary (counting commutes), so no sort is needed;
+//             * TAGGED (word lengths 9..15): dwords tag << 16 | index, four per unit.
 //   count   = one block per (query, tile): 2^15 counters live in LDS -- 8 bits each (32 KB, 512 threads, four blocks per CU) for
 //             queries with at most 255 unique words, 16 bits (64 KB, 1024 threads) otherwise; the query's unique words
 //             select one bucket each, whose postings are streamed (coalesced 16-byte loads) into ds_add_u32 on the packed fields;
