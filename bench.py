@@ -200,15 +200,10 @@ def main():
             # step is posted and the PREVIOUS step's is collected, so it travels while the next step's kernels run
             rec, runs = sharding.export_records(plan, n_pairs, dev, scratch, host=gloo)
             if fixed is not None:
-                try:
-                    ticket = fixed.post(rec, runs)
-                except OverflowError:                      # (a step larger than the fixed capacity: this one goes the synchronous way)
-                    ticket = None
+                ticket = fixed.post(rec, runs)             # (a step that does not fit on SOME rank is redone synchronously by ALL ranks inside collect)
                 if pending is not None:
                     gathered = fixed.collect(pending)
                 pending = ticket
-                if ticket is None:
-                    gathered = sharding.gather_results(rec, runs, dist, dst=0)
             else:
                 gathered = sharding.gather_results(rec, runs, dist, dst=0)
         return tm

@@ -248,7 +248,6 @@ auto search_batch(struct Parameters const & parameters, struct Dbindex const & d
                         max_results_per_query, result_counts);
   };
   if (!g_search.ensure(parameters, db, false)) { reference(); return; }
-  trace("search_batch -> vsx_multi_search_batch", query_count);
   uint64_t const n = (uint64_t) query_count;
   std::vector<uint64_t> off(n), size(n);
   std::vector<uint32_t> len(n);
@@ -268,6 +267,7 @@ auto search_batch(struct Parameters const & parameters, struct Dbindex const & d
       reference();
       return;
     }
+  trace("search_batch -> vsx_multi_search_batch", query_count);          // only once the fast path HAS answered (the tests key on it)
   // search_joinhits order (accepted / weak hits of both strands, best first), the first max_results of it (search.cpp:463-488)
   for (uint64_t k = 0; k < n; ++k)
     {
@@ -380,15 +380,16 @@ auto cluster_assign_batch(struct cluster_session_s * cs, int start_seqno, int co
   if (c.mode == FastCluster::reference_code) { vsxref_cluster_assign_batch(c.ref, start_seqno, count, results); return; }
   if (!c.have)
     {
-      trace("cluster_assign_batch -> vsx_cluster_fast", (long) c.db->getsequencecount());
       if (!run_fast(c))
         {
+          trace("cluster_assign_batch -> reference code (fast path failed)", (long) c.db->getsequencecount());
           // nothing has been answered from the fast path yet (this is the session's first batch): the reference's session, which
           // cluster_session_init prepared alongside, takes over for the rest of the session
           c.mode = FastCluster::reference_code;
           vsxref_cluster_assign_batch(c.ref, start_seqno, count, results);
           return;
         }
+      trace("cluster_assign_batch -> vsx_cluster_fast", (long) c.db->getsequencecount());          // the fast path has answered
     }
   for (int k = 0; k < count; ++k) materialise(c, (uint64_t) (start_seqno + k), results[k]);
 }

@@ -333,11 +333,12 @@ def test_chunked_plan_equals_single_chunk(gpu_required, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [
     {"VSX_TRACEBACK": "dirs"}, {"VSX_TB_ARITH": "packed"}, {"VSX_SCORE": "arith"}, {"VSX_NO_SHARE_SUB": "1"}, {"VSX_ROWS": "4"},
-    {"VSX_TILT": "0"}, {"VSX_TILT": "0", "VSX_ROWS": "4"},
+    {"VSX_TILT": "0"}, {"VSX_TILT": "0", "VSX_ROWS": "4"}, {"VSX_MAX3": "0"}, {"VSX_MAX3": "0", "VSX_ROWS": "4"},
 ], ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_kernel_modes(gpu_required, env):
     """the A/B switches of DESIGN.md section 8 select other kernel variants (stored direction bits, saturating packed traceback,
-    table-free scores, unshared subtraction, many strips, plain instead of tilted coordinates): each must reproduce the golden vectors and the torture slice"""
+    table-free scores, unshared subtraction, many strips, plain instead of tilted coordinates, the 16-bit TILT class instead of its
+    MAX3 sub-class -- r02's default, which the fixtures otherwise reach only for 1 900 < Q + D < 3 900): each must reproduce the golden vectors and the torture slice"""
     import subprocess
     import sys
     e = dict(os.environ)
@@ -398,3 +399,59 @@ def test_pipelined_slices_equal_one_plan(gpu_required):
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
         outs.append([ln for ln in p.stdout.splitlines() if ln.startswith("HASH")])
     assert outs[0] and outs[0] == outs[1]
+
+
+def _tilt_reach(P, Q, D):
+    """the planner's bound (vsx_host.cpp tilt_possible()): |any value the tilted kernel forms| stays below this"""
+    B = max(abs(P[0]), abs(P[1]), *P[8:14])
+    G = max(P[2:8])
+    return 4 * G + 2 * (Q + ((D + 3) & ~3) + 64) * B
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["default", "nmismatch", "zero_terminal", "uniform10_1"])
+def test_tilt_class_boundaries(gpu_required, oracle, name):
+    """pairs on both sides of both thresholds of tilt_possible() -- reach < 15 800: MAX3 (values are fp16 bit patterns), < 32 000:
+    the 16-bit TILT class, beyond: plain coordinates -- under the four tilt-eligible scoring sets; the class each task took is read
+    back through vsx_plan_describe, every field of every pair is compared with the oracle.  One query per task (all of a task's
+    targets sit on the same side: the planner classifies a task by its longest target)."""
+    from vsearch_amd import Aligner
+    sc = common.load_golden()["scorings"][name]
+    P, nmm = sc["P"], sc["n_mismatch"]
+    import zlib
+    rng = random.Random(zlib.crc32(name.encode()))
+    qs, ts, qi, ti, want = [], [], [], [], []           # want[k] = class of query k's task: 2 MAX3, 1 TILT, 0 plain
+    for Q in (250, 400, 90, 520):
+        for limit, below, above in ((15800, 2, 1), (32000, 1, 0)):
+            # largest padded target length that keeps reach(Q, D) < limit
+            D = 8
+            while _tilt_reach(P, Q, D + 4) < limit:
+                D += 4
+            for side, cls in ((0, below), (1, above)):
+                q = common.rnd_seq(rng, Q)
+                k = len(qs)
+                qs.append(q)
+                want.append(cls)
+                for x in range(5):
+                    d = D - x if side == 0 else D + 1 + x                  # D, D-1, ... stay below; D+1 ... pad to D+4: above
+                    assert (_tilt_reach(P, Q, d) < limit) == (side == 0)
+                    left = rng.randint(0, d - Q) if d > Q else 0
+                    t = (common.rnd_seq(rng, left) + common.mutate(rng, q, 0.08) + common.rnd_seq(rng, d))[:d]
+                    qi.append(k)
+                    ti.append(len(ts))
+                    ts.append(t)
+    qi = np.array(qi, np.uint32)
+    ti = np.array(ti, np.uint32)
+    with Aligner(scoring=P, n_mismatch=nmm) as al:
+        Qs, Ts = al.sequences(qs), al.sequences(ts)
+        p = al.plan(Qs, Ts, qi, ti)
+        info = p.describe()
+        p.run()
+        res = p.fetch()
+        p.close()
+    assert info["tasks"] == len(qs)
+    assert info["tasks_max3"] == want.count(2), info
+    assert info["tasks_tilted"] == want.count(2) + want.count(1), info
+    assert info["tasks_tracked"] == 0, info
+    for k in range(len(qi)):
+        assert res.row(k) == tuple(oracle.align(qs[qi[k]], ts[ti[k]], P, nmm)), (name, k, len(qs[qi[k]]), len(ts[ti[k]]))

@@ -440,6 +440,28 @@ def test_device_kmer_region_overflow_second_pass(gpu_required, monkeypatch):
     assert host == dev and max(len(h) for h in host) > 3
 
 
+@pytest.mark.gpu
+def test_device_kmer_sliced_passes_equal_one_pass(gpu_required, monkeypatch):
+    """the counting scratch is bounded -- a batch whose per-(query, tile) regions exceed the budget runs as several
+    passes over slices of its queries.  With the budget forced down (64 queries per pass; mixed 8-bit / 16-bit counter classes,
+    several tiles, a forced second pass on top) the candidate lists must equal the host restatement's"""
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(6)
+    db, _ = common.family_db(rng, 10, 20, 320, div=0.05)
+    qs, _ = common.queries_from_db(rng, db, 150, 150)
+    long_qs, _ = common.queries_from_db(rng, db, 50, 300)          # > 255 unique words: the 16-bit counter class
+    qs = qs[:70] + long_qs + qs[70:]
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.5, maxaccepts=4, maxrejects=16)
+        host = ss.candidates_batch(qs, device=False)
+        whole = ss.candidates_batch(qs, device=True)
+        monkeypatch.setenv("VSX_KMER_SCRATCH_BYTES", "65536")
+        sliced = ss.candidates_batch(qs, device=True)
+        monkeypatch.setenv("VSX_KMER_CAP", "3")
+        sliced2 = ss.candidates_batch(qs, device=True)
+    assert host == whole == sliced == sliced2 and max(len(h) for h in host) > 3
+
+
 def test_infinite_gap_penalties_match_reference_cli(gpu_required, tmp_path):
     """--gapext "2I/*E": terminal gaps longer than one are forbidden (cli.cc:203-228, searchcore.cpp:621-660); every pair
     takes the linear-memory fallback (search16 refuses penalties beyond the 16-bit range, align_simd.cpp:1463-1479)"""

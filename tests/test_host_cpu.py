@@ -164,13 +164,25 @@ for dst in (0, None):
     got = fg.collect(tickets[-1])
     if dst is None or rank == dst:
         assert torch.equal(got[0], rec_all) and torch.equal(got[1], runs_all) and got[2] == counts
-    # a step beyond the fixed capacity is refused loudly
-    big = np.concatenate([rec] * 3)
-    try:
-        fg.post(torch.from_numpy(big), torch.from_numpy(np.concatenate([runs] * 3).view(np.int32)))
-        raise SystemExit("FixedGather accepted a payload beyond its capacity")
-    except OverflowError:
-        pass
+    # a step beyond the fixed capacity ON ONE RANK ONLY (ADVICE r03: per-rank sizes differ): the decision is collective -- both
+    # ranks redo that step through the synchronous gather inside collect(), nobody is left in another collective sequence; a
+    # normal step is already in flight behind it, and the steps after it use the grown capacities
+    big = (np.concatenate([rec] * 3), np.concatenate([runs] * 3)) if rank == 1 else (rec, runs)
+    seq = [big, (rec, runs), big, (rec, runs)]
+    tk = []
+    for k, (rc_, rn_) in enumerate(seq):
+        tk.append(fg.post(torch.from_numpy(np.ascontiguousarray(rc_)), torch.from_numpy(np.ascontiguousarray(rn_).view(np.int32))))
+        if k >= 1:
+            got = fg.collect(tk[k - 1])
+            exp = sharding.gather_results(torch.from_numpy(np.ascontiguousarray(seq[k - 1][0])), torch.from_numpy(np.ascontiguousarray(seq[k - 1][1]).view(np.int32)), dist, dst=dst)
+            if dst is None or rank == dst:
+                assert torch.equal(got[0], exp[0]) and torch.equal(got[1], exp[1]) and got[2] == exp[2], (dst, k)
+            else:
+                assert got == (None, None, None)
+    got = fg.collect(tk[-1])
+    if dst is None or rank == dst:
+        assert torch.equal(got[0], rec_all) and torch.equal(got[1], runs_all) and got[2] == counts
+    assert fg.sync_steps == 1, fg.sync_steps          # the first big step only: the second one fits the grown buffers
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """

@@ -1539,6 +1539,34 @@ vsx_purity_kernel(const uint8_t * __restrict__ codes, const uint64_t * __restric
   if (lane == 0) impure[s] = any ? 1 : 0;
 }
 
+// the MAX3 class rests on v_pk_maximum3_f16 being an INTEGER maximum on the bit patterns 0x0000 .. 0x7BFF (the
+// non-negative finite fp16 numbers, denormals included, no flush).  One-off self-test per device (vsx_create): every pattern of
+// that range against two others drawn from the boundaries and a hash, both halves; bad[0] counts disagreements.
+__global__ void __launch_bounds__(256)
+vsx_max3_selftest_kernel(u32 * bad)
+{
+  const u32 x = blockIdx.x * 256u + threadIdx.x;              // 0 .. 0x7BFF
+  if (x > 0x7BFFu) return;
+  const u32 edge[8] = {0u, 1u, 0x03FFu, 0x0400u, 0x3C00u, 0x3E00u, 0x7BFEu, 0x7BFFu};
+  u32 wrong = 0;
+  for (u32 k = 0; k < 64; ++k)
+    {
+      const u32 h = (x * 2654435761u) ^ (k * 0x9E3779B9u);
+      const u32 y = (k < 8) ? edge[k] : (h >> 7) % 0x7C00u;
+      const u32 z = (k < 16) ? edge[(k + 3) & 7] : (h >> 17) % 0x7C00u;
+      const u32 a = x | (y << 16), b = y | (z << 16), c = z | (x << 16);
+      const u32 got = pk_max3_bits(a, b, c);
+      const u32 m = x > y ? (x > z ? x : z) : (y > z ? y : z);
+      if (got != (m | (m << 16))) ++wrong;
+    }
+  if (wrong) atomicAdd(bad, wrong);
+}
+extern "C" hipError_t vsx_launch_max3_selftest(u32 * d_bad, hipStream_t st)
+{
+  hipLaunchKernelGGL(vsx_max3_selftest_kernel, dim3((0x7C00 + 255) / 256), dim3(256), 0, st, d_bad);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------

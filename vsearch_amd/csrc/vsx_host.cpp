@@ -287,6 +287,8 @@ struct Chunk {
 }  // namespace
 
 extern "C" int vsx_internal_usable_cpus(void);
+// per device: 0 = not tested yet, 1 = v_pk_maximum3_f16 is the integer maximum on [0, 0x7BFF] (vsx_create's self-test), 2 = it is not
+static std::atomic<int> g_max3_state[64];
 template <typename T>
 static T * dup_array(const std::vector<T> & v)
 {
@@ -645,6 +647,21 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   P.hleft = c->d_hleft.p;
   P.matrix = c->d_matrix.p;
   P.tilt = 0;
+  // once per device, check on the hardware what the MAX3 class assumes (v_pk_maximum3_f16 == integer maximum on
+  // the patterns 0 .. 0x7BFF, denormals included); a device that fails keeps the 16-bit TILT class (tilt_possible())
+  if (device < 64 && g_max3_state[device].load() == 0)
+    {
+      DevBuf<uint32_t> d_bad;
+      uint32_t bad = 1;
+      if (d_bad.alloc(1) == hipSuccess && hipMemsetAsync(d_bad.p, 0, 4, c->stream) == hipSuccess &&
+          vsx_launch_max3_selftest(d_bad.p, c->stream) == hipSuccess &&
+          hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess)
+        {
+          if (bad) std::fprintf(stderr, "libvsx: device %d: v_pk_maximum3_f16 disagrees with the integer maximum on %u probes -- MAX3 class disabled\n", device, bad);
+          g_max3_state[device].store(bad ? 2 : 1);
+        }
+      else (void) hipGetLastError();
+    }
 
   // Tilted coordinates X* = X + (i + j) g, g = the interior extension (VsxDevParams::tilt): available when both interior
   // extensions are g > 0 and the interior QR coincide (the DP kernel's shared H - QR); per task the planner still has to
@@ -888,7 +905,7 @@ static int tilt_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
     if (k < 6) G = std::max<int64_t>(G, ctx->pen[k]); else B = std::max<int64_t>(B, ctx->pen[k]);
   const int64_t Dp = (D + 3) & ~3ll;
   const int64_t reach = 4 * G + 2 * (Q + Dp + 64) * B;          // |value| of anything the kernel forms stays below this
-  if (reach < 15800 && !max3_off && !VSX_CKT) return 2;         // 0x3E00 = 15872 each way inside [0, 0x7BFF]
+  if (reach < 15800 && !max3_off && !VSX_CKT && g_max3_state[ctx->device & 63].load(std::memory_order_relaxed) != 2) return 2;         // 0x3E00 = 15872 each way inside [0, 0x7BFF]
   return reach < 32000 ? 1 : 0;
 }
 

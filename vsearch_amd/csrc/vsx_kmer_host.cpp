@@ -491,39 +491,69 @@ int vsx_kmer_count_batch(VsxKmerIndex * ix, uint64_t nq, const uint64_t * qk_sta
       }
     return true;
   };
-  std::vector<uint32_t> ordered;
-  uint32_t n8 = 0;
-  Buf<uint32_t> d_order;
-  int rc;
-  if (by_class(nullptr, ordered, n8))
-    {
-      KCHK(d_order.alloc(ordered.size()));
-      KCHK(hipMemcpyAsync(d_order.p, ordered.data(), ordered.size() * 4, hipMemcpyHostToDevice, sc->st));
-      rc = count_pass(ix, sc, (uint32_t) nq, n8, d_order.p, &ordered, cap, keep, out, overflow, overflow_max, ms);
-    }
-  else rc = count_pass(ix, sc, (uint32_t) nq, n8, nullptr, nullptr, cap, keep, out, overflow, overflow_max, ms);
+  // One pass over a set of queries (NULL = the whole batch in its own order): class split, slot list, counting + selection.
+  auto run_subset = [&](const std::vector<uint32_t> * subset, uint32_t subcap, std::vector<uint32_t> & over, uint32_t & over_max) -> int {
+    std::vector<uint32_t> ordered;
+    uint32_t n8 = 0;
+    Buf<uint32_t> d_list;
+    const uint32_t n = subset ? (uint32_t) subset->size() : (uint32_t) nq;
+    const std::vector<uint32_t> * list = subset;
+    if (by_class(subset, ordered, n8)) list = &ordered;
+    if (list)
+      {
+        KCHK(d_list.alloc(list->size()));
+        KCHK(hipMemcpyAsync(d_list.p, list->data(), list->size() * 4, hipMemcpyHostToDevice, sc->st));
+      }
+    return count_pass(ix, sc, n, n8, list ? d_list.p : nullptr, list, subcap, keep, out, over, over_max, ms);
+  };
+  // the per-(query, tile) record sub-regions and range tables grow with queries x tiles -- 10 M sequences are
+  // ~307 tiles, i.e. ~30 GB per 16 k-query window and scratch set.  The scratch of one pass is bounded instead: a batch whose
+  // regions would exceed the budget runs as several passes over slices of its queries through the same buffers (results are per
+  // query, so the slicing is invisible); VSX_KMER_SCRATCH_BYTES overrides the budget (tests force the sliced path with it).
+  const uint64_t scratch_budget = []() -> uint64_t {
+    if (const char * c = std::getenv("VSX_KMER_SCRATCH_BYTES")) return (uint64_t) std::max<long long>(1 << 16, std::atoll(c));
+    return 6ull << 30;
+  }();
+  auto run_sliced = [&](const std::vector<uint32_t> * subset, uint32_t subcap, std::vector<uint32_t> & over, uint32_t & over_max) -> int {
+    const uint64_t n = subset ? subset->size() : nq;
+    const uint64_t per_slot = (uint64_t) ix->ntiles * ((uint64_t) subcap * 8 + 256 * 8 + 4);
+    const uint64_t gmax = std::max<uint64_t>(64, scratch_budget / per_slot);
+    if (n <= gmax) return run_subset(subset, subcap, over, over_max);
+    std::vector<uint32_t> slice;
+    for (uint64_t b = 0; b < n; b += gmax)
+      {
+        const uint64_t e = std::min(n, b + gmax);
+        slice.clear();
+        for (uint64_t x = b; x < e; ++x) slice.push_back(subset ? (*subset)[x] : (uint32_t) x);
+        const int r = run_subset(&slice, subcap, over, over_max);
+        if (r != VSX_OK) return r;
+      }
+    return VSX_OK;
+  };
+  int rc = run_sliced(nullptr, cap, overflow, overflow_max);
   if (rc != VSX_OK) return rc;
-  if (std::getenv("VSX_KMER_DEBUG")) std::fprintf(stderr, "kmer: %zu of %llu queries overflowed cap %u (max %u records), %u in the 8-bit class, %.1f ms\n", overflow.size(), (unsigned long long) nq, cap, overflow_max, n8, ms);
+  if (std::getenv("VSX_KMER_DEBUG")) std::fprintf(stderr, "kmer: %zu of %llu queries overflowed cap %u (max %u records), %.1f ms\n", overflow.size(), (unsigned long long) nq, cap, overflow_max, ms);
   if (!overflow.empty())
     {
       // queries with more than `cap` sequences at or above their threshold (low-complexity words): a second pass over
       // just these, with regions of the size the first pass measured
-      std::vector<uint32_t> list;
-      uint32_t m8 = 0;
-      if (!by_class(&overflow, list, m8)) list = overflow;
-      Buf<uint32_t> d_qlist;
-      KCHK(d_qlist.alloc(list.size()));
-      KCHK(hipMemcpyAsync(d_qlist.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, sc->st));
       std::vector<uint32_t> again;
       uint32_t again_max = 0;
-      rc = count_pass(ix, sc, (uint32_t) list.size(), m8, d_qlist.p, &list, overflow_max, keep, out, again, again_max, ms);
+      rc = run_sliced(&overflow, overflow_max, again, again_max);
       if (rc != VSX_OK) return rc;
       if (!again.empty()) { vsx_internal_set_error("vsx_kmer_count_batch: record region overflow in the second pass"); return VSX_EHIP; }
     }
   // A search index (vsx_kmer_index_create) is counted against by up to three windows at once.  The further scratch sets are made
   // HERE, behind the first batch and with its buffer sizes: created on demand, the first call that happens to overlap three
   // windows paid ~0.4 s of hipMalloc in the middle of a warm search (one in seven calls of the bench took 0.55 s instead of 0.15)
-  if (ix->prewarm)
+  // (... unless a spare set of this size would eat into the memory the aligner contexts need -- large databases keep ONE set)
+  auto room_for_spare = [&]() -> bool {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); return false; }
+    const uint64_t set_bytes = (uint64_t) sc->d_rec.n * 8 + (uint64_t) sc->d_ranges.n * 8 + (uint64_t) sc->d_dense.n * 8 + (uint64_t) sc->d_qk.n * 4;
+    return (uint64_t) free_b > 2 * set_bytes + (uint64_t) total_b / 4;
+  };
+  if (ix->prewarm && room_for_spare())
     {
       // ... and an idle set that has not met a batch of this size yet grows now rather than in the middle of a later call
       auto grow_like = [&](KmerScratch * o) -> bool {

@@ -10,7 +10,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define KM_HD __host__ __device__ __forceinline__
 #else
 #define KM_HD inline

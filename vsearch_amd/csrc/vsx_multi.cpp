@@ -44,6 +44,8 @@ struct vsx_multi_searcher {
   }
 };
 
+extern "C" int vsx_internal_usable_cpus(void);
+
 namespace {
 
 int mfail(int code, const std::string & msg) { vsx_internal_set_error(msg.c_str()); return code; }
@@ -131,12 +133,21 @@ int vsx_multi_searcher_create(vsx_multi_searcher ** out, const vsx_scoring * sco
   m->rep.resize((size_t) n_devices);
   m->n_db = n;
   for (int32_t d = 0; d < n_devices; ++d) m->rep[(size_t) d].device = devices[d];
+  // every replica starts its own host workers (word stage, rank workers, consumers): D replicas with the caller's
+  // whole thread budget each oversubscribe the host D times, so the budget is shared out (at least 2 per replica).  Listing one
+  // device twice still doubles that device's context memory (three aligner contexts + counting scratch per replica).
+  vsx_search_opts ropts = *opts;
+  {
+    int budget = ropts.threads > 0 ? ropts.threads : vsx_internal_usable_cpus();
+    if (budget <= 0) budget = 2;
+    ropts.threads = std::max(2, budget / n_devices);
+  }
   // every replica uploads and indexes on its own device at the same time
   const int rc = on_all(m.get(), [&](size_t d) -> int {
     vsx_multi_searcher::Replica & r = m->rep[d];
     int e = vsx_create(&r.ctx, scoring, r.device);
     if (e != VSX_OK) return e;
-    e = vsx_searcher_create(r.ctx, &r.S, opts, n, blob, blob_bytes, offsets, lengths);
+    e = vsx_searcher_create(r.ctx, &r.S, &ropts, n, blob, blob_bytes, offsets, lengths);
     if (e != VSX_OK) return e;
     return meta ? vsx_searcher_set_meta(r.S, meta) : VSX_OK;
   });
@@ -159,6 +170,7 @@ int vsx_multi_search_batch(vsx_multi_searcher * m, uint64_t nq, const char * qbl
 {
   if (!m || !out || (nq && (!qblob || !qoff || !qlen))) return mfail(VSX_EINVAL, "vsx_multi_search_batch: null argument");
   std::memset(out, 0, sizeof *out);
+  if (nq > 0xFFFFFFFFull) return mfail(VSX_EINVAL, "vsx_multi_search_batch: more than 2^32 - 1 queries (vsx_hit.query is 32 bits wide)");
   const size_t D = m->rep.size();
   // contiguous blocks: block d = [lo[d], lo[d + 1])
   std::vector<uint64_t> lo(D + 1, 0);

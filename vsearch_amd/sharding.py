@@ -276,9 +276,13 @@ class FixedGather:
     records, run words} into ONE fixed-capacity byte buffer and posts ONE non-blocking gather to `dst` (all-gather when dst is
     None); nothing synchronises on the counts first, so the collective of step k travels over xGMI while the kernels of step
     k + 1 run, and the receiver rebases the CIGAR run offsets when it collects the step (`collect`).  Two send buffers
-    alternate.  The capacities are fixed by the first call (its sizes plus `slack`); a later step that does not fit raises
-    OverflowError on every rank that sees it -- the caller then uses the synchronous gather_results for that step (the counts
-    differ by a few per cent between steps of one workload, the default slack is 25 %).
+    alternate.  The capacities are fixed by the first call (its sizes plus `slack`).  A later step that does not fit on SOME rank
+    must not split the ranks into different collective sequences (per-rank sizes differ, one rank can overflow alone),
+    so the decision is itself collective: every post carries a second, tiny non-blocking all-reduce(MAX) of an overflow flag; a
+    rank that overflows posts an empty payload; `collect` waits for both and, if ANY rank raised the flag, every rank redoes that
+    step through the synchronous gather_results (the step's data is still in the send buffer, or in a private copy on the rank
+    that overflowed) and the capacities grow on all ranks together.  The counts differ by a few per cent between steps of one
+    workload, the default slack is 25 %.
 
     post(records, runs) -> ticket;  collect(ticket) -> (records_all, runs_all, counts) at the receiver(s), (None, None, None) elsewhere.
     Works on CPU tensors over gloo (tests) and on device tensors over RCCL."""
@@ -293,6 +297,8 @@ class FixedGather:
         self.send = [None, None]
         self.recv = [None, None]
         self.turn = 0
+        self.relayout = False
+        self.sync_steps = 0        # steps that took the synchronous path (some rank overflowed)
 
     def _layout(self, device):
         import torch
@@ -300,8 +306,10 @@ class FixedGather:
         nbytes = (nbytes + 15) & ~15
         for k in (0, 1):
             self.send[k] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+            self.recv[k] = None
             if self.dst is None or self.rank == self.dst:
                 self.recv[k] = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(self.world)]
+        self.relayout = False
 
     def post(self, records, runs):
         import torch
@@ -314,34 +322,59 @@ class FixedGather:
             self.cap_rec = int(int(m[0]) * (1 + self.slack)) + 64
             self.cap_runs = int(int(m[1]) * (1 + self.slack)) + 1024
             self._layout(records.device)
-        if n_rec > self.cap_rec or n_runs > self.cap_runs:
-            raise OverflowError(f"FixedGather: {n_rec} records / {n_runs} run words exceed the fixed capacity {self.cap_rec} / {self.cap_runs}")
+        elif self.relayout:
+            self._layout(records.device)          # the capacities grew (on every rank, in the same collect); tickets in flight keep their buffers
+        over = n_rec > self.cap_rec or n_runs > self.cap_runs
+        flag = torch.tensor([n_rec if over else 0, n_runs if over else 0], dtype=torch.int64, device=records.device)
+        flag_work = self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, async_op=True)
         k = self.turn
         self.turn ^= 1
-        buf = self.send[k]
+        buf, recv, cap_rec = self.send[k], self.recv[k], self.cap_rec
+        keep = None
+        if over:
+            keep = (records.clone(), runs.clone())           # the caller's export buffers are reused by the next step
+            n_rec = n_runs = 0
         buf[:self.HEADER].view(torch.int64).copy_(torch.tensor([n_rec, n_runs], dtype=torch.int64, device=buf.device), non_blocking=True)
         o = self.HEADER
-        buf[o:o + n_rec * HIT_RECORD_BYTES].copy_(records.reshape(-1), non_blocking=True)
-        o = self.HEADER + self.cap_rec * HIT_RECORD_BYTES
-        buf[o:o + n_runs * 4].copy_(runs.reshape(-1).view(torch.uint8), non_blocking=True)
+        buf[o:o + n_rec * HIT_RECORD_BYTES].copy_(records.reshape(-1)[:n_rec * HIT_RECORD_BYTES], non_blocking=True)
+        o = self.HEADER + cap_rec * HIT_RECORD_BYTES
+        buf[o:o + n_runs * 4].copy_(runs.reshape(-1)[:n_runs].view(torch.uint8), non_blocking=True)
         if self.dst is None:
-            work = self.dist.all_gather(self.recv[k], buf, async_op=True)
+            work = self.dist.all_gather(recv, buf, async_op=True)
         elif self.rank == self.dst:
-            work = self.dist.gather(buf, self.recv[k], dst=self.dst, async_op=True)
+            work = self.dist.gather(buf, recv, dst=self.dst, async_op=True)
         else:
             work = self.dist.gather(buf, None, dst=self.dst, async_op=True)
-        return (k, work)
+        return {"work": work, "flag_work": flag_work, "flag": flag, "keep": keep, "send": buf, "recv": recv, "cap_rec": cap_rec}
 
     def collect(self, ticket):
         import torch
-        k, work = ticket
-        work.wait()
-        if self.dst is not None and self.rank != self.dst:
+        ticket["work"].wait()
+        ticket["flag_work"].wait()
+        need_rec, need_runs = (int(x) for x in ticket["flag"].tolist())
+        o_runs = self.HEADER + ticket["cap_rec"] * HIT_RECORD_BYTES
+        receiver = self.dst is None or self.rank == self.dst
+        if need_rec or need_runs:
+            # some rank did not fit: EVERY rank takes the synchronous path for this step (same collective sequence everywhere)
+            if ticket["keep"] is not None:
+                records, runs = ticket["keep"]
+            else:
+                b = ticket["send"]
+                n_rec, n_runs = (int(x) for x in b[:self.HEADER].view(torch.int64).tolist())
+                records = b[self.HEADER:self.HEADER + n_rec * HIT_RECORD_BYTES].reshape(n_rec, HIT_RECORD_BYTES).clone()
+                runs = b[o_runs:o_runs + n_runs * 4].view(torch.int32).clone()
+            out = gather_results(records, runs, self.dist, self.dst)
+            # ... and the capacities grow together: the next post lays new buffers out (the flag is the MAX over ranks: same numbers everywhere)
+            self.cap_rec = max(self.cap_rec, int(need_rec * (1 + self.slack)) + 64)
+            self.cap_runs = max(self.cap_runs, int(need_runs * (1 + self.slack)) + 1024)
+            self.relayout = True
+            self.sync_steps += 1
+            return out if receiver else (None, None, None)
+        if not receiver:
             return None, None, None
         recs, runs_all, counts, base = [], [], [], 0
-        o_runs = self.HEADER + self.cap_rec * HIT_RECORD_BYTES
         for r in range(self.world):
-            b = self.recv[k][r]
+            b = ticket["recv"][r]
             n_rec, n_runs = (int(x) for x in b[:self.HEADER].view(torch.int64).tolist())
             part = b[self.HEADER:self.HEADER + n_rec * HIT_RECORD_BYTES].reshape(n_rec, HIT_RECORD_BYTES).clone()
             if n_rec:
