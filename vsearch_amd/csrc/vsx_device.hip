@@ -25,6 +25,7 @@
 //   * no MFMA: this is a max-plus recurrence on int16, bound by VALU issue.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <cstdlib>
 #include "vsx_internal.h"
 
 typedef unsigned int u32;
@@ -932,6 +933,24 @@ struct __attribute__((aligned(4))) Trio { u32 x, y, z; };
 
 #include "vsx_accept.h"
 
+// -DVSX_TB_STATS=1 (A/B build, measurements only): what the checkpoint traceback does per launch -- [0] wave iterations of the
+// tile loop, [1] busy (pair, tile) visits, [2] distinct tiles among the <= 8 lanes of a task summed over the iterations (= how
+// many separate sets of checkpoint lines a task's lanes ask for), [3] cells walked, [4] walk-loop trips (wave level), [5] pairs;
+// vsx_traceback_tilt_kernel also: [8 ..] wave cycles (s_memtime) per phase of an iteration: loads of tile 1 until they have landed,
+// recompute 1, walk 1, loads of tile 2, recompute 2, walk 2, the rest; [15] = the whole kernel per wave (out16: 16 values)
+#ifndef VSX_TB_STATS
+#define VSX_TB_STATS 0
+#endif
+#if VSX_TB_STATS
+__device__ unsigned long long vsx_tb_stats_dev[16];
+extern "C" hipError_t vsx_internal_tb_stats(unsigned long long * out8, int reset)
+{
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(vsx_tb_stats_dev), sizeof(unsigned long long) * 16);
+  if (e == hipSuccess && reset) { unsigned long long z[16] = {0}; e = hipMemcpyToSymbol(HIP_SYMBOL(vsx_tb_stats_dev), z, sizeof z); }
+  return e;
+}
+#endif
+
 // CK8 = the compressed checkpoint layout of the TILT class (VSX_ROWCK_PAIR_DW / VSX_COLCK_NB): FAST arithmetic, tilted constants
 // Occupancy (r02 PMC: the kernel is latency bound -- 40 % of the wave cycles in s_waitcnt at 10 waves per CU, profiles/r02_ckt_ab.txt):
 // a workgroup is TWO independent waves (no barrier after the table set-up) that share the score table, the symbols of a tile are
@@ -1165,6 +1184,19 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
       const bool one_row = (rmax_raw == 0) && (RT >= 4);          // e.g. the left-terminal run in query row 0
       const int rmax = one_row ? 0 : (rmax_raw | 3);              // rows are funnelled four to a dword
       const int cmax = __builtin_amdgcn_readfirstlane(wave_max_i32(jj - c0));     // columns c0 .. c0 + cmax
+#if VSX_TB_STATS
+      {
+        const unsigned key = busy ? (((unsigned) task & 0x3FFu) << 22) | ((unsigned) L << 12) | ((unsigned) m << 1) | (unsigned) hh : 0xFFFFFFFFu;
+        bool leader = busy;
+        for (int o = 1; o < 8; ++o)
+          {
+            const unsigned other = (unsigned) __shfl((int) key, (tid & ~7) | ((tid - o) & 7), 64);
+            if ((tid & 7) >= o && other == key) leader = false;
+          }
+        const unsigned long long nb = __popcll(__ballot(busy)), nl = __popcll(__ballot(leader));
+        if (tid == 0) { atomicAdd(&vsx_tb_stats_dev[0], 1ull); atomicAdd(&vsx_tb_stats_dev[1], nb); atomicAdd(&vsx_tb_stats_dev[2], nl); }
+      }
+#endif
 
       // top boundary for columns c0-1 .. c0+15 (entry 1 is the corner column c0 - 1) and the target symbols
       if (MID && hh == 1)
@@ -1402,10 +1434,16 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
               else if (bts & A::LEFT) { if (op != 1) ++ga; --j; push(1); }
               else if (bts & A::UP) { if (op != 2) ++ga; --i; --r; push(2); }
               else { --i; --r; --j; push(0); }
+#if VSX_TB_STATS
+              atomicAdd(&vsx_tb_stats_dev[3], 1ull);
+#endif
             }
           if (r < 0 && L > 0) { --L; r = (L == 0 ? rtop0 : R) - 1; }
         }
     }
+#if VSX_TB_STATS
+  if (valid) atomicAdd(&vsx_tb_stats_dev[5], 1ull);
+#endif
   if (!valid) return;
 
   VsxPairOut o;
@@ -1462,6 +1500,579 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   u32 verdict = 0;
   if (FL.enabled && nruns > 0) verdict = accept_verdict(FL, Q, D, (int) al, (int) ma, (int) mi, (int) ga, my[nruns - 1], my[0]);
   if (verdict == 3u) nruns = 0;                          // rejected: the runs never leave the device
+
+  const unsigned long long base = atomicAdd(cursor, (unsigned long long) nruns);
+  if (base + nruns <= runs_capacity)
+    for (u32 x = 0; x < nruns; ++x) runs[base + x] = my[x];
+
+  o.score = so.score;
+  o.aligned = (uint16_t) al; o.matches = (uint16_t) ma; o.mismatches = (uint16_t) mi; o.gaps = (uint16_t) ga;
+  o.pad = (uint16_t) verdict;
+  o.nruns = nruns;
+  o.run_off = base;
+  out[pair_ids[k]] = o;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Traceback of the TILT class, second design (r04): vsx_traceback_tilt_kernel<R, MID>.
+//
+// What r03's kernel (above, still used for the plain classes) was bound by, measured (profiles/r04/r04a_fetch_calibration.txt,
+// r04b_tb_stats.txt): (1) every 12- or 16-byte checkpoint read costs HBM a whole 128-byte line (a sparse one-read-per-line kernel runs
+// at the same 45 G lines/s as a coalesced stream, and FETCH_SIZE tallies 64 B per line either way), and the 8 lanes of a task shared
+// their lines only 2.95 : 1 -- they drift apart by a tile step whenever one of them leaves a tile through the top instead of the
+// left edge -- so a launch fetched 1.55e8 lines = 19.8 GB: a floor of 3.4 ms under a 4.7 ms kernel; (2) 14 unpacked instructions per
+// recomputed cell, for the whole 16 x 16 tile whatever part of it a lane needs.
+//
+// This kernel: * an iteration of the wave is one POSITION (MID: half position) of every lane, not one tile: the lane stages the tile
+//   under its cursor AND the tile left of it (column blocks m and m - 1) with one batch of loads, then recomputes / walks them one
+//   after the other.  A lane spends exactly one iteration per position unless its path spans more than two column blocks there, so
+//   the lanes of a task stay together and read the same lines; half as many dependent round trips to HBM.
+//   * the recompute packs TWO ROWS OF THE SAME PAIR into the halves of a register: rows x (low half) and x + HR (high half, HR =
+//   half the tile height), the high half one column behind (it needs the low half's bottom row of that column, handed over in
+//   registers).  All values are plain int16 (checkpoints minus the class's bias), every instruction is a packed one:
+//   add, 4 saturating subtractions whose signs ARE the direction bits (exact for any int16 pair), 4 maxima, H - QR = 10 per row
+//   pair in an interior tile; the eight sign bits of a row pair are collected by two v_perm_b32 (selectors 8 .. 11 replicate a sign
+//   bit over a byte) and two v_bfi_b32 into one dword per four row pairs = 4 instead of 8; the substitution scores of both rows
+//   come from ONE v_perm_b32 over the two columns' score dwords when the tile's query symbols are plain A C G T (else two byte reads).
+//   15 instructions per two cells instead of 28.
+//   Bit layout of a bits dword (column slot `it`, group of four row pairs): byte 0 = rows x (column it): bits 0-3 UP of the four
+//   rows, bits 4-7 EXT_UP; byte 1 = the same for rows x + HR (column it - 1); byte 2 / 3 = LEFT | EXT_LEFT of the two halves.
+// Same inputs, same outputs and the same walk rules (backtrack16, align_simd.cpp:1137-1235) as the kernel above.
+// ---------------------------------------------------------------------------------------------------------------------------------
+DEV u32 pk_add(u32 a, u32 b) { return UI((us2) (U2(a) + U2(b))); }                                 // v_pk_add_u16 (wraps; the planner proves that no int16 overflows)
+DEV u32 pk_sub(u32 a, u32 b) { return psubw(a, b); }                                                // v_pk_sub_u16
+#ifdef VSX_TB2_WAVES_N
+#define VSX_TB2_WAVES(R_, MID_) VSX_TB2_WAVES_N
+#endif
+// occupancy floor (r04 same-box A/B, profiles/r04/r04k_tb2_occupancy_ab.txt): the 14.7 KB of LDS per wave cap a CU at 11 waves whatever the
+// registers; asking the allocator for 3 waves per SIMD (168 VGPRs) spills 276 B per lane at R = 16 and LOSES to 2 waves without spills
+// (250 x 1000: 4.53 -> 4.06 ms, 400 x 400: 7.66 -> 6.89); the short tiles (<= 10 rows) fit and prefer 3 (150 x 300: 2.75 vs 2.84)
+#ifndef VSX_TB2_WAVES
+#define VSX_TB2_WAVES(R_, MID_) ((((MID_) ? (R_) / 2 : (R_)) <= 10) ? 3 : 2)
+#endif
+#ifndef VSX_TB2_EARLY2
+#define VSX_TB2_EARLY2 0
+#endif
+template <int R, bool MID>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VSX_TB2_WAVES(R, MID), 8)))
+vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTask * __restrict__ tasks,
+                          const u32 * __restrict__ pair_slot, const u32 * __restrict__ pair_ids, u32 npairs,
+                          const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
+                          const u32 * __restrict__ ck, const VsxSlotOut * __restrict__ slot,
+                          u32 * __restrict__ slab, const uint64_t * __restrict__ slab_off,
+                          u32 * __restrict__ runs, uint64_t runs_capacity, unsigned long long * cursor,
+                          VsxPairOut * __restrict__ out)
+{
+  static_assert(R >= 4 && (!MID || R % 2 == 0), "R = 1 keeps the first kernel");
+  constexpr int RT = MID ? R / 2 : R;              // rows of a tile
+  constexpr int HR = (RT + 1) / 2;                 // row pairs: rows x and x + HR share a register (row RT of an odd tile is junk)
+  constexpr int NG = (HR + 3) / 4;                 // bits dwords per column slot
+  constexpr int XL = RT - 1 - HR;                  // the row pair whose HIGH half is the tile's last row
+  constexpr int NBQ = MID ? VSX_COLCK_NBH(RT) : VSX_COLCK_NB(R, true);      // 16-byte blocks of one (half-)column checkpoint
+  // One wave per workgroup: 14.5 KB of LDS each = 11 waves per CU (the wave's own arrays are lane-minor: no bank conflicts)
+  __shared__ uint8_t Ssh[512];                     // S'[target code][query code], row stride 32; query "code" 16 = a dummy row of position 0
+  __shared__ u32 Ssh4[16];                         // S'[target code][A | C << 8 | G << 16 | T << 24]: the fast score pick
+  __shared__ u32 bitsL[17 * NG * 64];              // [column slot 0 .. 16][group of four row pairs][lane]
+  __shared__ u32 tbL[19 * 64];                     // top boundary of the tile in work, H (low 16) | F (high 16), int16 values: entry e = column cst - 1 + e
+  __shared__ uint8_t symL[10 * 64];                // target symbols of columns cst .. cst + 19, two to a byte
+  const int tid = (int) threadIdx.x;
+  for (int x = tid; x < 512; x += 64)
+    Ssh[x] = (uint8_t) (((x & 31) < 16) ? P.matrix[(x >> 5) * 16 + (x & 15)] : (int16_t) (-P.top_step + 2 * P.tilt));
+  if (tid < 16)
+    {
+      const int16_t * mr = P.matrix + tid * 16;
+      Ssh4[tid] = (u32) (uint8_t) mr[1] | ((u32) (uint8_t) mr[2] << 8) | ((u32) (uint8_t) mr[4] << 16) | ((u32) (uint8_t) mr[8] << 24);
+    }
+  __syncthreads();
+
+  const u32 k = blockIdx.x * 64 + (u32) threadIdx.x;
+  const bool valid = k < npairs;
+  const u32 ts = pair_slot[valid ? k : 0];
+  const u32 task = ts >> 3, sl = ts & 7;
+  const VsxTask & T = tasks[task];
+  const VsxSlotOut so = slot[ts];
+  const bool live = valid && !so.overflow;
+
+  const int Q = (int) T.qlen;
+  const int D = (int) T.tlen[sl];
+  const int total_lanes = (Q + R - 1) / R;
+  const int rcnt0 = Q - (total_lanes - 1) * R;
+  const int pad = R - rcnt0;                       // dummy slots above the rows of position 0 (TOPPAD layout)
+  const int nstrips = (total_lanes + 15) >> 4;
+  const size_t steps = T.steps;
+  const size_t nblk = (steps + 15) >> 4;
+  const size_t rowsteps = ((size_t) nstrips * steps + 1) & ~(size_t) 1;
+  const size_t rowck_dw = (rowsteps >> 1) * VSX_ROWCK_PAIR_DW(true);
+  constexpr size_t COL_DW = (size_t) 64 * 4 * VSX_COLCK_NB(R, true);
+  const u32 * __restrict__ rowck = ck + T.dir_off;
+  const u32 * __restrict__ colck = ck + T.dir_off + rowck_dw;
+  const u32 * __restrict__ midck = colck + (size_t) nstrips * nblk * COL_DW;
+  const int g = (int) (sl >> 1);
+  const bool hi = (sl & 1) != 0;
+  const u32 half_sel = hi ? 0x07060302u : 0x05040100u;           // v_perm_b32(b, a, sel) = this pair's half of a | of b << 16
+  const u32 bias = P.max3 ? 0x3E00u : 0x8000u;                   // what the DP kernel's class added to every stored value
+  const u32 bias_pk = bias * 0x10001u;
+  const int tl = P.tilt;
+  auto pk16 = [](int v) -> u32 { const u32 x = (u32) v & 0xffffu; return x | (x << 16); };
+  auto pk2 = [](int lo, int hi_) -> u32 { return ((u32) lo & 0xffffu) | ((u32) hi_ << 16); };
+  const int qrt_i = P.qrt_i, qrt_r = P.qrt_r, rt_i = P.rt_i, rt_r = P.rt_r;
+  const int qrq_i = (int) (int16_t) (P.qrq_i_pk & 0xffffu), rq_i = (int) (int16_t) (P.rq_i_pk & 0xffffu);
+  const int qrq_r = (int) (int16_t) (P.qrq_r_pk & 0xffffu), rq_r = (int) (int16_t) (P.rq_r_pk & 0xffffu);
+  const uint8_t * __restrict__ q = qc + T.qoff;
+  const uint8_t * __restrict__ d = tc + T.toff[sl];
+  u32 * __restrict__ my = slab + slab_off[valid ? k : 0];
+
+  int i = live ? Q - 1 : -1, j = live ? D - 1 : -1;
+  int L = total_lanes - 1;
+  int r = R - 1;
+  int op = -1;
+  u32 runlen = 0, nruns = 0;
+  u32 al = 0, ga = 0;
+  auto push_n = [&](int newop, u32 n) {
+    if (newop == op) { runlen += n; return; }
+    if (op >= 0) my[nruns++] = (runlen << 2) | (u32) op;
+    op = newop;
+    runlen = n;
+  };
+  auto push = [&](int newop) { push_n(newop, 1u); };
+
+  // the run of 'I' moves along the last query row: one CIGAR run (VsxSlotOut::leave, see the first kernel)
+  if (live)
+    {
+      const int lv = (so.leave == 0xFFFFu) ? -1 : (int) so.leave;
+      if (lv < D - 1)
+        {
+          const u32 n = (u32) (D - 1 - lv);
+          al += n; ++ga;
+          push_n(1, n);
+          j = lv;
+        }
+    }
+
+  // masks of the bit collection: row pair k of a group owns bit k (UP / LEFT) and bit 4 + k (EXT_UP / EXT_LEFT) of every byte
+  const u32 mA[4] = {0x01010101u, 0x02020202u, 0x04040404u, 0x08080808u};
+  const u32 mB[4] = {0x10101010u, 0x20202020u, 0x40404040u, 0x80808080u};
+
+#if VSX_TB_STATS
+  const unsigned long long t_kernel0 = __builtin_readcyclecounter();
+  unsigned n_iter = 0;
+  unsigned long long tphase[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  for (;;)
+    {
+      const bool busy = (i >= 0) && (j >= 0);
+      if (!__any(busy)) break;
+#if VSX_TB_STATS
+      ++n_iter;
+#endif
+
+      // ---- this iteration: position L (MID: its half hh), column blocks m (tile 1, under the cursor) and m - 1 (tile 2) ----
+      const int s = L >> 4, l = L & 15;
+      const int jj = busy ? j : 0;
+      const int m = (jj + l) >> 4;
+      const int c0 = (16 * m - l) > 0 ? 16 * m - l : 0;                     // tile 1 = columns c0 .. c0 + 15
+      const int c0b = (m >= 1 && 16 * (m - 1) - l > 0) ? 16 * (m - 1) - l : 0; // tile 2 = columns c0b .. c0 - 1 (m >= 1)
+      const int i0 = (L == 0) ? -pad : rcnt0 + (L - 1) * R;
+      const bool lastpos = (L == total_lanes - 1);
+      const int hh = (MID && busy && r >= RT) ? 1 : 0;
+      const int r0h = hh * RT;
+      const bool lastrow_here = lastpos && (!MID || hh == 1);
+      const bool top_is_border = (L == 0) && (hh == 0);
+#if VSX_TB_STATS & 1
+      {
+        const unsigned key = busy ? (((unsigned) task & 0x3FFu) << 22) | ((unsigned) L << 12) | ((unsigned) m << 1) | (unsigned) hh : 0xFFFFFFFFu;
+        bool leader = busy;
+        for (int o = 1; o < 8; ++o)
+          {
+            const unsigned other = (unsigned) __shfl((int) key, (tid & ~7) | ((tid - o) & 7), 64);
+            if ((tid & 7) >= o && other == key) leader = false;
+          }
+        const unsigned long long nb = __popcll(__ballot(busy)), nl = __popcll(__ballot(leader));
+        if (tid == 0) { atomicAdd(&vsx_tb_stats_dev[1], nb); atomicAdd(&vsx_tb_stats_dev[2], nl); }
+      }
+#endif
+
+      // ---- what a tile reads from HBM: nine two-step pairs of the row (or mid-row) checkpoints above it, the column checkpoint left of
+      // it, 20 target symbols.  Issued as one batch; tile 2's batch is issued between tile 1's recompute and its walk ----
+      struct TileIn { Trio v3[9]; int par; Quad fq[NBQ]; u32 sw[5]; };
+      auto load_tile = [&](TileIn & in, const int cst, const int mleft) __attribute__((always_inline)) {
+        in.par = 0;
+        if (!top_is_border)
+          {
+            const u32 * base;
+            long gstart;
+            if (MID && hh == 1)
+              {
+                base = midck + (size_t) VSX_CK_SLOT(true, g, l) * 3;         // the mid-row checkpoint of THIS position (column c at step c + l)
+                gstart = (long) ((size_t) s * steps) + (long) (cst - 1 + l);
+              }
+            else
+              {
+                const int Lp = L - 1, sp = Lp >> 4, lp = Lp & 15;
+                base = rowck + (size_t) VSX_CK_SLOT(true, g, lp) * 3;
+                gstart = (long) ((size_t) sp * steps) + (long) (cst - 1 + lp);
+              }
+            const long maxpair = (long) (rowsteps >> 1) - 1;
+            const long p0 = gstart >> 1;                                     // floor, also for gstart = -1
+            in.par = (int) (gstart - 2 * p0);
+#pragma unroll
+            for (int e = 0; e < 9; ++e)
+              {
+                long p = p0 + e;
+                p = p < 0 ? 0 : (p > maxpair ? maxpair : p);                 // (clamped pairs feed entries nobody reads)
+                in.v3[e] = *reinterpret_cast<const Trio *>(base + (size_t) p * VSX_ROWCK_PAIR_DW(true));
+              }
+          }
+        const u32 * cb = colck + ((size_t) s * nblk + (size_t) (mleft > 0 ? mleft : 0)) * COL_DW + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), VSX_CK_SLOT(true, g, l), 0)
+                         + (MID ? (size_t) (hh * NBQ) * (4 * VSX_COLCK_CG) : 0);
+#pragma unroll
+        for (int b = 0; b < NBQ; ++b) in.fq[b] = *reinterpret_cast<const Quad *>(cb + (size_t) b * (4 * VSX_COLCK_CG));
+#pragma unroll
+        for (int e = 0; e < 5; ++e) in.sw[e] = *reinterpret_cast<const u32_unaligned *>(d + cst + 4 * e);     // VSX_CODE_SLACK bytes follow the codes
+      };
+
+      // ---- the tile's query rows: codes of both halves, fast-pick selectors (both tiles of the iteration share them) ----
+      u32 qcd[HR], qsel[HR];
+      bool plain_acgt = true;
+      {
+        u32 w[(RT + 3) / 4];
+#pragma unroll
+        for (int e = 0; e < (RT + 3) / 4; ++e) w[e] = *reinterpret_cast<const u32_unaligned *>(q + i0 + r0h + 4 * e);
+        auto code_of = [&](int x) -> u32 {
+          const int xx = x < RT ? x : RT - 1;                                // the junk row of an odd tile repeats the last one
+          u32 c = (w[xx >> 2] >> (8 * (xx & 3))) & 15u;
+          if (L == 0 && r0h + xx < pad) c = 16u;                             // dummy row of position 0: score -ge
+          return c;
+        };
+#pragma unroll
+        for (int x = 0; x < HR; ++x)
+          {
+            const u32 a = code_of(x), b = code_of(x + HR);
+            qcd[x] = a | (b << 16);
+            const u32 ia = (a >> 1) - (a >> 3), ib = (b >> 1) - (b >> 3);    // 1 2 4 8 -> 0 1 2 3
+            qsel[x] = ia | 0x0C000C00u | ((4u + ib) << 16);
+            plain_acgt = plain_acgt && (a == 1 || a == 2 || a == 4 || a == 8) && (b == 1 || b == 2 || b == 4 || b == 8);
+          }
+      }
+      const bool fastV = !__any(busy && !plain_acgt);
+
+      // row penalties, packed per half: only the row pair XL differs (its high half may be the query's last row)
+      const u32 qrq_pk_i = pk16(qrq_i), rq_pk_i = pk16(rq_i);
+      const u32 qrq_pk_x = pk2(qrq_i, lastrow_here ? qrq_r : qrq_i), rq_pk_x = pk2(rq_i, lastrow_here ? rq_r : rq_i);
+
+      // ---- a tile's staged inputs -> LDS / registers, then the recompute with the direction bits into bitsL ----
+      auto recompute = [&](const TileIn & in, const bool border_left, const int cst, const int rmax_raw, const int cmax, const bool tile_int)
+                       __attribute__((always_inline)) {
+        // top boundary: entry e = column cst - 1 + e (e = 0 .. 16; entry 17 is read by the junk column only)
+        if (top_is_border)
+          {
+            const u32 corner = (u32) (uint16_t) (((pad > 0) ? -P.top_open : 0) - (pad + 2) * tl);      // the DP kernel's diag seed
+#pragma unroll
+            for (int e = 0; e < 17; ++e)
+              {
+                int c = cst - 1 + e;
+                if (c > jj) c = jj;
+                tbL[e * 64 + tid] = (c < 0) ? (corner & 0xffffu) : (u32) (uint16_t) (P.htop[c] - pad * tl);   // F is derived from H in the column loop
+              }
+          }
+        else
+          {
+            u32 * dst = tbL + tid - in.par * 64;                              // entry of step 2 (p0 + e) is 2 e - par
+#pragma unroll
+            for (int e = 0; e < 9; ++e)
+              {
+                // {H_t, H_t+1, bytes d_t(lo) d_t(hi) d_t+1(lo) d_t+1(hi)}: F = H - d; everything minus the class's bias
+                const u32 h0 = (half_lo(in.v3[e].x, hi) - bias) & 0xffffu, h1 = (half_lo(in.v3[e].y, hi) - bias) & 0xffffu;
+                const u32 dd = hi ? (in.v3[e].z >> 8) : in.v3[e].z;
+                const int d0 = (int) (int8_t) (dd & 0xffu), d1 = (int) (int8_t) ((dd >> 16) & 0xffu);
+                if (e > 0 || in.par == 0) dst[(2 * e) * 64] = h0 | ((h0 - (u32) d0) << 16);
+                dst[(2 * e + 1) * 64] = h1 | ((h1 - (u32) d1) << 16);        // (entries 0 .. 17)
+              }
+            if (cst == 0)
+              {
+                // corner H(row above the tile, -1)
+                u32 cv;
+                if (MID && hh == 1)
+                  {
+                    const int xs = RT - 1;                                    // the slot above the tile inside this position
+                    int ii = i0 + xs; if (ii > Q - 1) ii = Q - 1;
+                    cv = (u32) (uint16_t) P.hleft[ii < 0 ? 0 : ii];
+                    if (L == 0 && xs < pad) cv = (u32) (uint16_t) (((xs == pad - 1) ? 0 : -P.top_open) + (xs - pad - 1) * tl);
+                  }
+                else cv = (u32) (uint16_t) P.hleft[i0 - 1];
+                tbL[tid] = cv;
+              }
+          }
+#pragma unroll
+        for (int c2 = 0; c2 < 10; ++c2)
+          {
+            const u32 lo = (in.sw[c2 >> 1] >> (16 * (c2 & 1))) & 15u, hi4 = (in.sw[c2 >> 1] >> (16 * (c2 & 1) + 8)) & 15u;
+            symL[c2 * 64 + tid] = (uint8_t) (lo | (hi4 << 4));
+          }
+        u32 hp[HR], ee[HR];
+        if (border_left)
+          {
+#pragma unroll
+            for (int x = 0; x < HR; ++x)
+              {
+                u32 hv[2], ev[2];
+#pragma unroll
+                for (int hf_ = 0; hf_ < 2; ++hf_)
+                  {
+                    const int xs = r0h + x + hf_ * HR;                        // slot inside the position
+                    int ii = i0 + xs; if (ii > Q - 1) ii = Q - 1;
+                    if (ii < 0) ii = 0;
+                    int hl = P.hleft[ii];
+                    int e0 = hl - ((ii < Q - 1) ? qrq_i : qrq_r);
+                    if (L == 0 && xs < pad)                                   // border state of the dummy rows, as the DP kernel seeds it
+                      {
+                        const int sh = (xs - pad - 1) * tl;
+                        hl = ((xs == pad - 1) ? 0 : -P.top_open) + sh;
+                        e0 = -P.top_open - P.top_step + sh - qrq_i;
+                      }
+                    hv[hf_] = (u32) hl & 0xffffu; ev[hf_] = (u32) e0 & 0xffffu;
+                  }
+                hp[x] = hv[0] | (hv[1] << 16);
+                ee[x] = ev[0] | (ev[1] << 16);
+              }
+          }
+        else
+          {
+            auto flat = [&](int z) -> u32 {
+              const Quad & qd = in.fq[z >> 2];
+              return (z & 3) == 0 ? qd.x : (z & 3) == 1 ? qd.y : (z & 3) == 2 ? qd.z : qd.w;
+            };
+#pragma unroll
+            for (int x = 0; x < HR; ++x)
+              {
+                const int xa = x, xb = (x + HR < RT) ? x + HR : RT - 1;
+                const u32 h = pk_sub(__builtin_amdgcn_perm(flat(xb), flat(xa), half_sel), bias_pk);
+                const int da = (int) (int8_t) ((flat(RT + (xa >> 1)) >> (8 * ((xa & 1) * 2 + (hi ? 1 : 0)))) & 0xffu);
+                const int db = (int) (int8_t) ((flat(RT + (xb >> 1)) >> (8 * ((xb & 1) * 2 + (hi ? 1 : 0)))) & 0xffu);
+                hp[x] = h;
+                ee[x] = pk_sub(h, ((u32) da & 0xffffu) | ((u32) db << 16));
+              }
+          }
+        const int xmax = rmax_raw >= HR ? HR - 1 : rmax_raw;                  // row pairs somebody needs (wave-uniform)
+        // column loop state: the high half runs one column behind; the LDS reads of column it + 1 are issued during column it
+        u32 tb_prev = tbL[tid];                                               // column cst - 1: the low half's first diagonal
+        u32 Hd_end = 0, F_end = 0;                                            // what the low half's last row hands to the high half
+        u32 cr_prev = 0, qrt_prev = 0, rt_prev = 0;
+        auto sym_at = [&](int it) -> u32 { return ((u32) symL[(it >> 1) * 64 + tid] >> (4 * (it & 1))) & 15u; };
+        const bool FASTV_any = fastV;
+        u32 tbv_n = tbL[64 + tid];                                            // column cst
+        u32 cr_n = FASTV_any ? Ssh4[sym_at(0)] : sym_at(0) * 32u;             // (two-deep: the symbol of column it + 2 is read during column it,
+        u32 sy_n = sym_at(1);                                                 //  the score dword of column it + 1 from the symbol read a column earlier)
+        auto column = [&](const int it, auto int_tag, auto fast_tag, auto first_tag) __attribute__((always_inline)) {
+          constexpr bool INT = decltype(int_tag)::value;
+          constexpr bool FASTV = decltype(fast_tag)::value;
+          constexpr bool FIRST = decltype(first_tag)::value;
+          const int c = cst + it;
+          const u32 tbv = tbv_n;
+          const u32 cr = cr_n;                                                // fast: the column's four scores; slow: its table row
+          cr_n = FASTV ? Ssh4[sy_n] : sy_n * 32u;
+          tbv_n = tbL[(it + 2) * 64 + tid];                                   // (column it + 1: lands while this column computes)
+          sy_n = sym_at(it + 2);
+          u32 qrt_pk = 0, rt_pk = 0;
+          if (!INT)
+            {
+              const u32 ql = (u32) ((c < D - 1) ? qrt_i : qrt_r) & 0xffffu, rl = (u32) ((c < D - 1) ? rt_i : rt_r) & 0xffffu;
+              qrt_pk = ql | (qrt_prev << 16); rt_pk = rl | (rt_prev << 16);
+              qrt_prev = ql; rt_prev = rl;
+            }
+          else qrt_pk = pk16(qrt_i);
+          u32 Ftop = tbv >> 16;
+          if (top_is_border) Ftop = ((tbv & 0xffffu) - (INT ? (u32) qrt_i : (qrt_pk & 0xffffu))) & 0xffffu;      // F = Htop - QR_t (align_simd.cpp:830-833)
+          u32 Hd = (tb_prev & 0xffffu) | (Hd_end << 16);
+          u32 F = Ftop | (F_end << 16);
+          u32 acc = 0;
+#pragma unroll
+          for (int x = 0; x < HR; ++x)
+            if ((x & ~3) <= xmax)                                             // (wave-uniform: groups of four row pairs nobody needs are skipped)
+              {
+                u32 V;
+                if (FASTV) V = __builtin_amdgcn_perm(cr_prev, cr, qsel[x]);
+                else V = (u32) Ssh[cr + (qcd[x] & 0xffffu)] | ((u32) Ssh[cr_prev + (qcd[x] >> 16)] << 16);
+                const u32 h0 = pk_add(Hd, V);
+                const u32 dU = ssub(h0, F);                                   // sign <=> F > h0   (up)
+                const u32 h1 = pmax(h0, F);
+                const u32 dL = ssub(h1, ee[x]);                               // sign <=> E > h1   (left)
+                const u32 h2 = pmax(h1, ee[x]);
+                Hd = hp[x];
+                hp[x] = FIRST ? bfi(0x0000FFFFu, h2, hp[x]) : h2;             // (first column: the high half has not started, its boundary stays)
+                const u32 hf = pk_sub(h2, qrt_pk);
+                const u32 f = INT ? F : pk_sub(F, rt_pk);
+                const u32 dEU = ssub(hf, f);                                  // sign <=> F - R > H - QR (extend up)
+                F = pmax(f, hf);
+                const bool plain = INT && x != XL;
+                const u32 he = plain ? hf : pk_sub(h2, x == XL ? qrq_pk_x : qrq_pk_i);
+                const u32 e = plain ? ee[x] : pk_sub(ee[x], x == XL ? rq_pk_x : rq_pk_i);
+                const u32 dEL = ssub(he, e);                                  // sign <=> E - R > H - QR (extend left)
+                const u32 en = pmax(e, he);
+                ee[x] = FIRST ? bfi(0x0000FFFFu, en, ee[x]) : en;
+                acc = a_bfi(mA[x & 3], __builtin_amdgcn_perm(dL, dU, 0x0B0A0908u), acc);
+                acc = a_bfi(mB[x & 3], __builtin_amdgcn_perm(dEL, dEU, 0x0B0A0908u), acc);
+                if ((x & 3) == 3 || x == HR - 1) { bitsL[(it * NG + (x >> 2)) * 64 + tid] = acc; acc = 0; }
+              }
+          Hd_end = Hd & 0xffffu;                                              // H(row HR - 1, column c - 1): the high half's next diagonal
+          F_end = F & 0xffffu;                                                // F leaving row HR - 1 in column c
+          tb_prev = tbv;
+          cr_prev = cr;
+        };
+        auto sweep = [&](auto int_tag, auto fast_tag) __attribute__((always_inline)) {
+          column(0, int_tag, fast_tag, std::true_type {});
+          for (int it = 1; it <= cmax + 1; ++it) column(it, int_tag, fast_tag, std::false_type {});
+        };
+        if (tile_int) { if (fastV) sweep(std::true_type {}, std::true_type {}); else sweep(std::true_type {}, std::false_type {}); }
+        else          { if (fastV) sweep(std::false_type {}, std::true_type {}); else sweep(std::false_type {}, std::false_type {}); }
+      };
+      // ---- walk inside the tile (backtrack16 :1137-1211); matches are counted from the finished CIGAR below ----
+      auto walk = [&](const int cst) __attribute__((always_inline)) {
+        while (r >= r0h && j >= cst && i >= 0)
+          {
+            const int cw = j - cst;
+            const int rv = r - r0h;
+            const bool up_half = rv >= HR;
+            const int rx = up_half ? rv - HR : rv;
+            const u32 w = bitsL[((cw + (up_half ? 1 : 0)) * NG + (rx >> 2)) * 64 + tid] >> ((rx & 3) + (up_half ? 8 : 0));
+            ++al;
+            // backtrack16's five-way choice without divergence (r03: ~50 instructions per cell walked as nested branches): continue-I on
+            // ext-left > continue-D on ext-up > left > up > diagonal; only the run hand-over to the slab is a branch
+            const u32 inI = (op == 1) ? 1u : 0u, inD = (op == 2) ? 1u : 0u;
+            const u32 c1 = inI & (w >> 20);                                   // EXT_LEFT
+            const u32 c2 = (c1 ^ 1u) & inD & (w >> 4);                        // EXT_UP
+            const u32 c12 = c1 | c2;
+            const u32 c3 = (c12 ^ 1u) & (w >> 16);                            // LEFT
+            const u32 c4 = ((c12 | c3) ^ 1u) & w;                             // UP
+            const u32 isI = (c1 | c3) & 1u, isD = (c2 | c4) & 1u;
+            const int newop = (int) (isI + 2u * isD);                         // 0 M, 1 I (consumes a target column), 2 D
+            ga += ((c3 & (inI ^ 1u)) | (c4 & (inD ^ 1u))) & 1u;               // a gap opens
+            j -= (int) (isD ^ 1u);
+            const int di = (int) (isI ^ 1u);
+            i -= di; r -= di;
+            if (newop != op)
+              {
+                if (op >= 0) my[nruns++] = (runlen << 2) | (u32) op;
+                op = newop;
+                runlen = 0;
+              }
+            ++runlen;
+#if VSX_TB_STATS & 1
+            atomicAdd(&vsx_tb_stats_dev[3], 1ull);
+#endif
+          }
+      };
+
+#if VSX_TB_STATS & 2
+#define TBMARK(k_) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long now_ = __builtin_readcyclecounter(); tphase[k_] += now_ - tmark; tmark = now_; } while (0)
+      unsigned long long tmark = __builtin_readcyclecounter();
+#else
+#define TBMARK(k_) do { } while (0)
+#endif
+      {
+        TileIn in1;
+        load_tile(in1, c0, m - 1);
+        TBMARK(0);
+        const int rr = busy ? r - r0h : 0;
+        const int rmax_raw = __builtin_amdgcn_readfirstlane(wave_max_i32(rr));
+        const int cmax = __builtin_amdgcn_readfirstlane(wave_max_i32(jj - c0));
+        const bool tile_int = !__any(busy && (c0 + cmax >= D - 1));
+        recompute(in1, m == 0, c0, rmax_raw, cmax, tile_int);
+        TBMARK(1);
+      }
+#if VSX_TB2_EARLY2
+      // A/B: tile 2's batch issued before tile 1 is walked (it lands during the walk, at the price of ~56 VGPRs held across it)
+      TileIn in2;
+      const bool any2 = __any(busy && m >= 1);
+      if (any2) load_tile(in2, c0b, m - 2);
+#endif
+      if (busy) walk(c0);
+      TBMARK(2);
+      // tile 2: the lanes that left tile 1 through its left edge and are still inside this (half) position.  Every lane of the wave
+      // that has a second tile asks for its inputs HERE, in the same iteration, whichever way it left tile 1: the lanes of a task
+      // stay on the same lines
+      {
+        const bool need2 = busy && (m >= 1) && (r >= r0h) && (i >= 0) && (j >= 0) && (j < c0);
+        if (__any(need2))
+          {
+#if !VSX_TB2_EARLY2
+            TileIn in2;
+            load_tile(in2, c0b, m - 2);
+#endif
+            TBMARK(3);
+            const int rmax_raw = __builtin_amdgcn_readfirstlane(wave_max_i32(need2 ? r - r0h : 0));
+            const int cmax = __builtin_amdgcn_readfirstlane(wave_max_i32(need2 ? j - c0b : 0));
+            recompute(in2, m <= 1, c0b, rmax_raw, cmax, true);
+            TBMARK(4);
+            if (need2) walk(c0b);
+            TBMARK(5);
+          }
+      }
+      if (busy && r < 0 && L > 0) { --L; r = R - 1; }
+    }
+#if VSX_TB_STATS
+  if (valid) atomicAdd(&vsx_tb_stats_dev[5], 1ull);
+  if (tid == 0)
+    {
+      atomicAdd(&vsx_tb_stats_dev[15], __builtin_readcyclecounter() - t_kernel0); atomicAdd(&vsx_tb_stats_dev[0], (unsigned long long) n_iter);
+      for (int k2 = 0; k2 < 6; ++k2) atomicAdd(&vsx_tb_stats_dev[8 + k2], tphase[k2]);
+    }
+#endif
+  if (!valid) return;
+
+  VsxPairOut o;
+  o.pad = 0; o.nruns = 0; o.run_off = 0;
+  if (so.overflow)
+    {
+      o.score = 32767; o.aligned = 0; o.matches = 0; o.mismatches = 0; o.gaps = 0;
+      out[pair_ids[k]] = o;
+      return;
+    }
+  if (i >= 0) { al += (u32) (i + 1); if (op != 2) ++ga; push_n(2, (u32) (i + 1)); }     // left-terminal runs
+  if (j >= 0) { al += (u32) (j + 1); if (op != 1) ++ga; push_n(1, (u32) (j + 1)); }
+  if (op >= 0) my[nruns++] = (runlen << 2) | (u32) op;
+
+  // matches / mismatches of the M runs: replay the runs from the end, eight symbols a trip (see the first kernel)
+  u32 ma = 0, mi = 0;
+  {
+    int qi = Q - 1, tj = D - 1;
+    for (u32 x = 0; x < nruns; ++x)
+      {
+        const u32 w = my[x];
+        const int len = (int) (w >> 2);
+        const u32 o2 = w & 3u;
+        if (o2 == 0)
+          {
+            for (int b = 0; b < len; b += 8)
+              {
+                const int rem = (len - b < 8) ? len - b : 8;
+                const unsigned long long aw = *reinterpret_cast<const u64_unaligned *>(q + (qi - b - 7));
+                const unsigned long long cw = *reinterpret_cast<const u64_unaligned *>(d + (tj - b - 7));
+                const unsigned long long ones = 0x0101010101010101ull;
+                const unsigned long long x2 = aw & cw;
+                unsigned long long t = (x2 | (x2 >> 1) | (x2 >> 2) | (x2 >> 3)) & ones;
+                if (P.n_mismatch)
+                  {
+                    const unsigned long long a15 = aw & (aw >> 1) & (aw >> 2) & (aw >> 3);
+                    const unsigned long long c15 = cw & (cw >> 1) & (cw >> 2) & (cw >> 3);
+                    t &= ~(a15 | c15);
+                  }
+                t &= ~0ull << (8 * (8 - rem));
+                const u32 m8 = (u32) __builtin_popcountll(t);
+                ma += m8;
+                mi += (u32) rem - m8;
+              }
+            qi -= len; tj -= len;
+          }
+        else if (o2 == 1) tj -= len;
+        else qi -= len;
+      }
+  }
+
+  u32 verdict = 0;
+  if (FL.enabled && nruns > 0) verdict = accept_verdict(FL, Q, D, (int) al, (int) ma, (int) mi, (int) ga, my[nruns - 1], my[0]);
+  if (verdict == 3u) nruns = 0;
 
   const unsigned long long base = atomicAdd(cursor, (unsigned long long) nruns);
   if (base + nruns <= runs_capacity)
@@ -1558,9 +2169,17 @@ vsx_max3_selftest_kernel(u32 * bad)
       const u32 got = pk_max3_bits(a, b, c);
       const u32 m = x > y ? (x > z ? x : z) : (y > z ? y : z);
       if (got != (m | (m << 16))) ++wrong;
+      // vsx_traceback_tilt_kernel collects direction bits with v_perm_b32 selectors 8 .. 11 (a byte of 0x00 / 0xFF from the sign of
+      // bytes 1, 3 of the second and 1, 3 of the first source): bad[1] counts disagreements with that reading
+      const u32 pa = h ^ (x << 13), pb = (h * 0x85EBCA6Bu) ^ k;
+      const u32 pg = __builtin_amdgcn_perm(pa, pb, 0x0B0A0908u);
+      const u32 pe = ((pb >> 15) & 1u) * 0xFFu | (((pb >> 31) & 1u) * 0xFFu) << 8 | (((pa >> 15) & 1u) * 0xFFu) << 16 | (((pa >> 31) & 1u) * 0xFFu) << 24;
+      if (pg != pe) atomicAdd(bad + 1, 1u);
     }
   if (wrong) atomicAdd(bad, wrong);
 }
+static int g_tb_v2 = 1;          // 0: the TILT class keeps the first traceback kernel (self-test failed, or VSX_TB_V1=1)
+extern "C" void vsx_internal_set_tb_v2(int on) { g_tb_v2 = on; }
 extern "C" hipError_t vsx_launch_max3_selftest(u32 * d_bad, hipStream_t st)
 {
   hipLaunchKernelGGL(vsx_max3_selftest_kernel, dim3((0x7C00 + 255) / 256), dim3(256), 0, st, d_bad);
@@ -1678,6 +2297,18 @@ extern "C" hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tas
   return hipGetLastError();
 }
 
+template <int R, bool MID>
+static hipError_t launch_tbtilt(const VsxDevParams & P, const VsxFilterDev & F, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
+                                const uint32_t * d_pair_ids, uint32_t npairs, const uint8_t * q, const uint8_t * t,
+                                const uint32_t * ck, const VsxSlotOut * slot, uint32_t * slab, const uint64_t * slab_off,
+                                uint32_t * runs, uint64_t cap, unsigned long long * cursor, VsxPairOut * out, hipStream_t st)
+{
+  if constexpr (R >= 4)
+    hipLaunchKernelGGL((vsx_traceback_tilt_kernel<R, MID>), dim3((npairs + 63) / 64), dim3(64), 0, st,
+                       P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, cap, cursor, out);
+  return hipGetLastError();
+}
+
 template <int R, bool FAST, bool CK8 = false, bool MID = false>
 static hipError_t launch_tbck(const VsxDevParams & P, const VsxFilterDev & F, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
                               const uint32_t * d_pair_ids, uint32_t npairs, const uint8_t * q, const uint8_t * t,
@@ -1698,7 +2329,10 @@ extern "C" hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams
                                               VsxPairOut * out, hipStream_t st)
 {
   if (npairs == 0) return hipSuccess;
-#define TBCK(RR) case RR: return (fast16 && P.tilt != 0) ? launch_tbck<RR, true, true, VSX_MID(RR, true)>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
+  static const bool v1_env = std::getenv("VSX_TB_V1") != nullptr;          // A/B: the first kernel for the TILT class too
+  const bool v2 = g_tb_v2 && !v1_env && !VSX_CKT;
+#define TBCK(RR) case RR: return (fast16 && P.tilt != 0 && v2 && RR >= 4) ? launch_tbtilt<RR, VSX_MID(RR, true)>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
+                                 : (fast16 && P.tilt != 0) ? launch_tbck<RR, true, true, VSX_MID(RR, true)>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
                                  : fast16 ? launch_tbck<RR, true>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
                                         : launch_tbck<RR, false>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st)
   switch (rows)

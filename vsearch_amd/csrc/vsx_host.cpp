@@ -652,13 +652,20 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   if (device < 64 && g_max3_state[device].load() == 0)
     {
       DevBuf<uint32_t> d_bad;
-      uint32_t bad = 1;
-      if (d_bad.alloc(1) == hipSuccess && hipMemsetAsync(d_bad.p, 0, 4, c->stream) == hipSuccess &&
+      uint32_t bad2[2] = {1, 1};
+      if (d_bad.alloc(2) == hipSuccess && hipMemsetAsync(d_bad.p, 0, 8, c->stream) == hipSuccess &&
           vsx_launch_max3_selftest(d_bad.p, c->stream) == hipSuccess &&
-          hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess)
+          hipMemcpyAsync(bad2, d_bad.p, 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess)
         {
+          const uint32_t bad = bad2[0];
           if (bad) std::fprintf(stderr, "libvsx: device %d: v_pk_maximum3_f16 disagrees with the integer maximum on %u probes -- MAX3 class disabled\n", device, bad);
           g_max3_state[device].store(bad ? 2 : 1);
+          // the second traceback kernel reads sign bits with v_perm_b32 selectors 8 .. 11: same one-off check, same kind of fallback
+          if (bad2[1])
+            {
+              std::fprintf(stderr, "libvsx: device %d: v_perm_b32 sign selectors disagree on %u probes -- the first traceback kernel is used\n", device, bad2[1]);
+              vsx_internal_set_tb_v2(0);
+            }
         }
       else (void) hipGetLastError();
     }

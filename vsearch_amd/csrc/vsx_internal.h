@@ -169,7 +169,8 @@ hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams P, VsxFilt
                                    uint32_t * d_runs, uint64_t runs_capacity, unsigned long long * d_cursor,
                                    VsxPairOut * d_out, hipStream_t st);
 // bad[0] += disagreements of v_pk_maximum3_f16 with the integer maximum over the MAX3 class's value range (must stay 0)
-hipError_t vsx_launch_max3_selftest(uint32_t * d_bad, hipStream_t st);
+hipError_t vsx_launch_max3_selftest(uint32_t * d_bad /* [2]: max3, v_perm sign selectors */, hipStream_t st);
+void vsx_internal_set_tb_v2(int on);
 uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t rows, int tilt /* compressed layout of the TILT class */);
 const int * vsx_supported_rows(int * count);
 
