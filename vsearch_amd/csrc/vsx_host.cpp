@@ -229,9 +229,13 @@ struct vsx_ctx {
   // plan i still reads its block, so the launch tails of one fill with the other's waves (a pipeline of small plans lost 15 %
   // to tails when every plan waited for its predecessor's traceback: r02 timeline in DESIGN 5).  ev_tb[s] = "the last traceback
   // that read block s has finished".
-  SharedSlot shared_dir[2], shared_slab;   // declared after the pool: released first
-  hipEvent_t ev_tb[2] = {nullptr, nullptr};
-  bool ev_tb_used[2] = {false, false};
+  // r04: THREE blocks (VSX_CK_BLOCKS=2 restores two for A/B).  In a pipeline of slices the DP kernel of slice i + 2 used to wait for the
+  // traceback of slice i, which shares the device with the DP kernel of slice i + 1 on bad terms (rocprofv3 trace of one call,
+  // profiles/r03/r03v_e2e_trace_*.csv); with a third block only slice i + 3 waits for it.  A block is sized by the largest plan that
+  // used it (<= 0.4 of what is free when it is made), 20 GB for the 200 k-pair slices of the bench shape.
+  SharedSlot shared_dir[3], shared_slab;   // declared after the pool: released first
+  hipEvent_t ev_tb[3] = {nullptr, nullptr, nullptr};
+  bool ev_tb_used[3] = {false, false, false};
   std::atomic<unsigned> plan_seq {0};
   // pinned host memory: results cross PCIe into it (vsx_plan_fetch), one fetch at a time; grow-only
   std::mutex stage_mu;
@@ -627,13 +631,23 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);            // numerically: high < low
   static const bool flat_env = std::getenv("VSX_ALIGN_FLAT_PRIORITY") != nullptr;      // A/B
   const int prio_dp = (!flat_env && prio_low - prio_high >= 2) ? prio_high + 1 : prio_high;
-  if ((e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_dp)) != hipSuccess ||
-      (e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_high)) != hipSuccess ||
-      (e = hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, prio_dp)) != hipSuccess ||
+  // VSX_TB_CUS=n (A/B, r04): a fixed share of the device for the traceback stream -- CU-mask bits [0, n) (on this part bit b is CU
+  // b / 8 of XCD b % 8, so n = 8 k gives k CUs of every XCD: vsearch_amd/csrc/ubench_cumask.hip) -- and the rest for the DP streams
+  const int tb_cus = std::getenv("VSX_TB_CUS") ? std::atoi(std::getenv("VSX_TB_CUS")) : 0;
+  auto masked = [&](hipStream_t * st, int lo, int hi) -> hipError_t {
+    uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = lo; b < hi; ++b) m[b >> 5] |= 1u << (b & 31);
+    return hipExtStreamCreateWithCUMask(st, 8, m);
+  };
+  const bool use_mask = tb_cus >= 8 && tb_cus <= 128 && tb_cus % 8 == 0;
+  if ((e = use_mask ? masked(&c->stream, tb_cus, 256) : hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_dp)) != hipSuccess ||
+      (e = use_mask ? masked(&c->stream2, 0, tb_cus) : hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_high)) != hipSuccess ||
+      (e = use_mask ? masked(&c->stream_b, tb_cus, 256) : hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, prio_dp)) != hipSuccess ||
       (e = hipStreamCreateWithPriority(&c->stream_up, hipStreamNonBlocking, prio_high)) != hipSuccess ||
       (e = hipStreamCreateWithPriority(&c->stream_dn, hipStreamNonBlocking, prio_high)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_tb[0], hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_tb[1], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_tb[2], hipEventDisableTiming)) != hipSuccess ||
       (e = c->d_htop.alloc(VSX_TABLE_LEN)) != hipSuccess || (e = c->d_hleft.alloc(VSX_TABLE_LEN)) != hipSuccess ||
       (e = c->d_matrix.alloc(256)) != hipSuccess ||
       (e = hipMemcpy(c->d_htop.p, htop.data(), VSX_TABLE_LEN * 2, hipMemcpyHostToDevice)) != hipSuccess ||
@@ -724,6 +738,7 @@ void vsx_destroy(vsx_ctx * c)
   if (c->stream_dn) { (void) hipStreamSynchronize(c->stream_dn); (void) hipStreamDestroy(c->stream_dn); }
   c->shared_dir[0].reset();
   c->shared_dir[1].reset();
+  c->shared_dir[2].reset();
   c->shared_slab.reset();
   c->pool.retire();
   delete c;
@@ -963,7 +978,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
 
   std::unique_ptr<vsx_plan> pl(new vsx_plan);
   pl->ctx = ctx; pl->Q = queries; pl->T = targets; pl->n_pairs = n_pairs;
-  pl->dir_slot = (int) (ctx->plan_seq.fetch_add(1) & 1u);
+  static const unsigned ck_blocks = (std::getenv("VSX_CK_BLOCKS") && std::atoi(std::getenv("VSX_CK_BLOCKS")) == 2) ? 2u : 3u;
+  pl->dir_slot = (int) (ctx->plan_seq.fetch_add(1) % ck_blocks);
 
   // ---- the reference's closed-form / sentinel cases (no DP) ----
   // host threads classify contiguous slices: the common case (a pair for the GPU) is handled in place, the rare closed-form
@@ -1829,17 +1845,35 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
   // (the first and the last slice are half-size: the GPU starts after planning the first one, and the last one's fetch is
   //  the only one nothing overlaps)
   std::vector<uint64_t> cut {0};
+  // r04: the slices RAMP -- a quarter and a half slice first, a half and a quarter last.  The timeline of one 800 k-pair call
+  // (profiles/r04/r04m_e2e_timeline.txt) is GPU-bound from the first launch to the last kernel, so what the caller waits for beyond
+  // the kernels is the planning of the first slice (2.7 ms for 100 k pairs) and the traceback + text + download of the last one;
+  // both shrink with their slice, and the planner (15 ns per pair) outruns the GPU (35 ns per pair) by the second slice.
+  // VSX_PIPELINE_RAMP=0: the r03 schedule (half, full ..., half).
+  static const bool ramp = !(std::getenv("VSX_PIPELINE_RAMP") && std::strcmp(std::getenv("VSX_PIPELINE_RAMP"), "0") == 0);
+  std::vector<uint64_t> sizes;
+  if (ramp && n_pairs >= 3 * slice_pairs)
+    {
+      const uint64_t head[2] = {slice_pairs / 4, slice_pairs / 2};
+      const uint64_t mid = n_pairs - 2 * (head[0] + head[1]);
+      const uint64_t k = (mid + slice_pairs - 1) / slice_pairs;
+      sizes.push_back(head[0]); sizes.push_back(head[1]);
+      for (uint64_t x = 0; x < k; ++x) sizes.push_back(mid * (x + 1) / k - mid * x / k);
+      sizes.push_back(head[1]); sizes.push_back(head[0]);
+    }
+  size_t next_size = 0;
   while (cut.back() < n_pairs)
     {
       const uint64_t left = n_pairs - cut.back();
       uint64_t want = slice_pairs;
-      if (cut.size() == 1) want = slice_pairs / 2;
+      if (!sizes.empty()) want = next_size < sizes.size() ? sizes[next_size++] : left;
+      else if (cut.size() == 1) want = slice_pairs / 2;
       else if (left <= slice_pairs / 2 + slice_pairs / 8) want = left;
       else if (left <= slice_pairs + slice_pairs / 2) want = left - slice_pairs / 2;
       uint64_t e = std::min<uint64_t>(n_pairs, cut.back() + want);
       const uint64_t limit = sink ? n_pairs : std::min<uint64_t>(n_pairs, e + want / 2);      // ranked: a query is never split
       while (e < limit && qidx[e] == qidx[e - 1]) ++e;
-      if (n_pairs - e < slice_pairs / 8) e = n_pairs;
+      if (n_pairs - e < slice_pairs / 16) e = n_pairs;
       cut.push_back(e);
     }
   const size_t S = cut.size() - 1;
@@ -1856,13 +1890,14 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
   std::condition_variable cv;
   size_t ready = 0, consumed = 0;
   bool stop = false;
+  static const size_t depth = std::getenv("VSX_PIPELINE_DEPTH") ? (size_t) std::max(1, std::min(6, std::atoi(std::getenv("VSX_PIPELINE_DEPTH")))) : 2;
   std::thread planner([&]() {
     (void) hipSetDevice(ctx->device);
     for (size_t i = 0; i < S; ++i)
       {
         {
           std::unique_lock<std::mutex> lk(mu);
-          cv.wait(lk, [&] { return stop || i < consumed + 4; });      // at most four plans alive beyond the fetched ones
+          cv.wait(lk, [&] { return stop || i < consumed + depth + 2; });      // at most depth + 2 plans alive beyond the fetched ones
           if (stop) return;
         }
         vsx_plan * pl = nullptr;
@@ -1911,11 +1946,13 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
       if (timing) std::fprintf(stderr, "  slice %zu: queued at %.1f ms\n", i, (now() - t_begin) * 1e3);
       if (rc != VSX_OK) { msg = vsx_last_error(); break; }
       launched = i + 1;
-      // two slices stay queued behind the one being fetched: the DP kernels of slice i+1 overlap the traceback of slice i, so
-      // the GPU needs the next launch in its queue before the previous slice has drained
-      if (i >= 2) { rc = finish(i - 2); if (rc != VSX_OK) msg = vsx_last_error(); }
+      // `depth` slices stay queued behind the one being fetched (VSX_PIPELINE_DEPTH, default 2): the DP kernels of slice i+1 overlap
+      // the traceback of slice i, so the GPU needs the next launch in its queue before the previous slice has drained.  r04 A/B
+      // (profiles/r04/r04q_e2e_depth_ab.txt): 3 or 4 queued slices are no better -- a traceback makes little progress beside the DP
+      // kernels queued after it (its waves need 256 VGPRs, a retiring DP wave frees 128), so deeper queues only move the wait.
+      if (i >= depth) { rc = finish(i - depth); if (rc != VSX_OK) msg = vsx_last_error(); }
     }
-  for (size_t i = (launched >= 2 ? launched - 2 : 0); i < launched && rc == VSX_OK && launched == S; ++i)
+  for (size_t i = (launched >= depth ? launched - depth : 0); i < launched && rc == VSX_OK && launched == S; ++i)
     { rc = finish(i); if (rc != VSX_OK) msg = vsx_last_error(); }
   {
     std::lock_guard<std::mutex> lk(mu);
