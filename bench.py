@@ -117,6 +117,7 @@ def parse():
     ap.add_argument("--kernels-only", action="store_true", help="only the timed kernel steps (profiling passes)")
     ap.add_argument("--e2e-calls", type=int, default=5, help="timed vsx_align_pairs calls of the end-to-end figure")
     ap.add_argument("--no-search", action="store_true", help="skip the vsx_search_batch end-to-end figure")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the kernels-only runs of the other BASELINE shapes (configs 3 / 4 / 5)")
     ap.add_argument("--search-mask", choices=["none", "dust"], default="none",
                     help="masking of the search_end_to_end leg on BOTH sides (the reference CLI is run with the same): none = --qmask none "
                          "--dbmask none (the round-1 figure), dust = the reference's default (DB masked on the device, queries on host threads)")
@@ -130,6 +131,9 @@ def parse():
                     help="N > 1: the final gather of hit records + CIGAR run words per step -- async: one fixed-capacity non-blocking "
                          "collective that overlaps the next step's kernels (sharding.FixedGather); sync: counts first, then padded payload")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: the one-GPU tests)")
+    ap.add_argument("--dry-collectives", action="store_true",
+                    help="N > 1: run ONLY the gather path (sharding.gather_results and FixedGather, incl. a forced overflow step) on tiny "
+                         "tensors -- no database, no kernels -- and print one JSON line: tells a collective failure from a kernel failure")
     return ap.parse_args()
 
 
@@ -141,11 +145,13 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    dev_index = local_rank % torch.cuda.device_count()         # (several ranks may share a GPU: the one-GPU tests)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not (a.dry_collectives and a.backend == "gloo"):
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")      # (the gloo dry run of the gather path is the one thing a CPU box can do)
+    dev_index = local_rank % torch.cuda.device_count() if have_gpu else 0     # (several ranks may share a GPU: the one-GPU tests)
+    if have_gpu:
+        torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index) if have_gpu else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -154,7 +160,33 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    from vsearch_amd import Aligner, SequenceSet, sharding, workload
+    from vsearch_amd import sharding
+
+    # what the collectives run on (VERDICT r03 "next" 8: the line of an N > 1 run describes its own transport)
+    rccl = None
+    if world > 1:
+        try:
+            nccl_version = ".".join(str(x) for x in torch.cuda.nccl.version()) if a.backend == "nccl" else None
+        except Exception as e:                              # (never lose the run over a version string)
+            nccl_version = repr(e)
+        ident = torch.tensor([rank, dev_index, torch.cuda.device_count() if have_gpu else 0], dtype=torch.int64, device=(dev if a.backend == "nccl" else torch.device("cpu")))
+        idents = [torch.zeros_like(ident) for _ in range(world)]
+        dist.all_gather(idents, ident)                      # the first collective of the job: a transport problem shows HERE
+        rccl = {"world": world, "backend": a.backend, "nccl_version": nccl_version, "torch": torch.__version__,
+                "hip": getattr(torch.version, "hip", None),
+                "device_of_rank": [int(t[1]) for t in idents], "visible_devices_of_rank": [int(t[2]) for t in idents],
+                "gpu": torch.cuda.get_device_name(dev_index) if have_gpu else None,
+                "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "MASTER_ADDR", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}}
+    if a.dry_collectives:
+        if world == 1:
+            raise SystemExit("--dry-collectives needs N > 1 ranks")
+        res = dry_collectives(dist, sharding, dev if a.backend == "nccl" else torch.device("cpu"), rank, world)
+        if rank == 0:
+            print(json.dumps({"dry_collectives": res, "rccl": rccl, "n_gpus": world}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    from vsearch_amd import Aligner, SequenceSet, workload
 
     # ---- synthetic inputs, generated in HBM.  Weak scaling: the job has world x a.queries queries, rank r owns the
     # contiguous block sharding.shard_queries() gives it (generated here from its own seed) and a replica of the DB
@@ -238,9 +270,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     job_cells, job_pairs = cells, n_pairs
+    per_rank_ms = None
     if world > 1:
         cdev = torch.device("cpu") if gloo else dev
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        tall = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(tall, tmax)                          # every rank's own clock: a straggler shows in the line
+        per_rank_ms = [round(float(t.item()) / a.steps * 1e3, 3) for t in tall]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         tot = torch.tensor([cells, n_pairs], dtype=torch.int64, device=cdev)
@@ -354,6 +390,12 @@ def main():
         out["roofline"]["traffic_note"] = pmc_note
     if gather_check is not None:
         out["gather_check"] = gather_check
+    if rccl is not None:
+        rccl["per_rank_ms_per_step"] = per_rank_ms
+        rccl["gather"] = a.gather
+        if fixed is not None:
+            rccl["fixed_gather_sync_steps"] = fixed.sync_steps
+        out["rccl"] = rccl
 
     if not a.kernels_only and world == 1:
         # ---- end to end through the one-call entry (host index arrays in, host result arrays + CIGAR text out) ----
@@ -379,10 +421,120 @@ def main():
             out["search_end_to_end"] = search_end_to_end(a, al, db_ascii, db_off, db_len, q_ascii, q_off, q_len)
         except Exception as e:
             out["search_end_to_end"] = {"error": repr(e)}
+    if not a.kernels_only and not a.no_shapes and world == 1:
+        try:
+            plan.close()
+        except Exception:
+            pass
+        try:
+            out["shapes"] = shapes_leg(a, al, dev)
+        except Exception as e:
+            out["shapes"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# the pair shapes of BASELINE configs 5 / 3 / 4 (VERDICT r03 "next" 4: driver-timed instead of builder-only): 100 k queries x 8 family
+# candidates each, kernels only (DP + traceback + CIGAR text, results resident), same generator and seeds as the main workload
+SHAPES = (("config5_150x300", 150, 300, 400_000), ("config3_300x300", 300, 300, 400_000), ("config4_400x400", 400, 400, 300_000))
+
+
+def shapes_leg(a, al, dev, steps=3):
+    import types
+    from vsearch_amd import SequenceSet, workload
+    out = {}
+    for name, qlen, dlen, dbn in SHAPES:
+        db_ascii, db_off, db_len, fam = workload.make_family_db(dbn, dlen, seed=17, device=dev)
+        q_ascii, q_off, q_len, src = workload.make_queries(db_ascii, db_off, db_len, 100_000, qlen, seed=11, device=dev)
+        qidx, tidx = workload.family_candidates(src, fam, per_query=8, seed=5)
+        torch.cuda.synchronize()
+        T = SequenceSet(al, blob=db_ascii.numel(), offsets=db_off, lengths=db_len, device_ptr=db_ascii.data_ptr())
+        Q = SequenceSet(al, blob=q_ascii.numel(), offsets=q_off, lengths=q_len, device_ptr=q_ascii.data_ptr())
+        plan = al.plan(Q, T, qidx, tidx)
+        cells = int((q_len[qidx].astype(np.int64) * db_len[tidx].astype(np.int64)).sum())
+        plan.run()
+        plan.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fwd = tb = tot = 0.0
+        for _ in range(steps):
+            plan.run()
+            tm = plan.sync()
+            fwd += tm.forward_ms; tb += tm.traceback_ms; tot += tm.total_ms
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        info = plan.describe()
+        entry = {"value": round(cells * steps / elapsed / 1e9, 2), "unit": "GCUPS", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps,
+                 "pairs_per_step": len(qidx), "rows_per_lane": info["rows_dominant"],
+                 "kernel_split_ms_per_step": {"forward": round(fwd / steps, 3), "traceback": round(tb / steps, 3),
+                                              "cigar_text_and_rest": round((tot - fwd - tb) / steps, 3)}}
+        if not a.no_cpu:
+            try:
+                res = plan.fetch()
+                ns = types.SimpleNamespace(cpu_pairs=40_000, cands=8, cpu_threads=a.cpu_threads)
+                cb = cpu_baseline(ns, db_ascii, db_off, db_len, q_ascii, q_off, q_len, qidx, tidx, res)
+                entry["parity_all_fields_match"] = cb.get("parity_all_fields_match", cb.get("parity_match"))
+                entry["parity_sample_pairs"] = 40_000 if "parity_all_fields_match" in cb else 2000
+                entry["cpu_reference_GCUPS"] = cb.get("value")
+            except Exception as e:
+                entry["parity_error"] = repr(e)
+        out[name] = entry
+        plan.close()
+        Q.close(); T.close()
+        del db_ascii, q_ascii
+        torch.cuda.empty_cache()
+    return out
+
+
+def dry_collectives(dist, sharding, device, rank, world):
+    """The gather path alone, on tiny synthetic records: the synchronous gather, the asynchronous fixed-capacity form with two steps in
+    flight, and a step that overflows the fixed capacity on ONE rank (every rank then redoes it synchronously).  Each rank builds every
+    rank's payload deterministically, so every receiver checks what it got."""
+    def payload(r, step, scale=1):
+        n = (5 + 3 * r + step) * scale
+        nr = np.arange(n, dtype=np.uint32) % 3 + 1
+        off = np.concatenate([[0], np.cumsum(nr[:-1])]).astype(np.uint64)
+        rec = sharding.pack_records(np.arange(n) + 100 * r, nr * 2, nr, nr * 0, nr * 0, nr, off)
+        runs = (np.arange(int(nr.sum()), dtype=np.int32) * 4 + r)
+        return torch.from_numpy(rec).to(device), torch.from_numpy(runs).to(device)
+
+    def expect(step, scale_of_rank):
+        recs, runs, counts, base = [], [], [], 0
+        for r in range(world):
+            rc, rn = payload(r, step, scale_of_rank(r))
+            rc = rc.clone()
+            if rc.shape[0]:
+                rc.view(torch.int64).view(-1, 3)[:, 2] += base
+            recs.append(rc); runs.append(rn); counts.append(int(rc.shape[0])); base += int(rn.numel())
+        return torch.cat(recs), torch.cat(runs), counts
+
+    checks = {}
+    rec, runs = payload(rank, 0)
+    got = sharding.gather_results(rec, runs, dist, dst=0)
+    if rank == 0:
+        e = expect(0, lambda r: 1)
+        checks["gather_results_to_rank0"] = bool(torch.equal(got[0], e[0]) and torch.equal(got[1], e[1]) and got[2] == e[2])
+    fg = sharding.FixedGather(dist, dst=0)
+    scales = [lambda r: 1, lambda r: 1, lambda r: (40 if r == world - 1 else 1), lambda r: 1]       # step 2 overflows on the last rank only
+    tickets = []
+    ok = True
+    for step, sc in enumerate(scales):
+        rec, runs = payload(rank, step, sc(rank))
+        tickets.append(fg.post(rec, runs))
+        if step >= 1:
+            got = fg.collect(tickets[step - 1])
+            if rank == 0:
+                e = expect(step - 1, scales[step - 1])
+                ok = ok and bool(torch.equal(got[0], e[0]) and torch.equal(got[1], e[1]) and got[2] == e[2])
+    got = fg.collect(tickets[-1])
+    if rank == 0:
+        e = expect(len(scales) - 1, scales[-1])
+        ok = ok and bool(torch.equal(got[0], e[0]) and torch.equal(got[1], e[1]) and got[2] == e[2])
+        checks["fixed_gather_async_incl_one_rank_overflow"] = ok
+    checks["fixed_gather_sync_steps"] = fg.sync_steps
+    return checks
 
 
 def end_to_end(a, al, Q, T, qidx, tidx, cells, res):

@@ -575,3 +575,18 @@ def test_packed_postings_format_counts_every_posting_once():
     for bad in ([251], [7, 7], [9, 3], [130 * 252]):
         a = np.array(bad, dtype=np.uint32)
         assert enc(a.ctypes.data, len(a), None, 0) == -1
+
+
+def test_bench_dry_collectives_world2_gloo():
+    """bench.py --dry-collectives (VERDICT r03 'next' 8): only the gather path -- the synchronous gather, the asynchronous fixed-capacity
+    form and a step that overflows on ONE rank -- launched exactly as the driver launches an N-GPU run, here over gloo without a GPU"""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-collectives"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["dry_collectives"] == {"gather_results_to_rank0": True, "fixed_gather_async_incl_one_rank_overflow": True, "fixed_gather_sync_steps": 1}, d
+    assert d["rccl"]["world"] == 2 and d["rccl"]["backend"] == "gloo" and d["rccl"]["device_of_rank"] == [0, 0]
