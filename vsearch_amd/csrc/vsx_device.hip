@@ -1886,34 +1886,44 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
           if (top_is_border) Ftop = ((tbv & 0xffffu) - (INT ? (u32) qrt_i : (qrt_pk & 0xffffu))) & 0xffffu;      // F = Htop - QR_t (align_simd.cpp:830-833)
           u32 Hd = (tb_prev & 0xffffu) | (Hd_end << 16);
           u32 F = Ftop | (F_end << 16);
-          u32 acc = 0;
 #pragma unroll
-          for (int x = 0; x < HR; ++x)
-            if ((x & ~3) <= xmax)                                             // (wave-uniform: groups of four row pairs nobody needs are skipped)
+          for (int g4 = 0; g4 < NG; ++g4)
+            if (4 * g4 <= xmax)                                               // (wave-uniform: ONE branch per group of four row pairs; groups nobody needs are skipped)
               {
-                u32 V;
-                if (FASTV) V = __builtin_amdgcn_perm(cr_prev, cr, qsel[x]);
-                else V = (u32) Ssh[cr + (qcd[x] & 0xffffu)] | ((u32) Ssh[cr_prev + (qcd[x] >> 16)] << 16);
-                const u32 h0 = pk_add(Hd, V);
-                const u32 dU = ssub(h0, F);                                   // sign <=> F > h0   (up)
-                const u32 h1 = pmax(h0, F);
-                const u32 dL = ssub(h1, ee[x]);                               // sign <=> E > h1   (left)
-                const u32 h2 = pmax(h1, ee[x]);
-                Hd = hp[x];
-                hp[x] = FIRST ? bfi(0x0000FFFFu, h2, hp[x]) : h2;             // (first column: the high half has not started, its boundary stays)
-                const u32 hf = pk_sub(h2, qrt_pk);
-                const u32 f = INT ? F : pk_sub(F, rt_pk);
-                const u32 dEU = ssub(hf, f);                                  // sign <=> F - R > H - QR (extend up)
-                F = pmax(f, hf);
-                const bool plain = INT && x != XL;
-                const u32 he = plain ? hf : pk_sub(h2, x == XL ? qrq_pk_x : qrq_pk_i);
-                const u32 e = plain ? ee[x] : pk_sub(ee[x], x == XL ? rq_pk_x : rq_pk_i);
-                const u32 dEL = ssub(he, e);                                  // sign <=> E - R > H - QR (extend left)
-                const u32 en = pmax(e, he);
-                ee[x] = FIRST ? bfi(0x0000FFFFu, en, ee[x]) : en;
-                acc = a_bfi(mA[x & 3], __builtin_amdgcn_perm(dL, dU, 0x0B0A0908u), acc);
-                acc = a_bfi(mB[x & 3], __builtin_amdgcn_perm(dEL, dEU, 0x0B0A0908u), acc);
-                if ((x & 3) == 3 || x == HR - 1) { bitsL[(it * NG + (x >> 2)) * 64 + tid] = acc; acc = 0; }
+                u32 acc = 0;
+#pragma unroll
+                for (int x = 4 * g4; x < 4 * g4 + 4; ++x)
+                  if (x < HR)
+                    {
+                      u32 V;
+                      if (FASTV) V = __builtin_amdgcn_perm(cr_prev, cr, qsel[x]);
+                      else
+                        {
+                          u32 qc2 = qcd[x];
+                          asm volatile("" : "+v"(qc2));                       // (keeps the two table addresses of this rare path from being hoisted into 2 more VGPRs per row pair)
+                          V = (u32) Ssh[cr + (qc2 & 0xffffu)] | ((u32) Ssh[cr_prev + (qc2 >> 16)] << 16);
+                        }
+                      const u32 h0 = pk_add(Hd, V);
+                      const u32 dU = ssub(h0, F);                             // sign <=> F > h0   (up)
+                      const u32 h1 = pmax(h0, F);
+                      const u32 dL = ssub(h1, ee[x]);                         // sign <=> E > h1   (left)
+                      const u32 h2 = pmax(h1, ee[x]);
+                      Hd = hp[x];
+                      hp[x] = FIRST ? bfi(0x0000FFFFu, h2, hp[x]) : h2;       // (first column: the high half has not started, its boundary stays)
+                      const u32 hf = pk_sub(h2, qrt_pk);
+                      const u32 f = INT ? F : pk_sub(F, rt_pk);
+                      const u32 dEU = ssub(hf, f);                            // sign <=> F - R > H - QR (extend up)
+                      F = pmax(f, hf);
+                      const bool plain = INT && x != XL;
+                      const u32 he = plain ? hf : pk_sub(h2, x == XL ? qrq_pk_x : qrq_pk_i);
+                      const u32 e = plain ? ee[x] : pk_sub(ee[x], x == XL ? rq_pk_x : rq_pk_i);
+                      const u32 dEL = ssub(he, e);                            // sign <=> E - R > H - QR (extend left)
+                      const u32 en = pmax(e, he);
+                      ee[x] = FIRST ? bfi(0x0000FFFFu, en, ee[x]) : en;
+                      acc = a_bfi(mA[x & 3], __builtin_amdgcn_perm(dL, dU, 0x0B0A0908u), acc);
+                      acc = a_bfi(mB[x & 3], __builtin_amdgcn_perm(dEL, dEU, 0x0B0A0908u), acc);
+                    }
+                bitsL[(it * NG + g4) * 64 + tid] = acc;
               }
           Hd_end = Hd & 0xffffu;                                              // H(row HR - 1, column c - 1): the high half's next diagonal
           F_end = F & 0xffffu;                                                // F leaving row HR - 1 in column c
@@ -1970,45 +1980,27 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
 #else
 #define TBMARK(k_) do { } while (0)
 #endif
-      {
-        TileIn in1;
-        load_tile(in1, c0, m - 1);
-        TBMARK(0);
-        const int rr = busy ? r - r0h : 0;
-        const int rmax_raw = __builtin_amdgcn_readfirstlane(wave_max_i32(rr));
-        const int cmax = __builtin_amdgcn_readfirstlane(wave_max_i32(jj - c0));
-        const bool tile_int = !__any(busy && (c0 + cmax >= D - 1));
-        recompute(in1, m == 0, c0, rmax_raw, cmax, tile_int);
-        TBMARK(1);
-      }
-#if VSX_TB2_EARLY2
-      // A/B: tile 2's batch issued before tile 1 is walked (it lands during the walk, at the price of ~56 VGPRs held across it)
-      TileIn in2;
-      const bool any2 = __any(busy && m >= 1);
-      if (any2) load_tile(in2, c0b, m - 2);
-#endif
-      if (busy) walk(c0);
-      TBMARK(2);
-      // tile 2: the lanes that left tile 1 through its left edge and are still inside this (half) position.  Every lane of the wave
-      // that has a second tile asks for its inputs HERE, in the same iteration, whichever way it left tile 1: the lanes of a task
-      // stay on the same lines
-      {
-        const bool need2 = busy && (m >= 1) && (r >= r0h) && (i >= 0) && (j >= 0) && (j < c0);
-        if (__any(need2))
-          {
-#if !VSX_TB2_EARLY2
-            TileIn in2;
-            load_tile(in2, c0b, m - 2);
-#endif
-            TBMARK(3);
-            const int rmax_raw = __builtin_amdgcn_readfirstlane(wave_max_i32(need2 ? r - r0h : 0));
-            const int cmax = __builtin_amdgcn_readfirstlane(wave_max_i32(need2 ? j - c0b : 0));
-            recompute(in2, m <= 1, c0b, rmax_raw, cmax, true);
-            TBMARK(4);
-            if (need2) walk(c0b);
-            TBMARK(5);
-          }
-      }
+      // tile 1 (under the cursor), then tile 2 (left of it) for the lanes that left tile 1 through its left edge and are still inside
+      // this (half) position.  Every lane of the wave that has a second tile asks for its inputs in the same iteration, whichever way
+      // it left tile 1: the lanes of a task stay on the same lines.  ONE copy of the code (a two-trip loop, not unrolled): half the
+      // instruction footprint and the register allocation of a single tile.
+#pragma unroll 1
+      for (int tno = 0; tno < 2; ++tno)
+        {
+          const bool need = (tno == 0) ? busy : (busy && (m >= 1) && (r >= r0h) && (i >= 0) && (j >= 0) && (j < c0));
+          if (tno == 1 && !__any(need)) break;
+          const int cst = tno ? c0b : c0;
+          TileIn in;
+          load_tile(in, cst, tno ? m - 2 : m - 1);
+          TBMARK(3 * tno);
+          const int rmax_raw = __builtin_amdgcn_readfirstlane(wave_max_i32(need ? r - r0h : 0));
+          const int cmax = __builtin_amdgcn_readfirstlane(wave_max_i32(need ? j - cst : 0));
+          const bool tile_int = tno ? true : !__any(busy && (c0 + cmax >= D - 1));
+          recompute(in, tno ? (m <= 1) : (m == 0), cst, rmax_raw, cmax, tile_int);
+          TBMARK(3 * tno + 1);
+          if (need) walk(cst);
+          TBMARK(3 * tno + 2);
+        }
       if (busy && r < 0 && L > 0) { --L; r = R - 1; }
     }
 #if VSX_TB_STATS
