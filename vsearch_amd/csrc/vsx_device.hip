@@ -1713,16 +1713,13 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
                 base = rowck + (size_t) VSX_CK_SLOT(true, g, lp) * 3;
                 gstart = (long) ((size_t) sp * steps) + (long) (cst - 1 + lp);
               }
-            const long maxpair = (long) (rowsteps >> 1) - 1;
             const long p0 = gstart >> 1;                                     // floor, also for gstart = -1
             in.par = (int) (gstart - 2 * p0);
+            // pairs p0 .. p0 + 8, unclamped: one base address and immediate offsets.  Pairs outside the region (p0 = -1, or past the
+            // last pair) feed entries nobody reads; the chunk's block has VSX_CK_SLACK_DW readable dwords at both ends (vsx_host.cpp)
+            const u32 * bp = base + p0 * (long) VSX_ROWCK_PAIR_DW(true);
 #pragma unroll
-            for (int e = 0; e < 9; ++e)
-              {
-                long p = p0 + e;
-                p = p < 0 ? 0 : (p > maxpair ? maxpair : p);                 // (clamped pairs feed entries nobody reads)
-                in.v3[e] = *reinterpret_cast<const Trio *>(base + (size_t) p * VSX_ROWCK_PAIR_DW(true));
-              }
+            for (int e = 0; e < 9; ++e) in.v3[e] = *reinterpret_cast<const Trio *>(bp + e * VSX_ROWCK_PAIR_DW(true));
           }
         const u32 * cb = colck + ((size_t) s * nblk + (size_t) (mleft > 0 ? mleft : 0)) * COL_DW + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), VSX_CK_SLOT(true, g, l), 0)
                          + (MID ? (size_t) (hh * NBQ) * (4 * VSX_COLCK_CG) : 0);
@@ -1823,6 +1820,8 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
                     const int xs = r0h + x + hf_ * HR;                        // slot inside the position
                     int ii = i0 + xs; if (ii > Q - 1) ii = Q - 1;
                     if (ii < 0) ii = 0;
+                    asm volatile("" : "+v"(ii));                              // (this path runs in the first column block only: without the barrier its 2 HR table
+                                                                              //  addresses are hoisted out of the tile loop and held in 4 HR VGPRs for the whole iteration)
                     int hl = P.hleft[ii];
                     int e0 = hl - ((ii < Q - 1) ? qrq_i : qrq_r);
                     if (L == 0 && xs < pad)                                   // border state of the dummy rows, as the DP kernel seeds it

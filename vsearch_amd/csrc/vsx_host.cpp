@@ -284,7 +284,9 @@ struct Chunk {
   uint32_t task_first = 0, task_count = 0;
   uint32_t pair_first = 0, pair_count = 0;      // into the gpu-pair arrays
   std::vector<Launch> launches;
-  uint64_t dir_dwords = 0, strip_elems = 0, slab_words = 0;
+  // (a chunk's checkpoint block starts and ends with VSX_CK_SLACK_DW dwords nobody writes: the traceback reads the nine row-checkpoint
+  //  pairs around a tile without clamping their addresses -- vsx_internal.h)
+  uint64_t dir_dwords = VSX_CK_SLACK_DW, strip_elems = 0, slab_words = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr, e1b = nullptr, e2 = nullptr;   // DP begin/end (stream), traceback begin/end (stream2)
 };
 
@@ -1180,7 +1182,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       const ProtoTask & pt = protos[x];
       VsxTask & t = pl->tasks[x];
       const uint64_t dwords = t_dwords[x], strip = t.strip_off;
-      if (cur.task_count && cur.dir_dwords + dwords > budget_dwords) close_chunk();
+      if (cur.task_count && cur.dir_dwords + dwords + VSX_CK_SLACK_DW > budget_dwords) close_chunk();
       t.dir_off = cur.dir_dwords;
       t.strip_off = cur.strip_elems;
       cur.dir_dwords += dwords;
@@ -1223,7 +1225,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   uint64_t max_dir = 1, max_strip = 1, max_slab = 1, worst_runs = 0;
   for (const Chunk & c : pl->chunks)
     {
-      max_dir = std::max(max_dir, c.dir_dwords);
+      max_dir = std::max(max_dir, c.dir_dwords + VSX_CK_SLACK_DW);
       max_strip = std::max(max_strip, c.strip_elems);
       max_slab = std::max(max_slab, c.slab_words);
       worst_runs += c.slab_words;

@@ -11,6 +11,8 @@
 #define VSX_MAX_SEQLEN_PRODUCT 25000000LL // reference core/align_simd.cpp:88
 #define VSX_TABLE_LEN (65536 + 64)
 #define VSX_CODE_SLACK 64          // readable bytes before and after a sequence set's 4-bit codes
+#define VSX_CK_SLACK_DW 4096        // readable dwords before the first and after the last task's checkpoints of a chunk (vsx_traceback_tilt_kernel
+                                   // loads the row-checkpoint pairs p0 - 1 .. p0 + 8 around a tile unclamped: affine addresses, immediate offsets)
 // TILT class: checkpoints leave the DP kernel through an LDS transposition, so that in HBM every pipeline lane owns CONTIGUOUS
 // 48-byte segments (8 steps of row checkpoints; a third of a column checkpoint at R = 16) while every store instruction still
 // writes 1 KB of full lines -- the traceback then reads whole segments instead of 12-16 bytes out of fifteen 128-byte lines per
