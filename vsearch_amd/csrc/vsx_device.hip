@@ -1596,18 +1596,12 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
 
   const int Q = (int) T.qlen;
   const int D = (int) T.tlen[sl];
-  const int total_lanes = (Q + R - 1) / R;
-  const int rcnt0 = Q - (total_lanes - 1) * R;
-  const int pad = R - rcnt0;                       // dummy slots above the rows of position 0 (TOPPAD layout)
-  const int nstrips = (total_lanes + 15) >> 4;
-  const size_t steps = T.steps;
-  const size_t nblk = (steps + 15) >> 4;
-  const size_t rowsteps = ((size_t) nstrips * steps + 1) & ~(size_t) 1;
-  const size_t rowck_dw = (rowsteps >> 1) * VSX_ROWCK_PAIR_DW(true);
+  // (what follows from Q, the task's step count and its block offset -- positions, strips, the three checkpoint regions -- is derived
+  //  again at the top of every iteration, behind a barrier: a dozen cheap instructions per iteration instead of ~20 VGPRs held for the
+  //  whole kernel)
+  const u32 steps32 = T.steps;
+  const unsigned long long dir_off = T.dir_off;
   constexpr size_t COL_DW = (size_t) 64 * 4 * VSX_COLCK_NB(R, true);
-  const u32 * __restrict__ rowck = ck + T.dir_off;
-  const u32 * __restrict__ colck = ck + T.dir_off + rowck_dw;
-  const u32 * __restrict__ midck = colck + (size_t) nstrips * nblk * COL_DW;
   const int g = (int) (sl >> 1);
   const bool hi = (sl & 1) != 0;
   const u32 half_sel = hi ? 0x07060302u : 0x05040100u;           // v_perm_b32(b, a, sel) = this pair's half of a | of b << 16
@@ -1624,7 +1618,7 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
   u32 * __restrict__ my = slab + slab_off[valid ? k : 0];
 
   int i = live ? Q - 1 : -1, j = live ? D - 1 : -1;
-  int L = total_lanes - 1;
+  int L = (Q + R - 1) / R - 1;
   int r = R - 1;
   int op = -1;
   u32 runlen = 0, nruns = 0;
@@ -1668,6 +1662,20 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
 #endif
 
       // ---- this iteration: position L (MID: its half hh), column blocks m (tile 1, under the cursor) and m - 1 (tile 2) ----
+      u32 Qb = (u32) Q, stb = steps32;
+      unsigned long long dob = dir_off;
+      asm volatile("" : "+v"(Qb), "+v"(stb), "+v"(dob));
+      const int total_lanes = ((int) Qb + R - 1) / R;
+      const int rcnt0 = (int) Qb - (total_lanes - 1) * R;
+      const int pad = R - rcnt0;                   // dummy slots above the rows of position 0 (TOPPAD layout)
+      const int nstrips = (total_lanes + 15) >> 4;
+      const size_t steps = stb;
+      const size_t nblk = (steps + 15) >> 4;
+      const size_t rowsteps = ((size_t) nstrips * steps + 1) & ~(size_t) 1;
+      const size_t rowck_dw = (rowsteps >> 1) * VSX_ROWCK_PAIR_DW(true);
+      const u32 * __restrict__ rowck = ck + dob;
+      const u32 * __restrict__ colck = rowck + rowck_dw;
+      const u32 * __restrict__ midck = colck + (size_t) nstrips * nblk * COL_DW;
       const int s = L >> 4, l = L & 15;
       const int jj = busy ? j : 0;
       const int m = (jj + l) >> 4;
