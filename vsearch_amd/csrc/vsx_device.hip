@@ -1545,11 +1545,13 @@ DEV u32 pk_sub(u32 a, u32 b) { return psubw(a, b); }                            
 #ifdef VSX_TB2_WAVES_N
 #define VSX_TB2_WAVES(R_, MID_) VSX_TB2_WAVES_N
 #endif
-// occupancy floor (r04 same-box A/B, profiles/r04/r04k_tb2_occupancy_ab.txt): the 14.7 KB of LDS per wave cap a CU at 11 waves whatever the
-// registers; asking the allocator for 3 waves per SIMD (168 VGPRs) spills 276 B per lane at R = 16 and LOSES to 2 waves without spills
-// (250 x 1000: 4.53 -> 4.06 ms, 400 x 400: 7.66 -> 6.89); the short tiles (<= 10 rows) fit and prefer 3 (150 x 300: 2.75 vs 2.84)
+// occupancy floor: the 14.7 KB of LDS per wave cap a CU at 11 waves whatever the registers.  First build (r04k_tb2_occupancy_ab.txt): asking
+// for 3 waves per SIMD (168 VGPRs) spilled 276 B per lane at R = 16 and LOST to 2 waves without spills (4.53 vs 4.06 ms).  After the
+// register diet (rare-path table addresses behind barriers, invariants re-derived per iteration, one rolled two-tile loop: 250 -> 211
+// VGPRs unconstrained, 160 B of spills at 168, none of them in the column loop) 3 waves are level or ahead on every shape
+// (r04v_tb2_waves_ab.txt: 400 x 400 6.54 -> 6.35 ms)
 #ifndef VSX_TB2_WAVES
-#define VSX_TB2_WAVES(R_, MID_) ((((MID_) ? (R_) / 2 : (R_)) <= 10) ? 3 : 2)
+#define VSX_TB2_WAVES(R_, MID_) 3
 #endif
 #ifndef VSX_TB2_EARLY2
 #define VSX_TB2_EARLY2 0
