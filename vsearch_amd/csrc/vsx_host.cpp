@@ -181,8 +181,12 @@ struct SharedSlot {
     std::lock_guard<std::mutex> lk(mu);
     if (cur && cur->bytes >= bytes) { out = cur; return hipSuccess; }
     auto b = std::make_shared<SharedBlock>();
+    static const bool dbg = std::getenv("VSX_DEBUG_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     // a little headroom: the slices of a pipeline differ by a few per cent, and replacing a multi-GB block costs a hipMalloc
     hipError_t e = pool->get(headroom ? bytes + bytes / 8 : bytes, &b->p, &b->bytes);
+    if (dbg) std::fprintf(stderr, "  shared block: %zu bytes wanted (had %zu), got %zu in %.2f ms\n", bytes, cur ? cur->bytes : (size_t) 0, b->bytes,
+                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3);
     if (e == hipErrorOutOfMemory) { (void) hipGetLastError(); e = pool->get(bytes, &b->p, &b->bytes); }
     if (e != hipSuccess) { b->p = nullptr; return e; }
     b->pool = pool;
@@ -234,6 +238,7 @@ struct vsx_ctx {
   // profiles/r03/r03v_e2e_trace_*.csv); with a third block only slice i + 3 waits for it.  A block is sized by the largest plan that
   // used it (<= 0.4 of what is free when it is made), 20 GB for the 200 k-pair slices of the bench shape.
   SharedSlot shared_dir[3], shared_slab;   // declared after the pool: released first
+  std::atomic<uint64_t> req_hwm[2] {{0}, {0}};      // largest checkpoint block / slab a plan of this context asked for since the last reset (bytes)
   hipEvent_t ev_tb[3] = {nullptr, nullptr, nullptr};
   bool ev_tb_used[3] = {false, false, false};
   std::atomic<unsigned> plan_seq {0};
@@ -492,23 +497,31 @@ int vsx_internal_pool_selftest(int regions, int width)
   return bad.load();
 }
 int vsx_internal_device(const vsx_ctx * ctx) { return ctx->device; }
-// The big stream-ordered scratch blocks of a context (two checkpoint blocks, the traceback slab): their sizes, and a reservation
+// The big stream-ordered scratch blocks of a context (three checkpoint blocks, the traceback slab): their sizes, and a reservation
 // of at least those sizes.  A search runs its windows on several contexts of one device; a context that meets its first full
 // window in the middle of a warm search would pay the multi-GB hipMalloc there (0.5-1 s in a 0.15 s call), so the searcher levels
 // the contexts after a call (vsx_search.cpp).
-void vsx_internal_scratch_sizes(vsx_ctx * ctx, uint64_t out[3])
+// what the plans of a context asked for since the last reset: {checkpoint block, slab} bytes.  The searcher levels its contexts to
+// THESE (r04: it used to level to the blocks the contexts hold, and a context that had also run somebody else's 80 GB plan -- the
+// bench's aligner context is the searcher's first -- made every search call try, and fail, to give all contexts 88 GB blocks:
+// 13 ms of refused hipMallocs per call)
+void vsx_internal_scratch_requests(vsx_ctx * ctx, uint64_t out[2], int reset)
 {
-  out[0] = ctx->shared_dir[0].bytes(); out[1] = ctx->shared_dir[1].bytes(); out[2] = ctx->shared_slab.bytes();
+  for (int k = 0; k < 2; ++k) out[k] = reset ? ctx->req_hwm[k].exchange(0) : ctx->req_hwm[k].load();
 }
-int vsx_internal_scratch_reserve(vsx_ctx * ctx, const uint64_t want[3])
+void vsx_internal_scratch_sizes(vsx_ctx * ctx, uint64_t out[4])
+{
+  out[0] = ctx->shared_dir[0].bytes(); out[1] = ctx->shared_dir[1].bytes(); out[2] = ctx->shared_dir[2].bytes(); out[3] = ctx->shared_slab.bytes();
+}
+int vsx_internal_scratch_reserve(vsx_ctx * ctx, const uint64_t want[4])
 {
   if (hipSetDevice(ctx->device) != hipSuccess) { (void) hipGetLastError(); return VSX_EHIP; }
-  SharedSlot * slot[3] = {&ctx->shared_dir[0], &ctx->shared_dir[1], &ctx->shared_slab};
-  for (int k = 0; k < 3; ++k)
+  SharedSlot * slot[4] = {&ctx->shared_dir[0], &ctx->shared_dir[1], &ctx->shared_dir[2], &ctx->shared_slab};
+  for (int k = 0; k < 4; ++k)
     if (want[k] > slot[k]->bytes())
       {
         std::shared_ptr<SharedBlock> hold;
-        const hipError_t e = slot[k]->acquire(&ctx->pool, (size_t) want[k], hold, false);     // (the size asked for already carries headroom)
+        const hipError_t e = slot[k]->acquire(&ctx->pool, (size_t) want[k], hold, true);
         if (e != hipSuccess) { (void) hipGetLastError(); return e == hipErrorOutOfMemory ? VSX_ENOMEM : VSX_EHIP; }
       }
   return VSX_OK;
@@ -1263,6 +1276,12 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   if (!pl->h_cursor) HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&pl->h_cursor), 64, hipHostMallocDefault));
   // one checkpoint buffer, reused chunk after chunk: overlapping chunk k's traceback with chunk k+1's DP bought nothing
   // (both are issue-bound), while a second buffer doubled a multi-second hipMalloc
+  for (int k = 0; k < 2; ++k)
+    {
+      const uint64_t need = (k == 0 ? max_dir : max_slab) * 4;
+      uint64_t seen = ctx->req_hwm[k].load();
+      while (need > seen && !ctx->req_hwm[k].compare_exchange_weak(seen, need)) { }
+    }
   HIPCHK(pl->d_dir[0].alloc(ctx->shared_dir[pl->dir_slot], &ctx->pool, max_dir));
   HIPCHK(pl->d_strip.alloc(&ctx->pool, max_strip));
   HIPCHK(pl->d_slab.alloc(ctx->shared_slab, &ctx->pool, max_slab));

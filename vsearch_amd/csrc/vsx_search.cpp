@@ -34,8 +34,9 @@
 extern "C" void vsx_internal_set_error(const char * msg);
 extern "C" const vsx_scoring * vsx_internal_scoring(const vsx_ctx * ctx);
 extern "C" int vsx_internal_device(const vsx_ctx * ctx);
-extern "C" void vsx_internal_scratch_sizes(vsx_ctx * ctx, uint64_t out[3]);
-extern "C" int vsx_internal_scratch_reserve(vsx_ctx * ctx, const uint64_t want[3]);
+extern "C" void vsx_internal_scratch_sizes(vsx_ctx * ctx, uint64_t out[4]);
+extern "C" void vsx_internal_scratch_requests(vsx_ctx * ctx, uint64_t out[2], int reset);
+extern "C" int vsx_internal_scratch_reserve(vsx_ctx * ctx, const uint64_t want[4]);
 extern "C" int vsx_internal_seqset_create_cased(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const char * blob, uint64_t blob_bytes,
                                                 const uint64_t * offsets, const uint32_t * lengths, int mode);
 extern "C" int vsx_internal_seqset_lower_download(const vsx_seqset * s, uint8_t * dst, uint64_t nbytes);
@@ -539,41 +540,60 @@ static int fill_hit(const vsx_searcher & S, FQ qtext, int64_t ql, Hit & h, const
 static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out)
 {
   const uint64_t nq = kept.size();
-  uint64_t total = 0;
-  for (auto & v : kept) total += v.size();
   out->n_queries = nq;
-  out->n_hits = total;
   out->first = (uint64_t *) std::malloc((nq + 1) * sizeof(uint64_t));
-  out->hit = (vsx_hit *) std::malloc(std::max<uint64_t>(total, 1) * sizeof(vsx_hit));
-  std::string blob;
-  if (!out->first || !out->hit) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "host allocation failed"); }
-  uint64_t pos = 0;
+  if (!out->first) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "host allocation failed"); }
+  // positions first (a serial scan over two numbers per query), then the copies on host threads (r04: the serial form was 4-5 ms of a
+  // 140 ms search call of 100 k queries)
+  std::vector<uint64_t> blob_at(nq + 1);
+  uint64_t total = 0, bytes = 0;
   for (uint64_t q = 0; q < nq; ++q)
     {
-      out->first[q] = pos;
-      for (const Hit & h : kept[q])
-        {
-          vsx_hit & o = out->hit[pos++];
-          std::memset(&o, 0, sizeof o);
-          o.query = (uint32_t) q; o.target = h.target; o.count = h.count;
-          o.accepted = h.accepted; o.weak = h.weak; o.used_fallback = h.fallback; o.strand = h.minus ? 1 : 0;
-          o.nwscore = h.nwscore; o.nwdiff = h.nwdiff; o.nwgaps = h.nwgaps; o.nwindels = h.nwindels;
-          o.nwalignmentlength = h.nwalignmentlength; o.matches = h.matches; o.mismatches = h.mismatches;
-          o.internal_alignmentlength = h.internal_alignmentlength; o.internal_gaps = h.internal_gaps;
-          o.internal_indels = h.internal_indels;
-          o.trim_q_left = h.trim_q_left; o.trim_q_right = h.trim_q_right; o.trim_t_left = h.trim_t_left; o.trim_t_right = h.trim_t_right;
-          o.shortest = h.shortest; o.longest = h.longest;
-          o.nwid = h.nwid; o.id = h.id; o.id0 = h.id0; o.id1 = h.id1; o.id2 = h.id2; o.id3 = h.id3; o.id4 = h.id4;
-          o.cigar_off = blob.size();
-          blob += h.cigar;
-          blob.push_back('\0');
-        }
+      out->first[q] = total;
+      blob_at[q] = bytes;
+      total += kept[q].size();
+      for (const Hit & h : kept[q]) bytes += h.cigar.size() + 1;
     }
-  out->first[nq] = pos;
-  out->cigar_bytes = blob.size();
-  out->cigar_blob = (char *) std::malloc(std::max<size_t>(blob.size(), 1));
-  if (!out->cigar_blob) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "host allocation failed"); }
-  std::memcpy(out->cigar_blob, blob.data(), blob.size());
+  out->first[nq] = total;
+  blob_at[nq] = bytes;
+  out->n_hits = total;
+  out->cigar_bytes = bytes;
+  out->hit = (vsx_hit *) std::malloc(std::max<uint64_t>(total, 1) * sizeof(vsx_hit));
+  out->cigar_blob = (char *) std::malloc(std::max<uint64_t>(bytes, 1));
+  if (!out->hit || !out->cigar_blob) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "host allocation failed"); }
+  auto fill = [&](uint64_t q0, uint64_t q1) {
+    for (uint64_t q = q0; q < q1; ++q)
+      {
+        uint64_t pos = out->first[q], at = blob_at[q];
+        for (const Hit & h : kept[q])
+          {
+            vsx_hit & o = out->hit[pos++];
+            std::memset(&o, 0, sizeof o);
+            o.query = (uint32_t) q; o.target = h.target; o.count = h.count;
+            o.accepted = h.accepted; o.weak = h.weak; o.used_fallback = h.fallback; o.strand = h.minus ? 1 : 0;
+            o.nwscore = h.nwscore; o.nwdiff = h.nwdiff; o.nwgaps = h.nwgaps; o.nwindels = h.nwindels;
+            o.nwalignmentlength = h.nwalignmentlength; o.matches = h.matches; o.mismatches = h.mismatches;
+            o.internal_alignmentlength = h.internal_alignmentlength; o.internal_gaps = h.internal_gaps;
+            o.internal_indels = h.internal_indels;
+            o.trim_q_left = h.trim_q_left; o.trim_q_right = h.trim_q_right; o.trim_t_left = h.trim_t_left; o.trim_t_right = h.trim_t_right;
+            o.shortest = h.shortest; o.longest = h.longest;
+            o.nwid = h.nwid; o.id = h.id; o.id0 = h.id0; o.id1 = h.id1; o.id2 = h.id2; o.id3 = h.id3; o.id4 = h.id4;
+            o.cigar_off = at;
+            std::memcpy(out->cigar_blob + at, h.cigar.data(), h.cigar.size());
+            at += h.cigar.size();
+            out->cigar_blob[at++] = '\0';
+          }
+      }
+  };
+  const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::min(usable_cpus(), 8), total / 16384));
+  if (nth <= 1) fill(0, nq);
+  else
+    {
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nth; ++t) pool.emplace_back(fill, nq * (uint64_t) t / (uint64_t) nth, nq * (uint64_t) (t + 1) / (uint64_t) nth);
+      fill(0, nq / (uint64_t) nth);
+      for (std::thread & t : pool) t.join();
+    }
   return VSX_OK;
 }
 
@@ -1515,6 +1535,8 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
           }
         s2.abort();
       };
+      for (vsx_ctx * c : {S->ctx, S->ctx2, S->ctx3})
+        if (c) { uint64_t drop[2]; vsx_internal_scratch_requests(c, drop, 1); }      // (requests are counted per call: the levelling below)
       std::thread consumer2, consumer3;
       if (n_consumers >= 2 && S->ctx2) consumer2 = std::thread(consumer, S->ctx2);
       if (n_consumers >= 3 && S->ctx3) consumer3 = std::thread(consumer, S->ctx3);
@@ -1530,11 +1552,20 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       // allocates gigabytes in the middle of a later, warm call (failure to reserve is not an error: that context grows on demand)
       {
         vsx_ctx * all[3] = {S->ctx, S->ctx2, S->ctx3};
-        uint64_t want[3] = {0, 0, 0};
+        uint64_t want[4] = {0, 0, 0, 0};
+        // (levelled to what THIS call's plans asked for, with the blocks' usual headroom -- not to whatever a context happens to hold)
         for (vsx_ctx * c : all)
-          if (c) { uint64_t have[3]; vsx_internal_scratch_sizes(c, have); for (int k = 0; k < 3; ++k) want[k] = std::max(want[k], have[k]); }
-        want[0] = want[1] = std::max(want[0], want[1]);            // the two checkpoint blocks alternate
+          if (c)
+            {
+              uint64_t asked[2];
+              vsx_internal_scratch_requests(c, asked, 1);
+              want[0] = std::max(want[0], asked[0]);                       // (the bare requests: a block that served them is big enough;
+              want[3] = std::max(want[3], asked[1]);                       //  a block that has to grow gets the usual headroom on top)
+            }
+        want[1] = want[2] = want[0];                                     // the checkpoint blocks rotate
+        if (timeline) std::fprintf(stderr, "  [%7.1f ms] stages joined\n", (now_s() - t_begin) * 1e3);
         for (vsx_ctx * c : all) if (c) (void) vsx_internal_scratch_reserve(c, want);
+        if (timeline) std::fprintf(stderr, "  [%7.1f ms] scratch levelled\n", (now_s() - t_begin) * 1e3);
       }
     }
 
@@ -1544,6 +1575,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
     const int mrc = marshal_hits(kept, out);
     if (mrc != VSX_OK) return mrc;
   }
+  if (timeline) std::fprintf(stderr, "  [%7.1f ms] hits marshalled\n", (now_s() - t_begin) * 1e3);
   out->pairs_aligned = pairs; out->cells_aligned = cells; out->stages = stages; out->sentinel_pairs = sentinels;
   out->seconds_kmer = t_kmer; out->seconds_align = t_align; out->seconds_total = now_s() - t_begin;
   if (std::getenv("VSX_DEBUG_TIMING"))
