@@ -376,7 +376,13 @@ def main():
                  "traceback": {"hbm_bytes_per_launch": tb.get("hbm_bytes_per_launch"), "SQ_INSTS_VALU": tb.get("sq", {}).get("SQ_INSTS_VALU"),
                                "SQ_WAIT_ANY_over_WAVE_CYCLES": round(tb["sq"]["SQ_WAIT_ANY"] / tb["sq"]["SQ_WAVE_CYCLES"], 3)
                                if tb.get("sq", {}).get("SQ_WAVE_CYCLES") else None,
-                               "note": "latency / occupancy bound (12 waves per CU at R <= 16), not HBM bound: profiles/r02_ckt_ab.txt"},
+                               "kernel": tb.get("kernel"),
+                               "lines_per_launch": int(tb["hbm_read_bytes_per_launch"] / 128) if tb.get("hbm_read_bytes_per_launch") else None,
+                               "line_rate_floor_ms": round(tb["hbm_read_bytes_per_launch"] / 128 / 45e9 * 1e3, 3) if tb.get("hbm_read_bytes_per_launch") else None,
+                               "note": "r04: every partial-line checkpoint read costs HBM a whole 128-byte line (FETCH_SIZE calibrated on the kernel's own "
+                                       "pattern, profiles/r04/r04a_fetch_calibration.txt; 45 G lines/s); the position-synchronous kernel keeps the lanes of a "
+                                       "task on the same lines (5.05 pairs per fetched tile instead of 2.95) and issues 15 instead of 28 instructions per two "
+                                       "recomputed cells: it is VALU-issue bound in the recompute (61 % of a wave's time), latency bound in loads and walk"},
                  "forward_sq": {k: sq.get(k) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
                                                        "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE")}}
         if sq.get("SQ_INSTS_VALU"):

@@ -85,7 +85,8 @@ WORKLOAD = {"queries": 100000, "qlen": 250, "db": 1000000, "dlen": 1000, "cands"
 if os.environ.get("VSX_SUMMARY_WORKLOAD"):
     q_, d_, db_ = (int(x) for x in os.environ["VSX_SUMMARY_WORKLOAD"].split(","))
     WORKLOAD = {"queries": 100000, "qlen": q_, "db": db_, "dlen": d_, "cands": 8}
-fwd, tb = kernel_block("vsx_forward_kernel"), kernel_block("vsx_traceback_ck_kernel")
+TB = "vsx_traceback_tilt_kernel" if per_launch("pmc_fetch", "FETCH_SIZE", "vsx_traceback_tilt_kernel") is not None else "vsx_traceback_ck_kernel"
+fwd, tb = kernel_block("vsx_forward_kernel"), kernel_block(TB)
 if fwd is not None:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     try:
@@ -106,8 +107,10 @@ if fwd is not None:
                 "active_inst_valu_over_busy": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_BUSY_CYCLES"]}
     doc = {"kernel_source_sha": sha, "kernel_sources": list(getattr(bench, "KERNEL_SOURCES", [])) if sha else None,
            "workload": WORKLOAD,
-           "forward": dict(fwd, kernel="vsx_forward_kernel", sq=sq), "traceback": dict(tb or {}, kernel="vsx_traceback_ck_kernel",
-                                                                                     sq=sq_block("vsx_traceback_ck_kernel")),
+           "forward": dict(fwd, kernel="vsx_forward_kernel", sq=sq), "traceback": dict(tb or {}, kernel=TB, sq=sq_block(TB),
+                                                                                     fetch_calibration="r04: one 12- or 16-byte read per 128-byte line is tallied as 64 B by FETCH_SIZE and costs HBM a whole "
+                                                                                                       "line (45 G lines/s, the rate of a coalesced stream): the x2 applies to this kernel's pattern too "
+                                                                                                       "(profiles/r04/r04a_fetch_calibration.txt)"),
            "valu_issue": valu,
            "method": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ set 1 | SQ set 2, one pass each) of `bench.py --kernels-only "
                      "--steps 1 --warmup 0`; per-launch = sum / dispatches; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "

@@ -1891,10 +1891,12 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
               qrt_prev = ql; rt_prev = rl;
             }
           else qrt_pk = pk16(qrt_i);
-          u32 Ftop = tbv >> 16;
-          if (top_is_border) Ftop = ((tbv & 0xffffu) - (INT ? (u32) qrt_i : (qrt_pk & 0xffffu))) & 0xffffu;      // F = Htop - QR_t (align_simd.cpp:830-833)
-          u32 Hd = (tb_prev & 0xffffu) | (Hd_end << 16);
-          u32 F = Ftop | (F_end << 16);
+          // low half: this column's top boundary (H of column c - 1 as the diagonal, F of column c); high half: what the low half's last
+          // row left behind one column ago -- one v_perm_b32 each (Hd_end / F_end keep their junk high halves)
+          u32 Hd = __builtin_amdgcn_perm(Hd_end, tb_prev, 0x05040100u);
+          u32 F = __builtin_amdgcn_perm(F_end, tbv, 0x05040302u);
+          if (top_is_border)                                                  // F = Htop - QR_t (align_simd.cpp:830-833)
+            F = __builtin_amdgcn_perm(F_end, ((tbv & 0xffffu) - (INT ? (u32) qrt_i : (qrt_pk & 0xffffu))), 0x05040100u);
 #pragma unroll
           for (int g4 = 0; g4 < NG; ++g4)
             if (4 * g4 <= xmax)                                               // (wave-uniform: ONE branch per group of four row pairs; groups nobody needs are skipped)
@@ -1934,8 +1936,8 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
                     }
                 bitsL[(it * NG + g4) * 64 + tid] = acc;
               }
-          Hd_end = Hd & 0xffffu;                                              // H(row HR - 1, column c - 1): the high half's next diagonal
-          F_end = F & 0xffffu;                                                // F leaving row HR - 1 in column c
+          Hd_end = Hd;                                                        // low half = H(row HR - 1, column c - 1): the high half's next diagonal
+          F_end = F;                                                          // low half = F leaving row HR - 1 in column c
           tb_prev = tbv;
           cr_prev = cr;
         };
