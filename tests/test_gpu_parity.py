@@ -455,3 +455,27 @@ def test_tilt_class_boundaries(gpu_required, oracle, name):
     assert info["tasks_tracked"] == 0, info
     for k in range(len(qi)):
         assert res.row(k) == tuple(oracle.align(qs[qi[k]], ts[ti[k]], P, nmm)), (name, k, len(qs[qi[k]]), len(ts[ti[k]]))
+
+
+@pytest.mark.gpu
+def test_sparse_kernel_class_joins_the_dense_one(gpu_required, oracle):
+    """r04: a handful of queries a few symbols short of the others would form a kernel class of their own (18 instead of 20 rows per
+    lane) and cost a one-wave launch of each kernel; the planner promotes them into the dense class (any row count with 16 R >= Q
+    is valid).  One DP launch, and the promoted pairs -- plus a query too short to be promoted -- still equal the oracle."""
+    from vsearch_amd import Aligner
+    rng = random.Random(404)
+    qs = [common.rnd_seq(rng, 300) for _ in range(400)] + [common.rnd_seq(rng, 280) for _ in range(3)] + [common.rnd_seq(rng, 12)]
+    ts = [common.mutate(rng, q, 0.06) + common.rnd_seq(rng, rng.randint(0, 30)) for q in qs]
+    idx = np.arange(len(qs), dtype=np.uint32)
+    with Aligner() as al:
+        Q, T = al.sequences(qs), al.sequences(ts)
+        p = al.plan(Q, T, idx, idx)
+        p.run()
+        tm = p.sync()
+        res = p.fetch()
+        info = p.describe()
+        p.close()
+    assert info["rows_dominant"] == 20
+    assert tm.forward_launches == 2, tm.forward_launches          # the dense class (with the three promoted queries) + the 12-symbol query
+    for k in list(range(0, 400, 37)) + [400, 401, 402, 403]:
+        assert res.row(k) == tuple(oracle.align(qs[k], ts[k])), k

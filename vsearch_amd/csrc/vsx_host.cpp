@@ -1115,6 +1115,51 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
     protos.reserve(total);
     for (auto & v : part) protos.insert(protos.end(), v.begin(), v.end());
   }
+  // r04: a class with a handful of tasks still costs a launch of each kernel on the plan's streams, and a one-wave launch is a pure
+  // latency chain (profiles/r04/r04z_shape_300x300_summary.txt: four tasks with 18 rows per lane beside 99 996 with 20 -- queries a few
+  // symbols short of 289 -- took 0.15 ms of DP and 0.61 ms of traceback, 11 % of the step's traceback time).  Any row count with
+  // 16 R >= Q is valid for a query, so the tasks of a sparse class join the next denser class of the same kind.
+  {
+    static const bool no_promote = std::getenv("VSX_NO_PROMOTE") != nullptr;      // A/B, tests
+    struct Cls { int rows, generic, track, tilt; size_t count; };
+    std::vector<Cls> cls;
+    for (const ProtoTask & pt : protos)
+      {
+        bool found = false;
+        for (Cls & c : cls) if (c.rows == pt.rows && c.generic == pt.generic && c.track == pt.track && c.tilt == pt.tilt) { ++c.count; found = true; break; }
+        if (!found) cls.push_back(Cls {pt.rows, pt.generic, pt.track, pt.tilt, 1});
+      }
+    std::vector<std::pair<size_t, int>> move;                                 // class index -> new rows
+    for (size_t a = 0; a < cls.size() && !no_promote; ++a)
+      {
+        int best = 0;
+        for (const Cls & c : cls)
+          if (c.generic == cls[a].generic && c.track == cls[a].track && c.tilt == cls[a].tilt && c.rows > cls[a].rows &&
+              c.count >= 32 * cls[a].count && (best == 0 || c.rows < best))
+            best = c.rows;
+        if (best && cls[a].count < 4096) move.emplace_back(a, best);
+      }
+    for (auto & mv : move)                                                    // (a target class that moves itself takes its newcomers along)
+      for (int hop = 0; hop < 4; ++hop)
+        for (const auto & other : move)
+          {
+            const Cls & a = cls[mv.first], & o = cls[other.first];
+            if (o.rows == mv.second && o.generic == a.generic && o.track == a.track && o.tilt == a.tilt) { mv.second = other.second; break; }
+          }
+    if (!move.empty())
+      for (ProtoTask & pt : protos)
+        for (const auto & mv : move)
+          {
+            const Cls & c = cls[mv.first];
+            if (pt.rows == c.rows && pt.generic == c.generic && pt.track == c.track && pt.tilt == c.tilt)
+              {
+                // (only queries that still span two pipeline positions: a query shorter than one position of the new class would make
+                //  position 0 the last position as well, a shape no row count chosen by pick_rows() ever produces)
+                if ((int) queries->len[pt.q] > mv.second) pt.rows = mv.second;
+                break;
+              }
+          }
+  }
   // kernel classes together (one launch per class and chunk)
   auto by_class = [](const ProtoTask & a, const ProtoTask & b) {
     if (a.rows != b.rows) return a.rows < b.rows;
