@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="")
     ap.add_argument("--max-rounds", type=int, default=0, help="stop after this many rounds (0: run for --seconds): a deterministic set of rounds for a given seed")
+    ap.add_argument("--force-round-size", type=int, default=0, help="stress: every round of the soak uses this GPU round size (3: hundreds of tiny rounds per data set)")
+    ap.add_argument("--only-by-size", action="store_true", help="stress: only the abundance-sorted commands (--cluster_size / --cluster_unoise)")
+    ap.add_argument("--only-round", type=int, default=-1, help="replay: draw every round of the seed but run only this one (and print its first difference)")
     a = ap.parse_args()
     if not refcli.available():
         raise SystemExit("oracle/_ref/vsearch_ref missing: make -C oracle ref_full")
@@ -140,12 +143,22 @@ def main():
         fa, uc = os.path.join(tmp, "c.fa"), os.path.join(tmp, "c.uc")
         while time.time() < t_end and (a.max_rounds <= 0 or rounds < a.max_rounds):
             o, scoring, cli, by_size, round_size = draw(rng)
+            if a.force_round_size:
+                round_size = a.force_round_size
             unoise = by_size == "unoise"
             seqs, names, sz, order = data(rng, bool(by_size))
+            if a.only_by_size and not by_size:
+                continue
             refcli.write_fasta(fa, names, seqs)
             # the CIGAR consumer too (msa.cpp): star MSA, consensus and profile of every cluster, on the device, in half of the
             # cluster_fast rounds without masking (masking changes the case of the printed rows)
             want_msa = (not by_size) and o["soft_mask"] == 0 and rng.random() < 0.5
+            if a.only_round >= 0:
+                if rounds < a.only_round:
+                    rounds += 1
+                    continue
+                if rounds > a.only_round:
+                    break
             msa_args = ["--msaout", tmp + "/m.msa", "--consout", tmp + "/m.cons", "--profile", tmp + "/m.prof"] if want_msa else []
             p = subprocess.run([refcli.REF_BIN, "--cluster_unoise" if unoise else ("--cluster_size" if by_size else "--cluster_fast"), fa, "--threads", "1", "--uc", uc, "--quiet"] + cli + msa_args,
                                capture_output=True, text=True)

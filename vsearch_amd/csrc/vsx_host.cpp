@@ -11,6 +11,14 @@
 #include "vsx_internal.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+// VSX_POISON=1 (debugging aid, r04): every device block this library hands out is filled with 0xA5 first, so a read of memory nobody
+// has written gives the same junk in every run instead of whatever an earlier plan, index or process left there
+extern "C" void vsx_internal_poison(void * p, size_t bytes)
+{
+  static const bool on = std::getenv("VSX_POISON") != nullptr;
+  if (on && p && bytes) { (void) hipMemset(p, 0xA5, bytes); (void) hipDeviceSynchronize(); }
+}
 
 #include <algorithm>
 #include <cinttypes>
@@ -72,7 +80,7 @@ struct DevBuf {
     release();
     if (count == 0) count = 1;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
-    if (e == hipSuccess) n = count;
+    if (e == hipSuccess) { n = count; vsx_internal_poison(p, count * sizeof(T)); }
     return e;
   }
   hipError_t ensure(size_t count) { return (count <= n && p) ? hipSuccess : alloc(count); }
@@ -104,12 +112,13 @@ struct ScratchPool {
         {
           *out = free_blocks[best].p; *got = free_blocks[best].bytes;
           free_blocks.erase(free_blocks.begin() + (long) best);
+          vsx_internal_poison(*out, std::min<size_t>(*got, (size_t) 256 << 20));
           return hipSuccess;
         }
     }
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipErrorOutOfMemory) { trim(); (void) hipGetLastError(); e = hipMalloc(out, bytes); }
-    if (e == hipSuccess) *got = bytes;
+    if (e == hipSuccess) { *got = bytes; vsx_internal_poison(*out, std::min<size_t>(bytes, (size_t) 256 << 20)); }
     return e;
   }
   void put(void * p, size_t bytes)

@@ -32,6 +32,7 @@ extern "C" hipError_t vsx_kmer_launch_select_packed(const void * rec, uint32_t s
                                                     uint32_t keep, void * dense, unsigned long long * cursor, uint64_t capacity,
                                                     void * sel_m_n, uint64_t * sel_off, hipStream_t st);
 
+extern "C" void vsx_internal_poison(void * p, size_t bytes);
 namespace {
 
 int kfail(int code, const char * what, hipError_t e)
@@ -49,7 +50,7 @@ template <typename T> struct Buf {
   {
     if (p) { (void) hipFree(p); p = nullptr; n = 0; }
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T));
-    if (e == hipSuccess) n = count;
+    if (e == hipSuccess) { n = count; vsx_internal_poison(p, std::max<size_t>(count, 1) * sizeof(T)); }
     return e;
   }
   hipError_t ensure(size_t count) { return (p && count <= n) ? hipSuccess : alloc(count); }
