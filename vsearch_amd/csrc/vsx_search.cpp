@@ -1946,6 +1946,13 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
           if (pre_thread.joinable()) pre_thread.join();
           if (pre_rc != VSX_OK) { vsx_internal_set_error(pre_err.c_str()); return pre_rc; }
           const bool have_main = (pre_main_s0 == s0);              // the helper already ranked this round against the main index
+          // Take the helper's ranking of THIS round now, before the helper of the next round is started below: that one begins with
+          // pre_cands.assign(...), and with tiny rounds (3 sequences: its word stage takes microseconds) it could win the race against
+          // the swap that used to sit after its launch -- the round then lost every main-index candidate and its members founded
+          // clusters of their own.  Found by oracle/soak_cluster.py in r04 (one round in ~300, GPU round size 3; the r03 library too).
+          std::vector<std::vector<Cand>> cands_pre;
+          std::vector<uint64_t> fallback_pre;
+          if (have_main) { cands_pre.swap(pre_cands); fallback_pre.swap(pre_fallback); }
           if (pre_s0 == s0) kmers.swap(pre_kmers);
           else words_of_round(s0, kmers, main_seen, nth);
           tm_words += now_s() - t0;
@@ -1998,7 +2005,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
           std::vector<std::vector<Cand>> cands(wn);
           const uint32_t keep_n = (uint32_t) std::max<int64_t>(S->tophits, 1);
           int krc = VSX_OK;
-          if (have_main) { cands.swap(pre_cands); fallback.swap(pre_fallback); }
+          if (have_main) { cands.swap(cands_pre); fallback.swap(fallback_pre); }
           else krc = device_rank(S, cix.get(), &main_list, wn, kmers, keep_n, 1024, true, cands, fallback, kacct);
           if (krc != VSX_OK) return krc;
           if (!delta_list.empty())
