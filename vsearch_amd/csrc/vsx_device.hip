@@ -14,8 +14,9 @@
 //     same DPP pipeline; lane 0 is fed from a 16-column block parked in LDS once per 16 steps;
 //   * default (CKPT): no direction bits are stored.  Every step each lane stores the (H, F) pair it hands to the next pipeline
 //     position (row checkpoints) and every 16 steps its column state hprev[R], E[R] (column checkpoints); the traceback kernel
-//     (vsx_traceback_ck_kernel, one lane per pair) recomputes the direction bits only for the <= R x 16 tiles the path crosses
-//     and walks them with backtrack16's rules, emitting statistics and the run-length CIGAR;
+//     (one lane per pair: vsx_traceback_tilt_kernel for the tilted class -- r04: position-synchronous iterations, two rows of a pair
+//     per register -- vsx_traceback_ck_kernel for the plain classes) recomputes the direction bits only for the <= R x 16 tiles
+//     the path crosses and walks them with backtrack16's rules, emitting statistics and the run-length CIGAR;
 //   * default arithmetic (TILT, tasks whose score range the planner can bound): tilted coordinates X* = X + (i + j) g remove
 //     F - R and E - R from the interior (7 instructions per lane-row); values biased into unsigned halves so that the add and
 //     the subtraction are 32-bit ops over both halves.  Exact: every maximum compares two values of the same cell;
@@ -1552,9 +1553,6 @@ DEV u32 pk_sub(u32 a, u32 b) { return psubw(a, b); }                            
 // (r04v_tb2_waves_ab.txt: 400 x 400 6.54 -> 6.35 ms)
 #ifndef VSX_TB2_WAVES
 #define VSX_TB2_WAVES(R_, MID_) 3
-#endif
-#ifndef VSX_TB2_EARLY2
-#define VSX_TB2_EARLY2 0
 #endif
 template <int R, bool MID>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VSX_TB2_WAVES(R, MID), 8)))
