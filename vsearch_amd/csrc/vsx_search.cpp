@@ -2079,6 +2079,44 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       }
       t_kmer += now_s() - t0;
 
+      // ---- phase 1c's device part, started here (r04): the intra-round shared k-mer counts need the round's words only -- nothing
+      //      the staged search decides -- so a helper rebuilds the round's own index, counts and pairs up the candidates while phase
+      //      1b aligns (k-mer kernels and aligner kernels on their own streams; 1.07 s of a 6.6 s run at 2 M sequences sat behind it) ----
+      struct Near { uint32_t k, shared; int64_t res; };            // res = index into the speculative results, -1 none
+      std::vector<std::vector<Near>> near(wn);
+      std::vector<uint32_t> sq, stg;
+      int near_rc = VSX_OK;
+      std::string near_err;
+      const bool near_on_device = dev_kmer && fallback.empty();
+      auto near_device = [&]() {
+        // the same counting problem on the device: members of the round against an index of the round
+        std::vector<uint32_t> round_list(wn);
+        for (uint64_t i = 0; i < wn; ++i) round_list[i] = (uint32_t) (s0 + i);
+        near_rc = vsx_kmer_index_rebuild(rix.get(), round_list.data(), wn);
+        std::vector<std::vector<Cand>> nc(wn);
+        std::vector<uint64_t> none;
+        if (near_rc == VSX_OK) near_rc = device_rank(S, rix.get(), &round_list, wn, kmers, 0xffffffffu, 1024, false, nc, none, kacct);
+        if (near_rc != VSX_OK) { near_err = vsx_last_error(); return; }
+        for (uint64_t i = 0; i < wn; ++i)
+          for (const Cand & c : nc[i])                              // ascending target
+            {
+              const uint32_t k = (uint32_t) (c.target - s0);
+              if (k >= i) break;                                    // only earlier members can have become centroids
+              Near nr {k, c.count, -1};
+              if (acceptable_unaligned(*S, seq_of(s0 + i), S->len[s0 + i], (uint32_t) (s0 + k), S->meta_of(s0 + i)))
+                {
+                  nr.res = (int64_t) sq.size();
+                  sq.push_back((uint32_t) (s0 + i));
+                  stg.push_back((uint32_t) (s0 + k));
+                }
+              near[i].push_back(nr);
+            }
+      };
+      static const bool near_overlap = !(std::getenv("VSX_CLUSTER_NEAR_OVERLAP") && std::strcmp(std::getenv("VSX_CLUSTER_NEAR_OVERLAP"), "0") == 0);   // A/B
+      std::thread near_thread;
+      struct NearJoiner { std::thread & t; ~NearJoiner() { if (t.joinable()) t.join(); } } near_joiner {near_thread};
+      if (near_on_device && near_overlap) near_thread = std::thread(near_device);
+
       // ---- phase 1b: staged GPU search (queries and targets both live in the database sequence set) ----
       const double ts0 = now_s();
       int rc = run_stages(*S, st, [&](uint64_t k) { return seq_of(s0 + k); }, [&](uint64_t k) { return seq_of(s0 + k); },
@@ -2090,34 +2128,11 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       // ---- phase 1c: intra-round shared k-mer counts (unique_count_shared, core/unique.cpp:356-395) and the
       //      speculative alignments of (member i, earlier member k) pairs that the fix-up could ask for ----
       t0 = now_s();
-      struct Near { uint32_t k, shared; int64_t res; };            // res = index into the speculative results, -1 none
-      std::vector<std::vector<Near>> near(wn);
-      std::vector<uint32_t> sq, stg;
-      if (dev_kmer && fallback.empty())
+      if (near_on_device)
         {
-          // the same counting problem on the device: members of the round against an index of the round
-          std::vector<uint32_t> round_list(wn);
-          for (uint64_t i = 0; i < wn; ++i) round_list[i] = (uint32_t) (s0 + i);
-          const int irc = vsx_kmer_index_rebuild(rix.get(), round_list.data(), wn);
-          if (irc != VSX_OK) return irc;
-          std::vector<std::vector<Cand>> nc(wn);
-          std::vector<uint64_t> none;
-          const int krc = device_rank(S, rix.get(), &round_list, wn, kmers, 0xffffffffu, 1024, false, nc, none, kacct);
-          if (krc != VSX_OK) return krc;
-          for (uint64_t i = 0; i < wn; ++i)
-            for (const Cand & c : nc[i])                              // ascending target
-              {
-                const uint32_t k = (uint32_t) (c.target - s0);
-                if (k >= i) break;                                    // only earlier members can have become centroids
-                Near nr {k, c.count, -1};
-                if (acceptable_unaligned(*S, seq_of(s0 + i), S->len[s0 + i], (uint32_t) (s0 + k), S->meta_of(s0 + i)))
-                  {
-                    nr.res = (int64_t) sq.size();
-                    sq.push_back((uint32_t) (s0 + i));
-                    stg.push_back((uint32_t) (s0 + k));
-                  }
-                near[i].push_back(nr);
-              }
+          if (near_thread.joinable()) near_thread.join();
+          else near_device();
+          if (near_rc != VSX_OK) { vsx_internal_set_error(near_err.c_str()); return near_rc; }
         }
       else
       {
