@@ -25,8 +25,10 @@
 //     reference's code; nothing aborts the embedding process.
 //   * devices: VSX_DEVICES=0,1,2,... (one database replica per device, queries sharded over them: include/vsx_search.h multi-device
 //     form), else VSX_DEVICE=n, else device 0.  Clustering runs on the first device.
-//   * the Database must not be modified while a session uses it; a cheap fingerprint (lengths, abundances, sampled sequence
-//     bytes) catches in-place changes between calls (dust_all / hardmask_all after the first batch) and rebuilds the searcher.
+//   * the Database must not be modified while a session uses it; a cheap best-effort fingerprint (count, sampled sequence and
+//     header bytes; lengths and abundances of all up to 65 536 sequences) catches in-place changes between calls (dust_all /
+//     hardmask_all after the first batch) and rebuilds the searcher.  VSX_API_FINGERPRINT=full hashes every byte on every call;
+//     vsx_api_invalidate() (extern "C") drops the replica explicitly.
 #include "vsearch_api.h"
 
 #include "vsx.h"
@@ -162,28 +164,52 @@ struct Fast {
   vsx_scoring sc {};
   void drop() { vsx_multi_searcher_destroy(M); M = nullptr; }
   vsx_searcher * first() { return vsx_multi_searcher_replica(M, 0); }
-  // lengths, abundances, header and sequence bytes of a spread of at most 256 sequences, and the totals: cheap enough for every
-  // call, and an in-place re-masking or re-annotation of the Database changes it
+  // Best-effort detection of an in-place change of the Database between calls (the reference has no generation counter to ask):
+  // the count, and length + header + sequence bytes of a spread of sequences (256; 1 024 above 65 536 sequences) plus the last
+  // one.  Up to 65 536 sequences the lengths and abundances of ALL are folded in as well; above that the walk is skipped, so a
+  // small batch against a multi-million-sequence database does not pay O(n) per call.  dust_all / hardmask_all
+  // rewrite most sequences and are caught by the sample; an edit of one unsampled sequence is not -- an embedder that edits in
+  // place calls vsx_api_invalidate() (below), or sets VSX_API_FINGERPRINT=full (every byte hashed on every call).
+  static int fingerprint_mode()
+  {
+    static int const mode = [] {
+      char const * e = std::getenv("VSX_API_FINGERPRINT");
+      if (e == nullptr || std::strcmp(e, "sample") == 0) return 0;
+      if (std::strcmp(e, "full") == 0) return 1;
+      std::fprintf(stderr, "vsx adapter: VSX_API_FINGERPRINT=%s not understood (sample | full); using sample\n", e);
+      return 0;
+    }();
+    return mode;
+  }
   static uint64_t fingerprint(struct Database const & d)
   {
     uint64_t const n = d.getsequencecount();
     uint64_t h = 1469598103934665603ull;
     auto mix = [&h](void const * p, size_t bytes) {
       auto const * c = static_cast<unsigned char const *>(p);
-      for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+      size_t i = 0;
+      for (; i + 8 <= bytes; i += 8) { uint64_t w; std::memcpy(&w, c + i, 8); h ^= w; h *= 1099511628211ull; h ^= h >> 29; }
+      for (; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
     };
-    uint64_t total = 0, sizes = 0;
-    for (uint64_t i = 0; i < n; ++i) { total += d.getsequencelen(i); sizes += (uint64_t) d.getabundance(i); }
-    mix(&n, sizeof n); mix(&total, sizeof total); mix(&sizes, sizeof sizes);
-    uint64_t const step = n > 256 ? n / 256 : 1;
+    bool const full = fingerprint_mode() == 1;
+    mix(&n, sizeof n);
+    if (full || n <= 65536)
+      {
+        uint64_t total = 0, sizes = 0;
+        for (uint64_t i = 0; i < n; ++i) { total += d.getsequencelen(i); sizes += (uint64_t) d.getabundance(i); }
+        mix(&total, sizeof total); mix(&sizes, sizeof sizes);
+      }
+    uint64_t const spread = n > 65536 ? 1024 : 256;
+    uint64_t const step = full ? 1 : (n > spread ? n / spread : 1);
     for (uint64_t i = 0; i < n; i += step)
       {
         uint64_t const len = d.getsequencelen(i);
-        mix(&len, sizeof len);
+        uint64_t const size = (uint64_t) d.getabundance(i);
+        mix(&len, sizeof len); mix(&size, sizeof size);
         mix(d.getsequence(i), (size_t) len);
         mix(d.getheader(i), (size_t) d.getheaderlen(i));
       }
-    if (n) { uint64_t const len = d.getsequencelen(n - 1); mix(d.getsequence(n - 1), (size_t) len); }
+    if (n) { uint64_t const len = d.getsequencelen(n - 1); mix(&len, sizeof len); mix(d.getsequence(n - 1), (size_t) len); }
     return h;
   }
   bool ensure(struct Parameters const & p, struct Database const & d, bool clustering)
@@ -222,6 +248,9 @@ struct Fast {
 Fast g_search;            // search_batch is not re-entrant in the reference either (core/search.hpp:128)
 
 }  // namespace
+
+// for an embedder that edits the Database in place between batches: the next call rebuilds the device replica
+extern "C" void vsx_api_invalidate(void) { g_search.drop(); }
 
 
 auto search_batch(struct Parameters const & parameters, struct Dbindex const & dbindex, struct Database const & db,
