@@ -412,7 +412,8 @@ def _tilt_reach(P, Q, D):
 @pytest.mark.parametrize("name", ["default", "nmismatch", "zero_terminal", "uniform10_1"])
 def test_tilt_class_boundaries(gpu_required, oracle, name):
     """pairs on both sides of both thresholds of tilt_possible() -- reach < 15 800: MAX3 (values are fp16 bit patterns), < 32 000:
-    the 16-bit TILT class, beyond: plain coordinates -- under the four tilt-eligible scoring sets; the class each task took is read
+    the 16-bit TILT class, beyond: plain coordinates -- under the four tilt-eligible scoring sets (zero_terminal: no MAX3, its
+    right-end gap open is 0); the class each task took is read
     back through vsx_plan_describe, every field of every pair is compared with the oracle.  One query per task (all of a task's
     targets sit on the same side: the planner classifies a task by its longest target)."""
     from vsearch_amd import Aligner
@@ -428,6 +429,8 @@ def test_tilt_class_boundaries(gpu_required, oracle, name):
             while _tilt_reach(P, Q, D + 4) < limit:
                 D += 4
             for side, cls in ((0, below), (1, above)):
+                if cls == 2 and P[6] <= 0:
+                    cls = 1         # MAX3 needs a positive right-end gap open of the query (the kernel's last-row tracking): zero_terminal
                 q = common.rnd_seq(rng, Q)
                 k = len(qs)
                 qs.append(q)

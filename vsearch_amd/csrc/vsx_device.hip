@@ -382,6 +382,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       // INTERIOR (phase A of the strip, see the loops below): no lane of the wave has reached a last / padded column yet, so
       // the column penalties are the interior constants (not pipelined), H - QR is shared by E and F, no score capture.
       u32 pendH = 0, pendF = 0;                    // row checkpoint of the even step, stored together with the odd step's
+      u32 jpk_run = 0;                             // the column of this lane in both halves, carried by the steady loop
       u32 pendMH = 0, pendMF = 0, curMH = 0, curMF = 0;          // the same for the mid-row checkpoint (MIDCK)
       bool pend_on = false;
       // per-lane base addresses of this strip's checkpoint regions (computed once: the step only adds a uniform offset)
@@ -462,6 +463,12 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               // every row but R-1: 9 instead of 10 instructions per lane-row.
               auto rows = [&](auto shared_tag) __attribute__((always_inline)) {
               constexpr bool SHARED = decltype(shared_tag)::value;
+              // LASTFAST (r04): in the last query row "left" implies "ext-left" when its gap-open penalty is positive -- E > max(h0, F)
+              // makes H = E, and then (E - R) - (H - QR) = QR - R = go > 0 -- so `cont` of the leave-column tracking is the sign of
+              // he - e alone: no h1 of its own (the row takes the three-way maximum like the others), no h1 - E, no OR.  The planner
+              // admits a pair to the MAX3 class only with go_q(right end) > 0 (vsx_host.cpp tilt_possible()); phase B needs
+              // left(D - 1) by itself and keeps the long form.
+              constexpr bool LASTFAST = MAX3 && SHARED && CKPT;
 #pragma unroll
               for (int r = 0; r < R; ++r)
                 {
@@ -506,9 +513,11 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   else V = a_pk_mad(a_pk_minu(ac[r] ^ code, 0x00010001u), nd, P.match_pk);
                   // onestep (:765-780)
                   const u32 h0 = vadd(Hd, V);
-                  // (row R-1 keeps the two-step maximum: the leave-column tracking needs h1 = max(h0, F) on its own)
-                  const u32 h1 = (MAX3 && r < R - 1) ? 0u : vmax(h0, F);
-                  h2 = (MAX3 && r < R - 1) ? pk_max3_bits(h0, F, E[r]) : vmax(h1, E[r]);
+                  // (row R-1 keeps the two-step maximum where the leave-column tracking needs h1 = max(h0, F) on its own: the steps of
+                  //  phase B.  In the interior steps of the MAX3 class the tracking reads ext-left alone -- LASTFAST below)
+                  const bool ONE_MAX = MAX3 && (r < R - 1 || LASTFAST);     // (folds after unrolling)
+                  const u32 h1 = ONE_MAX ? 0u : vmax(h0, F);
+                  h2 = ONE_MAX ? pk_max3_bits(h0, F, E[r]) : vmax(h1, E[r]);
                   if (TRACK) { smn = pmin(smn, h2); smx = pmax(smx, h2); }
                   Hd = hin[r];
                   hout[r] = h2;
@@ -518,7 +527,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   const u32 hf = (SHARED && r < R - 1) ? he : vsub(h2, qrt);
                   const u32 f = (TILT && INTERIOR) ? F : vsub(F, rt);                      // tilted interior: R' = 0
                   const u32 e = (TILT && INTERIOR && r < R - 1) ? E[r] : vsub(E[r], rq);   // (row R-1 may be the query's last row)
-                  if (CKPT && r == R - 1) { lastL = vsub(h1, E[r]); lastEL = vsub(he, e); }     // the last row's left / ext-left diffs
+                  if (CKPT && r == R - 1) { lastL = LASTFAST ? 0u : vsub(h1, E[r]); lastEL = vsub(he, e); }     // the last row's left / ext-left diffs
                   if (!CKPT)
                     {
                       const u32 dU = ssub(h0, F);          // sign <=> F > H      (up)
@@ -546,13 +555,15 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               diag = inH;
               if (CKPT)
                 {
-                  const u32 jpk = (u32) j | ((u32) j << 16);
+                  // (the steady loop carries j in both halves along: one add per step instead of forming it from t and the lane)
+                  const u32 jpk = STEADY ? jpk_run : ((u32) j | ((u32) j << 16));
+                  if (STEADY) jpk_run += 0x00010001u;
                   if (!INTERIOR)
                     {
                       const u32 atlast = a_pk_ashr15(sym << 7);               // bit 8 (column == D-1)
                       leave = a_bfi_v(atlast, a_bfi_v(a_pk_ashr15(lastL), lv1, jpk), leave);
                     }
-                  lv1 = a_bfi_v(a_pk_ashr15(lastL | lastEL), lv1, jpk);
+                  lv1 = a_bfi_v(a_pk_ashr15((MAX3 && INTERIOR) ? lastEL : (lastL | lastEL)), lv1, jpk);
                 }
 
               // per-block h_min/h_max tracking incl. padded columns (:772-773, :1774-1786), gated per half
@@ -726,7 +737,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                                                               //  The transposed checkpoint stores need EVERY lane of the wave in
                                                               //  the step -- each copies its share of the staging block -- so
                                                               //  there the lanes of empty groups run along on junk)
-        for (; t < t_switch; t += 2)
+        for (jpk_run = (u32) (t - l) * 0x00010001u; t < t_switch; t += 2)
           {
             step(t, hprev, hnext, profA, profB, std::true_type {}, std::false_type {}, std::true_type {});
             step(t + 1, hnext, hprev, profB, profA, std::true_type {}, std::true_type {}, std::true_type {});

@@ -951,7 +951,10 @@ static int tilt_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
     if (k < 6) G = std::max<int64_t>(G, ctx->pen[k]); else B = std::max<int64_t>(B, ctx->pen[k]);
   const int64_t Dp = (D + 3) & ~3ll;
   const int64_t reach = 4 * G + 2 * (Q + Dp + 64) * B;          // |value| of anything the kernel forms stays below this
-  if (reach < 15800 && !max3_off && !VSX_CKT && g_max3_state[ctx->device & 63].load(std::memory_order_relaxed) != 2) return 2;         // 0x3E00 = 15872 each way inside [0, 0x7BFF]
+  // (pen[4] = the query's right-end gap open: the MAX3 kernel's interior steps read "the last row continues to the left" off ext-left
+  //  alone, which covers "left" only when that penalty is positive -- vsx_forward_kernel LASTFAST; the reference's default is 1)
+  if (reach < 15800 && !max3_off && !VSX_CKT && ctx->pen[4] > 0 &&
+      g_max3_state[ctx->device & 63].load(std::memory_order_relaxed) != 2) return 2;         // 0x3E00 = 15872 each way inside [0, 0x7BFF]
   return reach < 32000 ? 1 : 0;
 }
 
