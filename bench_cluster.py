@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--len", type=int, default=300)
     ap.add_argument("--round", type=int, default=0, help="sequences per GPU round; 0 = the library default (16384)")
     ap.add_argument("--id", type=float, default=0.97)
+    ap.add_argument("--rounds", default="", help="A/B: comma-separated round sizes, one vsx_cluster_fast call each on the same searcher "
+                                                 "(one short JSON line per call on stderr; the first one is cold, the others find the pools warm)")
     ap.add_argument("--parity-prefix", type=int, default=30000,
                     help="cross-check the S/H records of the first N sequences against the reference CLI run on that prefix (0 = skip)")
     a = ap.parse_args()
@@ -58,6 +60,14 @@ def main():
         check(lib.vsx_searcher_create(al.h, C.byref(h), C.byref(o), len(lens), C.cast(C.c_char_p(blob), C.c_void_p),
                                       len(blob), vp(offs), vp(lens)), "vsx_searcher_create")
         try:
+            for r_ in [int(x) for x in a.rounds.split(",") if x]:
+                o2 = _lib.ClusterOut()
+                t0 = time.perf_counter()
+                check(lib.vsx_cluster_fast(h, r_, C.byref(o2)), "vsx_cluster_fast")
+                w2 = time.perf_counter() - t0
+                print(json.dumps({"round": r_, "wall_s": round(w2, 3), "clusters": int(o2.n_clusters), "stages": int(o2.hits.stages),
+                                  "pairs_aligned": int(o2.hits.pairs_aligned)}), file=sys.stderr, flush=True)
+                lib.vsx_cluster_out_free(C.byref(o2))
             out = _lib.ClusterOut()
             t0 = time.perf_counter()
             check(lib.vsx_cluster_fast(h, a.round, C.byref(out)), "vsx_cluster_fast")
