@@ -732,11 +732,13 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           step(t, hprev, hnext, profA, profB, std::true_type {}, std::false_type {}, std::false_type {});
           step(t + 1, hnext, hprev, profB, profA, std::true_type {}, std::true_type {}, std::false_type {});
         }
-      if (!TRACK && (CKST || Dpg > 0))                                // (a group without targets never becomes active; with overflow
-                                                              //  tracking the junk of the idle lanes would reach the min/max.
-                                                              //  The transposed checkpoint stores need EVERY lane of the wave in
-                                                              //  the step -- each copies its share of the staging block -- so
-                                                              //  there the lanes of empty groups run along on junk)
+      if (!TRACK)                                             // (with overflow tracking the junk of idle lanes would reach the min/max.
+                                                              //  The lanes of a group WITHOUT targets run along on junk -- r04: skipping
+                                                              //  the loop for them made the step counter divergent, and those lanes then
+                                                              //  walked phase B's loop over the whole step range on their own after the
+                                                              //  others had finished: a task with fewer than 7 of its 8 targets took 2.3 x
+                                                              //  the time of a full one, profiles/r04/r04w_uniform_steps_ab.txt.  Their
+                                                              //  stores land in their own, unread checkpoint slots)
         for (jpk_run = (u32) (t - l) * 0x00010001u; t < t_switch; t += 2)
           {
             step(t, hprev, hnext, profA, profB, std::true_type {}, std::false_type {}, std::true_type {});
