@@ -1,7 +1,8 @@
 #!/bin/bash
-# profiles/ab_uni.sh -- same-box A/B of the "uniform step counter" DP build (experiments/dp_uniform_steps.patch -> vsearch_amd/libvsx_uni.so)
-# against libvsx.so on a partial-task workload (5 candidates per query: every task has an empty target group), on the bench shape, and
-# the parity tests of the aligner on the variant.  Evidence for the next round; the variant is not the shipped library.
+# profiles/ab_uni.sh -- how profiles/r04/r04w_uniform_steps_ab.txt was measured: same-box A/B of a library whose DP kernel lets every lane
+# run the steady loop (vsearch_amd/libvsx_uni.so: vsx_device.hip with that one condition changed, linked with the other objects of the
+# default build) against libvsx.so of commit 04baad9, on a partial-task workload (5 candidates per query: every task has an empty
+# target group) and on the bench shape, plus the aligner's parity tests on the variant.  The change is in the sources since 0254dd2.
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/r04w_uni
