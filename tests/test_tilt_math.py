@@ -90,3 +90,37 @@ def test_tilted_recurrence_is_the_same_alignment(seed, oracle):
             for j in range(D):
                 assert lo <= dF[i][j] <= hi, (i, j, dF[i][j], lo, hi)
                 assert lo <= dE[i][j] <= hi, (i, j, dE[i][j], lo, hi)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_last_row_left_implies_ext_left_with_positive_open(seed):
+    """What the MAX3 class's interior steps rely on (vsx_forward_kernel LASTFAST): along the LAST query row the
+    traceback's "the I run continues through column j" is left(j) or ext-left(j); with a positive gap open of the query's right end
+    left implies ext-left, so ext-left alone decides -- in plain and in tilted coordinates.  With a zero open the implication fails
+    (the planner keeps such scorings out of the class, vsx_host.cpp tilt_possible()): the test shows a counter-example exists."""
+    rng = random.Random(1000 + seed)
+    counter_examples = 0
+    for _ in range(60):
+        g = rng.choice([1, 2, 3])
+        pen = {"ge_q_i": g, "ge_t_i": g}
+        pen["go_q_i"] = pen["go_t_i"] = rng.choice([3, 10, 18])
+        for side in "qt":
+            for end in "lr":
+                pen[f"go_{side}_{end}"] = rng.choice([0, 1, 2, 20])
+                pen[f"ge_{side}_{end}"] = rng.choice([0, 1, 2, 4])
+        match, mismatch = rng.choice([(2, -4), (1, -2)])
+        if min(match, mismatch) + 2 * g < 0:
+            continue
+        Q, D = rng.randint(1, 24), rng.randint(2, 60)
+        q = [rng.choice("ACGT") for _ in range(Q)]
+        t = [rng.choice("ACGT") for _ in range(D)]
+        for tilt in (False, True):
+            _, bits, _, _ = _dp(q, t, match, mismatch, pen, tilt=tilt)
+            for j in range(D):
+                _, left, _, ext_left = bits[Q - 1][j]
+                if pen["go_q_r"] > 0:
+                    assert (not left) or ext_left, (pen, Q, D, j, tilt)
+                    assert (left or ext_left) == ext_left
+                elif left and not ext_left:
+                    counter_examples += 1
+    assert counter_examples > 0
