@@ -71,6 +71,14 @@ def row_body_instructions(info):
     return ((rows - 1) * 7.0 + 9.5) / rows
 
 
+def sparse_nq(info):
+    """tasks per wave of the dominant launch as vsx_plan_describe lets it be seen: 1 unless most tasks sit in a sparse-task class"""
+    if 2 * info.get("tasks_sparse", 0) < info["tasks"]:
+        return 1
+    w = max(1, info.get("waves", info["tasks"]))
+    return 4 if info["tasks"] / w > 3.0 else 2
+
+
 KERNEL_SOURCES = ("vsearch_amd/csrc/vsx_device.hip", "vsearch_amd/csrc/vsx_internal.h", "vsearch_amd/csrc/vsx_tbtext.hip")
 
 
@@ -340,7 +348,7 @@ def main():
             "cells_per_step_per_gpu": cells,
         },
         "roofline": {
-            "kernel": (f"vsx_forward_kernel<{info['rows_dominant']},true,false,true,true,{'true' if max3 else 'false'}>" if tilted
+            "kernel": (f"vsx_forward_kernel<{info['rows_dominant']},true,false,true,true,{'true' if max3 else 'false'},{sparse_nq(info)}>" if tilted
                        else f"vsx_forward_kernel<{info['rows_dominant']},true,...>"),
             "bound": "valu-issue",
             "achieved": round(achieved, 3),
@@ -426,7 +434,8 @@ def main():
         try:
             out["search_end_to_end"] = search_end_to_end(a, al, db_ascii, db_off, db_len, q_ascii, q_off, q_len)
         except Exception as e:
-            out["search_end_to_end"] = {"error": repr(e)}
+            import traceback
+            out["search_end_to_end"] = {"error": repr(e), "traceback": traceback.format_exc()[-1500:]}
     if not a.kernels_only and not a.no_shapes and world == 1:
         try:
             plan.close()

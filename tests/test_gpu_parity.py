@@ -334,18 +334,20 @@ def test_chunked_plan_equals_single_chunk(gpu_required, oracle):
 @pytest.mark.parametrize("env", [
     {"VSX_TRACEBACK": "dirs"}, {"VSX_TB_ARITH": "packed"}, {"VSX_SCORE": "arith"}, {"VSX_NO_SHARE_SUB": "1"}, {"VSX_ROWS": "4"},
     {"VSX_TILT": "0"}, {"VSX_TILT": "0", "VSX_ROWS": "4"}, {"VSX_MAX3": "0"}, {"VSX_MAX3": "0", "VSX_ROWS": "4"},
+    {"VSX_SPARSE": "0"}, {"VSX_SPARSE": "0", "VSX_MAX3": "0"},
 ], ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_kernel_modes(gpu_required, env):
     """the A/B switches of DESIGN.md section 8 select other kernel variants (stored direction bits, saturating packed traceback,
     table-free scores, unshared subtraction, many strips, plain instead of tilted coordinates, the 16-bit TILT class instead of its
-    MAX3 sub-class -- r02's default, which the fixtures otherwise reach only for 1 900 < Q + D < 3 900): each must reproduce the golden vectors and the torture slice"""
+    MAX3 sub-class -- r02's default, which the fixtures otherwise reach only for 1 900 < Q + D < 3 900; r05: every task a whole wave --
+    the golden fixtures are one-target tasks, which by default share their waves four at a time): each must reproduce the golden vectors and the torture slice"""
     import subprocess
     import sys
     e = dict(os.environ)
     e.update(env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q",
-                        "-k", "golden or torture or multi_strip or reference_batch"], env=e, capture_output=True, text=True,
+                        "-k", "golden or torture or multi_strip or reference_batch or sparse_task"], env=e, capture_output=True, text=True,
                        timeout=600, cwd=root)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
 
@@ -482,3 +484,63 @@ def test_sparse_kernel_class_joins_the_dense_one(gpu_required, oracle):
     assert tm.forward_launches == 2, tm.forward_launches          # the dense class (with the three promoted queries) + the 12-symbol query
     for k in list(range(0, 400, 37)) + [400, 401, 402, 403]:
         assert res.row(k) == tuple(oracle.align(qs[k], ts[k])), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["default", "nmismatch", "zero_terminal", "uniform10_1", "distinct12"])
+def test_sparse_task_classes(gpu_required, oracle, name):
+    """r05: tasks of <= 2 / <= 4 targets share a wave four / two at a time (vsx_forward_kernel NQ).  Queries of many lengths (several
+    row classes, IUPAC symbols, one longer than a strip: never sparse) with 1 .. 7 targets each, the targets of wildly different
+    lengths -- so the sub-tasks of a wave have different step ranges, the interior phase ends early for all of them, and the last wave
+    of a launch is partly empty -- under the tilt-eligible scoring sets (MAX3 and the 16-bit TILT class) and one that is not (no
+    sparse class there).  Every field of every pair against the oracle; the class counts are read back through vsx_plan_describe."""
+    from vsearch_amd import Aligner
+    doc = common.load_golden()
+    sc = doc["scorings"][name]
+    P, nmm = sc["P"], sc["n_mismatch"]
+    import zlib
+    rng = random.Random(zlib.crc32(name.encode()) ^ 0x5A5A)
+    qs, ts, qi, ti = [], [], [], []
+    ntargets = []
+    for rep in range(3):
+        for Q in (40, 63, 64, 97, 150, 160, 250, 256, 300, 333, 420, 512, 530):
+            q = common.rnd_seq(rng, Q, common.IUPAC + "ACGT" * 6) if rng.random() < 0.25 else common.rnd_seq(rng, Q)
+            k = len(qs)
+            qs.append(q)
+            n = 1 + (k % 7)
+            ntargets.append(n)
+            for x in range(n):
+                shape = rng.random()
+                if shape < 0.3:
+                    t = common.mutate(rng, q, 0.08)[:max(1, rng.randint(1, Q))]                    # a prefix: shorter than the query
+                elif shape < 0.6:
+                    t = common.rnd_seq(rng, rng.randint(0, 300)) + common.mutate(rng, q, 0.1) + common.rnd_seq(rng, rng.randint(0, 700))
+                elif shape < 0.8:
+                    t = common.rnd_seq(rng, rng.randint(1, 24))                                      # a few symbols: the wave's t_switch
+                else:
+                    t = common.mutate(rng, q, 0.3, "ACGTN")
+                qi.append(k)
+                ti.append(len(ts))
+                ts.append(t)
+    qi = np.array(qi, np.uint32)
+    ti = np.array(ti, np.uint32)
+    with Aligner(scoring=P, n_mismatch=nmm) as al:
+        Qs, Ts = al.sequences(qs), al.sequences(ts)
+        p = al.plan(Qs, Ts, qi, ti)
+        info = p.describe()
+        p.run()
+        res = p.fetch()
+        p.close()
+        Qs.close()
+        Ts.close()
+    if os.environ.get("VSX_SPARSE") == "0" or os.environ.get("VSX_TILT") == "0" or os.environ.get("VSX_TRACEBACK") == "dirs" \
+            or os.environ.get("VSX_TB_ARITH") == "packed" or os.environ.get("VSX_SCORE") == "arith" or os.environ.get("VSX_ROWS"):
+        pass                                   # (re-run by test_alternate_kernel_modes: other classes, same results)
+    elif info["tasks_tilted"] == 0:
+        assert info["tasks_sparse"] == 0 and info["waves"] == info["tasks"], info
+    else:
+        # every query of at most 512 symbols with <= 4 targets whose task took the TILT family is a sparse task
+        assert info["tasks_sparse"] > 0 and info["waves"] < info["tasks"], info
+        assert info["tasks_sparse"] <= sum(1 for k, n in enumerate(ntargets) if n <= 4 and len(qs[k]) <= 512), info
+    for k in range(len(qi)):
+        assert res.row(k) == tuple(oracle.align(qs[qi[k]], ts[ti[k]], P, nmm)), (name, k, len(qs[qi[k]]), len(ts[ti[k]]))

@@ -591,17 +591,3 @@ def test_bench_dry_collectives_world2_gloo():
     assert d["dry_collectives"] == {"gather_results_to_rank0": True, "fixed_gather_async_incl_one_rank_overflow": True, "fixed_gather_sync_steps": 1}, d
     assert d["rccl"]["world"] == 2 and d["rccl"]["backend"] == "gloo" and d["rccl"]["device_of_rank"] == [0, 0]
 
-
-def test_prepared_experiments_still_apply():
-    """experiments/*.patch are kernel changes that were compiled and read in the ISA but never run (experiments/README.md); they must at
-    least keep applying to the sources they were written against, or say so here."""
-    import glob
-    import shutil
-    import subprocess
-    if shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")):
-        pytest.skip("no git checkout here")
-    patches = sorted(glob.glob(os.path.join(ROOT, "experiments", "*.patch")))
-    assert patches
-    for p in patches:
-        r = subprocess.run(["git", "apply", "--check", p], cwd=ROOT, capture_output=True, text=True)
-        assert r.returncode == 0, (os.path.basename(p), r.stderr[-500:])

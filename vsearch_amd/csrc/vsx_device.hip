@@ -126,6 +126,10 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // spills: measured better than 3 without), 3 up to R = 24 (168 VGPRs; r03: the allocator left to itself took 244 = 2 waves,
 // 300 x 300: 12.23 -> 11.17 ms, 360 x 360: 15.9 -> 15.0 ms; 4 waves at R = 18 / 20: 12.7 ms), 2 beyond (256 VGPRs; 3 there
 // spills into the loop: 500 x 500 25.5 -> 30.8 ms) -- profiles/r03/r03c_occupancy_ab.txt.  A/B builds override VSX_FWD_WAVES
+// FEED2 (r05, prepared in r04 as experiments/dp_feed2.patch): the feed record of the look-ahead classes, see vsx_forward_kernel
+#ifndef VSX_FEED2
+#define VSX_FEED2 0
+#endif
 #ifndef VSX_FWD_WAVES
 #define VSX_FWD_WAVES(R_, TILT_) ((R_) <= 16 ? 4 : ((R_) <= 24 ? 3 : 2))
 #endif
@@ -143,11 +147,24 @@ DEV u32 pk_max3_bits(u32 a, u32 b, u32 c)            // IEEE maximum of three: t
   const f16x2 x = __builtin_bit_cast(f16x2, a), y = __builtin_bit_cast(f16x2, b), z = __builtin_bit_cast(f16x2, c);
   return __builtin_bit_cast(u32, __builtin_elementwise_maximum(__builtin_elementwise_maximum(x, y), z));
 }
-template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false, bool MAX3 = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VSX_FWD_WAVES(R, TILT), 8)))
+// NQ (r05, the SPARSE-TASK classes of the TILT family): a wave works on NQ = 2 or 4 TASKS at once -- sub-task u = lane groups
+// u * (4 / NQ) .. of the wave, i.e. a task of <= 4 (NQ = 2) or <= 2 (NQ = 4) targets whose targets sit in its first slots.  The
+// reference refills its 8 SIMD lanes with new targets as old ones finish (align_simd.cpp:1823-1946); here a task was one wave whatever
+// the number of its targets (a query with 1 candidate paid for 8: VERDICT r04 missing 3).  Everything a task owns stays per task --
+// VsxTask, its checkpoint block (slots l * 4 + group-in-task, as the traceback expects: the traceback kernels do not know about NQ),
+// its VsxSlotOut entries -- so the only wave-level quantities are the step range (the longest sub-task) and t_switch (the shortest
+// target).  Each sub-task has its own LDS profile (NQ x 256 RP bytes), which is what bounds the occupancy of these classes
+// (VSX_FWD_WAVES_NQ); single-strip queries only (the planner's job, vsx_host.cpp).  Sub-tasks beyond `ntasks` (the last wave of a
+// launch) and the steps of a sub-task beyond its own range store nothing.
+#ifndef VSX_FWD_WAVES_NQ
+#define VSX_FWD_WAVES_NQ(R_, NQ_) ((NQ_) == 4 ? 2 : ((R_) <= 24 ? 3 : 2))
+#endif
+DEV int wave_max_i32(int v);
+template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false, bool MAX3 = false, int NQ = 1>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? VSX_FWD_WAVES(R, TILT) : VSX_FWD_WAVES_NQ(R, NQ), 8)))
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
-                   u32 * __restrict__ dir, uint2 * strip, VsxSlotOut * __restrict__ slot_out)
+                   u32 * __restrict__ dir, uint2 * strip, VsxSlotOut * __restrict__ slot_out, const u32 ntasks)
 {
   constexpr int ND = (R + 3) / 4;                  // direction dwords per lane per step
   // TOPPAD: pipeline position 0 holds fewer than R query rows.  In this class its spare slots sit ABOVE the real rows and
@@ -184,7 +201,10 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   constexpr bool QPL = TILT && (VSX_QPL != 0);      // byte profile, read one step ahead
   constexpr bool QP8 = CKST || QPL;
   constexpr int RP = (R + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) int16_t QP[GENERIC ? (QP8 ? (16 * 16 * RP) / 2 : 16 * 16 * R) : 8];
+  static_assert(NQ == 1 || NQ == 2 || NQ == 4, "tasks per wave");
+  static_assert(NQ == 1 || (TILT && VSX_QPL != 0 && !VSX_CKT), "the sparse-task classes exist for the look-ahead TILT kernels only");
+  constexpr int QPBYTES = 16 * 16 * RP;              // one byte profile
+  __shared__ __attribute__((aligned(16))) int16_t QP[GENERIC ? (QP8 ? (NQ * QPBYTES) / 2 : 16 * 16 * R) : 8];
   uint8_t * const QPb = reinterpret_cast<uint8_t *>(QP);
   // checkpoint staging of the transposed layout: [slot][12 dwords]
   __shared__ __attribute__((aligned(16))) u32 RS[CKST ? 64 * 12 : 4];
@@ -192,21 +212,33 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   // steps by the 16 lanes of a group, read back one column per step for lane 0 (replaces five v_mov_b32_dpp row_ror rotations)
   __shared__ uint4 FEED4[(TILT && VSX_QPL ? 2 : 1) * 4 * 16];         // QPL: two blocks (the next one is built a step early)
   __shared__ u32 FEEDF[(TILT && VSX_QPL ? 2 : 1) * 4 * 16], FEEDN[GENERIC ? 1 : 4 * 16];
+  // FEED2 (the classes with the look-ahead byte profile): the record of a column is (byte offsets of the two targets' profile rows in
+  // the halves of one dword, symbols + flags, H, F) -- an interior step reads H and F of its column and the offsets of the next column
+  // from three neighbouring dwords, and the profile addresses are two adds -- and (QR_t, R_t) live in a second array for phase B
+  constexpr bool FEED2 = (VSX_FEED2 != 0) && TOPPAD && (TILT && (VSX_QPL != 0));
+  __shared__ uint2 FEEDB[FEED2 ? 2 * 4 * 16 : 1];
 
-  const VsxTask & T = tasks[blockIdx.x];
   const int lane = (int) threadIdx.x;
-  const int g = lane >> 4;
+  const int gw = lane >> 4;                        // lane group of the wave
+  constexpr int GPT = 4 / NQ;                      // lane groups per task
+  const int sq = (NQ == 1) ? 0 : gw / GPT;         // this lane's sub-task
+  const int g = (NQ == 1) ? gw : gw % GPT;         // its group inside the task (targets 2g, 2g + 1; checkpoint slot l * 4 + g)
   const int l = lane & 15;
+  const u32 tix = (NQ == 1) ? blockIdx.x : blockIdx.x * (u32) NQ + (u32) sq;
+  const bool sub_on = (NQ == 1) ? true : (tix < ntasks);
+  const VsxTask & T = tasks[sub_on ? tix : ntasks - 1];
+  uint8_t * const QPl = reinterpret_cast<uint8_t *>(QP) + ((NQ == 1) ? 0 : sq * QPBYTES);      // this lane's profile
 
   const int Q = (int) T.qlen;
   const int total_lanes = (Q + R - 1) / R;         // pipeline positions holding query rows
   const int rcnt0 = Q - (total_lanes - 1) * R;     // rows in position 0 (1..R); all others hold R
   const int rc0 = __builtin_amdgcn_readfirstlane(rcnt0);   // provably scalar: keeps the per-row capture test on the SALU
-  const int nstrips = (total_lanes + 15) >> 4;
-  const int steps = (int) T.steps;
+  const int nstrips = (NQ == 1) ? (total_lanes + 15) >> 4 : 1;
+  const int steps_own = (int) T.steps;             // the range of THIS task's checkpoint regions
+  const int steps = (NQ == 1) ? steps_own : __builtin_amdgcn_readfirstlane(wave_max_i32(sub_on ? steps_own : 0));   // the wave's loop
 
-  const int DA = (int) T.tlen[2 * g];
-  const int DB = (int) T.tlen[2 * g + 1];
+  const int DA = sub_on ? (int) T.tlen[2 * g] : 0;
+  const int DB = sub_on ? (int) T.tlen[2 * g + 1] : 0;
   const int DpA = (DA + 3) & ~3;                   // the reference pads the last 4-column block
   const int DpB = (DB + 3) & ~3;
   const int Dpg = DpA > DpB ? DpA : DpB;
@@ -235,7 +267,9 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           __syncthreads();                           // previous strip's readers are done
           if (QP8)
             {
-              for (int idx = lane; idx < 16 * 16 * RP; idx += 64)
+              // (NQ > 1: the 64 / NQ lanes of a sub-task fill THEIR profile from their own task's query)
+              constexpr int LPT = 64 / NQ;
+              for (int idx = (NQ == 1) ? lane : lane % LPT; idx < 16 * 16 * RP; idx += LPT)
                 {
                   const int code = idx / (16 * RP), row = idx % (16 * RP);
                   const int Lr = 16 * s + row / RP, rr = row % RP;
@@ -249,7 +283,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                           v = P.matrix[code * 16 + (int) qq[gi]];
                         }
                     }
-                  QPb[idx] = (uint8_t) v;
+                  QPl[idx] = (uint8_t) v;
                 }
             }
           else
@@ -302,14 +336,16 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       const u32 rq_last = lastpos ? P.rq_r_pk : P.rq_i_pk;
 
       // ---- column pipeline ----
-      u32 sym = 0, nd = 0, qrt = 0, rt = 0;        // this lane's current column descriptor
+      u32 sym = 0, nd = 0, qrt = 0, rt = 0;        // this lane's current column descriptor (FEED2: sym = the profile byte offsets)
+      u32 symf = 0;                                // FEED2: symbols + flags of the column, shifted along in phase B only (no column in
+                                                   // flight at the switch is a last column: 0 is what every lane would hold)
       u32 outH = 0, outF = 0;                      // H(bottom row, j), F(bottom row + 1, j)
       u32 f_sym = 0, f_nd = 0, f_qrt = 0, f_rt = 0, f_H = 0, f_F = 0;   // 16-column feed block
       u32 rawA = 0, rawB = 0;
       int rawH = 0;
       uint2 rawS = make_uint2(0, 0);
-      const uint2 * strip_in = strip + T.strip_off + (size_t) (((s + 1) & 1) * 4 + g) * (size_t) steps;
-      uint2 * strip_outp = strip + T.strip_off + (size_t) ((s & 1) * 4 + g) * (size_t) steps;
+      const uint2 * strip_in = strip + T.strip_off + (size_t) (((s + 1) & 1) * 4 + g) * (size_t) steps_own;
+      uint2 * strip_outp = strip + T.strip_off + (size_t) ((s & 1) * 4 + g) * (size_t) steps_own;
 
       auto prefetch = [&](int blk) {
         const int c = 16 * blk + l;
@@ -351,9 +387,18 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   f_F = rawS.y;
                 }
               const int fo = QPL ? (blk & 1) * 64 : 0;
-              FEED4[fo + g * 16 + l] = make_uint4(f_sym, f_qrt, f_rt, f_H);
-              FEEDF[fo + g * 16 + l] = f_F;
-              if (!GENERIC) FEEDN[g * 16 + l] = f_nd;
+              if (FEED2)
+                {
+                  const u32 f_off = rawA * (u32) (16 * RP) | ((rawB * (u32) (16 * RP)) << 16);      // QPb[code][16 positions][RP] bytes
+                  FEED4[fo + gw * 16 + l] = make_uint4(f_off, f_sym, f_H, f_F);
+                  FEEDB[fo + gw * 16 + l] = make_uint2(f_qrt, f_rt);
+                }
+              else
+                {
+                  FEED4[fo + gw * 16 + l] = make_uint4(f_sym, f_qrt, f_rt, f_H);
+                  FEEDF[fo + gw * 16 + l] = f_F;
+                }
+              if (!GENERIC) FEEDN[gw * 16 + l] = f_nd;
               prefetch(blk + 1);
       };
       // QPL: byte profile rows of BOTH targets for one step, in registers ([target][4 rows per dword]); two sets ping-pong with
@@ -363,20 +408,56 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       u32 profA[2][QPL ? PD : 1], profB[2][QPL ? PD : 1];
       auto load_profile = [&](u32 (&buf)[2][QPL ? PD : 1], u32 sy) __attribute__((always_inline)) {
         const u32 cd = sy & 0x000F000Fu;
-        const u32 * a = reinterpret_cast<const u32 *>(QPb + (cd & 0xFu) * (16 * RP) + l * RP);
-        const u32 * b = reinterpret_cast<const u32 *>(QPb + (cd >> 16) * (16 * RP) + l * RP);
+        // (the offsets are multiples of 16 RP: the rows keep the alignment of l RP, which the compiler cannot see through the feed --
+        //  so the FEED2 form spells the wide LDS reads out)
+        constexpr int QPA = (RP % 16 == 0) ? 16 : ((RP % 8 == 0) ? 8 : 4);
+        if (FEED2)
+          {
+            const uint8_t * pa = QPl + l * RP + (sy & 0xFFFFu);
+            const uint8_t * pb = QPl + l * RP + (sy >> 16);
+            constexpr int PDN = QPL ? PD : 1;
+            if constexpr (QPA == 16)
+              {
+#pragma unroll
+                for (int k = 0; k < PDN; k += 4)
+                  {
+                    const uint4 va = *reinterpret_cast<const uint4 *>(pa + 4 * k), vb = *reinterpret_cast<const uint4 *>(pb + 4 * k);
+                    buf[0][k] = va.x; buf[0][k + 1] = va.y; buf[0][k + 2] = va.z; buf[0][k + 3] = va.w;
+                    buf[1][k] = vb.x; buf[1][k + 1] = vb.y; buf[1][k + 2] = vb.z; buf[1][k + 3] = vb.w;
+                  }
+              }
+            else if constexpr (QPA == 8)
+              {
+#pragma unroll
+                for (int k = 0; k < PDN; k += 2)
+                  {
+                    const uint2 va = *reinterpret_cast<const uint2 *>(pa + 4 * k), vb = *reinterpret_cast<const uint2 *>(pb + 4 * k);
+                    buf[0][k] = va.x; buf[0][k + 1] = va.y;
+                    buf[1][k] = vb.x; buf[1][k + 1] = vb.y;
+                  }
+              }
+            else
+              {
+#pragma unroll
+                for (int k = 0; k < PDN; ++k)
+                  { buf[0][k] = reinterpret_cast<const u32 *>(pa)[k]; buf[1][k] = reinterpret_cast<const u32 *>(pb)[k]; }
+              }
+            return;
+          }
+        const u32 * a = reinterpret_cast<const u32 *>(QPl + (cd & 0xFu) * (16 * RP) + l * RP);
+        const u32 * b = reinterpret_cast<const u32 *>(QPl + (cd >> 16) * (16 * RP) + l * RP);
 #pragma unroll
         for (int k = 0; k < (QPL ? PD : 1); ++k) { buf[0][k] = a[k]; buf[1][k] = b[k]; }
       };
       if (QPL)
         {
           build_feed(0);
-          sym = dpp_shr1(FEED4[g * 16].x, 0u);           // the symbols of step 0
+          sym = dpp_shr1(FEED4[gw * 16].x, 0u);           // the symbols of step 0
           load_profile(profA, sym);
         }
 
-      const uint4 * const feed4_g = FEED4 + g * 16;
-      const u32 * const feedf_g = FEEDF + g * 16;
+      const uint4 * const feed4_g = FEED4 + gw * 16;
+      const u32 * const feedf_g = FEEDF + gw * 16;
       // one pipeline step; reads the left-neighbour row state from hin[] and writes hout[] (the caller ping-pongs the two
       // arrays over an even number of steps, so no per-step register copies remain)
       // INTERIOR (phase A of the strip, see the loops below): no lane of the wave has reached a last / padded column yet, so
@@ -386,19 +467,19 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       u32 pendMH = 0, pendMF = 0, curMH = 0, curMF = 0;          // the same for the mid-row checkpoint (MIDCK)
       bool pend_on = false;
       // per-lane base addresses of this strip's checkpoint regions (computed once: the step only adds a uniform offset)
-      const size_t ck_rowdw = ((((size_t) nstrips * steps + 1) & ~(size_t) 1) >> 1) * VSX_ROWCK_PAIR_DW(TILT);
-      const size_t ck_nblk = ((size_t) steps + 15) >> 4;
+      const size_t ck_rowdw = ((((size_t) nstrips * steps_own + 1) & ~(size_t) 1) >> 1) * VSX_ROWCK_PAIR_DW(TILT);
+      const size_t ck_nblk = ((size_t) steps_own + 15) >> 4;
       constexpr int CK_LANE_DW = TILT ? 3 : 4;                                                                     // row checkpoint dwords per lane and pair
       constexpr size_t CK_COL_DW = TILT ? (size_t) 64 * 4 * VSX_COLCK_NB(R, true) : (size_t) 64 * (2 * R);           // column checkpoint dwords per wave
       const int ck_slot = VSX_CK_SLOT(TILT, g, l);
-      u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps) >> 1) * 64 + ck_slot) * CK_LANE_DW;         // + (t >> 1) * VSX_ROWCK_PAIR_DW
+      u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps_own) >> 1) * 64 + ck_slot) * CK_LANE_DW;         // + (t >> 1) * VSX_ROWCK_PAIR_DW
       u32 * const cck_base = dir + T.dir_off + ck_rowdw + (size_t) s * ck_nblk * CK_COL_DW;                        // + (t >> 4) * CK_COL_DW
       // mid-row checkpoints: a third region behind the column checkpoints, laid out like the row checkpoints
       u32 * const mck_base = dir + T.dir_off + ck_rowdw + (size_t) nstrips * ck_nblk * CK_COL_DW
-                             + ((((size_t) s * steps) >> 1) * 64 + ck_slot) * CK_LANE_DW;                           // + (t >> 1) * 192
+                             + ((((size_t) s * steps_own) >> 1) * 64 + ck_slot) * CK_LANE_DW;                           // + (t >> 1) * 192
       // transposed layout: block bases (steps is a multiple of 8 there); a lane adds (k * 64 + lane) * 4 dwords per store
-      u32 * const rck_blk = dir + T.dir_off + (((size_t) s * steps) >> 3) * VSX_CKT_BLOCK_DW;                       // + (t >> 3) * 768
-      u32 * const cck_blk = dir + T.dir_off + (((size_t) nstrips * steps) >> 3) * VSX_CKT_BLOCK_DW
+      u32 * const rck_blk = dir + T.dir_off + (((size_t) s * steps_own) >> 3) * VSX_CKT_BLOCK_DW;                       // + (t >> 3) * 768
+      u32 * const cck_blk = dir + T.dir_off + (((size_t) nstrips * steps_own) >> 3) * VSX_CKT_BLOCK_DW
                             + (size_t) s * ck_nblk * VSX_COLCK_NCHUNK(R) * VSX_CKT_BLOCK_DW;                        // + ((t >> 4) * NCHUNK + c) * 768
       // one 3 KB block: LDS -> HBM as it lies (three full 1 KB stores); the barriers order the lanes' LDS accesses (one wave)
       auto flush_block = [&](u32 * gdst) __attribute__((always_inline)) {
@@ -428,7 +509,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           const int fo = QPL ? ((t >> 4) & 1) * 64 : 0;
           const u32 fslot = (u32) (fo + (t & 15));
           const uint4 fv = feed4_g[fslot];
-          const u32 fF = feedf_g[fslot];
+          const u32 fF = FEED2 ? fv.w : feedf_g[fslot];
           if (QPL)
             {
               // `sym` already holds this step's symbols; look one step ahead and request that step's profile rows now
@@ -437,13 +518,22 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               load_profile(pn, symn);
             }
           else sym = dpp_shr1(fv.x, sym);
-          if (!GENERIC) nd = dpp_shr1(FEEDN[g * 16 + (t & 15)], nd);
-          if (!INTERIOR) { qrt = dpp_shr1(fv.y, qrt); rt = dpp_shr1(fv.z, rt); }
-          const u32 inH = dpp_shr1(fv.w, outH);
+          if (!GENERIC) nd = dpp_shr1(FEEDN[gw * 16 + (t & 15)], nd);
+          if (!INTERIOR)
+            {
+              if (FEED2)
+                {
+                  const uint2 fb = FEEDB[fo + gw * 16 + (t & 15)];
+                  qrt = dpp_shr1(fb.x, qrt); rt = dpp_shr1(fb.y, rt);
+                  symf = dpp_shr1(fv.y, symf);
+                }
+              else { qrt = dpp_shr1(fv.y, qrt); rt = dpp_shr1(fv.z, rt); }
+            }
+          const u32 inH = dpp_shr1(FEED2 ? fv.z : fv.w, outH);
           const u32 inF = dpp_shr1(fF, outF);
 
           const int j = t - l;
-          const bool active = STEADY ? true : (lane_on && j >= 0 && j < Dpg);
+          const bool active = STEADY ? (NQ == 1 ? true : sub_on) : (lane_on && j >= 0 && j < Dpg);   // (NQ > 1: a sub-task past the launch's last task stores nothing)
           if (active)
             {
               const u32 code = sym & 0x000F000Fu;
@@ -560,7 +650,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                   if (STEADY) jpk_run += 0x00010001u;
                   if (!INTERIOR)
                     {
-                      const u32 atlast = a_pk_ashr15(sym << 7);               // bit 8 (column == D-1)
+                      const u32 atlast = a_pk_ashr15((FEED2 ? symf : sym) << 7);               // bit 8 (column == D-1)
                       leave = a_bfi_v(atlast, a_bfi_v(a_pk_ashr15(lastL), lv1, jpk), leave);
                     }
                   lv1 = a_bfi_v(a_pk_ashr15((MAX3 && INTERIOR) ? lastEL : (lastL | lastEL)), lv1, jpk);
@@ -575,13 +665,13 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                 }
               if (!INTERIOR)
                 {
-                  const u32 lm = a_pk_ashr15(sym << 7);     // bit 8 (column == D-1)
+                  const u32 lm = a_pk_ashr15((FEED2 ? symf : sym) << 7);     // bit 8 (column == D-1)
                   score = a_bfi_v(lm, hl, score);            // S[(D+3)%4] of the last row (:1835-1836)
                 }
 
               // [4-step block][lane][step in block][ND]: a lane's 4 consecutive steps share one 64 B line
               // (4x fewer lines for the traceback walk) while a wave-step still lands in one 4 KB window
-              const size_t gt = (size_t) s * steps + t;
+              const size_t gt = (size_t) s * steps_own + t;
               if (CKPT)
                 {
                   if (!ODD) { pendH = outH; pendF = outF; }             // stored by the odd step below
@@ -638,7 +728,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                     __builtin_nontemporal_store((u32x4) {pendH, pendF, outH, outF}, reinterpret_cast<u32x4 *>(rck_base + (size_t) (t >> 1) * 256));
                 }
             }
-          if (CKPT && (t & 15) == 15)
+          if (CKPT && (t & 15) == 15 && (NQ == 1 || (sub_on && t < steps_own)))       // (NQ > 1: the wave's loop may run past this task's own range)
             {
               // column checkpoint m = t / 16 of this lane: state after its column t - l (or its border state if it has
               // not started yet).  Layout VSX_COLCK_DW (R = 1: [strip][m][lane][2]).
@@ -779,8 +869,11 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       oA.leave = (uint16_t) (leave & 0xffff); oB.leave = (uint16_t) (leave >> 16); oA.pad = 0; oB.pad = 0;
       oA.overflow = (mnA <= P.smin || mxA >= 32767) ? 1 : 0;     // :1774-1786
       oB.overflow = (mnB <= P.smin || mxB >= 32767) ? 1 : 0;
-      slot_out[(size_t) blockIdx.x * VSX_TASK_SLOTS + 2 * g] = oA;
-      slot_out[(size_t) blockIdx.x * VSX_TASK_SLOTS + 2 * g + 1] = oB;
+      if (sub_on)
+        {
+          slot_out[(size_t) tix * VSX_TASK_SLOTS + 2 * g] = oA;
+          slot_out[(size_t) tix * VSX_TASK_SLOTS + 2 * g + 1] = oB;
+        }
     }
 }
 
@@ -2230,70 +2323,56 @@ extern "C" hipError_t vsx_launch_purity(const uint8_t * d_codes, const uint64_t 
   return hipGetLastError();
 }
 
+#define VSX_FWD_GO(GRID_, ...) hipLaunchKernelGGL((vsx_forward_kernel<__VA_ARGS__>), dim3(GRID_), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot, ntasks)
 template <int R, bool CK>
-static hipError_t launch_fwd2(int generic, int track, const VsxDevParams & P, const VsxTask * d_tasks, uint32_t ntasks,
+static hipError_t launch_fwd2(int generic, int track, int nq, const VsxDevParams & P, const VsxTask * d_tasks, uint32_t ntasks,
                               const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
                               VsxSlotOut * slot, hipStream_t st)
 {
+  if (nq != 1)
+    {
+      // the sparse-task classes (NQ tasks per wave): TILT family only, R >= 4 (a one-row-per-lane wave has nothing to share)
+      if (!(P.tilt != 0 && CK && generic && !track && (nq == 2 || nq == 4))) return hipErrorInvalidValue;
+      if constexpr (CK && R >= 4 && VSX_QPL != 0 && !VSX_CKT)
+        {
+          const uint32_t grid = (ntasks + (uint32_t) nq - 1) / (uint32_t) nq;
+          if (nq == 2) { if (P.max3) VSX_FWD_GO(grid, R, true, false, true, true, true, 2); else VSX_FWD_GO(grid, R, true, false, true, true, false, 2); }
+          else         { if (P.max3) VSX_FWD_GO(grid, R, true, false, true, true, true, 4); else VSX_FWD_GO(grid, R, true, false, true, true, false, 4); }
+          return hipGetLastError();
+        }
+      else return hipErrorInvalidValue;
+    }
   if (P.tilt != 0)
     {
       if (!(CK && generic && !track)) return hipErrorInvalidValue;
       if constexpr (CK)
         {
-          if (P.max3 && !VSX_CKT)
-            hipLaunchKernelGGL((vsx_forward_kernel<R, true, false, true, true, (VSX_CKT == 0)>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
-          else
-            hipLaunchKernelGGL((vsx_forward_kernel<R, true, false, true, true>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+          if (P.max3 && !VSX_CKT) VSX_FWD_GO(ntasks, R, true, false, true, true, (VSX_CKT == 0));
+          else VSX_FWD_GO(ntasks, R, true, false, true, true);
         }
     }
-  else if (generic && track)
-    hipLaunchKernelGGL((vsx_forward_kernel<R, true, true, CK>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
-  else if (generic)
-    hipLaunchKernelGGL((vsx_forward_kernel<R, true, false, CK>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
-  else if (track)
-    hipLaunchKernelGGL((vsx_forward_kernel<R, false, true, CK>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
-  else
-    hipLaunchKernelGGL((vsx_forward_kernel<R, false, false, CK>), dim3(ntasks), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot);
+  else if (generic && track) VSX_FWD_GO(ntasks, R, true, true, CK);
+  else if (generic) VSX_FWD_GO(ntasks, R, true, false, CK);
+  else if (track) VSX_FWD_GO(ntasks, R, false, true, CK);
+  else VSX_FWD_GO(ntasks, R, false, false, CK);
   return hipGetLastError();
 }
+#undef VSX_FWD_GO
 
-extern "C" hipError_t vsx_launch_forward(int rows, int generic, int track, int ckpt, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
+// nq = tasks per wave: 1, or 2 / 4 for the sparse-task classes (tasks of <= 4 / <= 2 targets, TILT family, single-strip queries)
+extern "C" hipError_t vsx_launch_forward(int rows, int generic, int track, int ckpt, int nq, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
                                          const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
                                          VsxSlotOut * slot, hipStream_t st)
 {
   if (ntasks == 0) return hipSuccess;
+#define FWDR(RR) case RR: return ckpt ? launch_fwd2<RR, true>(generic, track, nq, P, d_tasks, ntasks, q, t, dir, strip, slot, st) \
+                                       : launch_fwd2<RR, false>(generic, track, nq, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
   switch (rows)
     {
-    case 1:  return ckpt ? launch_fwd2<1, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<1, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 4:  return ckpt ? launch_fwd2<4, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<4, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 8:  return ckpt ? launch_fwd2<8, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<8, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 10: return ckpt ? launch_fwd2<10, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<10, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 12: return ckpt ? launch_fwd2<12, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<12, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 14: return ckpt ? launch_fwd2<14, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<14, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 16: return ckpt ? launch_fwd2<16, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<16, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 18: return ckpt ? launch_fwd2<18, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<18, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 20: return ckpt ? launch_fwd2<20, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<20, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 22: return ckpt ? launch_fwd2<22, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<22, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 24: return ckpt ? launch_fwd2<24, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<24, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 26: return ckpt ? launch_fwd2<26, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<26, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 28: return ckpt ? launch_fwd2<28, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<28, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
-    case 32: return ckpt ? launch_fwd2<32, true>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
-                          : launch_fwd2<32, false>(generic, track, P, d_tasks, ntasks, q, t, dir, strip, slot, st);
+    FWDR(1); FWDR(4); FWDR(8); FWDR(10); FWDR(12); FWDR(14); FWDR(16); FWDR(18); FWDR(20); FWDR(22); FWDR(24); FWDR(26); FWDR(28); FWDR(32);
     default: return hipErrorInvalidValue;
     }
+#undef FWDR
 }
 
 extern "C" hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,

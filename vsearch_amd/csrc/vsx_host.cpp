@@ -14,6 +14,7 @@
 #include <cstdlib>
 // VSX_POISON=1 (debugging aid, r04): every device block this library hands out is filled with 0xA5 first, so a read of memory nobody
 // has written gives the same junk in every run instead of whatever an earlier plan, index or process left there
+extern "C" uint64_t vsx_internal_memory_pressure(int device);
 extern "C" void vsx_internal_poison(void * p, size_t bytes)
 {
   static const bool on = std::getenv("VSX_POISON") != nullptr;
@@ -118,6 +119,13 @@ struct ScratchPool {
     }
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipErrorOutOfMemory) { trim(); (void) hipGetLastError(); e = hipMalloc(out, bytes); }
+    if (e == hipErrorOutOfMemory)
+      {
+        // r05: the idle blocks of the OTHER contexts of this device (a searcher's consumers, a context that ran one huge plan earlier)
+        int dev = 0;
+        (void) hipGetLastError();
+        if (hipGetDevice(&dev) == hipSuccess && vsx_internal_memory_pressure(dev) > 0) e = hipMalloc(out, bytes);
+      }
     if (e == hipSuccess) { *got = bytes; vsx_internal_poison(*out, std::min<size_t>(bytes, (size_t) 256 << 20)); }
     return e;
   }
@@ -292,7 +300,7 @@ struct vsx_seqset {
 
 namespace {
 
-struct Launch { int rows; int generic; int track; int tilt; uint32_t first, count; uint32_t pair_first, pair_count; };
+struct Launch { int rows; int generic; int track; int tilt; int nq /* tasks per wave: 1, or 2 / 4 = a sparse-task class */; uint32_t first, count; uint32_t pair_first, pair_count; };
 
 struct Chunk {
   uint32_t task_first = 0, task_count = 0;
@@ -309,6 +317,8 @@ struct Chunk {
 extern "C" int vsx_internal_usable_cpus(void);
 // per device: 0 = not tested yet, 1 = v_pk_maximum3_f16 is the integer maximum on [0, 0x7BFF] (vsx_create's self-test), 2 = it is not
 static std::atomic<int> g_max3_state[64];
+static std::mutex g_ctx_mu;                   // the live contexts of the process (vsx_internal_memory_pressure)
+static std::vector<vsx_ctx *> g_ctxs;
 template <typename T>
 static T * dup_array(const std::vector<T> & v)
 {
@@ -506,6 +516,25 @@ int vsx_internal_pool_selftest(int regions, int width)
   return bad.load();
 }
 int vsx_internal_device(const vsx_ctx * ctx) { return ctx->device; }
+// r05: device memory under pressure.  A context keeps its big stream-ordered blocks (three checkpoint blocks, the slab) and a pool of
+// idle scratch between plans, so that a warm call never meets a multi-GB hipMalloc; after ONE very large plan (BASELINE config 5's
+// per-GPU share: 3 x 62 GB of checkpoints) those blocks starved every other allocator of the device -- the k-mer scratch of a search on
+// the same GPU failed with "out of memory" (profiles/r05/r05a_config5_share_oom.json).  Whoever meets hipErrorOutOfMemory calls this
+// once and retries: every live context of the device drops the blocks no plan holds and frees its idle pool.  Returns the bytes released.
+uint64_t vsx_internal_memory_pressure(int device)
+{
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  uint64_t freed = 0;
+  for (vsx_ctx * c : g_ctxs)
+    if (c->device == device)
+      {
+        SharedSlot * slot[4] = {&c->shared_dir[0], &c->shared_dir[1], &c->shared_dir[2], &c->shared_slab};
+        for (SharedSlot * sl : slot) sl->reset();          // a block a plan still references lives until that plan dies
+        freed += c->pool.idle_bytes();
+        c->pool.trim();
+      }
+  return freed;
+}
 // The big stream-ordered scratch blocks of a context (three checkpoint blocks, the traceback slab): their sizes, and a reservation
 // of at least those sizes.  A search runs its windows on several contexts of one device; a context that meets its first full
 // window in the middle of a warm search would pay the multi-GB hipMalloc there (0.5-1 s in a 0.15 s call), so the searcher levels
@@ -747,6 +776,7 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
         }
       T.htop = c->d_htop_t.p; T.hleft = c->d_hleft_t.p; T.matrix = c->d_matrix_t.p;
     }
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.push_back(c); }
   *out = c;
   return VSX_OK;
 }
@@ -754,6 +784,7 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
 void vsx_destroy(vsx_ctx * c)
 {
   if (!c) return;
+  { std::lock_guard<std::mutex> lk(g_ctx_mu); g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end()); }
   (void) hipSetDevice(c->device);
   if (c->stream) { (void) hipStreamSynchronize(c->stream); (void) hipStreamDestroy(c->stream); }
   if (c->stream2) { (void) hipStreamSynchronize(c->stream2); (void) hipStreamDestroy(c->stream2); }
@@ -1072,7 +1103,10 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   // ---- group by query -> tasks of <= 8 targets, similar lengths together (host threads over query groups) ----
   auto by_query = [&](uint32_t a, uint32_t b) { return qidx[a] < qidx[b]; };
   if (!std::is_sorted(gpu_pairs.begin(), gpu_pairs.end(), by_query)) std::stable_sort(gpu_pairs.begin(), gpu_pairs.end(), by_query);
-  struct ProtoTask { uint32_t q; int rows; int generic; int track; int tilt; uint32_t n; uint32_t pair[8]; };
+  struct ProtoTask { uint32_t q; int rows; int generic; int track; int tilt; int nq; uint32_t n; uint32_t pair[8]; };
+  // r05, sparse tasks: a task of <= 2 (<= 4) targets of the TILT family shares its wave with three (one) other tasks of its class
+  // (vsx_forward_kernel NQ) instead of leaving three (two) of the four lane groups idle.  VSX_SPARSE=0: every task is a wave (A/B, tests)
+  static const bool sparse_on = !(std::getenv("VSX_SPARSE") && std::strcmp(std::getenv("VSX_SPARSE"), "0") == 0) && ctx->ckpt && VSX_QPL != 0 && !VSX_CKT;
   std::vector<size_t> group_begin;                       // start of every query's run in gpu_pairs, plus the end
   for (size_t b = 0; b < gpu_pairs.size();)
     {
@@ -1115,6 +1149,9 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
               }
             pt.track = (!ctx->tb_packed && no_overflow_possible(ctx, queries->len[q], dmax)) ? 0 : 1;
             pt.tilt = (pt.track == 0 && generic && ctx->ckpt) ? tilt_possible(ctx, queries->len[q], dmax) : 0;
+            pt.nq = 1;
+            if (sparse_on && pt.tilt && rows >= 4 && pt.n <= 4 && (int64_t) queries->len[q] <= 16ll * rows)      // (one strip: the hand-over rows are per wave)
+              pt.nq = pt.n <= 2 ? 4 : 2;
             outp.push_back(pt);
           }
       }
@@ -1133,20 +1170,20 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   // 16 R >= Q is valid for a query, so the tasks of a sparse class join the next denser class of the same kind.
   {
     static const bool no_promote = std::getenv("VSX_NO_PROMOTE") != nullptr;      // A/B, tests
-    struct Cls { int rows, generic, track, tilt; size_t count; };
+    struct Cls { int rows, generic, track, tilt, nq; size_t count; };
     std::vector<Cls> cls;
     for (const ProtoTask & pt : protos)
       {
         bool found = false;
-        for (Cls & c : cls) if (c.rows == pt.rows && c.generic == pt.generic && c.track == pt.track && c.tilt == pt.tilt) { ++c.count; found = true; break; }
-        if (!found) cls.push_back(Cls {pt.rows, pt.generic, pt.track, pt.tilt, 1});
+        for (Cls & c : cls) if (c.rows == pt.rows && c.generic == pt.generic && c.track == pt.track && c.tilt == pt.tilt && c.nq == pt.nq) { ++c.count; found = true; break; }
+        if (!found) cls.push_back(Cls {pt.rows, pt.generic, pt.track, pt.tilt, pt.nq, 1});
       }
     std::vector<std::pair<size_t, int>> move;                                 // class index -> new rows
     for (size_t a = 0; a < cls.size() && !no_promote; ++a)
       {
         int best = 0;
         for (const Cls & c : cls)
-          if (c.generic == cls[a].generic && c.track == cls[a].track && c.tilt == cls[a].tilt && c.rows > cls[a].rows &&
+          if (c.generic == cls[a].generic && c.track == cls[a].track && c.tilt == cls[a].tilt && c.nq == cls[a].nq && c.rows > cls[a].rows &&
               c.count >= 32 * cls[a].count && (best == 0 || c.rows < best))
             best = c.rows;
         if (best && cls[a].count < 4096) move.emplace_back(a, best);
@@ -1156,14 +1193,14 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
         for (const auto & other : move)
           {
             const Cls & a = cls[mv.first], & o = cls[other.first];
-            if (o.rows == mv.second && o.generic == a.generic && o.track == a.track && o.tilt == a.tilt) { mv.second = other.second; break; }
+            if (o.rows == mv.second && o.generic == a.generic && o.track == a.track && o.tilt == a.tilt && o.nq == a.nq) { mv.second = other.second; break; }
           }
     if (!move.empty())
       for (ProtoTask & pt : protos)
         for (const auto & mv : move)
           {
             const Cls & c = cls[mv.first];
-            if (pt.rows == c.rows && pt.generic == c.generic && pt.track == c.track && pt.tilt == c.tilt)
+            if (pt.rows == c.rows && pt.generic == c.generic && pt.track == c.track && pt.tilt == c.tilt && pt.nq == c.nq)
               {
                 // (only queries that still span two pipeline positions: a query shorter than one position of the new class would make
                 //  position 0 the last position as well, a shape no row count chosen by pick_rows() ever produces)
@@ -1172,12 +1209,36 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
               }
           }
   }
+  // a SMALL sparse class beside a large class of whole-wave tasks of the same kind is not worth its own launches (a launch of a few
+  // hundred waves is a latency chain of its own, the same tasks as whole waves inside the large launch cost next to nothing)
+  if (sparse_on)
+    {
+      static const size_t sparse_min = std::getenv("VSX_SPARSE_MIN") ? (size_t) std::atoll(std::getenv("VSX_SPARSE_MIN")) : 2048;
+      struct Key { int rows, generic, track, tilt, nq; size_t count; };
+      std::vector<Key> ks;
+      for (const ProtoTask & pt : protos)
+        {
+          bool found = false;
+          for (Key & c : ks) if (c.rows == pt.rows && c.generic == pt.generic && c.track == pt.track && c.tilt == pt.tilt && c.nq == pt.nq) { ++c.count; found = true; break; }
+          if (!found) ks.push_back(Key {pt.rows, pt.generic, pt.track, pt.tilt, pt.nq, 1});
+        }
+      std::vector<Key> demote;
+      for (const Key & c : ks)
+        if (c.nq > 1 && c.count < sparse_min)
+          for (const Key & w : ks)
+            if (w.nq == 1 && w.rows == c.rows && w.generic == c.generic && w.track == c.track && w.tilt == c.tilt && w.count >= 8 * c.count) { demote.push_back(c); break; }
+      if (!demote.empty())
+        for (ProtoTask & pt : protos)
+          for (const Key & c : demote)
+            if (pt.nq == c.nq && pt.rows == c.rows && pt.generic == c.generic && pt.track == c.track && pt.tilt == c.tilt) { pt.nq = 1; break; }
+    }
   // kernel classes together (one launch per class and chunk)
   auto by_class = [](const ProtoTask & a, const ProtoTask & b) {
     if (a.rows != b.rows) return a.rows < b.rows;
     if (a.generic != b.generic) return a.generic < b.generic;
     if (a.track != b.track) return a.track < b.track;
-    return a.tilt < b.tilt;
+    if (a.tilt != b.tilt) return a.tilt < b.tilt;
+    return a.nq < b.nq;
   };
   if (!std::is_sorted(protos.begin(), protos.end(), by_class)) std::stable_sort(protos.begin(), protos.end(), by_class);
 
@@ -1259,8 +1320,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       cur.strip_elems += strip;
       pl->dir_bytes_total += dwords * 4;
       if (cur.launches.empty() || cur.launches.back().rows != pt.rows || cur.launches.back().generic != pt.generic ||
-          cur.launches.back().track != pt.track || cur.launches.back().tilt != pt.tilt)
-        cur.launches.push_back(Launch {pt.rows, pt.generic, pt.track, pt.tilt, (uint32_t) x, 0, cur.pair_first + cur.pair_count, 0});
+          cur.launches.back().track != pt.track || cur.launches.back().tilt != pt.tilt || cur.launches.back().nq != pt.nq)
+        cur.launches.push_back(Launch {pt.rows, pt.generic, pt.track, pt.tilt, pt.nq, (uint32_t) x, 0, cur.pair_first + cur.pair_count, 0});
       cur.launches.back().count++;
       cur.launches.back().pair_count += pt.n;
       t_pair0[x] = np_out;
@@ -1408,7 +1469,7 @@ int vsx_plan_run(vsx_plan * pl)
         {
           VsxDevParams Pf = L.tilt ? ctx->Pt : ctx->P;
           Pf.max3 = (L.tilt == 2) ? 1 : 0;
-          HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, Pf, pl->d_tasks.p + L.first, L.count,
+          HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, L.nq, Pf, pl->d_tasks.p + L.first, L.count,
                                     pl->Q->codes(), pl->T->codes(), dir, pl->d_strip.p,
                                     pl->d_slot.p + (size_t) L.first * VSX_TASK_SLOTS, st));
         }
@@ -1483,6 +1544,8 @@ int vsx_plan_describe(const vsx_plan * pl, vsx_plan_info * info)
   for (const Chunk & c : pl->chunks)
     for (const Launch & L : c.launches)
       {
+        if (L.nq > 1) info->tasks_sparse += L.count;
+        info->waves += (L.count + (uint32_t) L.nq - 1) / (uint32_t) L.nq;
         if (L.tilt) info->tasks_tilted += L.count;
         if (L.tilt == 2) info->tasks_max3 += L.count;
         if (L.track) info->tasks_tracked += L.count;

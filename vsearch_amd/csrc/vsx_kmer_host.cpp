@@ -33,6 +33,7 @@ extern "C" hipError_t vsx_kmer_launch_select_packed(const void * rec, uint32_t s
                                                     void * sel_m_n, uint64_t * sel_off, hipStream_t st);
 
 extern "C" void vsx_internal_poison(void * p, size_t bytes);
+extern "C" uint64_t vsx_internal_memory_pressure(int device);      // vsx_host.cpp: every context of the device frees what no plan holds
 namespace {
 
 int kfail(int code, const char * what, hipError_t e)
@@ -50,6 +51,14 @@ template <typename T> struct Buf {
   {
     if (p) { (void) hipFree(p); p = nullptr; n = 0; }
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T));
+    if (e == hipErrorOutOfMemory)
+      {
+        // (r05) the aligner contexts of this device may sit on idle checkpoint blocks of an earlier, much larger plan: ask for them
+        int dev = 0;
+        (void) hipGetLastError();
+        if (hipGetDevice(&dev) == hipSuccess && vsx_internal_memory_pressure(dev) > 0)
+          e = hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T));
+      }
     if (e == hipSuccess) { n = count; vsx_internal_poison(p, std::max<size_t>(count, 1) * sizeof(T)); }
     return e;
   }

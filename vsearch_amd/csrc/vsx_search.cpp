@@ -2102,6 +2102,21 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       std::vector<uint32_t> sq, stg;
       int near_rc = VSX_OK;
       std::string near_err;
+      // the speculative alignments of the fix-up depend on the counts alone as well: with a second aligner context of the device the
+      // helper aligns them as soon as it has paired them up, beside the staged search (whose stages are chains of short round trips
+      // that leave the device idle most of the time); VSX_CLUSTER_SPEC_OVERLAP=0 / 1 overrides the default below (0: after the search, on
+      // the first context, as in r04)
+#ifndef VSX_CLUSTER_SPEC_OVERLAP_DEFAULT
+#define VSX_CLUSTER_SPEC_OVERLAP_DEFAULT 0
+#endif
+      vsx_results spec;
+      std::memset(&spec, 0, sizeof spec);
+      struct SpecGuard { vsx_results & r; ~SpecGuard() { vsx_results_free(&r); } } spec_guard {spec};     // (declared before the joiner below:
+                                                                                                          //  freed after the helper has ended)
+      bool spec_done = false;
+      double spec_s = 0;
+      static const bool spec_overlap = VSX_CLUSTER_SPEC_OVERLAP_DEFAULT ? !(std::getenv("VSX_CLUSTER_SPEC_OVERLAP") && std::strcmp(std::getenv("VSX_CLUSTER_SPEC_OVERLAP"), "0") == 0)
+                                                                        : (std::getenv("VSX_CLUSTER_SPEC_OVERLAP") && std::strcmp(std::getenv("VSX_CLUSTER_SPEC_OVERLAP"), "1") == 0);
       const bool near_on_device = dev_kmer && fallback.empty();
       auto near_device = [&]() {
         // the same counting problem on the device: members of the round against an index of the round
@@ -2126,11 +2141,24 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
                 }
               near[i].push_back(nr);
             }
+        if (spec_overlap && S->ctx2 != nullptr && !sq.empty())
+          {
+            const double ta = now_s();
+            near_rc = vsx_align_pairs(S->ctx2, S->dbset, S->dbset, sq.size(), sq.data(), stg.data(), &spec);
+            spec_s = now_s() - ta;
+            if (near_rc != VSX_OK) { near_err = vsx_last_error(); return; }
+            spec_done = true;
+          }
       };
       static const bool near_overlap = !(std::getenv("VSX_CLUSTER_NEAR_OVERLAP") && std::strcmp(std::getenv("VSX_CLUSTER_NEAR_OVERLAP"), "0") == 0);   // A/B
       std::thread near_thread;
       struct NearJoiner { std::thread & t; ~NearJoiner() { if (t.joinable()) t.join(); } } near_joiner {near_thread};
-      if (near_on_device && near_overlap) near_thread = std::thread(near_device);
+      if (near_on_device && near_overlap)
+        {
+          if (spec_overlap && S->ctx2 == nullptr && vsx_create(&S->ctx2, &S->scoring, vsx_internal_device(S->ctx)) != VSX_OK)
+            S->ctx2 = nullptr;                                       // (no second context: the alignments follow the search, as before)
+          near_thread = std::thread(near_device);
+        }
 
       // ---- phase 1b: staged GPU search (queries and targets both live in the database sequence set) ----
       const double ts0 = now_s();
@@ -2178,9 +2206,13 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       }
       t_kmer += now_s() - t0;
       tm_near += now_s() - t0;
-      vsx_results spec;
-      std::memset(&spec, 0, sizeof spec);
-      if (!sq.empty())
+      if (spec_done)
+        {
+          acct.t_align += spec_s;              // (wall time of the helper's call; it ran beside the search)
+          tm_spec += spec_s;
+          acct.pairs += sq.size();
+        }
+      else if (!sq.empty())
         {
           t0 = now_s();
           rc = vsx_align_pairs(S->ctx, S->dbset, S->dbset, sq.size(), sq.data(), stg.data(), &spec);
