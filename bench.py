@@ -244,6 +244,9 @@ def main():
                 if pending is not None:
                     gathered = fixed.collect(pending)
                 pending = ticket
+                if fixed.degraded:                         # (r05) the collectives never finished beside the next step's kernels: no
+                    gathered = fixed.collect(pending, immediate=True)      # point in holding a step back -- collect at once from now on
+                    pending = None
             else:
                 gathered = sharding.gather_results(rec, runs, dist, dst=0)
         return tm
@@ -409,6 +412,7 @@ def main():
         rccl["gather"] = a.gather
         if fixed is not None:
             rccl["fixed_gather_sync_steps"] = fixed.sync_steps
+            rccl["fixed_gather_overlap"] = fixed.stats()       # rank 0's view: did step k's collective finish while step k + 1 computed?
         out["rccl"] = rccl
 
     if not a.kernels_only and world == 1:
@@ -552,6 +556,8 @@ def dry_collectives(dist, sharding, device, rank, world):
         ok = ok and bool(torch.equal(got[0], e[0]) and torch.equal(got[1], e[1]) and got[2] == e[2])
         checks["fixed_gather_async_incl_one_rank_overflow"] = ok
     checks["fixed_gather_sync_steps"] = fg.sync_steps
+    st = fg.stats()                 # (r05) every collected step is an overlap sample: finished before the collect, or waited for
+    checks["fixed_gather_overlap_samples"] = st["collects"] == st["finished_before_collect"] + st["waited_for"] == len(scales)
     return checks
 
 
@@ -645,9 +651,9 @@ def search_end_to_end(a, al, db_ascii, db_off, db_len, q_ascii, q_off, q_len):
             # what --userfields query+target+id+caln prints for a hit (id with one decimal, commands/userfields: "%.1f")
             ours = set()
             for k in keep.tolist():
-                h = harr[k]
-                o0 = int(h["cigar_off"])
-                ours.add((int(h["query"]), int(h["target"]), "%.1f" % float(h["id"]), cblob[o0:cblob.index(b"\0", o0)].decode()))
+                hr = harr[k]                    # (not `h`: that is the searcher's handle, destroyed in the finally below)
+                o0 = int(hr["cigar_off"])
+                ours.add((int(hr["query"]), int(hr["target"]), "%.1f" % float(hr["id"]), cblob[o0:cblob.index(b"\0", o0)].decode()))
             try:                                            # (a 5 GB FASTA + the reference's index may not fit a box: never lose the search figures over it)
                 out["reference_cli"] = reference_search(ref_bin, db_blob, db_off, db_len, q_blob, q_off, q_len, nref, ours, a.search_mask)
             except Exception as e:

@@ -1,8 +1,8 @@
 cd /tmp && python - <<'PY'
 import sys, time, subprocess, os, random
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from vsearch_amd import workload
-R=os.environ["GRAFT_REPO_ROOT"]
+R=os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 flat, off, ln, fam = workload.make_family_db(20000, 1000, seed=17, device="cpu")
 q, qo, ql, src = workload.make_queries(flat, off, ln, 2000, 250, seed=11, device="cpu")
 b=flat.numpy().tobytes(); qb=q.numpy().tobytes()

@@ -166,10 +166,12 @@ struct Fast {
   vsx_searcher * first() { return vsx_multi_searcher_replica(M, 0); }
   // Best-effort detection of an in-place change of the Database between calls (the reference has no generation counter to ask):
   // the count, and length + header + sequence bytes of a spread of sequences (256; 1 024 above 65 536 sequences) plus the last
-  // one.  Up to 65 536 sequences the lengths and abundances of ALL are folded in as well; above that the walk is skipped, so a
-  // small batch against a multi-million-sequence database does not pay O(n) per call.  dust_all / hardmask_all
-  // rewrite most sequences and are caught by the sample; an edit of one unsampled sequence is not -- an embedder that edits in
-  // place calls vsx_api_invalidate() (below), or sets VSX_API_FINGERPRINT=full (every byte hashed on every call).
+  // one.  The lengths and abundances of ALL sequences are folded in as well -- up to 65 536 sequences always, above that whenever the
+  // call's own work dwarfs the walk (`work` >= n / 64 queries: a search of q queries costs O(q n) counter increments, the walk O(n);
+  // clustering always) -- so only a SMALL batch against a multi-million-sequence database skips it (no O(n) per tiny call;
+  // an in-place change of one unsampled length / abundance must not go unseen by every large call).  dust_all /
+  // hardmask_all rewrite most sequences and are caught by the sample; an edit of the BYTES of one unsampled sequence is not -- an
+  // embedder that edits in place calls vsx_api_invalidate() (below), or sets VSX_API_FINGERPRINT=full (every byte hashed on every call).
   static int fingerprint_mode()
   {
     static int const mode = [] {
@@ -181,7 +183,7 @@ struct Fast {
     }();
     return mode;
   }
-  static uint64_t fingerprint(struct Database const & d)
+  static uint64_t fingerprint(struct Database const & d, bool walk_all)
   {
     uint64_t const n = d.getsequencecount();
     uint64_t h = 1469598103934665603ull;
@@ -193,7 +195,7 @@ struct Fast {
     };
     bool const full = fingerprint_mode() == 1;
     mix(&n, sizeof n);
-    if (full || n <= 65536)
+    if (full || n <= 65536 || walk_all)
       {
         uint64_t total = 0, sizes = 0;
         for (uint64_t i = 0; i < n; ++i) { total += d.getsequencelen(i); sizes += (uint64_t) d.getabundance(i); }
@@ -212,12 +214,21 @@ struct Fast {
     if (n) { uint64_t const len = d.getsequencelen(n - 1); mix(&len, sizeof len); mix(d.getsequence(n - 1), (size_t) len); }
     return h;
   }
-  bool ensure(struct Parameters const & p, struct Database const & d, bool clustering)
+  bool walked = false;              // whether `mark` includes the totals over all sequences
+  bool ensure(struct Parameters const & p, struct Database const & d, bool clustering, uint64_t work /* queries of this call */)
   {
     uint64_t const n = d.getsequencecount();
     vsx_search_opts const want = opts_of(p, clustering);
     vsx_scoring const wsc = scoring_of(p);
-    uint64_t const fp = fingerprint(d);
+    bool const walk_all = clustering || work >= n / 64;
+    // a mark is comparable only with a mark of the same kind: a searcher built by a small call is re-marked (not rebuilt) by the
+    // first large one, whose totals then guard the later large calls
+    uint64_t fp = fingerprint(d, walk_all);
+    if (M != nullptr && db == &d && count == n && walked != walk_all && n > 65536 && fingerprint_mode() == 0)
+      {
+        uint64_t const same_kind = fingerprint(d, walked);
+        if (same_kind == mark) { mark = fp; walked = walk_all; }
+      }
     if (M != nullptr && db == &d && count == n && mark == fp &&
         std::memcmp(&want, &o, sizeof o) == 0 && std::memcmp(&wsc, &sc, sizeof sc) == 0)
       return true;
@@ -239,7 +250,7 @@ struct Fast {
     if (clustering) dev.resize(1);               // cluster_* does not shard (sequential centroid dependency)
     if (vsx_multi_searcher_create(&M, &wsc, dev.data(), (int32_t) dev.size(), &want, n, blob.data(), total, off.data(), len.data(), &meta) != VSX_OK)
       { M = nullptr; return complain("vsx_multi_searcher_create"); }
-    db = &d; count = n; mark = fp; o = want; sc = wsc;
+    db = &d; count = n; mark = fp; walked = walk_all; o = want; sc = wsc;
     return true;
   }
   ~Fast() { drop(); }
@@ -276,7 +287,7 @@ auto search_batch(struct Parameters const & parameters, struct Dbindex const & d
     vsxref_search_batch(parameters, dbindex, db, query_seqs, query_heads, query_lens, query_sizes, query_count, results,
                         max_results_per_query, result_counts);
   };
-  if (!g_search.ensure(parameters, db, false)) { reference(); return; }
+  if (!g_search.ensure(parameters, db, false, (uint64_t) query_count)) { reference(); return; }
   uint64_t const n = (uint64_t) query_count;
   std::vector<uint64_t> off(n), size(n);
   std::vector<uint32_t> len(n);
@@ -340,7 +351,7 @@ FastCluster * mine(struct cluster_session_s * cs) { return reinterpret_cast<Fast
 
 bool run_fast(FastCluster & c)
 {
-  if (!c.fast.ensure(*c.parameters, *c.db, true)) return false;
+  if (!c.fast.ensure(*c.parameters, *c.db, true, 0)) return false;
   if (vsx_cluster_fast(c.fast.first(), 0, &c.out) != VSX_OK) return complain("vsx_cluster_fast");
   c.have = true;
   return true;

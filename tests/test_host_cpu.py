@@ -588,6 +588,7 @@ def test_bench_dry_collectives_world2_gloo():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
-    assert d["dry_collectives"] == {"gather_results_to_rank0": True, "fixed_gather_async_incl_one_rank_overflow": True, "fixed_gather_sync_steps": 1}, d
+    assert d["dry_collectives"] == {"gather_results_to_rank0": True, "fixed_gather_async_incl_one_rank_overflow": True, "fixed_gather_sync_steps": 1,
+                                     "fixed_gather_overlap_samples": True}, d
     assert d["rccl"]["world"] == 2 and d["rccl"]["backend"] == "gloo" and d["rccl"]["device_of_rank"] == [0, 0]
 

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <cstdlib>
+#include <atomic>
 #include "vsx_internal.h"
 
 typedef unsigned int u32;
@@ -127,8 +128,10 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // 300 x 300: 12.23 -> 11.17 ms, 360 x 360: 15.9 -> 15.0 ms; 4 waves at R = 18 / 20: 12.7 ms), 2 beyond (256 VGPRs; 3 there
 // spills into the loop: 500 x 500 25.5 -> 30.8 ms) -- profiles/r03/r03c_occupancy_ab.txt.  A/B builds override VSX_FWD_WAVES
 // FEED2 (r05, prepared in r04 as experiments/dp_feed2.patch): the feed record of the look-ahead classes, see vsx_forward_kernel
+// r05 same-box A/B (profiles/r05/r05b_feed2_ab.txt, two runs each): DP 250 x 1000 22.73 -> 22.41 ms, 150 x 1000 16.65 -> 16.40, 150 x 300
+// 5.58 -> 5.45, 300 x 300 10.24 -> 10.20, 400 x 400 17.06 -> 17.12 (R = 26: level); parity suite + aligner soak green on the build.  Default ON.
 #ifndef VSX_FEED2
-#define VSX_FEED2 0
+#define VSX_FEED2 1
 #endif
 #ifndef VSX_FWD_WAVES
 #define VSX_FWD_WAVES(R_, TILT_) ((R_) <= 16 ? 4 : ((R_) <= 24 ? 3 : 2))
@@ -150,16 +153,17 @@ DEV u32 pk_max3_bits(u32 a, u32 b, u32 c)            // IEEE maximum of three: t
 // NQ (r05, the SPARSE-TASK classes of the TILT family): a wave works on NQ = 2 or 4 TASKS at once -- sub-task u = lane groups
 // u * (4 / NQ) .. of the wave, i.e. a task of <= 4 (NQ = 2) or <= 2 (NQ = 4) targets whose targets sit in its first slots.  The
 // reference refills its 8 SIMD lanes with new targets as old ones finish (align_simd.cpp:1823-1946); here a task was one wave whatever
-// the number of its targets (a query with 1 candidate paid for 8: VERDICT r04 missing 3).  Everything a task owns stays per task --
-// VsxTask, its checkpoint block (slots l * 4 + group-in-task, as the traceback expects: the traceback kernels do not know about NQ),
-// its VsxSlotOut entries -- so the only wave-level quantities are the step range (the longest sub-task) and t_switch (the shortest
-// target).  Each sub-task has its own LDS profile (NQ x 256 RP bytes), which is what bounds the occupancy of these classes
-// (VSX_FWD_WAVES_NQ); single-strip queries only (the planner's job, vsx_host.cpp).  Sub-tasks beyond `ntasks` (the last wave of a
-// launch) and the steps of a sub-task beyond its own range store nothing.
+// the number of its targets (a query with 1 candidate paid for 8: VERDICT r04 missing 3).  A task keeps its VsxTask and its VsxSlotOut
+// entries; the NQ tasks of a wave share ONE checkpoint block and ONE step range (VsxTask::steps = the longest of them, ::dir_off the
+// same: the planner's job, vsx_host.cpp), in which lane group gw of the wave owns the slots l * 4 + gw exactly as in a whole-wave
+// task -- every store instruction still writes 768 B of full lines (the first build gave each task a block of its own: 12-byte pieces
+// 48 bytes apart, 4 x the lines, each partially written: cands = 1 ran 1.5 x SLOWER than as whole waves,
+// profiles/r05/r05b_sparse_ab_first_build.txt).  The traceback finds a pair's lane group as VsxTask::group0 + slot / 2.  Each
+// sub-task has its own LDS profile (NQ x 256 RP bytes), which is what bounds the occupancy of these classes (VSX_FWD_WAVES_NQ);
+// single-strip queries only.  Sub-tasks beyond `ntasks` (the last wave of a launch) run on junk in slots nobody reads.
 #ifndef VSX_FWD_WAVES_NQ
 #define VSX_FWD_WAVES_NQ(R_, NQ_) ((NQ_) == 4 ? 2 : ((R_) <= 24 ? 3 : 2))
 #endif
-DEV int wave_max_i32(int v);
 template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false, bool MAX3 = false, int NQ = 1>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? VSX_FWD_WAVES(R, TILT) : VSX_FWD_WAVES_NQ(R, NQ), 8)))
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
@@ -234,8 +238,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   const int rcnt0 = Q - (total_lanes - 1) * R;     // rows in position 0 (1..R); all others hold R
   const int rc0 = __builtin_amdgcn_readfirstlane(rcnt0);   // provably scalar: keeps the per-row capture test on the SALU
   const int nstrips = (NQ == 1) ? (total_lanes + 15) >> 4 : 1;
-  const int steps_own = (int) T.steps;             // the range of THIS task's checkpoint regions
-  const int steps = (NQ == 1) ? steps_own : __builtin_amdgcn_readfirstlane(wave_max_i32(sub_on ? steps_own : 0));   // the wave's loop
+  const int steps = (NQ == 1) ? (int) T.steps : __builtin_amdgcn_readfirstlane((int) T.steps);   // (NQ > 1: the planner gives the tasks of a wave ONE step range)
 
   const int DA = sub_on ? (int) T.tlen[2 * g] : 0;
   const int DB = sub_on ? (int) T.tlen[2 * g + 1] : 0;
@@ -344,8 +347,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       u32 rawA = 0, rawB = 0;
       int rawH = 0;
       uint2 rawS = make_uint2(0, 0);
-      const uint2 * strip_in = strip + T.strip_off + (size_t) (((s + 1) & 1) * 4 + g) * (size_t) steps_own;
-      uint2 * strip_outp = strip + T.strip_off + (size_t) ((s & 1) * 4 + g) * (size_t) steps_own;
+      const uint2 * strip_in = strip + T.strip_off + (size_t) (((s + 1) & 1) * 4 + g) * (size_t) steps;
+      uint2 * strip_outp = strip + T.strip_off + (size_t) ((s & 1) * 4 + g) * (size_t) steps;
 
       auto prefetch = [&](int blk) {
         const int c = 16 * blk + l;
@@ -467,19 +470,19 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       u32 pendMH = 0, pendMF = 0, curMH = 0, curMF = 0;          // the same for the mid-row checkpoint (MIDCK)
       bool pend_on = false;
       // per-lane base addresses of this strip's checkpoint regions (computed once: the step only adds a uniform offset)
-      const size_t ck_rowdw = ((((size_t) nstrips * steps_own + 1) & ~(size_t) 1) >> 1) * VSX_ROWCK_PAIR_DW(TILT);
-      const size_t ck_nblk = ((size_t) steps_own + 15) >> 4;
+      const size_t ck_rowdw = ((((size_t) nstrips * steps + 1) & ~(size_t) 1) >> 1) * VSX_ROWCK_PAIR_DW(TILT);
+      const size_t ck_nblk = ((size_t) steps + 15) >> 4;
       constexpr int CK_LANE_DW = TILT ? 3 : 4;                                                                     // row checkpoint dwords per lane and pair
       constexpr size_t CK_COL_DW = TILT ? (size_t) 64 * 4 * VSX_COLCK_NB(R, true) : (size_t) 64 * (2 * R);           // column checkpoint dwords per wave
-      const int ck_slot = VSX_CK_SLOT(TILT, g, l);
-      u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps_own) >> 1) * 64 + ck_slot) * CK_LANE_DW;         // + (t >> 1) * VSX_ROWCK_PAIR_DW
+      const int ck_slot = VSX_CK_SLOT(TILT, gw, l);     // (NQ > 1: the wave's tasks share ONE checkpoint block, each in the slots of its own lane groups)
+      u32 * const rck_base = dir + T.dir_off + ((((size_t) s * steps) >> 1) * 64 + ck_slot) * CK_LANE_DW;         // + (t >> 1) * VSX_ROWCK_PAIR_DW
       u32 * const cck_base = dir + T.dir_off + ck_rowdw + (size_t) s * ck_nblk * CK_COL_DW;                        // + (t >> 4) * CK_COL_DW
       // mid-row checkpoints: a third region behind the column checkpoints, laid out like the row checkpoints
       u32 * const mck_base = dir + T.dir_off + ck_rowdw + (size_t) nstrips * ck_nblk * CK_COL_DW
-                             + ((((size_t) s * steps_own) >> 1) * 64 + ck_slot) * CK_LANE_DW;                           // + (t >> 1) * 192
+                             + ((((size_t) s * steps) >> 1) * 64 + ck_slot) * CK_LANE_DW;                           // + (t >> 1) * 192
       // transposed layout: block bases (steps is a multiple of 8 there); a lane adds (k * 64 + lane) * 4 dwords per store
-      u32 * const rck_blk = dir + T.dir_off + (((size_t) s * steps_own) >> 3) * VSX_CKT_BLOCK_DW;                       // + (t >> 3) * 768
-      u32 * const cck_blk = dir + T.dir_off + (((size_t) nstrips * steps_own) >> 3) * VSX_CKT_BLOCK_DW
+      u32 * const rck_blk = dir + T.dir_off + (((size_t) s * steps) >> 3) * VSX_CKT_BLOCK_DW;                       // + (t >> 3) * 768
+      u32 * const cck_blk = dir + T.dir_off + (((size_t) nstrips * steps) >> 3) * VSX_CKT_BLOCK_DW
                             + (size_t) s * ck_nblk * VSX_COLCK_NCHUNK(R) * VSX_CKT_BLOCK_DW;                        // + ((t >> 4) * NCHUNK + c) * 768
       // one 3 KB block: LDS -> HBM as it lies (three full 1 KB stores); the barriers order the lanes' LDS accesses (one wave)
       auto flush_block = [&](u32 * gdst) __attribute__((always_inline)) {
@@ -533,7 +536,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           const u32 inF = dpp_shr1(fF, outF);
 
           const int j = t - l;
-          const bool active = STEADY ? (NQ == 1 ? true : sub_on) : (lane_on && j >= 0 && j < Dpg);   // (NQ > 1: a sub-task past the launch's last task stores nothing)
+          const bool active = STEADY ? true : (lane_on && j >= 0 && j < Dpg);
           if (active)
             {
               const u32 code = sym & 0x000F000Fu;
@@ -671,7 +674,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
 
               // [4-step block][lane][step in block][ND]: a lane's 4 consecutive steps share one 64 B line
               // (4x fewer lines for the traceback walk) while a wave-step still lands in one 4 KB window
-              const size_t gt = (size_t) s * steps_own + t;
+              const size_t gt = (size_t) s * steps + t;
               if (CKPT)
                 {
                   if (!ODD) { pendH = outH; pendF = outF; }             // stored by the odd step below
@@ -728,7 +731,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                     __builtin_nontemporal_store((u32x4) {pendH, pendF, outH, outF}, reinterpret_cast<u32x4 *>(rck_base + (size_t) (t >> 1) * 256));
                 }
             }
-          if (CKPT && (t & 15) == 15 && (NQ == 1 || (sub_on && t < steps_own)))       // (NQ > 1: the wave's loop may run past this task's own range)
+          if (CKPT && (t & 15) == 15)
             {
               // column checkpoint m = t / 16 of this lane: state after its column t - l (or its border state if it has
               // not started yet).  Layout VSX_COLCK_DW (R = 1: [strip][m][lane][2]).
@@ -916,7 +919,7 @@ vsx_traceback_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   const int total_lanes = (Q + R - 1) / R;
   const int rcnt0 = Q - (total_lanes - 1) * R;
   const size_t steps = T.steps;
-  const int g = (int) (sl >> 1);
+  const int g = (int) (sl >> 1) + (int) T.group0;      // lane group of the DP wave (group0 > 0: a sparse task in a shared wave)
   const bool hi = (sl & 1) != 0;
   const uint8_t * __restrict__ q = qc + T.qoff;
   const uint8_t * __restrict__ d = tc + T.toff[sl];
@@ -1134,7 +1137,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
     const u32 * cb = colck + ((size_t) sp * nblk + (size_t) mb) * COL_DW;
     return (R % 2 == 0) ? cb[VSX_COLCK_DW(R, lanepos, x >> 2) + (x & 3)] : cb[(size_t) lanepos * (2 * R) + x];
   };
-  const int g = (int) (sl >> 1);
+  const int g = (int) (sl >> 1) + (int) T.group0;      // lane group of the DP wave (group0 > 0: a sparse task in a shared wave)
   const bool hi = (sl & 1) != 0;
   const u32 half_sel = hi ? 0x07060302u : 0x05040100u;           // v_perm_b32(F, H, sel) = this pair's H | F << 16
   // Border values (tables, corner seeds) enter the recompute through vin(): the FAST domain is the int16 value plus the class's bias --
@@ -1708,7 +1711,7 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
   const u32 steps32 = T.steps;
   const unsigned long long dir_off = T.dir_off;
   constexpr size_t COL_DW = (size_t) 64 * 4 * VSX_COLCK_NB(R, true);
-  const int g = (int) (sl >> 1);
+  const int g = (int) (sl >> 1) + (int) T.group0;      // lane group of the DP wave (group0 > 0: a sparse task in a shared wave)
   const bool hi = (sl & 1) != 0;
   const u32 half_sel = hi ? 0x07060302u : 0x05040100u;           // v_perm_b32(b, a, sel) = this pair's half of a | of b << 16
   const u32 bias = P.max3 ? 0x3E00u : 0x8000u;                   // what the DP kernel's class added to every stored value
@@ -2285,8 +2288,10 @@ vsx_max3_selftest_kernel(u32 * bad)
     }
   if (wrong) atomicAdd(bad, wrong);
 }
-static int g_tb_v2 = 1;          // 0: the TILT class keeps the first traceback kernel (self-test failed, or VSX_TB_V1=1)
-extern "C" void vsx_internal_set_tb_v2(int on) { g_tb_v2 = on; }
+// per device (one failing device must not decide for the others; contexts of several devices are created concurrently):
+// 1 = the TILT class keeps the first traceback kernel there (self-test failed or could not run).  Devices >= 64 share the last entry.
+static std::atomic<int> g_tb_v1_dev[65];
+extern "C" void vsx_internal_set_tb_v2(int device, int on) { g_tb_v1_dev[device < 0 || device > 64 ? 64 : device].store(on ? 0 : 1); }
 extern "C" hipError_t vsx_launch_max3_selftest(u32 * d_bad, hipStream_t st)
 {
   hipLaunchKernelGGL(vsx_max3_selftest_kernel, dim3((0x7C00 + 255) / 256), dim3(256), 0, st, d_bad);
@@ -2423,7 +2428,9 @@ extern "C" hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams
 {
   if (npairs == 0) return hipSuccess;
   static const bool v1_env = std::getenv("VSX_TB_V1") != nullptr;          // A/B: the first kernel for the TILT class too
-  const bool v2 = g_tb_v2 && !v1_env && !VSX_CKT;
+  int dev_now = 0;
+  if (hipGetDevice(&dev_now) != hipSuccess) { (void) hipGetLastError(); dev_now = 64; }
+  const bool v2 = g_tb_v1_dev[dev_now < 0 || dev_now > 64 ? 64 : dev_now].load(std::memory_order_relaxed) == 0 && !v1_env && !VSX_CKT;
 #define TBCK(RR) case RR: return (fast16 && P.tilt != 0 && v2 && RR >= 4) ? launch_tbtilt<RR, VSX_MID(RR, true)>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
                                  : (fast16 && P.tilt != 0) ? launch_tbck<RR, true, true, VSX_MID(RR, true)>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \
                                  : fast16 ? launch_tbck<RR, true>(P, F, d_tasks, d_pair_slot, d_pair_ids, npairs, q, t, ck, slot, slab, slab_off, runs, runs_capacity, cursor, out, st) \

@@ -117,6 +117,16 @@ struct ScratchPool {
           return hipSuccess;
         }
     }
+    if (bytes >= ((size_t) 16 << 20))
+      {
+        // (r05) never fill the device to the brim: the runtime needs room of its own (kernel scratch of every queue) and aborts the
+        // process when it finds none -- profiles/r05/r05b_config5_share_abort.txt.  Below the reserve, idle blocks go first.
+        size_t free_b = 0, total_b = 0;
+        int dev = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < bytes + ((size_t) 6 << 30) && hipGetDevice(&dev) == hipSuccess)
+          { trim(); (void) vsx_internal_memory_pressure(dev); }
+        (void) hipGetLastError();
+      }
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipErrorOutOfMemory) { trim(); (void) hipGetLastError(); e = hipMalloc(out, bytes); }
     if (e == hipErrorOutOfMemory)
@@ -197,6 +207,7 @@ struct SharedSlot {
   {
     std::lock_guard<std::mutex> lk(mu);
     if (cur && cur->bytes >= bytes) { out = cur; return hipSuccess; }
+    cur.reset();                       // (r05) too small: back to the pool as soon as no plan holds it, where memory pressure can free it
     auto b = std::make_shared<SharedBlock>();
     static const bool dbg = std::getenv("VSX_DEBUG_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -212,6 +223,8 @@ struct SharedSlot {
     return hipSuccess;
   }
   void reset() { std::lock_guard<std::mutex> lk(mu); cur.reset(); }
+  // (memory pressure may be raised from INSIDE an acquire of this very slot, whose lock is then held by the caller: skip it)
+  void try_reset() { if (mu.try_lock()) { cur.reset(); mu.unlock(); } }
   size_t bytes() { std::lock_guard<std::mutex> lk(mu); return cur ? cur->bytes : 0; }
 };
 template <typename T>
@@ -529,7 +542,7 @@ uint64_t vsx_internal_memory_pressure(int device)
     if (c->device == device)
       {
         SharedSlot * slot[4] = {&c->shared_dir[0], &c->shared_dir[1], &c->shared_dir[2], &c->shared_slab};
-        for (SharedSlot * sl : slot) sl->reset();          // a block a plan still references lives until that plan dies
+        for (SharedSlot * sl : slot) sl->try_reset();      // a block a plan still references lives until that plan dies
         freed += c->pool.idle_bytes();
         c->pool.trim();
       }
@@ -684,18 +697,11 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
   (void) hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);            // numerically: high < low
   static const bool flat_env = std::getenv("VSX_ALIGN_FLAT_PRIORITY") != nullptr;      // A/B
   const int prio_dp = (!flat_env && prio_low - prio_high >= 2) ? prio_high + 1 : prio_high;
-  // VSX_TB_CUS=n (A/B, r04): a fixed share of the device for the traceback stream -- CU-mask bits [0, n) (on this part bit b is CU
-  // b / 8 of XCD b % 8, so n = 8 k gives k CUs of every XCD: vsearch_amd/csrc/ubench_cumask.hip) -- and the rest for the DP streams
-  const int tb_cus = std::getenv("VSX_TB_CUS") ? std::atoi(std::getenv("VSX_TB_CUS")) : 0;
-  auto masked = [&](hipStream_t * st, int lo, int hi) -> hipError_t {
-    uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = lo; b < hi; ++b) m[b >> 5] |= 1u << (b & 31);
-    return hipExtStreamCreateWithCUMask(st, 8, m);
-  };
-  const bool use_mask = tb_cus >= 8 && tb_cus <= 128 && tb_cus % 8 == 0;
-  if ((e = use_mask ? masked(&c->stream, tb_cus, 256) : hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_dp)) != hipSuccess ||
-      (e = use_mask ? masked(&c->stream2, 0, tb_cus) : hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_high)) != hipSuccess ||
-      (e = use_mask ? masked(&c->stream_b, tb_cus, 256) : hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, prio_dp)) != hipSuccess ||
+  // (r04 measured CU-masked streams -- a fixed share of the CUs for the traceback -- and rejected them: the DP kernel ran 2 x slower,
+  //  profiles/r04/r04p_e2e_cumask_ab.txt; the VSX_TB_CUS switch is gone: masked streams also lose hipStreamNonBlocking and the priorities)
+  if ((e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_dp)) != hipSuccess ||
+      (e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_high)) != hipSuccess ||
+      (e = hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, prio_dp)) != hipSuccess ||
       (e = hipStreamCreateWithPriority(&c->stream_up, hipStreamNonBlocking, prio_high)) != hipSuccess ||
       (e = hipStreamCreateWithPriority(&c->stream_dn, hipStreamNonBlocking, prio_high)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_tb[0], hipEventDisableTiming)) != hipSuccess ||
@@ -731,11 +737,20 @@ int vsx_create(vsx_ctx ** out, const vsx_scoring * s, int device)
           if (bad2[1])
             {
               std::fprintf(stderr, "libvsx: device %d: v_perm_b32 sign selectors disagree on %u probes -- the first traceback kernel is used\n", device, bad2[1]);
-              vsx_internal_set_tb_v2(0);
+              vsx_internal_set_tb_v2(device, 0);
             }
         }
-      else (void) hipGetLastError();
+      else
+        {
+          //  a self-test that could not RUN proves nothing: fail closed -- the 16-bit TILT class and the first traceback
+          // kernel, which rest on no hardware assumption -- and say so
+          (void) hipGetLastError();
+          std::fprintf(stderr, "libvsx: device %d: the MAX3 / v_perm_b32 self-test could not run -- MAX3 class and second traceback kernel disabled\n", device);
+          g_max3_state[device].store(2);
+          vsx_internal_set_tb_v2(device, 0);
+        }
     }
+  else if (device >= 64) vsx_internal_set_tb_v2(device, 0);      // (no per-device state beyond 64 devices: the conservative kernels)
 
   // Tilted coordinates X* = X + (i + j) g, g = the interior extension (VsxDevParams::tilt): available when both interior
   // extensions are g > 0 and the interior QR coincide (the DP kernel's shared H - QR); per task the planner still has to
@@ -985,7 +1000,7 @@ static int tilt_possible(const vsx_ctx * ctx, int64_t Q, int64_t D)
   // (pen[4] = the query's right-end gap open: the MAX3 kernel's interior steps read "the last row continues to the left" off ext-left
   //  alone, which covers "left" only when that penalty is positive -- vsx_forward_kernel LASTFAST; the reference's default is 1)
   if (reach < 15800 && !max3_off && !VSX_CKT && ctx->pen[4] > 0 &&
-      g_max3_state[ctx->device & 63].load(std::memory_order_relaxed) != 2) return 2;         // 0x3E00 = 15872 each way inside [0, 0x7BFF]
+      ctx->device < 64 && g_max3_state[ctx->device].load(std::memory_order_relaxed) == 1) return 2;         // 0x3E00 = 15872 each way inside [0, 0x7BFF]
   return reach < 32000 ? 1 : 0;
 }
 
@@ -1308,13 +1323,41 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
     nc.pair_first = cur.pair_first + cur.pair_count;
     cur = nc;
   };
+  // sparse-task classes: the nq tasks of a wave -- consecutive tasks of the launch, counted from its first -- share ONE checkpoint block
+  // and one step range (the longest of them); `wave_left` tasks of the open wave are still to come, they take `wave_off` / `wave_steps`
+  uint32_t wave_left = 0, wave_steps = 0, wave_group = 0;
+  uint64_t wave_off = 0;
+  auto same_class = [&](size_t a, size_t b) {
+    return protos[a].rows == protos[b].rows && protos[a].generic == protos[b].generic && protos[a].track == protos[b].track &&
+           protos[a].tilt == protos[b].tilt && protos[a].nq == protos[b].nq;
+  };
   for (size_t x = 0; x < NT; ++x)
     {
       const ProtoTask & pt = protos[x];
       VsxTask & t = pl->tasks[x];
-      const uint64_t dwords = t_dwords[x], strip = t.strip_off;
-      if (cur.task_count && cur.dir_dwords + dwords + VSX_CK_SLACK_DW > budget_dwords) close_chunk();
-      t.dir_off = cur.dir_dwords;
+      uint64_t dwords = t_dwords[x];
+      const uint64_t strip = t.strip_off;
+      if (pt.nq > 1 && wave_left == 0)
+        {
+          // a new wave: its tasks are x .. x + nq - 1 as far as the class reaches (a chunk is never cut inside a wave)
+          uint32_t smax = t.steps, members = 1;
+          while (members < (uint32_t) pt.nq && x + members < NT && same_class(x, x + members)) { smax = std::max(smax, pl->tasks[x + members].steps); ++members; }
+          wave_left = members; wave_steps = smax; wave_group = 0;
+          dwords = vsx_ckpt_dwords(1, smax, (uint64_t) pt.rows, pt.tilt);
+          if (cur.task_count && cur.dir_dwords + dwords + VSX_CK_SLACK_DW > budget_dwords) close_chunk();
+          wave_off = cur.dir_dwords;
+        }
+      else if (pt.nq > 1) dwords = 0;                     // (the wave's block is already counted)
+      else if (cur.task_count && cur.dir_dwords + dwords + VSX_CK_SLACK_DW > budget_dwords) close_chunk();
+      if (pt.nq > 1)
+        {
+          t.dir_off = wave_off;
+          t.steps = wave_steps;
+          t.group0 = wave_group;
+          wave_group += 4u / (uint32_t) pt.nq;
+          --wave_left;
+        }
+      else t.dir_off = cur.dir_dwords;
       t.strip_off = cur.strip_elems;
       cur.dir_dwords += dwords;
       cur.strip_elems += strip;

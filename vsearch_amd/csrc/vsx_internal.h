@@ -73,7 +73,8 @@ struct VsxTask {
   uint32_t qlen;
   uint32_t steps;                     // per strip: max padded target length + 15
   uint32_t rows;                      // R: query rows per lane for this task's kernel variant
-  uint32_t pad;
+  uint32_t group0;                    // first lane group of the DP wave that works on this task: 0 for a whole-wave task; a sparse task
+                                      // (vsx_forward_kernel NQ) shares a wave -- and the wave's checkpoint block, dir_off -- with NQ - 1 others
 };
 
 // Accept filter evaluated in the traceback epilogue (include/vsx.h vsx_filter); enabled == 0: every pair is kept.
@@ -173,7 +174,7 @@ hipError_t vsx_launch_traceback_ck(int rows, int fast16, VsxDevParams P, VsxFilt
                                    VsxPairOut * d_out, hipStream_t st);
 // bad[0] += disagreements of v_pk_maximum3_f16 with the integer maximum over the MAX3 class's value range (must stay 0)
 hipError_t vsx_launch_max3_selftest(uint32_t * d_bad /* [2]: max3, v_perm sign selectors */, hipStream_t st);
-void vsx_internal_set_tb_v2(int on);
+void vsx_internal_set_tb_v2(int device, int on);      // on == 0: the first traceback kernel for the TILT class on that device
 uint64_t vsx_ckpt_dwords(uint64_t nstrips, uint64_t steps, uint64_t rows, int tilt /* compressed layout of the TILT class */);
 const int * vsx_supported_rows(int * count);
 

@@ -33,7 +33,10 @@ extern "C" hipError_t vsx_kmer_launch_select_packed(const void * rec, uint32_t s
                                                     void * sel_m_n, uint64_t * sel_off, hipStream_t st);
 
 extern "C" void vsx_internal_poison(void * p, size_t bytes);
-extern "C" uint64_t vsx_internal_memory_pressure(int device);      // vsx_host.cpp: every context of the device frees what no plan holds
+extern "C" uint64_t vsx_internal_memory_pressure(int device);
+#ifndef VSX_DEVICE_RESERVE_BYTES
+#define VSX_DEVICE_RESERVE_BYTES ((size_t) 6 << 30)      // what stays free for the runtime itself (kernel scratch of every queue, code objects)
+#endif      // vsx_host.cpp: every context of the device frees what no plan holds
 namespace {
 
 int kfail(int code, const char * what, hipError_t e)
@@ -50,6 +53,17 @@ template <typename T> struct Buf {
   hipError_t alloc(size_t count)
   {
     if (p) { (void) hipFree(p); p = nullptr; n = 0; }
+    const size_t want = std::max<size_t>(count, 1) * sizeof(T);
+    if (want >= ((size_t) 16 << 20))
+      {
+        // a device filled to the brim fails LATER and worse than a refused hipMalloc: the runtime cannot allocate a queue's kernel scratch
+        // and aborts the process (HSA_STATUS_ERROR_OUT_OF_RESOURCES, profiles/r05/r05b_config5_share_abort.txt).  Keep a reserve.
+        size_t free_b = 0, total_b = 0;
+        int dev = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < want + VSX_DEVICE_RESERVE_BYTES && hipGetDevice(&dev) == hipSuccess)
+          (void) vsx_internal_memory_pressure(dev);
+        (void) hipGetLastError();
+      }
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T));
     if (e == hipErrorOutOfMemory)
       {

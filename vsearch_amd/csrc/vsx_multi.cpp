@@ -138,9 +138,11 @@ int vsx_multi_searcher_create(vsx_multi_searcher ** out, const vsx_scoring * sco
   // device twice still doubles that device's context memory (three aligner contexts + counting scratch per replica).
   vsx_search_opts ropts = *opts;
   {
-    int budget = ropts.threads > 0 ? ropts.threads : vsx_internal_usable_cpus();
+    //  the floor of 2 applies to the auto-detected budget only: an explicit `threads` is the caller's limit and is never raised
+    const bool explicit_budget = ropts.threads > 0;
+    int budget = explicit_budget ? ropts.threads : vsx_internal_usable_cpus();
     if (budget <= 0) budget = 2;
-    ropts.threads = std::max(2, budget / n_devices);
+    ropts.threads = std::max(explicit_budget ? 1 : 2, budget / n_devices);
   }
   // every replica uploads and indexes on its own device at the same time
   const int rc = on_all(m.get(), [&](size_t d) -> int {

@@ -537,7 +537,7 @@ static int fill_hit(const vsx_searcher & S, FQ qtext, int64_t ql, Hit & h, const
   return VSX_OK;
 }
 
-static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out)
+static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out, int thread_budget /* the searcher's: S->threads */)
 {
   const uint64_t nq = kept.size();
   out->n_queries = nq;
@@ -585,7 +585,7 @@ static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out)
           }
       }
   };
-  const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::min(usable_cpus(), 8), total / 16384));
+  const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::min(std::max(1, thread_budget), 8), total / 16384));
   if (nth <= 1) fill(0, nq);
   else
     {
@@ -773,7 +773,8 @@ struct KmerAcct { double kernel_ms = 0, build_ms = 0; uint64_t streamed = 0, str
 // 16-bit tile counters cannot serve (threshold 0, > 32767 words) are listed in `fallback` and left empty.
 static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vector<uint32_t> * map, uint64_t nq,
                        const std::vector<std::vector<uint32_t>> & words, uint32_t keep, uint32_t cap_hint, bool rank,
-                       std::vector<std::vector<Cand>> & cands, std::vector<uint64_t> & fallback, KmerAcct & acct)
+                       std::vector<std::vector<Cand>> & cands, std::vector<uint64_t> & fallback, KmerAcct & acct,
+                       int thread_cap = 0 /* > 0: the caller runs beside other helpers and owns only this share of S->threads */)
 {
   // CSR + thresholds (:320)
   std::vector<uint64_t> qk_start(nq + 1, 0);
@@ -787,7 +788,7 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
       qk_start[k + 1] = qk_start[k] + nk;
     }
   std::vector<uint32_t> qk(qk_start[nq]);
-  const int nth = std::max(1, S->threads);
+  const int nth = std::max(1, thread_cap > 0 ? std::min(thread_cap, S->threads) : S->threads);
   {
     // the words of all queries back to back (threads: a round of clustering is 1.2 M words, a search window 4 M)
     std::atomic<uint64_t> nextq {0};
@@ -1572,7 +1573,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
   // ---- marshal ----
   const double tm = now_s();
   {
-    const int mrc = marshal_hits(kept, out);
+    const int mrc = marshal_hits(kept, out, S->threads);
     if (mrc != VSX_OK) return mrc;
   }
   if (timeline) std::fprintf(stderr, "  [%7.1f ms] hits marshalled\n", (now_s() - t_begin) * 1e3);
@@ -1825,7 +1826,7 @@ int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows
   }
   vsx_results_free(&res);
   }
-  rc = marshal_hits(kept, out);
+  rc = marshal_hits(kept, out, S->threads);
   if (rc != VSX_OK) return rc;
   for (uint64_t k = 0; k < out->n_hits; ++k) out->hit[k].query = rows[out->hit[k].query];       // vsx_hit.query = database sequence number
   out->pairs_aligned = n_list; out->cells_aligned = cells; out->stages = 1; out->sentinel_pairs = sentinels;
@@ -2012,7 +2013,8 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
                 const uint64_t cnt = std::min<uint64_t>(round, n - a0);
                 pre_cands.assign(cnt, {});
                 pre_fallback.clear();
-                pre_rc = device_rank(S, cix.get(), &main_list, cnt, pre_kmers, (uint32_t) std::max<int64_t>(S->tophits, 1), 1024, true, pre_cands, pre_fallback, kacct);
+                pre_rc = device_rank(S, cix.get(), &main_list, cnt, pre_kmers, (uint32_t) std::max<int64_t>(S->tophits, 1), 1024, true, pre_cands, pre_fallback, kacct,
+                                     std::max(1, nth / 2));      // (runs beside the staged search and the near helper)
                 if (pre_rc != VSX_OK) pre_err = vsx_last_error();
               });
             }
@@ -2117,6 +2119,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
       double spec_s = 0;
       static const bool spec_overlap = VSX_CLUSTER_SPEC_OVERLAP_DEFAULT ? !(std::getenv("VSX_CLUSTER_SPEC_OVERLAP") && std::strcmp(std::getenv("VSX_CLUSTER_SPEC_OVERLAP"), "0") == 0)
                                                                         : (std::getenv("VSX_CLUSTER_SPEC_OVERLAP") && std::strcmp(std::getenv("VSX_CLUSTER_SPEC_OVERLAP"), "1") == 0);
+      static const bool near_overlap = !(std::getenv("VSX_CLUSTER_NEAR_OVERLAP") && std::strcmp(std::getenv("VSX_CLUSTER_NEAR_OVERLAP"), "0") == 0);   // A/B
       const bool near_on_device = dev_kmer && fallback.empty();
       auto near_device = [&]() {
         // the same counting problem on the device: members of the round against an index of the round
@@ -2125,7 +2128,8 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
         near_rc = vsx_kmer_index_rebuild(rix.get(), round_list.data(), wn);
         std::vector<std::vector<Cand>> nc(wn);
         std::vector<uint64_t> none;
-        if (near_rc == VSX_OK) near_rc = device_rank(S, rix.get(), &round_list, wn, kmers, 0xffffffffu, 1024, false, nc, none, kacct);
+        if (near_rc == VSX_OK) near_rc = device_rank(S, rix.get(), &round_list, wn, kmers, 0xffffffffu, 1024, false, nc, none, kacct,
+                                                     (near_on_device && near_overlap) ? std::max(1, S->threads / 2) : 0);      // (beside the staged search: half the budget)
         if (near_rc != VSX_OK) { near_err = vsx_last_error(); return; }
         for (uint64_t i = 0; i < wn; ++i)
           for (const Cand & c : nc[i])                              // ascending target
@@ -2150,7 +2154,6 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
             spec_done = true;
           }
       };
-      static const bool near_overlap = !(std::getenv("VSX_CLUSTER_NEAR_OVERLAP") && std::strcmp(std::getenv("VSX_CLUSTER_NEAR_OVERLAP"), "0") == 0);   // A/B
       std::thread near_thread;
       struct NearJoiner { std::thread & t; ~NearJoiner() { if (t.joinable()) t.join(); } } near_joiner {near_thread};
       if (near_on_device && near_overlap)
@@ -2349,7 +2352,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
                          "intra-round counts %.2f  speculative align %.2f  reconcile %.2f  total %.2f s\n",
                  tm_words, tm_rebuild, tm_rank, tm_stages, acct.t_align - tm_spec, tm_near, tm_spec, tm_recon, now_s() - t_begin);
 
-  int rc = marshal_hits(kept, &out->hits);
+  int rc = marshal_hits(kept, &out->hits, S->threads);
   if (rc != VSX_OK) return rc;
   out->n = n;
   out->n_clusters = nclusters;
