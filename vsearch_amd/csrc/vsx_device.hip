@@ -1663,6 +1663,13 @@ DEV u32 pk_sub(u32 a, u32 b) { return psubw(a, b); }                            
 #ifndef VSX_TB2_WAVES
 #define VSX_TB2_WAVES(R_, MID_) 3
 #endif
+// VSX_TB_LDSSTAGE (r05): the nine row-checkpoint pairs above a tile -- 27 of the 56 staging VGPRs of a tile -- go from HBM straight into
+// LDS (global_load_lds_dwordx3: 12 bytes per lane, lane-linear) instead of through registers; the landing zone is the direction-bit array
+// of the tile before (dead between a tile's walk and the next tile's column loop), so no LDS is added.  Only where that array is large
+// enough (two bit words per column slot: every variant that spills).
+#ifndef VSX_TB_LDSSTAGE
+#define VSX_TB_LDSSTAGE 0
+#endif
 template <int R, bool MID>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VSX_TB2_WAVES(R, MID), 8)))
 vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTask * __restrict__ tasks,
@@ -1682,7 +1689,8 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
   // One wave per workgroup: 14.5 KB of LDS each = 11 waves per CU (the wave's own arrays are lane-minor: no bank conflicts)
   __shared__ uint8_t Ssh[512];                     // S'[target code][query code], row stride 32; query "code" 16 = a dummy row of position 0
   __shared__ u32 Ssh4[16];                         // S'[target code][A | C << 8 | G << 16 | T << 24]: the fast score pick
-  __shared__ u32 bitsL[17 * NG * 64];              // [column slot 0 .. 16][group of four row pairs][lane]
+  __shared__ __attribute__((aligned(16))) u32 bitsL[17 * NG * 64];              // [column slot 0 .. 16][group of four row pairs][lane]
+  constexpr bool LSTAGE = (VSX_TB_LDSSTAGE != 0) && (17 * NG * 64 >= 9 * 64 * 3);      // raw row checkpoints [pair e][lane][3 dwords] land in bitsL
   __shared__ u32 tbL[19 * 64];                     // top boundary of the tile in work, H (low 16) | F (high 16), int16 values: entry e = column cst - 1 + e
   __shared__ uint8_t symL[10 * 64];                // target symbols of columns cst .. cst + 19, two to a byte
   const int tid = (int) threadIdx.x;
@@ -1812,7 +1820,7 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
 
       // ---- what a tile reads from HBM: nine two-step pairs of the row (or mid-row) checkpoints above it, the column checkpoint left of
       // it, 20 target symbols.  Issued as one batch; tile 2's batch is issued between tile 1's recompute and its walk ----
-      struct TileIn { Trio v3[9]; int par; Quad fq[NBQ]; u32 sw[5]; };
+      struct TileIn { Trio v3[LSTAGE ? 1 : 9]; int par; Quad fq[NBQ]; u32 sw[5]; };
       auto load_tile = [&](TileIn & in, const int cst, const int mleft) __attribute__((always_inline)) {
         in.par = 0;
         if (!top_is_border)
@@ -1835,8 +1843,18 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
             // pairs p0 .. p0 + 8, unclamped: one base address and immediate offsets.  Pairs outside the region (p0 = -1, or past the
             // last pair) feed entries nobody reads; the chunk's block has VSX_CK_SLACK_DW readable dwords at both ends (vsx_host.cpp)
             const u32 * bp = base + p0 * (long) VSX_ROWCK_PAIR_DW(true);
+            if (LSTAGE)
+              {
 #pragma unroll
-            for (int e = 0; e < 9; ++e) in.v3[e] = *reinterpret_cast<const Trio *>(bp + e * VSX_ROWCK_PAIR_DW(true));
+                for (int e = 0; e < 9; ++e)
+                  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (bp + e * VSX_ROWCK_PAIR_DW(true)),
+                                                   (__attribute__((address_space(3))) void *) (bitsL + e * 192), 12, 0, 0);
+              }
+            else
+              {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) in.v3[LSTAGE ? 0 : e] = *reinterpret_cast<const Trio *>(bp + e * VSX_ROWCK_PAIR_DW(true));
+              }
           }
         const u32 * cb = colck + ((size_t) s * nblk + (size_t) (mleft > 0 ? mleft : 0)) * COL_DW + VSX_COLCK_CDW(VSX_COLCK_NB(R, true), VSX_CK_SLOT(true, g, l), 0)
                          + (MID ? (size_t) (hh * NBQ) * (4 * VSX_COLCK_CG) : 0);
@@ -1893,12 +1911,16 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
         else
           {
             u32 * dst = tbL + tid - in.par * 64;                              // entry of step 2 (p0 + e) is 2 e - par
+            if (LSTAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of load_tile has landed (one wave per workgroup: no barrier)
 #pragma unroll
             for (int e = 0; e < 9; ++e)
               {
                 // {H_t, H_t+1, bytes d_t(lo) d_t(hi) d_t+1(lo) d_t+1(hi)}: F = H - d; everything minus the class's bias
-                const u32 h0 = (half_lo(in.v3[e].x, hi) - bias) & 0xffffu, h1 = (half_lo(in.v3[e].y, hi) - bias) & 0xffffu;
-                const u32 dd = hi ? (in.v3[e].z >> 8) : in.v3[e].z;
+                Trio raw;
+                if (LSTAGE) raw = *reinterpret_cast<const Trio *>(bitsL + e * 192 + tid * 3);
+                else raw = in.v3[LSTAGE ? 0 : e];
+                const u32 h0 = (half_lo(raw.x, hi) - bias) & 0xffffu, h1 = (half_lo(raw.y, hi) - bias) & 0xffffu;
+                const u32 dd = hi ? (raw.z >> 8) : raw.z;
                 const int d0 = (int) (int8_t) (dd & 0xffu), d1 = (int) (int8_t) ((dd >> 16) & 0xffu);
                 if (e > 0 || in.par == 0) dst[(2 * e) * 64] = h0 | ((h0 - (u32) d0) << 16);
                 dst[(2 * e + 1) * 64] = h1 | ((h1 - (u32) d1) << 16);        // (entries 0 .. 17)
