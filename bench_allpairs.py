@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--len", type=int, default=400)
     ap.add_argument("--block", type=int, default=1000)
     ap.add_argument("--id", type=float, default=0.8)
+    ap.add_argument("--max-blocks", type=int, default=0, help="stop after this many blocks (0 = all): timelines of the first, largest blocks")
     ap.add_argument("--parity-prefix", type=int, default=1500,
                     help="cross-check the hits among the first N sequences against the reference CLI (0 = skip)")
     a = ap.parse_args()
@@ -56,6 +57,8 @@ def main():
             per_block = []
             t0 = time.perf_counter()
             for first in range(0, a.n, a.block):
+                if a.max_blocks and first >= a.max_blocks * a.block:
+                    break
                 cnt = min(a.block, a.n - first)
                 hits = _lib.Hits()
                 tb = time.perf_counter()

@@ -5,6 +5,11 @@ import pytest
 
 # the ranked allpairs path tolerates device/host floating-point drift in production; the suite wants to SEE any (vsx_search.cpp)
 os.environ.setdefault("VSX_RANK_STRICT", "1")
+# r05: in production a sparse-task class needs >= 4 096 tasks to be worth its own launches (vsx_host.cpp); the fixtures are small, and
+# the suite wants the sparse-task kernels exercised by every one- to four-target task it plans (the golden vectors are one-target
+# tasks).  test_sparse_class_threshold covers the production threshold in a child process; VSX_SPARSE=0 (test_alternate_kernel_modes)
+# the whole-wave classes.
+os.environ.setdefault("VSX_SPARSE_MIN", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

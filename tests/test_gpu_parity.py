@@ -544,3 +544,46 @@ def test_sparse_task_classes(gpu_required, oracle, name):
         assert info["tasks_sparse"] <= sum(1 for k, n in enumerate(ntargets) if n <= 4 and len(qs[k]) <= 512), info
     for k in range(len(qi)):
         assert res.row(k) == tuple(oracle.align(qs[qi[k]], ts[ti[k]], P, nmm)), (name, k, len(qs[qi[k]]), len(ts[ti[k]]))
+
+
+_SPARSE_THRESHOLD_SNIPPET = r"""
+import random, sys
+import numpy as np
+sys.path.insert(0, %r)
+from tests import common
+from vsearch_amd import Aligner
+rng = random.Random(8)
+seqs = [common.rnd_seq(rng, 150) for _ in range(300)]            # one query length: one row class (the threshold is per kernel class)
+out = []
+with Aligner() as al:
+    S = al.sequences(seqs)
+    for n in (600, 9000):
+        qi = np.arange(n, dtype=np.uint32) %% 300                      # n one-target tasks (a query may repeat: separate pairs of one query
+        qi.sort()                                                       #  group into tasks of <= 8, so use distinct (query, target) draws)
+        ti = np.array([rng.randrange(300) for _ in range(n)], np.uint32)
+        # one target per task: every pair gets a query of its own
+        Qn = al.sequences([seqs[q] for q in qi])
+        p = al.plan(Qn, S, np.arange(n, dtype=np.uint32), ti)
+        info = p.describe()
+        out.append((n, info["tasks"], info["tasks_sparse"], info["waves"]))
+        p.close(); Qn.close()
+    S.close()
+print("INFO", out)
+"""
+
+
+@pytest.mark.gpu
+def test_sparse_class_threshold(gpu_required):
+    """the production rule (no VSX_SPARSE_MIN in the environment): a sparse-task class below 4 096 tasks stays whole-wave tasks -- one
+    launch fewer, nothing to gain on a chip that is not full -- and a larger one shares its waves"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("VSX_SPARSE_MIN", "VSX_SPARSE")}
+    p = subprocess.run([sys.executable, "-c", _SPARSE_THRESHOLD_SNIPPET % root], env=e, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("INFO")][-1]
+    info = eval(line[5:])
+    small, large = info
+    assert small[1] == 600 and small[2] == 0 and small[3] == 600, info
+    assert large[1] == 9000 and large[2] == 9000 and large[3] == 2250, info

@@ -1224,28 +1224,29 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
               }
           }
   }
-  // a SMALL sparse class beside a large class of whole-wave tasks of the same kind is not worth its own launches (a launch of a few
-  // hundred waves is a latency chain of its own, the same tasks as whole waves inside the large launch cost next to nothing)
+  // a SMALL sparse class is not worth its own launches: below one round of the chip (256 CUs x <= 16 waves) whole-wave tasks already
+  // have the SIMDs largely to themselves -- packing four of them into one slower wave frees nothing -- and every extra class is one more
+  // DP launch in the plan's stream (r05c: the speculative alignments of --cluster_fast, ~30 k pairs per round in three classes, ran
+  // 0.44 -> 0.64 s with sparse classes of a few thousand tasks each).  VSX_SPARSE_MIN=n: the smallest class kept (tests: 1)
   if (sparse_on)
     {
-      static const size_t sparse_min = std::getenv("VSX_SPARSE_MIN") ? (size_t) std::atoll(std::getenv("VSX_SPARSE_MIN")) : 2048;
+      static const size_t sparse_min = std::getenv("VSX_SPARSE_MIN") ? (size_t) std::atoll(std::getenv("VSX_SPARSE_MIN")) : 4096;
       struct Key { int rows, generic, track, tilt, nq; size_t count; };
       std::vector<Key> ks;
       for (const ProtoTask & pt : protos)
         {
+          if (pt.nq == 1) continue;
           bool found = false;
           for (Key & c : ks) if (c.rows == pt.rows && c.generic == pt.generic && c.track == pt.track && c.tilt == pt.tilt && c.nq == pt.nq) { ++c.count; found = true; break; }
           if (!found) ks.push_back(Key {pt.rows, pt.generic, pt.track, pt.tilt, pt.nq, 1});
         }
-      std::vector<Key> demote;
-      for (const Key & c : ks)
-        if (c.nq > 1 && c.count < sparse_min)
-          for (const Key & w : ks)
-            if (w.nq == 1 && w.rows == c.rows && w.generic == c.generic && w.track == c.track && w.tilt == c.tilt && w.count >= 8 * c.count) { demote.push_back(c); break; }
-      if (!demote.empty())
+      bool any = false;
+      for (const Key & c : ks) any = any || c.count < sparse_min;
+      if (any)
         for (ProtoTask & pt : protos)
-          for (const Key & c : demote)
-            if (pt.nq == c.nq && pt.rows == c.rows && pt.generic == c.generic && pt.track == c.track && pt.tilt == c.tilt) { pt.nq = 1; break; }
+          if (pt.nq > 1)
+            for (const Key & c : ks)
+              if (c.count < sparse_min && pt.nq == c.nq && pt.rows == c.rows && pt.generic == c.generic && pt.track == c.track && pt.tilt == c.tilt) { pt.nq = 1; break; }
     }
   // kernel classes together (one launch per class and chunk)
   auto by_class = [](const ProtoTask & a, const ProtoTask & b) {
@@ -1521,14 +1522,22 @@ int vsx_plan_run(vsx_plan * pl)
       HIPCHK(hipEventRecord(c.e1b, st2));
       if (ctx->ckpt)
         {
-          for (const Launch & L : c.launches)      // the recompute traceback is specialised on R like the DP kernel
+          for (size_t li = 0; li < c.launches.size();)      // the recompute traceback is specialised on R like the DP kernel
             {
+              const Launch & L = c.launches[li];
+              // (the sparse-task variants of one class -- nq = 1, 2, 4, adjacent in the class order -- share ONE traceback launch: the
+              //  traceback finds a pair's lane group through its task and does not know about nq; their pairs are contiguous)
+              uint32_t pair_count = L.pair_count;
+              size_t lj = li + 1;
+              while (lj < c.launches.size() && c.launches[lj].rows == L.rows && c.launches[lj].generic == L.generic &&
+                     c.launches[lj].track == L.track && c.launches[lj].tilt == L.tilt) { pair_count += c.launches[lj].pair_count; ++lj; }
               VsxDevParams Pb = L.tilt ? ctx->Pt : ctx->P;
               Pb.max3 = (L.tilt == 2) ? 1 : 0;         // the checkpoints of the MAX3 class carry its bias
               HIPCHK(vsx_launch_traceback_ck(L.rows, (L.track == 0 && L.generic != 0) ? 1 : 0, Pb, pl->filter, pl->d_tasks.p, pl->d_pair_slot.p + L.pair_first,
-                                             pl->d_pair_ids.p + L.pair_first, L.pair_count, pl->Q->codes(), pl->T->codes(),
+                                             pl->d_pair_ids.p + L.pair_first, pair_count, pl->Q->codes(), pl->T->codes(),
                                              dir, pl->d_slot.p, pl->d_slab.p, pl->d_slab_off.p + L.pair_first,
                                              pl->d_runs.p, pl->runs_capacity, pl->d_cursor.p, pl->d_out.p, st2));
+              li = lj;
             }
         }
       else
