@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--len", type=int, default=400)
     ap.add_argument("--block", type=int, default=1000)
     ap.add_argument("--id", type=float, default=0.8)
+    ap.add_argument("--stream", type=int, default=1, help="1 (default): vsx_allpairs_stream -- the blocks' enumeration, alignment and hit completion "
+                                                          "overlapped inside the library; 0: one vsx_allpairs_block call per block (r01-r04)")
     ap.add_argument("--max-blocks", type=int, default=0, help="stop after this many blocks (0 = all): timelines of the first, largest blocks")
     ap.add_argument("--parity-prefix", type=int, default=1500,
                     help="cross-check the hits among the first N sequences against the reference CLI (0 = skip)")
@@ -55,15 +57,7 @@ def main():
             npfx = min(a.parity_prefix, a.n)
             sample = []                                  # userout lines (query, target, id, caln) of the pairs inside the prefix
             per_block = []
-            t0 = time.perf_counter()
-            for first in range(0, a.n, a.block):
-                if a.max_blocks and first >= a.max_blocks * a.block:
-                    break
-                cnt = min(a.block, a.n - first)
-                hits = _lib.Hits()
-                tb = time.perf_counter()
-                check(lib.vsx_allpairs_block(h, 0, first, cnt, C.byref(hits)), "vsx_allpairs_block")
-                per_block.append(round(time.perf_counter() - tb, 3))
+            def take(first, hits):
                 tot["pairs"] += int(hits.pairs_aligned)
                 tot["cells"] += int(hits.cells_aligned)
                 tot["hits"] += int(hits.n_hits)
@@ -74,7 +68,35 @@ def main():
                     for r in harr[(harr["query"] < npfx) & (harr["target"] < npfx)]:
                         o = int(r["cigar_off"])
                         sample.append("t%d\tt%d\t%.1f\t%s" % (r["query"], r["target"], r["id"], cig[o:cig.index(b"\0", o)].decode()))
-                lib.vsx_hits_free(C.byref(hits))
+
+            t0 = time.perf_counter()
+            nrows = a.n if not a.max_blocks else min(a.n, a.max_blocks * a.block)
+            if a.stream:
+                SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(_lib.Hits))
+                last = [time.perf_counter()]
+
+                def sink(_user, first, cnt, hp):
+                    try:
+                        take(int(first), hp.contents)
+                        now = time.perf_counter()
+                        per_block.append(round(now - last[0], 3))          # (time between two blocks' hand-overs)
+                        last[0] = now
+                        return 0
+                    except Exception:
+                        import traceback
+                        traceback.print_exc()
+                        return -99
+                cb = SINK(sink)
+                check(lib.vsx_allpairs_stream(h, 0, 0, nrows, a.block, C.cast(cb, C.c_void_p), None), "vsx_allpairs_stream")
+            else:
+                for first in range(0, nrows, a.block):
+                    cnt = min(a.block, nrows - first)
+                    hits = _lib.Hits()
+                    tb = time.perf_counter()
+                    check(lib.vsx_allpairs_block(h, 0, first, cnt, C.byref(hits)), "vsx_allpairs_block")
+                    per_block.append(round(time.perf_counter() - tb, 3))
+                    take(first, hits)
+                    lib.vsx_hits_free(C.byref(hits))
             wall = time.perf_counter() - t0
         finally:
             lib.vsx_searcher_destroy(h)

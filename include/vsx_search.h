@@ -156,6 +156,13 @@ int vsx_allpairs_block(vsx_searcher * s, int32_t acceptall, uint64_t first, uint
    interleaved rows (vsearch_amd/sharding.py shard_allpairs_rows), every rank runs its rows against its DB replica.
    hits.first has count + 1 entries (entry k = rows[k]); vsx_hit.query is the database sequence number. */
 int vsx_allpairs_rows(vsx_searcher * s, int32_t acceptall, const uint32_t * rows, uint64_t count, vsx_hits * out);
+/* the whole command as one call (r05): rows first .. first + count - 1 in blocks of `block` queries (0 = 1 000), the stages of consecutive
+   blocks overlapped -- while block i is on the GPU, block i + 1's pair list is enumerated and block i - 1's hits are completed on host
+   threads.  `sink` receives each block's hits (those of vsx_allpairs_block(first + i * block, ...)), in order, from a helper thread, one
+   call at a time; the hits belong to the library and are released when the sink returns.  A non-zero return of the sink stops the run
+   and becomes the function's result.  The reference's worker threads report each query as it finishes (commands/allpairs_global.cpp:394-527). */
+typedef int (*vsx_hits_sink)(void * user, uint64_t first, uint64_t count, const vsx_hits * hits);
+int vsx_allpairs_stream(vsx_searcher * s, int32_t acceptall, uint64_t first, uint64_t count, uint64_t block, vsx_hits_sink sink, void * user);
 
 /* ---- multi-device form: several GPUs of one node behind ONE handle (vsx_multi.cpp) ----------------------------------------
    The reference is one process with a pool of worker threads over a shared database (commands/usearch_global.cpp:500-535,

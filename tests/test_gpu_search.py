@@ -679,3 +679,27 @@ def test_dust_masking_refuses_overlapping_sequences(gpu_required):
                                      off2.ctypes.data_as(C.c_void_p), ln2.ctypes.data_as(C.c_void_p))
         assert rc == 0, lib.vsx_last_error()
         lib.vsx_searcher_destroy(h)
+
+
+@pytest.mark.gpu
+def test_allpairs_stream_equals_blocks(gpu_required):
+    """r05: vsx_allpairs_stream overlaps pair enumeration, alignment and hit completion of consecutive blocks; the hits it hands to its
+    sink, block after block, must be exactly those of one vsx_allpairs_block call -- ranked path and acceptall (every pair kept)"""
+    import random
+    from vsearch_amd import Aligner
+    from vsearch_amd.search import Searcher
+    rng = random.Random(77)
+    fam = [common.rnd_seq(rng, rng.randint(60, 220)) for _ in range(12)]
+    seqs = [common.mutate(rng, rng.choice(fam), rng.choice([0.02, 0.08, 0.2])) for _ in range(230)]
+    with Aligner() as al:
+        for acceptall, kw in ((False, dict(id=0.8)), (True, dict(id=0.5)), (False, dict(id=0.7, maxgaps=3, self=0))):
+            ss = Searcher(al, seqs, **kw)
+            whole = ss.allpairs(acceptall=acceptall)
+            pairs = ss.stats["pairs_aligned"]
+            for block in (1, 37, 100, 1000):
+                got = ss.allpairs_stream(block=block, acceptall=acceptall)
+                assert got == whole, (acceptall, kw, block)
+                assert ss.stats["pairs_aligned"] == pairs
+            part = ss.allpairs_stream(first=50, count=120, block=50, acceptall=acceptall)
+            assert part == whole[50:170]
+            ss.close()

@@ -25,7 +25,7 @@ SYMBOLS = [
 # include/vsx_search.h
 SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
                   "vsx_search_batch_meta", "vsx_searcher_set_meta",
-                  "vsx_hits_free", "vsx_search_candidates", "vsx_search_candidates_batch", "vsx_candidates_free", "vsx_lma_align", "vsx_allpairs_block", "vsx_allpairs_rows", "vsx_cluster_fast", "vsx_cluster_out_free", "vsx_msa", "vsx_msa_out_free",
+                  "vsx_hits_free", "vsx_search_candidates", "vsx_search_candidates_batch", "vsx_candidates_free", "vsx_lma_align", "vsx_allpairs_block", "vsx_allpairs_rows", "vsx_allpairs_stream", "vsx_cluster_fast", "vsx_cluster_out_free", "vsx_msa", "vsx_msa_out_free",
                   "vsx_msa_device", "vsx_msa_device_batch", "vsx_dust_mask", "vsx_abundance_ratio_cmp",
                   "vsx_multi_searcher_create", "vsx_multi_searcher_destroy", "vsx_multi_searcher_devices", "vsx_multi_searcher_replica",
                   "vsx_multi_search_batch", "vsx_multi_allpairs"]
@@ -197,6 +197,7 @@ def load():
     lib.vsx_candidates_free.restype = None
     lib.vsx_allpairs_block.argtypes = [vp, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(Hits)]
     lib.vsx_allpairs_rows.argtypes = [vp, C.c_int32, vp, C.c_uint64, C.POINTER(Hits)]
+    lib.vsx_allpairs_stream.argtypes = [vp, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, vp, vp]     # (sink: a CFUNCTYPE object, passed as a pointer)
     lib.vsx_dust_mask.argtypes = [vp, C.c_uint64, vp, vp, C.c_int32]
     lib.vsx_multi_searcher_create.argtypes = [C.POINTER(vp), vp, vp, C.c_int32, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp]
     lib.vsx_multi_searcher_destroy.argtypes = [vp]

@@ -1689,10 +1689,19 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
   // One wave per workgroup: 14.5 KB of LDS each = 11 waves per CU (the wave's own arrays are lane-minor: no bank conflicts)
   __shared__ uint8_t Ssh[512];                     // S'[target code][query code], row stride 32; query "code" 16 = a dummy row of position 0
   __shared__ u32 Ssh4[16];                         // S'[target code][A | C << 8 | G << 16 | T << 24]: the fast score pick
-  __shared__ __attribute__((aligned(16))) u32 bitsL[17 * NG * 64];              // [column slot 0 .. 16][group of four row pairs][lane]
-  constexpr bool LSTAGE = (VSX_TB_LDSSTAGE != 0) && (17 * NG * 64 >= 9 * 64 * 3);      // raw row checkpoints [pair e][lane][3 dwords] land in bitsL
-  __shared__ u32 tbL[19 * 64];                     // top boundary of the tile in work, H (low 16) | F (high 16), int16 values: entry e = column cst - 1 + e
-  __shared__ uint8_t symL[10 * 64];                // target symbols of columns cst .. cst + 19, two to a byte
+  // one arena: [bitsL | symL | tbL].  bitsL[17 * NG * 64]: [column slot 0 .. 16][group of four row pairs][lane]; symL[10 * 64] bytes: target
+  // symbols of columns cst .. cst + 19, two to a byte; tbL[19 * 64]: top boundary of the tile in work, H (low 16) | F (high 16), int16
+  // values, entry e = column cst - 1 + e.
+  // LSTAGE: the nine raw row-checkpoint pairs of a tile land at the start of the arena as [pair e][lane][4 dwords] -- a
+  // global_load_lds_dwordx3 writes lane l's 12 bytes at base + 16 l (measured: ubench_ldsdma.hip, profiles/r05/r05e_ubench_ldsdma.txt;
+  // NOT at 12 l) -- = 9 216 B: the direction bits of the tile before (dead between its walk and this tile's column loop) and the first
+  // 512 B of its symbols (dead since its column loop; rewritten only after the raw pairs have been decoded into tbL)
+  constexpr int BITS_DW = 17 * NG * 64, SYM_DW = 10 * 64 / 4;
+  __shared__ __attribute__((aligned(16))) u32 arenaL[BITS_DW + SYM_DW + 19 * 64];
+  u32 * const bitsL = arenaL;
+  uint8_t * const symL = reinterpret_cast<uint8_t *>(arenaL + BITS_DW);
+  u32 * const tbL = arenaL + BITS_DW + SYM_DW;
+  constexpr bool LSTAGE = (VSX_TB_LDSSTAGE != 0) && (BITS_DW + SYM_DW >= 9 * 64 * 4);
   const int tid = (int) threadIdx.x;
   for (int x = tid; x < 512; x += 64)
     Ssh[x] = (uint8_t) (((x & 31) < 16) ? P.matrix[(x >> 5) * 16 + (x & 15)] : (int16_t) (-P.top_step + 2 * P.tilt));
@@ -1848,7 +1857,7 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
 #pragma unroll
                 for (int e = 0; e < 9; ++e)
                   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (bp + e * VSX_ROWCK_PAIR_DW(true)),
-                                                   (__attribute__((address_space(3))) void *) (bitsL + e * 192), 12, 0, 0);
+                                                   (__attribute__((address_space(3))) void *) (arenaL + e * 256), 12, 0, 0);
               }
             else
               {
@@ -1917,7 +1926,7 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
               {
                 // {H_t, H_t+1, bytes d_t(lo) d_t(hi) d_t+1(lo) d_t+1(hi)}: F = H - d; everything minus the class's bias
                 Trio raw;
-                if (LSTAGE) raw = *reinterpret_cast<const Trio *>(bitsL + e * 192 + tid * 3);
+                if (LSTAGE) raw = *reinterpret_cast<const Trio *>(arenaL + e * 256 + tid * 4);
                 else raw = in.v3[LSTAGE ? 0 : e];
                 const u32 h0 = (half_lo(raw.x, hi) - bias) & 0xffffu, h1 = (half_lo(raw.y, hi) - bias) & 0xffffu;
                 const u32 dd = hi ? (raw.z >> 8) : raw.z;

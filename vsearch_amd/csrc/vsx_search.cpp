@@ -1588,24 +1588,46 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
 // allpairs_global (commands/allpairs_global.cpp:394-527): queries [first, first+count) of the database, each
 // against every LATER sequence that passes the unaligned filters (or all of them with acceptall); one GPU
 // plan for the whole block; hits kept if acceptall or accepted; order allpairs_hit_compare (:116-138).
-int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows, uint64_t count, vsx_hits * out)
-{
-  if (!S || !out || (count && !rows)) return sfail(VSX_EINVAL, "vsx_allpairs_rows: null argument");
-  std::memset(out, 0, sizeof *out);
-  const uint64_t n = S->len.size();
-  for (uint64_t k = 0; k < count; ++k)
-    if (rows[k] >= n || (k && rows[k] <= rows[k - 1])) return sfail(VSX_EINVAL, "vsx_allpairs_rows: rows must be ascending database sequence numbers");
-  const double t_begin = now_s();
-  // the pair list: each query of the block against every later sequence that passes the unaligned filters -- per-query
-  // target lists on host threads, concatenated in query order
-  // (plain arrays: a vector would zero 2 x 200 MB per block of 1 000 queries before the threads fill them)
-  std::unique_ptr<uint32_t[]> pq_buf, pt_buf;
-  uint32_t * pq = nullptr, * pt = nullptr;
+// allpairs in three stages (r05: vsx_allpairs_stream overlaps them across blocks; vsx_allpairs_rows runs them back to back):
+//   A  ap_enumerate  the pair list of a block of rows            host threads
+//   B  ap_align      DP + traceback + filter + ranking            the searcher's aligner context (one call at a time)
+//   C  ap_complete   derived hit fields, order, marshalling       host threads
+namespace {
+struct ApList {
+  std::vector<uint32_t> rows;
+  std::unique_ptr<uint32_t[]> pq_buf, pt_buf;      // (plain arrays: a vector would zero 2 x 200 MB per block of 1 000 queries before the threads fill them)
   uint64_t n_list = 0;
-  std::vector<uint64_t> qfirst(count + 1, 0), cell_part;
+  std::vector<uint64_t> qfirst, cell_part;
+  double t_begin = 0;
+};
+struct ApAligned {
+  bool ranked = false, have_rk = false, have_res = false;
+  vsx_ranked rk;
+  vsx_results res;
+  double t_align = 0;
+  ApAligned() { std::memset(&rk, 0, sizeof rk); std::memset(&res, 0, sizeof res); }
+  ApAligned(const ApAligned &) = delete;
+  ApAligned & operator=(const ApAligned &) = delete;
+  ~ApAligned() { if (have_rk) vsx_ranked_free(&rk); if (have_res) vsx_results_free(&res); }
+};
+}
+
+// stage A: each query of the block against every later sequence that passes the unaligned filters -- per-query target lists on host
+// threads, concatenated in query order
+static int ap_enumerate(const vsx_searcher * S, int32_t acceptall, const uint32_t * rows_in, uint64_t count, ApList & L, int thread_budget)
+{
+  const uint64_t n = S->len.size();
+  L.t_begin = now_s();
+  L.rows.assign(rows_in, rows_in + count);
+  const uint32_t * rows = L.rows.data();
+  std::unique_ptr<uint32_t[]> & pq_buf = L.pq_buf, & pt_buf = L.pt_buf;
+  uint32_t * pq = nullptr, * pt = nullptr;
+  uint64_t & n_list = L.n_list;
+  std::vector<uint64_t> & qfirst = L.qfirst, & cell_part = L.cell_part;
+  qfirst.assign(count + 1, 0);
   {
     std::vector<std::vector<uint32_t>> tl(count);
-    const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, S->threads), count / 8));
+    const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, thread_budget), count / 8));
     std::atomic<uint64_t> next {0};
     // search_acceptable_unaligned (searchcore.cpp:541-609) is true for EVERY pair when all twelve of its options sit at their defaults and
     // no sequence carries an abundance annotation (abundance 1 everywhere: the ratio clauses compare 1 with 0 and with DBL_MAX)
@@ -1664,23 +1686,55 @@ int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows
     place();
     for (auto & th : pool2) th.join();
   }
-  double t0 = now_s();
+  return VSX_OK;
+}
+
+static bool ap_device_decides(const vsx_searcher * S, int32_t acceptall) { return !(acceptall || S->o.gap_infinite || S->o.cluster_unoise); }
+static bool ap_ranked(const vsx_searcher * S, int32_t acceptall)
+{
+  static const bool rank_off = std::getenv("VSX_RANK") && std::strcmp(std::getenv("VSX_RANK"), "host") == 0;     // A/B, tests
+  return ap_device_decides(S, acceptall) && !rank_off;
+}
+
+// stage B: the block's pairs through the aligner.  Ranked path (vsx_rank.hip): the device filters, orders (id desc, target asc per
+// query: allpairs_hit_compare :116-138) and compacts; only accepted pairs come back.  Otherwise every pair's record, with the verdicts.
+static int ap_align(vsx_searcher * S, int32_t acceptall, const ApList & L, ApAligned & A)
+{
+  const double t0 = now_s();
   const vsx_filter flt = make_filter(*S);
+  A.ranked = ap_ranked(S, acceptall);
+  int rc;
+  if (A.ranked)
+    {
+      rc = vsx_align_pairs_ranked(S->ctx, S->dbset, S->dbset, L.n_list, L.pq_buf.get(), L.pt_buf.get(), &flt, 0, &A.rk);
+      A.have_rk = rc == VSX_OK;
+    }
+  else
+    {
+      rc = vsx_align_pairs_filtered(S->ctx, S->dbset, S->dbset, L.n_list, L.pq_buf.get(), L.pt_buf.get(),
+                                    ap_device_decides(S, acceptall) ? &flt : nullptr, &A.res);
+      A.have_res = rc == VSX_OK;
+    }
+  A.t_align = now_s() - t0;
+  return rc;
+}
+
+// stage C: the host completes the derived fields of the kept hits, orders them and marshals the block's result
+static int ap_complete(vsx_searcher * S, int32_t acceptall, const ApList & L, ApAligned & A, vsx_hits * out, int thread_budget)
+{
+  const uint64_t count = L.rows.size();
+  const uint32_t * rows = L.rows.data();
+  const uint32_t * pt = L.pt_buf.get();
+  const uint64_t n_list = L.n_list;
+  const std::vector<uint64_t> & qfirst = L.qfirst;
+  std::memset(out, 0, sizeof *out);
   std::vector<std::vector<Hit>> kept(count);
   uint64_t cells = 0, sentinels = 0;
-  for (uint64_t k = 0; k < count; ++k) cells += cell_part[k];
+  for (uint64_t k = 0; k < count; ++k) cells += L.cell_part[k];
   int rc = VSX_OK;
-  double t_align = 0;
-  const bool device_decides = !(acceptall || S->o.gap_infinite || S->o.cluster_unoise);
-  static const bool rank_off = std::getenv("VSX_RANK") && std::strcmp(std::getenv("VSX_RANK"), "host") == 0;     // A/B, tests
-  if (device_decides && !rank_off)
+  if (A.ranked)
     {
-      // Ranked path (vsx_rank.hip): the device filters, orders (id desc, target asc per query: allpairs_hit_compare :116-138)
-      // and compacts; only accepted pairs come back.  The host completes the derived fields of those, nothing else.
-      vsx_ranked rk;
-      rc = vsx_align_pairs_ranked(S->ctx, S->dbset, S->dbset, n_list, pq, pt, &flt, 0, &rk);
-      t_align = now_s() - t0;
-      if (rc != VSX_OK) return rc;
+      vsx_ranked & rk = A.rk;
       vsx_results view;
       std::memset(&view, 0, sizeof view);
       view.n_pairs = rk.n_hits; view.score = rk.score; view.aligned = rk.aligned; view.matches = rk.matches;
@@ -1696,7 +1750,7 @@ int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows
           }
         hfirst[count] = j;
       }
-      const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, S->threads), count / 8));
+      const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, thread_budget), count / 8));
       std::vector<int> err((size_t) nth, VSX_OK);
       std::atomic<uint64_t> next {0}, rank_drift {0};
       static const bool rank_strict = std::getenv("VSX_RANK_STRICT") != nullptr;
@@ -1746,11 +1800,8 @@ int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows
       }
       for (int t = 0; t < nth; ++t)
         if (err[(size_t) t] != VSX_OK)
-          {
-            vsx_ranked_free(&rk);
-            return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "vsx_allpairs_rows: device and host accept filters disagree"
-                                                                       : "vsx_allpairs_rows: fallback aligner failed");
-          }
+          return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "vsx_allpairs_rows: device and host accept filters disagree"
+                                                                     : "vsx_allpairs_rows: fallback aligner failed");
       if (rank_drift.load())
         {
           static std::atomic<bool> told {false};
@@ -1772,7 +1823,7 @@ int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows
           h.target = pt[r];
           const char * q = S->blob.data() + S->off[qi];
           const int frc = fill_hit(*S, [&]() { return q; }, (int64_t) S->len[qi], h, one, 0, sentinels);
-          if (frc != VSX_OK) { vsx_ranked_free(&rk); return sfail(frc, "vsx_allpairs_rows: fallback aligner failed"); }
+          if (frc != VSX_OK) return sfail(frc, "vsx_allpairs_rows: fallback aligner failed");
           if (acceptable_aligned(*S, S->len[qi], h, S->abundance(qi)))
             {
               kept[k].push_back(std::move(h));
@@ -1782,18 +1833,13 @@ int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows
               });
             }
         }
-      vsx_ranked_free(&rk);
     }
   else
   {
-  vsx_results res;
-  rc = vsx_align_pairs_filtered(S->ctx, S->dbset, S->dbset, n_list, pq, pt,
-                                    device_decides ? &flt : nullptr, &res);
-  t_align = now_s() - t0;
-  if (rc != VSX_OK) return rc;
+  vsx_results & res = A.res;
   {
     // per query: complete the accepted hits (derived fields, fallback on the sentinel) and order them -- host threads
-    const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, S->threads), count / 8));
+    const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, thread_budget), count / 8));
     std::vector<uint64_t> psent((size_t) nth, 0);
     std::vector<int> err((size_t) nth, VSX_OK);
     std::atomic<uint64_t> next {0};
@@ -1831,21 +1877,111 @@ int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows
       {
         sentinels += psent[(size_t) t];
         if (err[(size_t) t] != VSX_OK)
-          {
-            vsx_results_free(&res);
-            return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "vsx_allpairs_rows: device and host accept filters disagree"
-                                                                       : "vsx_allpairs_rows: fallback aligner failed");
-          }
+          return sfail(err[(size_t) t], err[(size_t) t] == VSX_EHIP ? "vsx_allpairs_rows: device and host accept filters disagree"
+                                                                     : "vsx_allpairs_rows: fallback aligner failed");
       }
   }
-  vsx_results_free(&res);
   }
-  rc = marshal_hits(kept, out, S->threads);
+  rc = marshal_hits(kept, out, thread_budget);
   if (rc != VSX_OK) return rc;
   for (uint64_t k = 0; k < out->n_hits; ++k) out->hit[k].query = rows[out->hit[k].query];       // vsx_hit.query = database sequence number
   out->pairs_aligned = n_list; out->cells_aligned = cells; out->stages = 1; out->sentinel_pairs = sentinels;
-  out->seconds_align = t_align; out->seconds_total = now_s() - t_begin;
+  out->seconds_align = A.t_align; out->seconds_total = now_s() - L.t_begin;
   return VSX_OK;
+}
+
+int vsx_allpairs_rows(vsx_searcher * S, int32_t acceptall, const uint32_t * rows, uint64_t count, vsx_hits * out)
+{
+  if (!S || !out || (count && !rows)) return sfail(VSX_EINVAL, "vsx_allpairs_rows: null argument");
+  std::memset(out, 0, sizeof *out);
+  const uint64_t n = S->len.size();
+  for (uint64_t k = 0; k < count; ++k)
+    if (rows[k] >= n || (k && rows[k] <= rows[k - 1])) return sfail(VSX_EINVAL, "vsx_allpairs_rows: rows must be ascending database sequence numbers");
+  ApList L;
+  int rc = ap_enumerate(S, acceptall, rows, count, L, S->threads);
+  if (rc != VSX_OK) return rc;
+  ApAligned A;
+  rc = ap_align(S, acceptall, L, A);
+  if (rc != VSX_OK) return rc;
+  return ap_complete(S, acceptall, L, A, out, S->threads);
+}
+
+// allpairs_global as ONE call (commands/allpairs_global.cpp:394-527 runs its query loop on worker threads and reports each query as it
+// finishes): the rows first .. first + count - 1 in blocks of `block` queries, the three stages of consecutive blocks overlapped -- while
+// block i is on the GPU, block i + 1's pair list is enumerated and block i - 1's hits are completed on host threads (r04: 4.0 of the
+// 53.4 s of a 50 000-sequence run lay outside the align calls and overlapped nothing).  `sink` receives every block's hits, in order,
+// on a helper thread (one call at a time); the hits belong to the library and die when the sink returns.  A non-zero return of the
+// sink stops the run and is handed back.
+int vsx_allpairs_stream(vsx_searcher * S, int32_t acceptall, uint64_t first, uint64_t count, uint64_t block, vsx_hits_sink sink, void * user)
+{
+  if (!S || !sink) return sfail(VSX_EINVAL, "vsx_allpairs_stream: null argument");
+  const uint64_t n = S->len.size();
+  if (first > n || count > n - first) return sfail(VSX_EINVAL, "vsx_allpairs_stream: query block out of range");
+  if (block == 0) block = 1000;
+  const uint64_t nb = (count + block - 1) / block;
+  const int side = std::max(1, S->threads / 2);                  // enumeration and completion run beside each other and beside the planner of stage B
+  auto rows_of = [&](uint64_t b) {
+    const uint64_t lo = first + b * block, hi = std::min(first + count, lo + block);
+    std::vector<uint32_t> r(hi - lo);
+    for (uint64_t k = 0; k < hi - lo; ++k) r[k] = (uint32_t) (lo + k);
+    return r;
+  };
+  struct Done { int rc = VSX_OK; std::string msg; };
+  std::unique_ptr<ApList> next(new ApList);
+  {
+    const std::vector<uint32_t> r = rows_of(0);
+    if (nb) { const int rc = ap_enumerate(S, acceptall, r.data(), r.size(), *next, S->threads); if (rc != VSX_OK) return rc; }
+  }
+  std::thread enum_thread, done_thread;
+  Done enum_done, comp_done;
+  auto join = [](std::thread & t) { if (t.joinable()) t.join(); };
+  int rc = VSX_OK;
+  std::string msg;
+  for (uint64_t b = 0; b < nb && rc == VSX_OK; ++b)
+    {
+      std::unique_ptr<ApList> cur = std::move(next);
+      next.reset(new ApList);
+      if (b + 1 < nb)
+        {
+          ApList * dst = next.get();
+          enum_done = Done {};
+          enum_thread = std::thread([&, dst, b]() {
+            const std::vector<uint32_t> r = rows_of(b + 1);
+            enum_done.rc = ap_enumerate(S, acceptall, r.data(), r.size(), *dst, side);
+            if (enum_done.rc != VSX_OK) enum_done.msg = vsx_last_error();
+          });
+        }
+      std::unique_ptr<ApAligned> A(new ApAligned);
+      rc = ap_align(S, acceptall, *cur, *A);
+      if (rc != VSX_OK) msg = vsx_last_error();
+      join(done_thread);                                         // block b - 1 has been handed to the sink
+      if (rc == VSX_OK && comp_done.rc != VSX_OK) { rc = comp_done.rc; msg = comp_done.msg; }
+      if (rc == VSX_OK)
+        {
+          ApList * lp = cur.release();
+          ApAligned * ap = A.release();
+          const uint64_t bfirst = first + b * block;
+          comp_done = Done {};
+          done_thread = std::thread([&, lp, ap, bfirst]() {
+            std::unique_ptr<ApList> lo(lp);
+            std::unique_ptr<ApAligned> ao(ap);
+            vsx_hits h;
+            int crc = ap_complete(S, acceptall, *lo, *ao, &h, side);
+            if (crc != VSX_OK) { comp_done.rc = crc; comp_done.msg = vsx_last_error(); return; }
+            ao.reset();                                          // (the device-side results are copied: free them before the sink runs)
+            const int src = sink(user, bfirst, lo->rows.size(), &h);
+            vsx_hits_free(&h);
+            if (src != 0) { comp_done.rc = src; comp_done.msg = "vsx_allpairs_stream: stopped by the sink"; }
+          });
+        }
+      join(enum_thread);
+      if (rc == VSX_OK && b + 1 < nb && enum_done.rc != VSX_OK) { rc = enum_done.rc; msg = enum_done.msg; }
+    }
+  join(enum_thread);
+  join(done_thread);
+  if (rc == VSX_OK && comp_done.rc != VSX_OK) { rc = comp_done.rc; msg = comp_done.msg; }
+  if (rc != VSX_OK) vsx_internal_set_error(msg.c_str());
+  return rc;
 }
 
 int vsx_allpairs_block(vsx_searcher * S, int32_t acceptall, uint64_t first, uint64_t count, vsx_hits * out)

@@ -142,6 +142,41 @@ class SearchSession:
         check(lib.vsx_allpairs_rows(self.h, 1 if acceptall else 0, r.ctypes.data_as(C.c_void_p), r.size, C.byref(res)), "vsx_allpairs_rows")
         return self._unpack(res)
 
+    def allpairs_stream(self, first=0, count=None, block=0, acceptall=False):
+        """vsx_allpairs_stream: the rows in blocks, enumeration / alignment / completion of consecutive blocks overlapped inside the
+        library; -> per-query hit lists as allpairs() returns them (the sink copies each block's hits)"""
+        lib = _lib.load()
+        count = len(self.db) - first if count is None else count
+        out = []
+        stats = []
+        SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(Hits))
+
+        def sink(_user, bfirst, bcount, hp):
+            try:
+                res = hp.contents
+                cig = C.string_at(res.cigar_blob, int(res.cigar_bytes)) if res.cigar_bytes else b""
+                assert int(res.n_queries) == int(bcount) and int(bfirst) == first + len(out)
+                for q in range(int(res.n_queries)):
+                    hs = []
+                    for k in range(int(res.first[q]), int(res.first[q + 1])):
+                        h = res.hit[k]
+                        d = {n: getattr(h, n) for n in HIT_FIELDS}
+                        o = int(h.cigar_off)
+                        d["cigar"] = cig[o:cig.index(b"\0", o)].decode()
+                        hs.append(d)
+                    out.append(hs)
+                stats.append((int(res.pairs_aligned), int(res.cells_aligned)))
+                return 0
+            except Exception:                    # (never let an exception cross the C boundary)
+                import traceback
+                traceback.print_exc()
+                return -99
+
+        cb = SINK(sink)
+        check(lib.vsx_allpairs_stream(self.h, 1 if acceptall else 0, first, count, block, C.cast(cb, C.c_void_p), None), "vsx_allpairs_stream")
+        self.stats = {"pairs_aligned": sum(p for p, _ in stats), "cells_aligned": sum(c for _, c in stats)}
+        return out
+
     def cluster_fast(self, round=0):
         """greedy centroid clustering of the session's sequences in their given order (sort them first).
         -> (clusterno list, per-sequence hit dict or None, number of clusters)"""
