@@ -687,13 +687,13 @@ def test_allpairs_stream_equals_blocks(gpu_required):
     sink, block after block, must be exactly those of one vsx_allpairs_block call -- ranked path and acceptall (every pair kept)"""
     import random
     from vsearch_amd import Aligner
-    from vsearch_amd.search import Searcher
+    from vsearch_amd.search import SearchSession
     rng = random.Random(77)
     fam = [common.rnd_seq(rng, rng.randint(60, 220)) for _ in range(12)]
     seqs = [common.mutate(rng, rng.choice(fam), rng.choice([0.02, 0.08, 0.2])) for _ in range(230)]
     with Aligner() as al:
-        for acceptall, kw in ((False, dict(id=0.8)), (True, dict(id=0.5)), (False, dict(id=0.7, maxgaps=3, self=0))):
-            ss = Searcher(al, seqs, **kw)
+        for acceptall, kw in ((False, dict(id=0.8)), (True, dict(id=0.5)), (False, dict(id=0.7, maxgaps=3))):
+            ss = SearchSession(al, seqs, **kw)
             whole = ss.allpairs(acceptall=acceptall)
             pairs = ss.stats["pairs_aligned"]
             for block in (1, 37, 100, 1000):

@@ -1667,8 +1667,14 @@ DEV u32 pk_sub(u32 a, u32 b) { return psubw(a, b); }                            
 // LDS (global_load_lds_dwordx3: 12 bytes per lane, lane-linear) instead of through registers; the landing zone is the direction-bit array
 // of the tile before (dead between a tile's walk and the next tile's column loop), so no LDS is added.  Only where that array is large
 // enough (two bit words per column slot: every variant that spills).
+// Same-box A/B, two runs each (profiles/r05/r05f_ldsst_ab.txt; scratch per lane from the ISA): R = 16 (168 -> 64 B) 3.825 -> 3.675 ms,
+// R = 26 (140 -> 52 B) 6.284 -> 6.203; R = 10 (44 -> 0 B) 2.43 -> 2.44 and 2.455 -> 2.455; R = 20 (52 -> 0 B) 4.82 -> 4.88: the DMA pays
+// where it removes most of a large spill area and costs a little where there was next to none.  Hence on for R = 14, 16 and R >= 26.
 #ifndef VSX_TB_LDSSTAGE
-#define VSX_TB_LDSSTAGE 0
+#define VSX_TB_LDSSTAGE 1
+#endif
+#ifndef VSX_TB_LDSSTAGE_FOR
+#define VSX_TB_LDSSTAGE_FOR(R_) ((R_) == 14 || (R_) == 16 || (R_) >= 26)
 #endif
 template <int R, bool MID>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(VSX_TB2_WAVES(R, MID), 8)))
@@ -1701,7 +1707,7 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
   u32 * const bitsL = arenaL;
   uint8_t * const symL = reinterpret_cast<uint8_t *>(arenaL + BITS_DW);
   u32 * const tbL = arenaL + BITS_DW + SYM_DW;
-  constexpr bool LSTAGE = (VSX_TB_LDSSTAGE != 0) && (BITS_DW + SYM_DW >= 9 * 64 * 4);
+  constexpr bool LSTAGE = (VSX_TB_LDSSTAGE != 0) && VSX_TB_LDSSTAGE_FOR(R) && (BITS_DW + SYM_DW >= 9 * 64 * 4);
   const int tid = (int) threadIdx.x;
   for (int x = tid; x < 512; x += 64)
     Ssh[x] = (uint8_t) (((x & 31) < 16) ? P.matrix[(x >> 5) * 16 + (x & 15)] : (int16_t) (-P.top_step + 2 * P.tilt));

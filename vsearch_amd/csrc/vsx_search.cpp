@@ -1927,11 +1927,23 @@ int vsx_allpairs_stream(vsx_searcher * S, int32_t acceptall, uint64_t first, uin
     return r;
   };
   struct Done { int rc = VSX_OK; std::string msg; };
-  std::unique_ptr<ApList> next(new ApList);
-  {
-    const std::vector<uint32_t> r = rows_of(0);
-    if (nb) { const int rc = ap_enumerate(S, acceptall, r.data(), r.size(), *next, S->threads); if (rc != VSX_OK) return rc; }
-  }
+  // block 0's list AND block 1's before the first align call: the first call of a process allocates its checkpoint blocks (tens of GB of
+  // hipMalloc), and a host thread page-faulting its way through a fresh 400 MB pair list at the same time made that allocation take
+  // 5.8 instead of 0.9 s (profiles/r05/r05f_allpairs_stream_first_build.txt).  From block 1 on the next list is built beside the GPU.
+  std::unique_ptr<ApList> next(new ApList), ahead;
+  if (nb)
+    {
+      const std::vector<uint32_t> r = rows_of(0);
+      const int rc0 = ap_enumerate(S, acceptall, r.data(), r.size(), *next, S->threads);
+      if (rc0 != VSX_OK) return rc0;
+    }
+  if (nb > 1)
+    {
+      ahead.reset(new ApList);
+      const std::vector<uint32_t> r = rows_of(1);
+      const int rc1 = ap_enumerate(S, acceptall, r.data(), r.size(), *ahead, S->threads);
+      if (rc1 != VSX_OK) return rc1;
+    }
   std::thread enum_thread, done_thread;
   Done enum_done, comp_done;
   auto join = [](std::thread & t) { if (t.joinable()) t.join(); };
@@ -1940,8 +1952,9 @@ int vsx_allpairs_stream(vsx_searcher * S, int32_t acceptall, uint64_t first, uin
   for (uint64_t b = 0; b < nb && rc == VSX_OK; ++b)
     {
       std::unique_ptr<ApList> cur = std::move(next);
-      next.reset(new ApList);
-      if (b + 1 < nb)
+      if (b == 0 && ahead) next = std::move(ahead);              // (built before the loop)
+      else next.reset(new ApList);
+      if (b + 1 < nb && b >= 1)
         {
           ApList * dst = next.get();
           enum_done = Done {};
@@ -1975,7 +1988,7 @@ int vsx_allpairs_stream(vsx_searcher * S, int32_t acceptall, uint64_t first, uin
           });
         }
       join(enum_thread);
-      if (rc == VSX_OK && b + 1 < nb && enum_done.rc != VSX_OK) { rc = enum_done.rc; msg = enum_done.msg; }
+      if (rc == VSX_OK && b + 1 < nb && b >= 1 && enum_done.rc != VSX_OK) { rc = enum_done.rc; msg = enum_done.msg; }
     }
   join(enum_thread);
   join(done_thread);
