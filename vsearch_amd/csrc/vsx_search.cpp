@@ -1928,8 +1928,8 @@ int vsx_allpairs_stream(vsx_searcher * S, int32_t acceptall, uint64_t first, uin
   };
   struct Done { int rc = VSX_OK; std::string msg; };
   // block 0's list AND block 1's before the first align call: the first call of a process allocates its checkpoint blocks (tens of GB of
-  // hipMalloc), and a host thread page-faulting its way through a fresh 400 MB pair list at the same time made that allocation take
-  // 5.8 instead of 0.9 s (profiles/r05/r05f_allpairs_stream_first_build.txt).  From block 1 on the next list is built beside the GPU.
+  // hipMalloc, 0.9 - 7 s from box to box: profiles/r05/r05f_allpairs_stream_first_build.txt, r05g_allpairs_20k_stream_ab.txt), and nothing
+  // should compete with it for the kernel's memory-management locks.  From block 1 on the next list is built beside the GPU.
   std::unique_ptr<ApList> next(new ApList), ahead;
   if (nb)
     {
