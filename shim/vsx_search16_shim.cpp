@@ -23,6 +23,7 @@
 
 #include "vsx.h"
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -62,15 +63,18 @@ struct Request {
 
 // the shared aligner of one (device, scoring): context + the queue of the group commit
 struct Combiner;
-static void run_batch(Combiner & c, std::vector<Request *> & batch);
+static void run_batch(Combiner & c, vsx_ctx * ctx, std::vector<Request *> & batch);
 struct Combiner {
   int device = 0;
   vsx_scoring sc {};
-  vsx_ctx * ctx = nullptr;
+  // TWO batches may be in flight, each on a context of its own: while one is on the GPU (a round trip is mostly latency -- a 64-pair
+  // batch fills 3 % of the chip) the other one's leader builds its query set and plan
+  static constexpr int LANES = 2;
+  vsx_ctx * ctx[LANES] = {nullptr, nullptr};
+  bool lane_busy[LANES] = {false, false};
   std::mutex mu;
   std::condition_variable cv;
   std::vector<Request *> pending;
-  bool leader_active = false;
   uint64_t calls = 0, batches = 0, pairs = 0;           // VSX_SHIM_STATS=1: printed at exit
   void submit(Request & rq)
   {
@@ -79,16 +83,23 @@ struct Combiner {
     ++calls;
     while (!rq.done)
       {
-        if (leader_active) { cv.wait(lk); continue; }
-        leader_active = true;                            // nobody is on the GPU: this thread leads everything queued so far
+        // (this request is either still queued -- then this thread may lead it -- or already part of somebody's batch: then it only waits)
+        const bool queued = std::find(pending.begin(), pending.end(), &rq) != pending.end();
+        int lane = -1;
+        if (queued)
+          for (int k = 0; k < LANES; ++k) if (!lane_busy[k]) { lane = k; break; }
+        if (lane < 0) { cv.wait(lk); continue; }
+        lane_busy[lane] = true;                          // a free context: this thread leads everything queued so far
         std::vector<Request *> batch;
         batch.swap(pending);
         ++batches;
+        if (ctx[lane] == nullptr && vsx_create(&ctx[lane], &sc, device) != VSX_OK) die("vsx_create");
+        vsx_ctx * const cx = ctx[lane];
         lk.unlock();
-        run_batch(*this, batch);
+        run_batch(*this, cx, batch);
         lk.lock();
         for (Request * r : batch) r->done = true;
-        leader_active = false;
+        lane_busy[lane] = false;
         cv.notify_all();
       }
   }
@@ -149,7 +160,7 @@ auto search16_init(int64_t score_match, int64_t score_mismatch,
   auto * c = new Combiner();
   c->device = dev;
   c->sc = sc;
-  if (vsx_create(&c->ctx, &sc, dev) != VSX_OK) die("vsx_create");
+  if (vsx_create(&c->ctx[0], &sc, dev) != VSX_OK) die("vsx_create");      // (the second lane's context is created by its first leader)
   if (g_comb.empty() && std::getenv("VSX_SHIM_STATS") != nullptr) std::atexit(shim_stats);
   g_comb.push_back(c);
   s->comb = c;
@@ -199,7 +210,7 @@ static vsx_seqset * mirror_db(Combiner * c, Database const & db)
 }
 
 // the leader's part: every request of the batch (same Database: a batch is cut where it changes) as one pair list
-static void run_batch(Combiner & c, std::vector<Request *> & batch)
+static void run_batch(Combiner & c, vsx_ctx * ctx, std::vector<Request *> & batch)
 {
   size_t b0 = 0;
   while (b0 < batch.size())
@@ -219,9 +230,9 @@ static void run_batch(Combiner & c, std::vector<Request *> & batch)
       for (size_t k = b0; k < b1; ++k)
         for (unsigned int x = 0; x < batch[k]->n; ++x) { qi[at] = (uint32_t) (k - b0); ti[at] = batch[k]->seqnos[x]; ++at; }
       vsx_seqset * qset = nullptr;
-      if (vsx_seqset_create(c.ctx, &qset, b1 - b0, qblob.data(), qtotal, qoff.data(), qlen.data()) != VSX_OK) die("vsx_seqset_create(queries)");
+      if (vsx_seqset_create(ctx, &qset, b1 - b0, qblob.data(), qtotal, qoff.data(), qlen.data()) != VSX_OK) die("vsx_seqset_create(queries)");
       vsx_results r;
-      if (vsx_align_pairs(c.ctx, qset, targets, npairs, qi.data(), ti.data(), &r) != VSX_OK) die("vsx_align_pairs");
+      if (vsx_align_pairs(ctx, qset, targets, npairs, qi.data(), ti.data(), &r) != VSX_OK) die("vsx_align_pairs");
       at = 0;
       for (size_t k = b0; k < b1; ++k)
         {
@@ -238,7 +249,7 @@ static void run_batch(Combiner & c, std::vector<Request *> & batch)
         }
       vsx_results_free(&r);
       vsx_seqset_destroy(qset);
-      c.pairs += npairs;
+      { std::lock_guard<std::mutex> lk(c.mu); c.pairs += npairs; }
       b0 = b1;
     }
 }
