@@ -67,11 +67,12 @@ static void run_batch(Combiner & c, vsx_ctx * ctx, std::vector<Request *> & batc
 struct Combiner {
   int device = 0;
   vsx_scoring sc {};
-  // TWO batches may be in flight, each on a context of its own: while one is on the GPU (a round trip is mostly latency -- a 64-pair
-  // batch fills 3 % of the chip) the other one's leader builds its query set and plan
-  static constexpr int LANES = 2;
-  vsx_ctx * ctx[LANES] = {nullptr, nullptr};
-  bool lane_busy[LANES] = {false, false};
+  // LANES batches may be in flight, each on a context of its own.  Two were measured (profiles/r05/r05h_shim_two_lanes.txt): the calls of
+  // 16 threads split into 375 - 412 batches of ~5 instead of 250 of 8 and the relinked CLI took 0.81 - 0.99 s instead of 0.79 -- a round
+  // trip is latency, not occupancy, and a second one in flight only halves what each carries.  One lane.
+  static constexpr int LANES = 1;
+  vsx_ctx * ctx[LANES] = {nullptr};
+  bool lane_busy[LANES] = {false};
   std::mutex mu;
   std::condition_variable cv;
   std::vector<Request *> pending;

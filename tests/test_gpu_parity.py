@@ -587,3 +587,47 @@ def test_sparse_class_threshold(gpu_required):
     small, large = info
     assert small[1] == 600 and small[2] == 0 and small[3] == 600, info
     assert large[1] == 9000 and large[2] == 9000 and large[3] == 2250, info
+
+
+@pytest.mark.gpu
+def test_memory_pressure_releases_idle_blocks(gpu_required, oracle):
+    """r05: a context keeps its checkpoint blocks, its slab and a pool of idle scratch between plans; whoever runs out of device memory
+    calls vsx_internal_memory_pressure(device) and every context of the device gives back what no plan holds (vsx_host.cpp).  Here: two
+    contexts with warm blocks, the hook called by hand -- the blocks are gone, bytes were released, and both contexts plan and align again
+    (a context with a LIVE plan keeps that plan's block until the plan dies)."""
+    import ctypes as C
+    from vsearch_amd import Aligner
+    lib = gpu_required
+    lib.vsx_internal_memory_pressure.argtypes = [C.c_int]
+    lib.vsx_internal_memory_pressure.restype = C.c_uint64
+    lib.vsx_internal_scratch_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 4)]
+    lib.vsx_internal_scratch_sizes.restype = None
+    rng = random.Random(31)
+    qs = [common.rnd_seq(rng, 200) for _ in range(64)]
+    ts = [common.mutate(rng, q, 0.1) + common.rnd_seq(rng, rng.randint(0, 300)) for q in qs]
+    idx = np.arange(len(qs), dtype=np.uint32)
+
+    def sizes(al):
+        out = (C.c_uint64 * 4)()
+        lib.vsx_internal_scratch_sizes(al.h, C.byref(out))
+        return list(out)
+
+    with Aligner() as a1, Aligner() as a2:
+        Q1, T1 = a1.sequences(qs), a1.sequences(ts)
+        Q2, T2 = a2.sequences(qs), a2.sequences(ts)
+        first = a1.align_pairs(Q1, T1, idx, idx)
+        a2.align_pairs(Q2, T2, idx, idx)
+        assert max(sizes(a1)) > 0 and max(sizes(a2)) > 0                  # warm: blocks are kept
+        live = a2.plan(Q2, T2, idx, idx)                                  # a2 holds a live plan on one of its blocks
+        live.run()
+        freed = int(lib.vsx_internal_memory_pressure(0))
+        assert freed > 0
+        assert sizes(a1) == [0, 0, 0, 0]                                  # a1's blocks went back
+        res_live = live.fetch()                                           # the live plan's block survived
+        live.close()
+        again1 = a1.align_pairs(Q1, T1, idx, idx)
+        again2 = a2.align_pairs(Q2, T2, idx, idx)
+        for k in range(len(qs)):
+            assert first.row(k) == again1.row(k) == again2.row(k) == res_live.row(k), k
+        for k in range(0, len(qs), 9):
+            assert first.row(k) == tuple(oracle.align(qs[k], ts[k])), k
