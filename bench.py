@@ -390,7 +390,7 @@ def main():
                                "kernel": tb.get("kernel"),
                                "lines_per_launch": int(tb["hbm_read_bytes_per_launch"] / 128) if tb.get("hbm_read_bytes_per_launch") else None,
                                "line_rate_floor_ms": round(tb["hbm_read_bytes_per_launch"] / 128 / 45e9 * 1e3, 3) if tb.get("hbm_read_bytes_per_launch") else None,
-                               "note": "r04: every partial-line checkpoint read costs HBM a whole 128-byte line (FETCH_SIZE calibrated on the kernel's own "
+                               "note": "r05: the row checkpoints of a tile go HBM -> LDS without passing registers (R = 14, 16, >= 26; DESIGN 4.2).  r04: every partial-line checkpoint read costs HBM a whole 128-byte line (FETCH_SIZE calibrated on the kernel's own "
                                        "pattern, profiles/r04/r04a_fetch_calibration.txt; 45 G lines/s); the position-synchronous kernel keeps the lanes of a "
                                        "task on the same lines (5.05 pairs per fetched tile instead of 2.95) and issues 15 instead of 28 instructions per two "
                                        "recomputed cells: it is VALU-issue bound in the recompute (61 % of a wave's time), latency bound in loads and walk"},
