@@ -116,6 +116,7 @@ typedef struct vsx_plan_info {
   uint64_t tasks_max3;      /* ... of the tilted ones in the MAX3 sub-class (15-bit range, v_pk_maximum3_f16)       */
   uint64_t tasks_sparse;    /* ... in a sparse-task class: tasks of <= 4 / <= 2 targets that share a wave with 1 / 3 others */
   uint64_t waves;           /* wavefronts the DP launches of one run start (= tasks without sparse-task classes)            */
+  uint64_t tasks_pair;      /* ... in a pair-profile class: groups of four tasks of one pure-ACGT query as one workgroup    */
 } vsx_plan_info;
 
 const char * vsx_version_string(void);

@@ -631,3 +631,74 @@ def test_memory_pressure_releases_idle_blocks(gpu_required, oracle):
             assert first.row(k) == again1.row(k) == again2.row(k) == res_live.row(k), k
         for k in range(0, len(qs), 9):
             assert first.row(k) == tuple(oracle.align(qs[k], ts[k])), k
+
+
+_PAIR_SNIPPET = r"""
+import random, sys
+import numpy as np
+sys.path.insert(0, %r)
+from tests import common
+from oracle import pyoracle
+from vsearch_amd import Aligner
+P = %r
+nmm = %r
+rng = random.Random(97)
+orc = pyoracle.Oracle()
+qs, ts, qi, ti = [], [], [], []
+# queries of several row classes (one multi-strip), plain ACGT except two; 33 .. 75 targets each, some targets with IUPAC symbols
+for k, Q in enumerate((120, 150, 250, 256, 300, 333, 400, 640, 200, 260)):
+    alpha = "ACGT" if k < 8 else common.IUPAC + "ACGT" * 4
+    q = common.rnd_seq(rng, Q, alpha)
+    qs.append(q)
+    for x in range(33 + 6 * k):
+        shape = rng.random()
+        if shape < 0.5:
+            t = common.rnd_seq(rng, rng.randint(0, 200)) + common.mutate(rng, q, 0.1) + common.rnd_seq(rng, rng.randint(0, 500))
+        elif shape < 0.7:
+            t = common.mutate(rng, q, 0.25)[:rng.randint(1, Q)]
+        elif shape < 0.8:
+            t = common.rnd_seq(rng, rng.randint(1, 30))
+        else:
+            t = common.mutate(rng, q, 0.15, common.IUPAC + "ACGT" * 8)            # may carry N, R, Y ...: such a task stays in the whole-wave class
+        qi.append(k); ti.append(len(ts)); ts.append(t)
+qi = np.array(qi, np.uint32); ti = np.array(ti, np.uint32)
+with Aligner(scoring=P, n_mismatch=nmm) as al:
+    Qs, Ts = al.sequences(qs), al.sequences(ts)
+    p = al.plan(Qs, Ts, qi, ti)
+    info = p.describe()
+    p.run()
+    res = p.fetch()
+    p.close()
+bad = 0
+for k in range(len(qi)):
+    if res.row(k) != tuple(orc.align(qs[qi[k]], ts[ti[k]], P, nmm)):
+        bad += 1
+print("INFO", info["tasks"], info["tasks_pair"], info["tasks_tilted"], bad)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["default", "zero_terminal", "uniform10_1", "distinct12"])
+def test_pair_profile_class(gpu_required, name):
+    """r05: groups of four whole-wave tasks of one pure-ACGT query with pure-ACGT targets run as a workgroup that shares a pair-indexed
+    dword profile (vsx_forward_kernel PAIR; VSX_PAIRPROF=1).  Queries of several row classes with 33 .. 87 targets each, some targets and
+    two queries with IUPAC symbols (those tasks stay whole-wave tasks), under the MAX3 class, the 16-bit TILT class and a scoring set that
+    cannot be tilted (no pair class there): every field of every pair against the oracle, with the switch on and off."""
+    import subprocess
+    import sys
+    sc = common.load_golden()["scorings"][name]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for mode in ("1", "0"):
+        e = dict(os.environ, VSX_PAIRPROF=mode)
+        p = subprocess.run([sys.executable, "-c", _PAIR_SNIPPET % (root, tuple(sc["P"]), bool(sc["n_mismatch"]))], env=e, capture_output=True, text=True,
+                           timeout=600, cwd=root)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        tasks, pair, tilted, bad = (int(x) for x in [ln for ln in p.stdout.splitlines() if ln.startswith("INFO")][-1].split()[1:])
+        assert bad == 0, (name, mode, bad)
+        seen[mode] = (tasks, pair, tilted)
+    assert seen["0"][1] == 0
+    if seen["1"][2] > 0:
+        assert seen["1"][1] >= 16 and seen["1"][1] % 4 == 0, seen          # whole groups of four, in several row classes
+    else:
+        assert seen["1"][1] == 0, seen

@@ -116,7 +116,7 @@ class PlanInfo(C.Structure):
     """vsx_plan_info (include/vsx.h)"""
     _fields_ = [("tasks", C.c_uint64), ("tasks_tilted", C.c_uint64), ("tasks_tracked", C.c_uint64),
                 ("rows_dominant", C.c_uint32), ("chunks", C.c_uint32), ("tasks_max3", C.c_uint64),
-                ("tasks_sparse", C.c_uint64), ("waves", C.c_uint64)]
+                ("tasks_sparse", C.c_uint64), ("waves", C.c_uint64), ("tasks_pair", C.c_uint64)]
 
 
 class Timing(C.Structure):

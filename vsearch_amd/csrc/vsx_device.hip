@@ -130,9 +130,7 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 // FEED2 (r05, prepared in r04 as experiments/dp_feed2.patch): the feed record of the look-ahead classes, see vsx_forward_kernel
 // r05 same-box A/B (profiles/r05/r05b_feed2_ab.txt, two runs each): DP 250 x 1000 22.73 -> 22.41 ms, 150 x 1000 16.65 -> 16.40, 150 x 300
 // 5.58 -> 5.45, 300 x 300 10.24 -> 10.20, 400 x 400 17.06 -> 17.12 (R = 26: level); parity suite + aligner soak green on the build.  Default ON.
-#ifndef VSX_FEED2
-#define VSX_FEED2 1
-#endif
+// (the default of VSX_FEED2 lives in vsx_internal.h: the planner needs it for the pair-profile classes)
 #ifndef VSX_FWD_WAVES
 #define VSX_FWD_WAVES(R_, TILT_) ((R_) <= 16 ? 4 : ((R_) <= 24 ? 3 : 2))
 #endif
@@ -164,8 +162,16 @@ DEV u32 pk_max3_bits(u32 a, u32 b, u32 c)            // IEEE maximum of three: t
 #ifndef VSX_FWD_WAVES_NQ
 #define VSX_FWD_WAVES_NQ(R_, NQ_) ((NQ_) == 4 ? 2 : ((R_) <= 24 ? 3 : 2))
 #endif
-template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false, bool MAX3 = false, int NQ = 1>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? VSX_FWD_WAVES(R, TILT) : VSX_FWD_WAVES_NQ(R, NQ), 8)))
+// PAIR (r05, the PAIR-PROFILE classes of the TILT family): a WORKGROUP of four waves = four whole-wave tasks of ONE query whose symbols
+// and whose targets' symbols are all plain A / C / G / T.  They share one LDS profile indexed by the PAIR of column symbols of a lane
+// group's two targets: PP[pair][position][row] = S'[a][q_row] | S'[b][q_row] << 16 -- the packed score of both halves is one LDS dword,
+// the row body loses its v_perm_b32: 5 instead of 6 instructions per lane-row.  The profile is 4 x the byte profile (16 pairs instead
+// of 16 codes at a dword instead of a byte per row), which one wave cannot afford (two waves per SIMD: measured +18 %);
+// four waves sharing it can, when a query has >= 32 targets (--allpairs_global).  No look-ahead register set: the R dwords of a step are
+// read at its top, row r's compute waits for its own quarter only.  Everything a task owns -- VsxTask, checkpoint block, VsxSlotOut -- is
+// as in the whole-wave class, so the traceback is unchanged.  The planner forms the groups of four (vsx_host.cpp).
+template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false, bool MAX3 = false, int NQ = 1, bool PAIR = false>
+__global__ void __launch_bounds__(PAIR ? 256 : 64) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? VSX_FWD_WAVES(R, TILT) : VSX_FWD_WAVES_NQ(R, NQ), 8)))
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
                    u32 * __restrict__ dir, uint2 * strip, VsxSlotOut * __restrict__ slot_out, const u32 ntasks)
@@ -207,29 +213,40 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   constexpr int RP = (R + 3) & ~3;
   static_assert(NQ == 1 || NQ == 2 || NQ == 4, "tasks per wave");
   static_assert(NQ == 1 || (TILT && VSX_QPL != 0 && !VSX_CKT), "the sparse-task classes exist for the look-ahead TILT kernels only");
+  static_assert(!PAIR || (NQ == 1 && TILT && VSX_QPL != 0 && VSX_FEED2 != 0 && !VSX_CKT && GENERIC), "the pair-profile classes extend the FEED2 look-ahead kernels");
+  constexpr int WPB = PAIR ? 4 : 1;                  // waves per workgroup
   constexpr int QPBYTES = 16 * 16 * RP;              // one byte profile
-  __shared__ __attribute__((aligned(16))) int16_t QP[GENERIC ? (QP8 ? (NQ * QPBYTES) / 2 : 16 * 16 * R) : 8];
+  // pair profile: row stride RPP dwords with RPP / 4 odd, so that the 16 lanes of a group (each reading whole 16-byte quarters) start
+  // in sixteen different 4-bank groups
+  constexpr int RPP = ((RP / 4) & 1) ? RP : RP + 4;
+  __shared__ __attribute__((aligned(16))) u32 PPf[PAIR ? 16 * 16 * RPP : 4];
+  __shared__ __attribute__((aligned(16))) int16_t QP[(GENERIC && !PAIR) ? (QP8 ? (NQ * QPBYTES) / 2 : 16 * 16 * R) : 8];
   uint8_t * const QPb = reinterpret_cast<uint8_t *>(QP);
   // checkpoint staging of the transposed layout: [slot][12 dwords]
   __shared__ __attribute__((aligned(16))) u32 RS[CKST ? 64 * 12 : 4];
   // feed block of the column pipeline: [lane group][column of the 16-block] (sym, QR_t, R_t, H) and F -- written once per 16
   // steps by the 16 lanes of a group, read back one column per step for lane 0 (replaces five v_mov_b32_dpp row_ror rotations)
-  __shared__ uint4 FEED4[(TILT && VSX_QPL ? 2 : 1) * 4 * 16];         // QPL: two blocks (the next one is built a step early)
-  __shared__ u32 FEEDF[(TILT && VSX_QPL ? 2 : 1) * 4 * 16], FEEDN[GENERIC ? 1 : 4 * 16];
+  constexpr int FSZ = (TILT && VSX_QPL ? 2 : 1) * 4 * 16;             // feed entries of one wave
+  __shared__ uint4 FEED4a[FSZ * WPB];                                  // QPL: two blocks (the next one is built a step early)
+  __shared__ u32 FEEDFa[FSZ * WPB], FEEDN[GENERIC ? 1 : 4 * 16];
   // FEED2 (the classes with the look-ahead byte profile): the record of a column is (byte offsets of the two targets' profile rows in
   // the halves of one dword, symbols + flags, H, F) -- an interior step reads H and F of its column and the offsets of the next column
   // from three neighbouring dwords, and the profile addresses are two adds -- and (QR_t, R_t) live in a second array for phase B
   constexpr bool FEED2 = (VSX_FEED2 != 0) && TOPPAD && (TILT && (VSX_QPL != 0));
-  __shared__ uint2 FEEDB[FEED2 ? 2 * 4 * 16 : 1];
+  __shared__ uint2 FEEDBa[FEED2 ? 2 * 4 * 16 * WPB : 1];
 
-  const int lane = (int) threadIdx.x;
+  const int wv = PAIR ? __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)) : 0;      // wave of the workgroup = task of the group of four (scalar: the task's fields stay in SGPRs)
+  uint4 * const FEED4 = FEED4a + wv * FSZ;
+  u32 * const FEEDF = FEEDFa + wv * FSZ;
+  uint2 * const FEEDB = FEEDBa + (FEED2 ? wv * FSZ : 0);
+  const int lane = PAIR ? (int) (threadIdx.x & 63) : (int) threadIdx.x;
   const int gw = lane >> 4;                        // lane group of the wave
   constexpr int GPT = 4 / NQ;                      // lane groups per task
   const int sq = (NQ == 1) ? 0 : gw / GPT;         // this lane's sub-task
   const int g = (NQ == 1) ? gw : gw % GPT;         // its group inside the task (targets 2g, 2g + 1; checkpoint slot l * 4 + g)
   const int l = lane & 15;
-  const u32 tix = (NQ == 1) ? blockIdx.x : blockIdx.x * (u32) NQ + (u32) sq;
-  const bool sub_on = (NQ == 1) ? true : (tix < ntasks);
+  const u32 tix = PAIR ? blockIdx.x * 4u + (u32) wv : ((NQ == 1) ? blockIdx.x : blockIdx.x * (u32) NQ + (u32) sq);
+  const bool sub_on = (NQ == 1 && !PAIR) ? true : (tix < ntasks);      // (PAIR: the planner launches whole groups of four)
   const VsxTask & T = tasks[sub_on ? tix : ntasks - 1];
   uint8_t * const QPl = reinterpret_cast<uint8_t *>(QP) + ((NQ == 1) ? 0 : sq * QPBYTES);      // this lane's profile
 
@@ -268,7 +285,29 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       if (GENERIC)
         {
           __syncthreads();                           // previous strip's readers are done
-          if (QP8)
+          if (PAIR)
+            {
+              // the pair profile of the group's query (the four waves hold tasks of ONE query: any wave's task describes it), by all 256 threads
+              for (int idx = (int) threadIdx.x; idx < 16 * 16 * RP; idx += 256)
+                {
+                  const int pr = idx / (16 * RP), row = idx % (16 * RP);
+                  const int Lr = 16 * s + row / RP, rr = row % RP;
+                  int va = 0, vb = 0;
+                  if (rr < R)
+                    {
+                      if (Lr == 0 && rr < pad) va = vb = -P.top_step + 2 * tl;
+                      else if (Lr < total_lanes)
+                        {
+                          const int gi = (Lr == 0) ? rr - pad : rcnt0 + (Lr - 1) * R + rr;
+                          const int qs = (int) qq[gi];
+                          va = P.matrix[(1 << (pr >> 2)) * 16 + qs];
+                          vb = P.matrix[(1 << (pr & 3)) * 16 + qs];
+                        }
+                    }
+                  PPf[(pr * 16 + row / RP) * RPP + rr] = ((u32) va & 0xffu) | (((u32) vb & 0xffu) << 16);
+                }
+            }
+          else if (QP8)
             {
               // (NQ > 1: the 64 / NQ lanes of a sub-task fill THEIR profile from their own task's query)
               constexpr int LPT = 64 / NQ;
@@ -392,7 +431,10 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               const int fo = QPL ? (blk & 1) * 64 : 0;
               if (FEED2)
                 {
-                  const u32 f_off = rawA * (u32) (16 * RP) | ((rawB * (u32) (16 * RP)) << 16);      // QPb[code][16 positions][RP] bytes
+                  // QPb[code][16 positions][RP] bytes; PAIR: the byte offset of PP[pair = 4 ia + ib] (codes 1 2 4 8 -> 0 1 2 3; a column
+                  // past a target's end has code 0 -> index 0: any valid address, nobody keeps what it yields)
+                  const u32 f_off = PAIR ? (((rawA >> 1) - (rawA >> 3)) * 4u + ((rawB >> 1) - (rawB >> 3))) * (u32) (16 * RPP * 4)
+                                         : (rawA * (u32) (16 * RP) | ((rawB * (u32) (16 * RP)) << 16));
                   FEED4[fo + gw * 16 + l] = make_uint4(f_off, f_sym, f_H, f_F);
                   FEEDB[fo + gw * 16 + l] = make_uint2(f_qrt, f_rt);
                 }
@@ -408,8 +450,9 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
       // the two-step unrolling: the set of step t+1 is requested at the top of step t, from the symbols the lane will hold then
       // (its neighbour's current ones)
       constexpr int PD = RP / 4;
-      u32 profA[2][QPL ? PD : 1], profB[2][QPL ? PD : 1];
-      auto load_profile = [&](u32 (&buf)[2][QPL ? PD : 1], u32 sy) __attribute__((always_inline)) {
+      u32 profA[2][(QPL && !PAIR) ? PD : 1], profB[2][(QPL && !PAIR) ? PD : 1];
+      auto load_profile = [&](u32 (&buf)[2][(QPL && !PAIR) ? PD : 1], u32 sy) __attribute__((always_inline)) {
+        if (PAIR) return;                            // (the pair profile is read at the top of the step it serves: see step())
         const u32 cd = sy & 0x000F000Fu;
         // (the offsets are multiples of 16 RP: the rows keep the alignment of l RP, which the compiler cannot see through the feed --
         //  so the FEED2 form spells the wide LDS reads out)
@@ -418,8 +461,9 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
           {
             const uint8_t * pa = QPl + l * RP + (sy & 0xFFFFu);
             const uint8_t * pb = QPl + l * RP + (sy >> 16);
-            constexpr int PDN = QPL ? PD : 1;
-            if constexpr (QPA == 16)
+            constexpr int PDN = (QPL && !PAIR) ? PD : 1;
+            if constexpr (PAIR) { }
+            else if constexpr (QPA == 16)
               {
 #pragma unroll
                 for (int k = 0; k < PDN; k += 4)
@@ -450,7 +494,7 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
         const u32 * a = reinterpret_cast<const u32 *>(QPl + (cd & 0xFu) * (16 * RP) + l * RP);
         const u32 * b = reinterpret_cast<const u32 *>(QPl + (cd >> 16) * (16 * RP) + l * RP);
 #pragma unroll
-        for (int k = 0; k < (QPL ? PD : 1); ++k) { buf[0][k] = a[k]; buf[1][k] = b[k]; }
+        for (int k = 0; k < ((QPL && !PAIR) ? PD : 1); ++k) { buf[0][k] = a[k]; buf[1][k] = b[k]; }
       };
       if (QPL)
         {
@@ -498,12 +542,25 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
 
       // STEADY (the part of phase A after the pipeline has filled, t >= 15): every lane that owns rows is inside its targets, so the
       // per-lane activity test and its EXEC mask are dropped (lanes beyond the query's positions compute junk nobody reads).
-      auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R], u32 (&pc)[2][QPL ? PD : 1], u32 (&pn)[2][QPL ? PD : 1],
+      auto step = [&](const int t, u32 (&hin)[R], u32 (&hout)[R], u32 (&pc)[2][(QPL && !PAIR) ? PD : 1], u32 (&pn)[2][(QPL && !PAIR) ? PD : 1],
                       auto interior_tag, auto odd_tag, auto steady_tag) __attribute__((always_inline)) {
           constexpr bool INTERIOR = decltype(interior_tag)::value;
           constexpr bool ODD = decltype(odd_tag)::value;
           constexpr bool STEADY = decltype(steady_tag)::value;
           u32 symn = 0;
+          // PAIR: this step's packed scores, one dword per row, straight from the pair profile (`sym` = the byte offset of the pair's
+          // block, as the feed delivers it); issued first, consumed a quarter at a time by the row loop below
+          u32 pp[PAIR ? RP : 1];
+          if (PAIR)
+            {
+              const u32 * ppa = PPf + (sym >> 2) + l * RPP;
+#pragma unroll
+              for (int k = 0; k < (PAIR ? RP : 0); k += 4)
+                {
+                  const uint4 v = *reinterpret_cast<const uint4 *>(ppa + k);
+                  pp[k] = v.x; pp[k + 1] = v.y; pp[k + 2] = v.z; pp[k + 3] = v.w;
+                }
+            }
           if (QPL) { if ((t & 15) == 15) build_feed((t >> 4) + 1); }      // the next block, one step early (look-ahead below)
           else if ((t & 15) == 0) build_feed(t >> 4);
 
@@ -566,7 +623,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
               for (int r = 0; r < R; ++r)
                 {
                   u32 V;
-                  if (GENERIC && QP8)
+                  if (PAIR) V = pp[r];
+                  else if (GENERIC && QP8)
                     {
                       if ((r & 3) == 0)
                         {
@@ -2366,11 +2424,23 @@ extern "C" hipError_t vsx_launch_purity(const uint8_t * d_codes, const uint64_t 
 }
 
 #define VSX_FWD_GO(GRID_, ...) hipLaunchKernelGGL((vsx_forward_kernel<__VA_ARGS__>), dim3(GRID_), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot, ntasks)
+#define VSX_FWD_GO4(GRID_, ...) hipLaunchKernelGGL((vsx_forward_kernel<__VA_ARGS__>), dim3(GRID_), dim3(256), 0, st, P, d_tasks, q, t, dir, strip, slot, ntasks)
 template <int R, bool CK>
 static hipError_t launch_fwd2(int generic, int track, int nq, const VsxDevParams & P, const VsxTask * d_tasks, uint32_t ntasks,
                               const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
                               VsxSlotOut * slot, hipStream_t st)
 {
+  if (nq == 8)
+    {
+      // the pair-profile classes: workgroups of four whole-wave tasks of one query (the planner launches whole groups)
+      if (!(P.tilt != 0 && CK && generic && !track) || (ntasks & 3u)) return hipErrorInvalidValue;
+      if constexpr (CK && R >= 4 && VSX_QPL != 0 && VSX_FEED2 != 0 && !VSX_CKT)
+        {
+          if (P.max3) VSX_FWD_GO4(ntasks / 4, R, true, false, true, true, true, 1, true); else VSX_FWD_GO4(ntasks / 4, R, true, false, true, true, false, 1, true);
+          return hipGetLastError();
+        }
+      else return hipErrorInvalidValue;
+    }
   if (nq != 1)
     {
       // the sparse-task classes (NQ tasks per wave): TILT family only, R >= 4 (a one-row-per-lane wave has nothing to share)
@@ -2400,8 +2470,10 @@ static hipError_t launch_fwd2(int generic, int track, int nq, const VsxDevParams
   return hipGetLastError();
 }
 #undef VSX_FWD_GO
+#undef VSX_FWD_GO4
 
-// nq = tasks per wave: 1, or 2 / 4 for the sparse-task classes (tasks of <= 4 / <= 2 targets, TILT family, single-strip queries)
+// nq = tasks per wave: 1, or 2 / 4 for the sparse-task classes (tasks of <= 4 / <= 2 targets, TILT family, single-strip queries);
+// 8 = the pair-profile class: workgroups of four whole-wave tasks of one pure-ACGT query (ntasks a multiple of 4)
 extern "C" hipError_t vsx_launch_forward(int rows, int generic, int track, int ckpt, int nq, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
                                          const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
                                          VsxSlotOut * slot, hipStream_t st)

@@ -329,6 +329,9 @@ struct Chunk {
 
 extern "C" int vsx_internal_usable_cpus(void);
 // per device: 0 = not tested yet, 1 = v_pk_maximum3_f16 is the integer maximum on [0, 0x7BFF] (vsx_create's self-test), 2 = it is not
+#ifndef VSX_PAIRPROF_DEFAULT
+#define VSX_PAIRPROF_DEFAULT 0
+#endif
 static std::atomic<int> g_max3_state[64];
 static std::mutex g_ctx_mu;                   // the live contexts of the process (vsx_internal_memory_pressure)
 static std::vector<vsx_ctx *> g_ctxs;
@@ -1048,6 +1051,18 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   HIPCHK(hipSetDevice(ctx->device));
   static const bool arith = std::getenv("VSX_SCORE") && std::strcmp(std::getenv("VSX_SCORE"), "arith") == 0;
   if (arith) { const int rc = ensure_impure(queries); if (rc != VSX_OK) return rc; }
+  // r05, pair-profile classes (vsx_forward_kernel PAIR): groups of four whole-wave tasks of ONE pure-ACGT query with pure-ACGT targets
+  // run as a workgroup that shares a pair-indexed dword profile (5 instead of 6 instructions per lane-row).  Worth it only for queries
+  // with many targets (--allpairs_global); needs the purity of both sets.  VSX_PAIRPROF=0 / 1 overrides the default below
+  static const bool pair_on = (std::getenv("VSX_PAIRPROF") ? std::strcmp(std::getenv("VSX_PAIRPROF"), "0") != 0 : (VSX_PAIRPROF_DEFAULT != 0)) &&
+                              !arith && ctx->ckpt && VSX_QPL != 0 && VSX_FEED2 != 0 && !VSX_CKT;
+  const bool pair_try = pair_on && n_pairs >= 32;
+  if (pair_try)
+    {
+      int rc = ensure_impure(queries);
+      if (rc == VSX_OK) rc = ensure_impure(targets);
+      if (rc != VSX_OK) return rc;
+    }
 
   std::unique_ptr<vsx_plan> pl(new vsx_plan);
   pl->ctx = ctx; pl->Q = queries; pl->T = targets; pl->n_pairs = n_pairs;
@@ -1151,6 +1166,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
                          [&](uint32_t x, uint32_t y) { return targets->len[tidx[x]] > targets->len[tidx[y]]; });
         const int rows = pick_rows((int) queries->len[q]);
         const int generic = (!arith || queries->impure[q]) ? 1 : 0;
+        const size_t first_of_query = outp.size();
         for (size_t x = b; x < e; x += VSX_TASK_SLOTS)
           {
             ProtoTask pt {};
@@ -1168,6 +1184,30 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
             if (sparse_on && pt.tilt && rows >= 4 && pt.n <= 4 && (int64_t) queries->len[q] <= 16ll * rows)      // (one strip: the hand-over rows are per wave)
               pt.nq = pt.n <= 2 ? 4 : 2;
             outp.push_back(pt);
+          }
+        if (pair_try && rows >= 4 && !queries->impure[q] && outp.size() - first_of_query >= 4)
+          {
+            // whole groups of four eligible tasks of this query (same kernel class, every target plain ACGT) -> nq = 8; what is left over
+            // stays in the whole-wave class.  The tasks of a query are consecutive and stay so through the stable class sort below.
+            std::vector<size_t> ok;
+            for (size_t k = first_of_query; k < outp.size(); ++k)
+              {
+                ProtoTask & pt = outp[k];
+                if (pt.nq != 1 || !pt.tilt) continue;
+                bool pure = true;
+                for (uint32_t sidx = 0; sidx < pt.n && pure; ++sidx) pure = !targets->impure[tidx[pt.pair[sidx]]];
+                if (pure) ok.push_back(k);
+              }
+            // (groups must not mix the MAX3 and the 16-bit TILT sub-class: take runs of equal tilt)
+            size_t i0 = 0;
+            while (i0 < ok.size())
+              {
+                size_t i1 = i0;
+                while (i1 < ok.size() && outp[ok[i1]].tilt == outp[ok[i0]].tilt) ++i1;
+                const size_t whole = (i1 - i0) / 4 * 4;
+                for (size_t k = i0; k < i0 + whole; ++k) outp[ok[k]].nq = 8;
+                i0 = i1;
+              }
           }
       }
   };
@@ -1235,7 +1275,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       std::vector<Key> ks;
       for (const ProtoTask & pt : protos)
         {
-          if (pt.nq == 1) continue;
+          if (pt.nq != 2 && pt.nq != 4) continue;
           bool found = false;
           for (Key & c : ks) if (c.rows == pt.rows && c.generic == pt.generic && c.track == pt.track && c.tilt == pt.tilt && c.nq == pt.nq) { ++c.count; found = true; break; }
           if (!found) ks.push_back(Key {pt.rows, pt.generic, pt.track, pt.tilt, pt.nq, 1});
@@ -1244,7 +1284,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       for (const Key & c : ks) any = any || c.count < sparse_min;
       if (any)
         for (ProtoTask & pt : protos)
-          if (pt.nq > 1)
+          if (pt.nq == 2 || pt.nq == 4)
             for (const Key & c : ks)
               if (c.count < sparse_min && pt.nq == c.nq && pt.rows == c.rows && pt.generic == c.generic && pt.track == c.track && pt.tilt == c.tilt) { pt.nq = 1; break; }
     }
@@ -1326,7 +1366,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   };
   // sparse-task classes: the nq tasks of a wave -- consecutive tasks of the launch, counted from its first -- share ONE checkpoint block
   // and one step range (the longest of them); `wave_left` tasks of the open wave are still to come, they take `wave_off` / `wave_steps`
-  uint32_t wave_left = 0, wave_steps = 0, wave_group = 0;
+  uint32_t wave_left = 0, wave_steps = 0, wave_group = 0, pair_left = 0;
   uint64_t wave_off = 0;
   auto same_class = [&](size_t a, size_t b) {
     return protos[a].rows == protos[b].rows && protos[a].generic == protos[b].generic && protos[a].track == protos[b].track &&
@@ -1338,7 +1378,18 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
       VsxTask & t = pl->tasks[x];
       uint64_t dwords = t_dwords[x];
       const uint64_t strip = t.strip_off;
-      if (pt.nq > 1 && wave_left == 0)
+      const bool sparse_task = pt.nq == 2 || pt.nq == 4;
+      if (pt.nq == 8)
+        {
+          // a pair-profile group of four (consecutive tasks of one query): never cut a chunk inside it
+          if (pair_left == 0)
+            {
+              pair_left = 4;
+              if (cur.task_count && cur.dir_dwords + dwords + VSX_CK_SLACK_DW > budget_dwords) close_chunk();
+            }
+          --pair_left;
+        }
+      else if (sparse_task && wave_left == 0)
         {
           // a new wave: its tasks are x .. x + nq - 1 as far as the class reaches (a chunk is never cut inside a wave)
           uint32_t smax = t.steps, members = 1;
@@ -1348,9 +1399,9 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
           if (cur.task_count && cur.dir_dwords + dwords + VSX_CK_SLACK_DW > budget_dwords) close_chunk();
           wave_off = cur.dir_dwords;
         }
-      else if (pt.nq > 1) dwords = 0;                     // (the wave's block is already counted)
+      else if (sparse_task) dwords = 0;                   // (the wave's block is already counted)
       else if (cur.task_count && cur.dir_dwords + dwords + VSX_CK_SLACK_DW > budget_dwords) close_chunk();
-      if (pt.nq > 1)
+      if (sparse_task)
         {
           t.dir_off = wave_off;
           t.steps = wave_steps;
@@ -1596,8 +1647,9 @@ int vsx_plan_describe(const vsx_plan * pl, vsx_plan_info * info)
   for (const Chunk & c : pl->chunks)
     for (const Launch & L : c.launches)
       {
-        if (L.nq > 1) info->tasks_sparse += L.count;
-        info->waves += (L.count + (uint32_t) L.nq - 1) / (uint32_t) L.nq;
+        if (L.nq == 2 || L.nq == 4) info->tasks_sparse += L.count;
+        if (L.nq == 8) info->tasks_pair += L.count;
+        info->waves += (L.nq == 2 || L.nq == 4) ? (L.count + (uint32_t) L.nq - 1) / (uint32_t) L.nq : L.count;
         if (L.tilt) info->tasks_tilted += L.count;
         if (L.tilt == 2) info->tasks_max3 += L.count;
         if (L.track) info->tasks_tracked += L.count;

@@ -29,6 +29,10 @@
 #ifndef VSX_QPL
 #define VSX_QPL 1
 #endif
+// TILT class: the FEED2 record of the look-ahead kernels (vsx_device.hip); 0 = the r04 record (A/B)
+#ifndef VSX_FEED2
+#define VSX_FEED2 1
+#endif
 // TILT class, R >= VSX_MID_MIN_ROWS rows per lane: the DP kernel stores a SECOND row checkpoint per step, after the middle row of
 // every pipeline position, and lays the column checkpoints out per half; the traceback's tiles are then R/2 rows high -- half the
 // recompute area per crossing and half the register state per lane (the R >= 18 tracebacks sat at 2 waves per SIMD on registers).
