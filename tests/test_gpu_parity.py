@@ -678,7 +678,7 @@ print("INFO", info["tasks"], info["tasks_pair"], info["tasks_tilted"], bad)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["default", "zero_terminal", "uniform10_1", "distinct12"])
+@pytest.mark.parametrize("name", ["default", "nmismatch", "zero_terminal", "uniform10_1", "distinct12"])
 def test_pair_profile_class(gpu_required, name):
     """r05: groups of four whole-wave tasks of one pure-ACGT query with pure-ACGT targets run as a workgroup that shares a pair-indexed
     dword profile (vsx_forward_kernel PAIR; VSX_PAIRPROF=1).  Queries of several row classes with 33 .. 87 targets each, some targets and

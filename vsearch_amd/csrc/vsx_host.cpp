@@ -329,8 +329,10 @@ struct Chunk {
 
 extern "C" int vsx_internal_usable_cpus(void);
 // per device: 0 = not tested yet, 1 = v_pk_maximum3_f16 is the integer maximum on [0, 0x7BFF] (vsx_create's self-test), 2 = it is not
+// r05j same-box A/B, 25 000 queries x 32 candidates, two runs each (profiles/r05/r05j_pairprof_first_contact.txt): DP 400 x 400 16.53 -> 14.45 ms,
+// 300 x 300 9.96 -> 8.68, 250 x 1000 22.12 -> 20.39, 150 x 1000 16.04 -> 14.50.  Default ON (it engages only where a query has >= 4 eligible tasks)
 #ifndef VSX_PAIRPROF_DEFAULT
-#define VSX_PAIRPROF_DEFAULT 0
+#define VSX_PAIRPROF_DEFAULT 1
 #endif
 static std::atomic<int> g_max3_state[64];
 static std::mutex g_ctx_mu;                   // the live contexts of the process (vsx_internal_memory_pressure)
@@ -1385,7 +1387,12 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
           if (pair_left == 0)
             {
               pair_left = 4;
-              if (cur.task_count && cur.dir_dwords + dwords + VSX_CK_SLACK_DW > budget_dwords) close_chunk();
+              // (the WHOLE group must fit: a chunk that overshoots the budget -- which is the size of the context's current block once one
+              //  exists -- by three tasks asks for a slightly larger block while the old one is still held by the plans in flight:
+              //  out of memory in the middle of an allpairs run, profiles/r05/r05j_pairprof_first_contact.txt)
+              uint64_t gsum = 0;
+              for (size_t y = x; y < std::min(NT, x + 4); ++y) gsum += t_dwords[y];
+              if (cur.task_count && cur.dir_dwords + gsum + VSX_CK_SLACK_DW > budget_dwords) close_chunk();
             }
           --pair_left;
         }
