@@ -464,9 +464,17 @@ int hit_compare_bysize(const vsx_searcher & S, const Hit & l, const Hit & r)
 
 // The while loop of search_onequery (:915-950) up to the point where align_delayed would be called.
 // Returns true if a batch of targets must be aligned now (appended to tq/tt), false if the query is finished.
+// LAZY (r05; VERDICT r04 "next" 5): the reference delays 8 candidates, aligns them in one search16 call and then walks them in order
+// until maxaccepts or maxrejects is reached -- what lies behind that point was aligned for nothing and is freed unread (:785, :875-878).
+// With the default maxaccepts = 1 and a database that holds the query's relatives, that is 7 of the 8 alignments of almost every query.
+// A query's FIRST batch here is only as many candidates as it still needs accepts (min(8, maxaccepts)); if they do not finish it, the
+// batches go on in eights.  The candidates are popped, filtered and judged in the same order under the same two limits, and a hit's
+// verdict does not depend on its batch, so accepts, rejects and every reported hit are the reference's; only the number of pairs
+// that reach the aligner shrinks (`pairs_aligned` <= the reference's).  The sparse-task classes make a window of one-target tasks cheap.
 bool advance(const vsx_searcher & S, QState & st, const char * q, int64_t qlen, uint32_t qlocal, const QMeta & qm,
-             std::vector<uint32_t> & pq, std::vector<uint32_t> & pt)
+             std::vector<uint32_t> & pq, std::vector<uint32_t> & pt, bool lazy)
 {
+  const int cap = (lazy && st.hits.empty()) ? (int) std::min<int64_t>(8, std::max<int64_t>(1, S.ma)) : 8;
   while ((st.finalized + st.delayed < S.ma + S.mr - 1) && (st.rejects < S.mr) && (st.accepts < S.ma) &&
          (st.next < st.cands.size()))
     {
@@ -475,7 +483,7 @@ bool advance(const vsx_searcher & S, QState & st, const char * q, int64_t qlen, 
       h.target = c.target; h.count = c.count;
       if (acceptable_unaligned(S, q, qlen, c.target, qm)) ++st.delayed; else h.rejected = true;
       st.hits.push_back(std::move(h));
-      if (st.delayed == 8) break;                      // MAXDELAYED
+      if (st.delayed == cap) break;                    // MAXDELAYED (the first batch of a lazy search: what the query still needs)
     }
   if (st.delayed == 0) { st.done = true; return false; }
   st.req_first = pq.size();
@@ -606,7 +614,7 @@ struct Acct { double t_align = 0, t_advance = 0, t_replay = 0; uint64_t pairs = 
 // qtext(k): the query as text for the linear-memory fallback (sentinel pairs only; may build it on demand).
 template <typename FSeq, typename FText, typename FLen, typename FIdx, typename FMeta>
 static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qseq, FText qtext, FLen qlen, FIdx qidx, FMeta qmeta,
-                      const vsx_seqset * qset, Acct & acct, vsx_ctx * ctx = nullptr /* default: the searcher's own */)
+                      const vsx_seqset * qset, Acct & acct, vsx_ctx * ctx = nullptr /* default: the searcher's own */, bool lazy = false)
 {
   if (!ctx) ctx = S.ctx;
   const uint64_t wn = st.size();
@@ -630,7 +638,7 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
           for (size_t w = b; w < e; ++w)
             {
               const uint32_t k = open[w];
-              if (advance(S, st[k], qseq(k), qlen(k), qidx(k), qmeta(k), p.pq, p.pt)) p.waiting.push_back(k);     // req_first: slice-relative
+              if (advance(S, st[k], qseq(k), qlen(k), qidx(k), qmeta(k), p.pq, p.pt, lazy)) p.waiting.push_back(k);     // req_first: slice-relative
             }
         };
         std::vector<std::thread> pool;
@@ -1196,6 +1204,8 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
     if (qoff[i] + qlen[i] > qbytes) return sfail(VSX_EINVAL, "vsx_search_batch: query exceeds the blob");
   const double t_begin = now_s();
   static const bool timeline = std::getenv("VSX_DEBUG_TIMELINE") != nullptr;
+  // lazy first batches (advance()): VSX_SEARCH_LAZY=0 aligns the reference's batches of eight from the start (A/B, tests)
+  static const bool lazy_search = !(std::getenv("VSX_SEARCH_LAZY") && std::strcmp(std::getenv("VSX_SEARCH_LAZY"), "0") == 0);
   // Windows of queries; the k-mer stage of window i+1 (host word extraction, device counting, host ranking) runs on a
   // producer thread while this thread aligns window i (a query's hits do not depend on its window).  Large batches use
   // smaller windows so that the two stages overlap; VSX_SEARCH_PIPELINE=0 = one thread, as before.
@@ -1410,7 +1420,7 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
         };
         if (both && W.joined.empty()) W.lazy_rc.assign(wn, std::string());
         const int src = run_stages(*S, st, seq_of, text_of, [&](uint64_t k) { return (int64_t) W.ln[k]; },
-                                   [&](uint64_t k) { return (uint32_t) k; }, meta_of, qset, acct, ctx);
+                                   [&](uint64_t k) { return (uint32_t) k; }, meta_of, qset, acct, ctx, lazy_search);
         {
           std::lock_guard<std::mutex> lk(acc_mu);
           t_qset += dq;
