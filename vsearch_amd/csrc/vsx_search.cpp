@@ -2337,10 +2337,13 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
         }
 
       // ---- phase 1b: staged GPU search (queries and targets both live in the database sequence set) ----
+      // (lazy first batches as in vsx_search_batch are an A/B here, VSX_CLUSTER_LAZY=1: a round's plans are latency-bound, and a
+      //  member whose best centroid fails pays one more stage)
+      static const bool cluster_lazy = std::getenv("VSX_CLUSTER_LAZY") && std::strcmp(std::getenv("VSX_CLUSTER_LAZY"), "1") == 0;
       const double ts0 = now_s();
       int rc = run_stages(*S, st, [&](uint64_t k) { return seq_of(s0 + k); }, [&](uint64_t k) { return seq_of(s0 + k); },
                           [&](uint64_t k) { return (int64_t) S->len[s0 + k]; },
-                          [&](uint64_t k) { return (uint32_t) (s0 + k); }, [&](uint64_t k) { return S->meta_of(s0 + k); }, S->dbset, acct);
+                          [&](uint64_t k) { return (uint32_t) (s0 + k); }, [&](uint64_t k) { return S->meta_of(s0 + k); }, S->dbset, acct, nullptr, cluster_lazy);
       if (rc != VSX_OK) return rc;
       tm_stages += now_s() - ts0;
 
