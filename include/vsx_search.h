@@ -17,8 +17,9 @@
   Control flow: instead of one search16 call of <= 8 targets per query, a WINDOW of queries advances in
   lock step -- every open query contributes its next delayed batch (exactly the targets the reference's
   align_delayed would pass to search16), all batches of the window go to the GPU as one vsx_plan, and the
-  accept/reject counters are then replayed per query in the reference's order.  The set of aligned pairs
-  and every hit field are identical to the reference's.
+  accept/reject counters are then replayed per query in the reference's order.  Every hit field is identical to
+  the reference's; the set of aligned pairs is the reference's or (vsx_search_batch, r05: lazy first batches) a subset
+  of it that leaves out only alignments the reference computes and frees unread.
 */
 #ifndef VSX_SEARCH_H
 #define VSX_SEARCH_H
@@ -104,7 +105,10 @@ typedef struct vsx_hits {
   vsx_hit  * hit;
   char     * cigar_blob;
   uint64_t   cigar_bytes;
-  /* accounting ("exactly the pairs the reference passes to search16") */
+  /* accounting.  pairs_aligned / cells_aligned: what reached the aligner.  vsx_search_batch aligns LAZILY since r05 -- a query's first batch is
+     as many candidates as it still needs accepts (min(8, maxaccepts)) instead of the reference's 8, later batches are eights -- so the number
+     is <= the pairs the reference passes to search16, with identical hits; VSX_SEARCH_LAZY=0 restores the reference's batches.
+     allpairs and clustering align exactly the reference's pairs. */
   uint64_t   pairs_aligned, cells_aligned, stages, sentinel_pairs;
   double     seconds_kmer, seconds_align, seconds_total;
 } vsx_hits;
