@@ -643,7 +643,7 @@ def search_end_to_end(a, al, db_ascii, db_off, db_len, q_ascii, q_off, q_len):
         first = np.ctypeslib.as_array(hits.first, shape=(nq + 1,)).copy()
         out = {"queries": nq, "seconds": round(best, 3), "seconds_first_call": round(secs[0], 3), "seconds_later_calls": [round(x, 4) for x in secs[1:]], "seconds_median": round(float(np.median(secs[1:])), 4), "queries_per_s": round(nq / best, 1),
                "pairs_aligned": int(hits.pairs_aligned), "cells_aligned": int(hits.cells_aligned),
-               "value": round(int(hits.cells_aligned) / best / 1e9, 2), "unit": "GCUPS (cells the reference's dispatch aligns / wall)",
+               "value": round(int(hits.cells_aligned) / best / 1e9, 2), "unit": "GCUPS (cells THIS dispatch aligns / wall; r05: lazy first batches -- a query's first batch is the accepts it still needs, so fewer cells than the reference's dispatch aligns for the same hits; VSX_SEARCH_LAZY=0 restores its batches of eight)",
                "hits": int(hits.n_hits), "queries_with_hit": int((first[1:] > first[:-1]).sum()),
                "seconds_kmer": round(hits.seconds_kmer, 3), "seconds_align": round(hits.seconds_align, 3),
                "searcher_create_s": round(t_create, 2), "masking": a.search_mask}
