@@ -703,3 +703,50 @@ def test_allpairs_stream_equals_blocks(gpu_required):
             part = ss.allpairs_stream(first=50, count=120, block=50, acceptall=acceptall)
             assert part == whole[50:170]
             ss.close()
+
+
+_LAZY_SNIPPET = r"""
+import hashlib, json, random, sys
+sys.path.insert(0, %r)
+from tests import common
+from vsearch_amd import Aligner
+from vsearch_amd.search import SearchSession
+rng = random.Random(2026)
+fam = [common.rnd_seq(rng, rng.randint(150, 400)) for _ in range(40)]
+db = [common.mutate(rng, rng.choice(fam), rng.choice([0.01, 0.04, 0.1, 0.2])) for _ in range(1200)]
+qs = [common.mutate(rng, rng.choice(db), rng.choice([0.0, 0.03, 0.08, 0.15]))[:rng.randint(80, 300)] for _ in range(500)] + [common.rnd_seq(rng, 200) for _ in range(20)]
+out = {}
+with Aligner() as al:
+    for name, kw in (("default", dict(id=0.9)), ("three", dict(id=0.93, maxaccepts=3, maxrejects=5)), ("strict", dict(id=0.97, maxaccepts=1, maxrejects=12)),
+                     ("all", dict(id=0.8, maxaccepts=0, maxrejects=0)), ("both", dict(id=0.9, strand_both=1, maxaccepts=2))):
+        ss = SearchSession(al, db, **kw)
+        res = ss.search_batch(qs)
+        h = hashlib.sha256(json.dumps(res, sort_keys=True).encode()).hexdigest()
+        out[name] = (h, int(ss.stats["pairs_aligned"]), sum(len(r) for r in res))
+        ss.close()
+print("OUT", json.dumps(out))
+"""
+
+
+@pytest.mark.gpu
+def test_lazy_first_batches_align_a_subset_with_the_same_hits(gpu_required):
+    """r05: vsx_search_batch aligns a query's first batch lazily -- as many candidates as it still needs accepts, then the rest of the
+    reference's first eight, then eights.  Five option sets (default, maxaccepts 3, a strict identity with many first-candidate failures,
+    unlimited accepts / rejects, both strands): every hit field identical to the run with the reference's batches (VSX_SEARCH_LAZY=0), and
+    never more pairs aligned -- fewer wherever maxaccepts is below eight."""
+    import json
+    import sys
+    outs = {}
+    for mode in ("0", "1"):
+        e = dict(os.environ, VSX_SEARCH_LAZY=mode)
+        p = subprocess.run([sys.executable, "-c", _LAZY_SNIPPET % ROOT], env=e, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+        outs[mode] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("OUT")][-1][4:])
+    for name in outs["0"]:
+        eager, lazy = outs["0"][name], outs["1"][name]
+        assert eager[0] == lazy[0] and eager[2] == lazy[2], name             # same hits, every field
+        assert lazy[1] <= eager[1], (name, lazy, eager)                      # a subset of the reference's pairs
+        if name in ("default", "three", "strict", "both"):
+            assert lazy[1] < eager[1], (name, lazy, eager)
+        else:
+            assert lazy[1] == eager[1], (name, lazy, eager)                  # unlimited accepts: the first batch is the reference's

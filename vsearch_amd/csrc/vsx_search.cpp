@@ -248,6 +248,7 @@ struct QState {
   std::vector<Hit> hits;        // si->hits[0 .. hit_count)
   int64_t accepts = 0, rejects = 0, finalized = 0;
   int delayed = 0;
+  int lazy_first = 0;           // lazy search: delayed candidates of the (short) first batch; the second batch completes the reference's eight
   bool done = false;
   uint64_t req_first = 0;       // first pair of this query's pending batch in the stage plan
   uint32_t req_count = 0;
@@ -468,13 +469,17 @@ int hit_compare_bysize(const vsx_searcher & S, const Hit & l, const Hit & r)
 // until maxaccepts or maxrejects is reached -- what lies behind that point was aligned for nothing and is freed unread (:785, :875-878).
 // With the default maxaccepts = 1 and a database that holds the query's relatives, that is 7 of the 8 alignments of almost every query.
 // A query's FIRST batch here is only as many candidates as it still needs accepts (min(8, maxaccepts)); if they do not finish it, the
-// batches go on in eights.  The candidates are popped, filtered and judged in the same order under the same two limits, and a hit's
-// verdict does not depend on its batch, so accepts, rejects and every reported hit are the reference's; only the number of pairs
-// that reach the aligner shrinks (`pairs_aligned` <= the reference's).  The sparse-task classes make a window of one-target tasks cheap.
+// second batch completes the reference's first eight and the batches go on in eights -- the batch boundaries are the reference's from
+// there on, so the pairs that reach the aligner are always a SUBSET of the reference's (`pairs_aligned` <= the reference's).  The
+// candidates are popped, filtered and judged in the same order under the same two limits, and a hit's verdict does not depend on its
+// batch, so accepts, rejects and every reported hit are the reference's.  The sparse-task classes make a window of one-target tasks cheap.
 bool advance(const vsx_searcher & S, QState & st, const char * q, int64_t qlen, uint32_t qlocal, const QMeta & qm,
              std::vector<uint32_t> & pq, std::vector<uint32_t> & pt, bool lazy)
 {
-  const int cap = (lazy && st.hits.empty()) ? (int) std::min<int64_t>(8, std::max<int64_t>(1, S.ma)) : 8;
+  const bool first_batch = lazy && st.hits.empty();
+  int cap = 8;
+  if (first_batch) cap = (int) std::min<int64_t>(8, std::max<int64_t>(1, S.ma));
+  else if (lazy && st.lazy_first > 0 && st.lazy_first < 8) { cap = 8 - st.lazy_first; st.lazy_first = 0; }      // back on the reference's boundaries
   while ((st.finalized + st.delayed < S.ma + S.mr - 1) && (st.rejects < S.mr) && (st.accepts < S.ma) &&
          (st.next < st.cands.size()))
     {
@@ -486,6 +491,7 @@ bool advance(const vsx_searcher & S, QState & st, const char * q, int64_t qlen, 
       if (st.delayed == cap) break;                    // MAXDELAYED (the first batch of a lazy search: what the query still needs)
     }
   if (st.delayed == 0) { st.done = true; return false; }
+  if (first_batch) st.lazy_first = st.delayed;
   st.req_first = pq.size();
   st.req_count = 0;
   for (size_t x = (size_t) st.finalized; x < st.hits.size(); ++x)
