@@ -271,6 +271,7 @@ struct vsx_ctx {
   std::atomic<uint64_t> req_hwm[2] {{0}, {0}};      // largest checkpoint block / slab a plan of this context asked for since the last reset (bytes)
   hipEvent_t ev_tb[3] = {nullptr, nullptr, nullptr};
   bool ev_tb_used[3] = {false, false, false};
+  int last_tb_slot = -1;            // the slot whose traceback was queued last (VSX_ALIGN_SERIAL: the next plan's DP waits for it)
   std::atomic<unsigned> plan_seq {0};
   // pinned host memory: results cross PCIe into it (vsx_plan_fetch), one fetch at a time; grow-only
   std::mutex stage_mu;
@@ -1566,6 +1567,10 @@ int vsx_plan_run(vsx_plan * pl)
       uint32_t * dir = pl->d_dir[0].p;
       if (k >= 1) HIPCHK(hipStreamWaitEvent(st, pl->chunks[k - 1].e2, 0));      // buffer reuse: the previous traceback is done
       else if (ctx->ev_tb_used[slot]) HIPCHK(hipStreamWaitEvent(st, ctx->ev_tb[slot], 0));
+      // VSX_ALIGN_SERIAL=1 (A/B, r05): no overlap between a plan's DP and the previous plan's traceback.  The trace of an allpairs run
+      // (profiles/r05/r05q_*) shows the R = 26 DP launches at 28.7 ms beside a traceback where the kernel alone takes 13.3 ms
+      static const bool serial_env = std::getenv("VSX_ALIGN_SERIAL") && std::strcmp(std::getenv("VSX_ALIGN_SERIAL"), "1") == 0;
+      if (k == 0 && serial_env && ctx->last_tb_slot >= 0 && ctx->last_tb_slot != slot) HIPCHK(hipStreamWaitEvent(st, ctx->ev_tb[ctx->last_tb_slot], 0));
       HIPCHK(hipEventRecord(c.e0, st));
       for (const Launch & L : c.launches)
         {
@@ -1608,6 +1613,7 @@ int vsx_plan_run(vsx_plan * pl)
   if (pl->chunks.empty()) HIPCHK(hipStreamWaitEvent(st2, pl->ev_begin, 0));          // (the cursor memset precedes the text kernel)
   HIPCHK(hipEventRecord(ctx->ev_tb[slot], st2));
   ctx->ev_tb_used[slot] = true;
+  ctx->last_tb_slot = slot;
   // run lists -> CIGAR text, records -> output arrays (pushop / finishop are part of the reference's timed path); st2 is in order
   HIPCHK(vsx_launch_cigar_text(pl->d_out.p, pl->d_pair_ids.p, (uint32_t) pl->pair_ids.size(), pl->d_runs.p, pl->runs_capacity,
                                pl->d_text.p, pl->text_capacity, pl->d_cursor.p + 1, pl->soa, st2));
