@@ -592,3 +592,56 @@ def test_bench_dry_collectives_world2_gloo():
                                      "fixed_gather_overlap_samples": True}, d
     assert d["rccl"]["world"] == 2 and d["rccl"]["backend"] == "gloo" and d["rccl"]["device_of_rank"] == [0, 0]
 
+
+def test_fixed_gather_overlap_accounting_and_degrade():
+    """r05 (sharding.FixedGather): every collected step is sampled -- had its collective finished when it was collected, or was it waited
+    for -- and a gather whose first `probe` steps ALL had to wait declares itself degraded (the caller then collects right after posting).
+    Driven here with a stand-in for torch.distributed whose collectives complete on demand: no process group needed."""
+    import torch
+    from vsearch_amd import sharding
+
+    class Work:
+        def __init__(self, done):
+            self.done = done
+
+        def is_completed(self):
+            return self.done
+
+        def wait(self):
+            self.done = True
+
+    class Dist:
+        class ReduceOp:
+            MAX = "max"
+
+        def __init__(self, finished):
+            self.finished = finished
+
+        def get_world_size(self):
+            return 1
+
+        def get_rank(self):
+            return 0
+
+        def all_reduce(self, t, op=None, async_op=False):
+            return Work(True) if async_op else None
+
+        def gather(self, buf, recv, dst=0, async_op=False):
+            if recv is not None:
+                recv[0].copy_(buf)
+            return Work(self.finished)
+
+    rec = torch.from_numpy(sharding.pack_records([1, 2], [3, 4], [1, 1], [0, 0], [0, 0], [1, 1], [0, 1]))
+    runs = torch.tensor([4, 8], dtype=torch.int32)
+    for finished, want_degraded in ((False, True), (True, False)):
+        fg = sharding.FixedGather(Dist(finished), dst=0)
+        for _ in range(4):
+            got = fg.collect(fg.post(rec, runs))
+            assert torch.equal(got[0], rec) and got[2] == [2]
+        st = fg.stats()
+        assert st["collects"] == 4 and st["finished_before_collect"] == (4 if finished else 0) and st["waited_for"] == (0 if finished else 4), st
+        assert st["degraded_to_sync"] is want_degraded and fg.degraded is want_degraded
+        # an immediate collect (degraded use) is not an overlap sample
+        fg.collect(fg.post(rec, runs), immediate=True)
+        assert fg.stats()["collects"] == 4
+
