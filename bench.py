@@ -227,11 +227,10 @@ def main():
     scratch = {}
     gathered = None
     fixed = sharding.FixedGather(dist, dst=0) if (world > 1 and a.gather == "async") else None
-    pending = None
     gloo = world > 1 and a.backend == "gloo"
 
     def step():
-        nonlocal gathered, pending
+        nonlocal gathered
         plan.run()
         tm = plan.sync()
         if world > 1:
@@ -240,22 +239,20 @@ def main():
             # step is posted and the PREVIOUS step's is collected, so it travels while the next step's kernels run
             rec, runs = sharding.export_records(plan, n_pairs, dev, scratch, host=gloo)
             if fixed is not None:
-                ticket = fixed.post(rec, runs)             # (a step that does not fit on SOME rank is redone synchronously by ALL ranks inside collect)
-                if pending is not None:
-                    gathered = fixed.collect(pending)
-                pending = ticket
-                if fixed.degraded:                         # (r05) the collectives never finished beside the next step's kernels: no
-                    gathered = fixed.collect(pending, immediate=True)      # point in holding a step back -- collect at once from now on
-                    pending = None
+                # post step k, collect step k - 1 (a step that does not fit on SOME rank is redone synchronously by ALL ranks inside collect;
+                # if the collectives never finish beside the next step's kernels ALL ranks agree -- through the same all-reduce -- to collect
+                # at once from the same step on: FixedGather.step)
+                for _, got in fixed.step(rec, runs):
+                    gathered = got
             else:
                 gathered = sharding.gather_results(rec, runs, dist, dst=0)
         return tm
 
     def drain():
-        nonlocal gathered, pending
-        if pending is not None:
-            gathered = fixed.collect(pending)
-            pending = None
+        nonlocal gathered
+        if fixed is not None:
+            for _, got in fixed.drain():
+                gathered = got
 
     def barrier():
         torch.cuda.synchronize()
@@ -563,6 +560,34 @@ def dry_collectives(dist, sharding, device, rank, world):
     checks["fixed_gather_sync_steps"] = fg.sync_steps
     st = fg.stats()                 # (r05) every collected step is an overlap sample: finished before the collect, or waited for
     checks["fixed_gather_overlap_samples"] = st["collects"] == st["finished_before_collect"] + st["waited_for"] == len(scales)
+    # r06: the ranks' OWN overlap samples disagree -- rank 0 always had to wait, the others never -- and steps
+    # overflow on one rank only: before the degrade decision became collective, rank 0 flipped alone and ran step 3's synchronous redo
+    # at another position of the collective sequence than its peers.  Now every rank flips while collecting the same ticket; the loop
+    # is FixedGather.step / drain, the one the timed steps use.  Step 3 overflows on the last rank (still pipelined), step 6 on rank 0
+    # (already degraded).
+    fg = sharding.FixedGather(dist, dst=0)
+    fg.force_sample = (rank != 0)
+    scales = [lambda r: 1, lambda r: 1, lambda r: 1, lambda r: (40 if r == world - 1 else 1), lambda r: 1, lambda r: 1,
+              lambda r: (400 if r == 0 else 1), lambda r: 1]
+    done, ok, flipped_at = [], True, None
+    for step, sc in enumerate(scales):
+        rec, runs = payload(rank, step, sc(rank))
+        was = fg.degraded
+        done += fg.step(rec, runs)
+        if fg.degraded and not was:
+            flipped_at = step
+    done += fg.drain()
+    ok = [k for k, _ in done] == list(range(len(scales)))
+    if rank == 0:
+        for k, got in done:
+            e = expect(k, scales[k])
+            ok = ok and bool(torch.equal(got[0], e[0]) and torch.equal(got[1], e[1]) and got[2] == e[2])
+    # every rank must have flipped in the same step and redone the same two steps
+    mine = torch.tensor([int(ok), -1 if flipped_at is None else flipped_at, fg.sync_steps], dtype=torch.int64, device=device)
+    views = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(views, mine)
+    checks["fixed_gather_mixed_votes_one_rank_overflows"] = all(int(v[0]) == 1 and int(v[1]) == int(views[0][1]) >= 0 and int(v[2]) == 2 for v in views)
+    checks["fixed_gather_degraded_at_step"] = int(views[0][1])
     return checks
 
 

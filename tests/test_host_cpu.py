@@ -589,7 +589,9 @@ def test_bench_dry_collectives_world2_gloo():
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["dry_collectives"] == {"gather_results_to_rank0": True, "fixed_gather_async_incl_one_rank_overflow": True, "fixed_gather_sync_steps": 1,
-                                     "fixed_gather_overlap_samples": True}, d
+                                     "fixed_gather_overlap_samples": True,
+                                     # r06: rank 0's samples say "always waited", rank 1's "never"; steps 3 and 6 overflow on one rank each
+                                     "fixed_gather_mixed_votes_one_rank_overflows": True, "fixed_gather_degraded_at_step": 5}, d
     assert d["rccl"]["world"] == 2 and d["rccl"]["backend"] == "gloo" and d["rccl"]["device_of_rank"] == [0, 0]
 
 

@@ -121,10 +121,20 @@ struct ScratchPool {
       {
         // (r05) never fill the device to the brim: the runtime needs room of its own (kernel scratch of every queue) and aborts the
         // process when it finds none -- profiles/r05/r05b_config5_share_abort.txt.  Below the reserve, idle blocks go first.
+        // r06: only as much as restores the reserve -- this pool's largest idle blocks first, the other contexts of the device
+        // only if that was not enough -- and said once: on a device that stays near full every plan would otherwise re-hipMalloc its
+        // multi-GB blocks (seconds apiece) and the warm-call promise of the pools would vanish silently.
         size_t free_b = 0, total_b = 0;
         int dev = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < bytes + ((size_t) 6 << 30) && hipGetDevice(&dev) == hipSuccess)
-          { trim(); (void) vsx_internal_memory_pressure(dev); }
+        const size_t need = bytes + ((size_t) 6 << 30);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need && hipGetDevice(&dev) == hipSuccess)
+          {
+            static std::atomic<bool> said {false};
+            if (!said.exchange(true))
+              std::fprintf(stderr, "vsx: device %d is nearly full (%.1f GB free, %.1f GB wanted + 6 GB reserve): idle scratch blocks are being "
+                                   "returned; later plans re-allocate theirs (said once)\n", dev, free_b / 1e9, bytes / 1e9);
+            if (!trim_until(need)) (void) vsx_internal_memory_pressure(dev);
+          }
         (void) hipGetLastError();
       }
     hipError_t e = hipMalloc(out, bytes);
@@ -167,6 +177,21 @@ struct ScratchPool {
     for (PoolBlock & b : free_blocks) (void) hipFree(b.p);
     free_blocks.clear();
   }
+  // free idle blocks, largest first, until the device reports `want_free` bytes free; false: the pool ran dry first
+  bool trim_until(size_t want_free)
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (;;)
+      {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= want_free) return true;
+        if (free_blocks.empty()) return false;
+        size_t m = 0;
+        for (size_t k = 1; k < free_blocks.size(); ++k) if (free_blocks[k].bytes > free_blocks[m].bytes) m = k;
+        (void) hipFree(free_blocks[m].p);
+        free_blocks.erase(free_blocks.begin() + (long) m);
+      }
+  }
   void retire() { trim(); std::lock_guard<std::mutex> lk(mu); retired = true; }
 };
 
@@ -200,12 +225,15 @@ struct SharedBlock {
   ScratchPool * pool = nullptr;
   ~SharedBlock() { if (p) { if (pool) pool->put(p, bytes); else (void) hipFree(p); } }
 };
+struct SharedSlot;
+thread_local const SharedSlot * tl_acquiring_slot = nullptr;      // the slot whose lock THIS thread holds inside acquire() (try_reset)
 struct SharedSlot {
   std::mutex mu;
   std::shared_ptr<SharedBlock> cur;
   hipError_t acquire(ScratchPool * pool, size_t bytes, std::shared_ptr<SharedBlock> & out, bool headroom = true)
   {
     std::lock_guard<std::mutex> lk(mu);
+    struct Mark { const SharedSlot * prev; explicit Mark(const SharedSlot * s) : prev(tl_acquiring_slot) { tl_acquiring_slot = s; } ~Mark() { tl_acquiring_slot = prev; } } mark(this);
     if (cur && cur->bytes >= bytes) { out = cur; return hipSuccess; }
     cur.reset();                       // (r05) too small: back to the pool as soon as no plan holds it, where memory pressure can free it
     auto b = std::make_shared<SharedBlock>();
@@ -223,8 +251,10 @@ struct SharedSlot {
     return hipSuccess;
   }
   void reset() { std::lock_guard<std::mutex> lk(mu); cur.reset(); }
-  // (memory pressure may be raised from INSIDE an acquire of this very slot, whose lock is then held by the caller: skip it)
-  void try_reset() { if (mu.try_lock()) { cur.reset(); mu.unlock(); } }
+  // (memory pressure may be raised from INSIDE an acquire of this very slot, whose lock is then held by the caller: skip it -- by the
+  //  thread-local mark, not by try_lock on a mutex the caller owns, which is undefined; the try_lock that remains is for
+  //  slots held by OTHER threads, which may themselves be waiting for a slot of ours)
+  void try_reset() { if (tl_acquiring_slot == this) return; if (mu.try_lock()) { cur.reset(); mu.unlock(); } }
   size_t bytes() { std::lock_guard<std::mutex> lk(mu); return cur ? cur->bytes : 0; }
 };
 template <typename T>
@@ -953,8 +983,10 @@ static int ensure_impure(const vsx_seqset * s)
   if (s->have_impure) return VSX_OK;
   vsx_ctx * ctx = s->ctx;
   HIPCHK(hipSetDevice(ctx->device));
-  DevBuf<uint8_t> d_flags;
-  HIPCHK(d_flags.alloc(s->n));
+  // (r06, ADVICE r05: the flags come from the scratch pool -- hipMalloc / hipFree synchronise the WHOLE device, and a search's plans are
+  //  made while the counting kernel of the next window runs: 15-42 ms per window, profiles/r06/r06a_search_timeline.txt)
+  PoolBuf<uint8_t> d_flags;
+  HIPCHK(d_flags.alloc(s->pool_ref ? s->pool_ref.get() : nullptr, s->n));
   HIPCHK(vsx_launch_purity(s->codes(), s->d_off.p, s->d_len.p, s->n, d_flags.p, ctx->stream));
   s->impure.assign(s->n, 0);
   if (s->n) HIPCHK(hipMemcpyAsync(s->impure.data(), d_flags.p, s->n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1057,15 +1089,12 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   // r05, pair-profile classes (vsx_forward_kernel PAIR): groups of four whole-wave tasks of ONE pure-ACGT query with pure-ACGT targets
   // run as a workgroup that shares a pair-indexed dword profile (5 instead of 6 instructions per lane-row).  Worth it only for queries
   // with many targets (--allpairs_global); needs the purity of both sets.  VSX_PAIRPROF=0 / 1 overrides the default below
-  static const bool pair_on = (std::getenv("VSX_PAIRPROF") ? std::strcmp(std::getenv("VSX_PAIRPROF"), "0") != 0 : (VSX_PAIRPROF_DEFAULT != 0)) &&
-                              !arith && ctx->ckpt && VSX_QPL != 0 && VSX_FEED2 != 0 && !VSX_CKT;
-  const bool pair_try = pair_on && n_pairs >= 32;
-  if (pair_try)
-    {
-      int rc = ensure_impure(queries);
-      if (rc == VSX_OK) rc = ensure_impure(targets);
-      if (rc != VSX_OK) return rc;
-    }
+  // (r06, ADVICE r05: the purity of the two sets is asked for only once the grouping below has found a query with four whole-wave tasks --
+  //  a search's windows never have one, and every new query set used to pay a purity pass with a device-wide synchronisation; only the
+  //  environment and build parts of the switches are process-wide, ctx->ckpt is this context's)
+  static const bool pair_env = (std::getenv("VSX_PAIRPROF") ? std::strcmp(std::getenv("VSX_PAIRPROF"), "0") != 0 : (VSX_PAIRPROF_DEFAULT != 0)) &&
+                               !arith && VSX_QPL != 0 && VSX_FEED2 != 0 && !VSX_CKT;
+  const bool pair_try = pair_env && ctx->ckpt && n_pairs >= 32;
 
   std::unique_ptr<vsx_plan> pl(new vsx_plan);
   pl->ctx = ctx; pl->Q = queries; pl->T = targets; pl->n_pairs = n_pairs;
@@ -1139,7 +1168,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   struct ProtoTask { uint32_t q; int rows; int generic; int track; int tilt; int nq; uint32_t n; uint32_t pair[8]; };
   // r05, sparse tasks: a task of <= 2 (<= 4) targets of the TILT family shares its wave with three (one) other tasks of its class
   // (vsx_forward_kernel NQ) instead of leaving three (two) of the four lane groups idle.  VSX_SPARSE=0: every task is a wave (A/B, tests)
-  static const bool sparse_on = !(std::getenv("VSX_SPARSE") && std::strcmp(std::getenv("VSX_SPARSE"), "0") == 0) && ctx->ckpt && VSX_QPL != 0 && !VSX_CKT;
+  static const bool sparse_env = !(std::getenv("VSX_SPARSE") && std::strcmp(std::getenv("VSX_SPARSE"), "0") == 0) && VSX_QPL != 0 && !VSX_CKT;
+  const bool sparse_on = sparse_env && ctx->ckpt;
   std::vector<size_t> group_begin;                       // start of every query's run in gpu_pairs, plus the end
   for (size_t b = 0; b < gpu_pairs.size();)
     {
@@ -1155,6 +1185,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   const size_t ngroups = group_begin.size() - 1;
   const int nth = (int) std::max<size_t>(1, std::min<size_t>((size_t) vsx_internal_usable_cpus(), gpu_pairs.size() / 16384));
   std::vector<std::vector<ProtoTask>> part((size_t) nth);
+  std::vector<std::vector<std::pair<size_t, size_t>>> pair_cand((size_t) nth);      // per slice: [first, end) task ranges of queries that may form PAIR groups
   auto work = [&](int t) {
     // contiguous ranges of groups with about the same number of pairs
     const size_t p_lo = gpu_pairs.size() * (size_t) t / (size_t) nth, p_hi = gpu_pairs.size() * (size_t) (t + 1) / (size_t) nth;
@@ -1188,12 +1219,34 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
               pt.nq = pt.n <= 2 ? 4 : 2;
             outp.push_back(pt);
           }
-        if (pair_try && rows >= 4 && !queries->impure[q] && outp.size() - first_of_query >= 4)
+        if (pair_try && rows >= 4 && outp.size() - first_of_query >= 4)
+          {
+            size_t eligible = 0;
+            for (size_t k = first_of_query; k < outp.size(); ++k) eligible += (outp[k].nq == 1 && outp[k].tilt) ? 1 : 0;
+            if (eligible >= 4) pair_cand[(size_t) t].emplace_back(first_of_query, outp.size());
+          }
+      }
+  };
+  run_threads(nth, work);
+  bool any_pair_cand = false;
+  for (const auto & v : pair_cand) any_pair_cand = any_pair_cand || !v.empty();
+  if (any_pair_cand)
+    {
+      int rc = ensure_impure(queries);
+      if (rc == VSX_OK) rc = ensure_impure(targets);
+      if (rc != VSX_OK) return rc;
+    }
+  auto mark_pairs = [&](int t) {
+    std::vector<ProtoTask> & outp = part[(size_t) t];
+    for (const std::pair<size_t, size_t> & range : pair_cand[(size_t) t])
+      {
+        const size_t first_of_query = range.first, end_of_query = range.second;
+        if (queries->impure[outp[first_of_query].q]) continue;
           {
             // whole groups of four eligible tasks of this query (same kernel class, every target plain ACGT) -> nq = 8; what is left over
             // stays in the whole-wave class.  The tasks of a query are consecutive and stay so through the stable class sort below.
             std::vector<size_t> ok;
-            for (size_t k = first_of_query; k < outp.size(); ++k)
+            for (size_t k = first_of_query; k < end_of_query; ++k)
               {
                 ProtoTask & pt = outp[k];
                 if (pt.nq != 1 || !pt.tilt) continue;
@@ -1214,7 +1267,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
           }
       }
   };
-  run_threads(nth, work);
+  if (any_pair_cand) run_threads(nth, mark_pairs);
   std::vector<ProtoTask> protos;
   {
     size_t total = 0;

@@ -285,7 +285,18 @@ class FixedGather:
     workload, the default slack is 25 %.
 
     post(records, runs) -> ticket;  collect(ticket) -> (records_all, runs_all, counts) at the receiver(s), (None, None, None) elsewhere.
-    Works on CPU tensors over gloo (tests) and on device tensors over RCCL."""
+    step(records, runs) / drain() are the pipelined loop built from the two (post step k, collect step k - 1; once degraded: collect
+    step k at once) -- bench.py and the tests drive the SAME loop.
+    Works on CPU tensors over gloo (tests) and on device tensors over RCCL.
+
+    r06: `degraded` is a COLLECTIVE decision too.  A rank's own overlap samples differ (the receiver of a gather
+    waits for everybody, a sender is done when its payload has left), and a rank that flipped alone would collect ticket k BEFORE posting
+    k + 1 while the others collect it AFTER: harmless until ticket k overflows, when `collect` runs the synchronous all-gathers of
+    gather_results at different positions of the collective sequence on different ranks (mismatched collectives on one communicator).
+    So a rank only VOTES (third element of the per-post flag all-reduce, MAX: "all my first `probe` samples had to wait"), and every rank
+    flips while collecting the same ticket -- the first whose flag carries a vote.  The state that orders the collectives (`degraded`,
+    the capacities, `relayout`) changes only inside collect(), only from all-reduced values: by induction every rank issues the same
+    sequence."""
 
     HEADER = 16            # two little-endian int64: records, run words
 
@@ -307,7 +318,10 @@ class FixedGather:
         self.overlapped = self.waited = 0
         self.wait_s = 0.0
         self.probe = 3
-        self.degraded = False
+        self.degraded = False      # collective: flips in collect() of the first ticket whose flag carries a vote (same ticket on every rank)
+        self.pending = None        # step() / drain(): the ticket posted by the previous step
+        self.steps_posted = 0
+        self.force_sample = None   # tests: None = ask the Work object; True / False = pretend the collective had / had not finished
 
     def _layout(self, device):
         import torch
@@ -334,7 +348,8 @@ class FixedGather:
         elif self.relayout:
             self._layout(records.device)          # the capacities grew (on every rank, in the same collect); tickets in flight keep their buffers
         over = n_rec > self.cap_rec or n_runs > self.cap_runs
-        flag = torch.tensor([n_rec if over else 0, n_runs if over else 0], dtype=torch.int64, device=records.device)
+        vote = 1 if (not self.degraded and self.overlapped == 0 and self.waited >= self.probe) else 0      # this rank's samples; MAX over ranks decides
+        flag = torch.tensor([n_rec if over else 0, n_runs if over else 0, vote], dtype=torch.int64, device=records.device)
         flag_work = self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, async_op=True)
         k = self.turn
         self.turn ^= 1
@@ -366,7 +381,7 @@ class FixedGather:
         import torch
         done = False
         try:
-            done = bool(ticket["work"].is_completed())
+            done = bool(ticket["work"].is_completed()) if self.force_sample is None else bool(self.force_sample)
         except Exception:                      # (a backend without the query: counted as waited)
             done = False
         t0 = time.perf_counter()
@@ -380,9 +395,9 @@ class FixedGather:
                 self.overlapped += 1
             else:
                 self.waited += 1
-            if not self.degraded and self.overlapped == 0 and self.waited >= self.probe:
-                self.degraded = True
-        need_rec, need_runs = (int(x) for x in ticket["flag"].tolist())
+        need_rec, need_runs, vote = (int(x) for x in ticket["flag"].tolist())
+        if vote and not self.degraded:
+            self.degraded = True               # every rank reads the same all-reduced vote in the collect of the same ticket
         o_runs = self.HEADER + ticket["cap_rec"] * HIT_RECORD_BYTES
         receiver = self.dst is None or self.rank == self.dst
         if need_rec or need_runs:
@@ -415,3 +430,27 @@ class FixedGather:
             counts.append(n_rec)
             base += n_runs
         return torch.cat(recs), torch.cat(runs_all), counts
+
+    def step(self, records, runs):
+        """One step of the pipelined loop: post this step's payload, collect the previous step's; once the gather is degraded
+        (collectively, see the class docstring) this step's is collected at once as well.  -> [(step number, collect() result), ...]
+        for the steps completed by this call (none for the first step, two in the step that degrades)."""
+        ticket = self.post(records, runs)
+        k = self.steps_posted
+        self.steps_posted += 1
+        out = []
+        if self.pending is not None:
+            prev, self.pending = self.pending, None
+            out.append((k - 1, self.collect(prev)))
+        if self.degraded:                      # the collectives never finished beside the next step's kernels: no point in holding a step back
+            out.append((k, self.collect(ticket, immediate=True)))
+        else:
+            self.pending = ticket
+        return out
+
+    def drain(self):
+        """Collect the step still in flight (end of the loop).  -> [(step number, result)] or []"""
+        if self.pending is None:
+            return []
+        prev, self.pending = self.pending, None
+        return [(self.steps_posted - 1, self.collect(prev))]
