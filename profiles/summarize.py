@@ -81,6 +81,21 @@ def sq_block(needle):
     return out
 
 
+def duration_in_pass(tag, needle):
+    """average duration (ns) of the kernel inside a PMC pass (its own --kernel-trace): the clock GRBM_GUI_ACTIVE is divided by"""
+    tot, n = 0.0, 0
+    for f in find(f"{tag}/**/*kernel_trace.csv"):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if needle in row.get("Kernel_Name", ""):
+                    try:
+                        tot += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                        n += 1
+                    except (KeyError, ValueError):
+                        pass
+    return (tot / n) if n else None
+
+
 WORKLOAD = {"queries": 100000, "qlen": 250, "db": 1000000, "dlen": 1000, "cands": 8}
 if os.environ.get("VSX_SUMMARY_WORKLOAD"):
     q_, d_, db_ = (int(x) for x in os.environ["VSX_SUMMARY_WORKLOAD"].split(","))
@@ -105,6 +120,12 @@ if fwd is not None:
                 "SQ_BUSY_CYCLES": sq.get("SQ_BUSY_CYCLES"), "SQ_WAVE_CYCLES": sq.get("SQ_WAVE_CYCLES"), "SQ_WAVES": sq.get("SQ_WAVES"),
                 "GRBM_GUI_ACTIVE": sq.get("GRBM_GUI_ACTIVE"),
                 "active_inst_valu_over_busy": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_BUSY_CYCLES"]}
+    # the effective shader clock of the profiled pass: GRBM_GUI_ACTIVE counts cycles per XCD (8 of them) while the kernel ran
+    for blk, needle in ((sq, "vsx_forward_kernel"),):
+        dur = duration_in_pass("pmc_sq2", needle)
+        if dur and blk.get("GRBM_GUI_ACTIVE"):
+            blk["duration_ns_in_pmc_pass"] = dur
+            blk["effective_clock_ghz"] = blk["GRBM_GUI_ACTIVE"] / 8.0 / dur
     doc = {"kernel_source_sha": sha, "kernel_sources": list(getattr(bench, "KERNEL_SOURCES", [])) if sha else None,
            "workload": WORKLOAD,
            "forward": dict(fwd, kernel="vsx_forward_kernel", sq=sq), "traceback": dict(tb or {}, kernel=TB, sq=sq_block(TB),

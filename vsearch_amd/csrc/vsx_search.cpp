@@ -551,9 +551,12 @@ static int fill_hit(const vsx_searcher & S, FQ qtext, int64_t ql, Hit & h, const
   return VSX_OK;
 }
 
-static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out, int thread_budget /* the searcher's: S->threads */)
+// (range_of(q) -> the hits of query q as a span; r06: the search keeps a window's hits in ONE vector -- a vector per query was 10^5 small
+//  blocks allocated on the consumer threads and released on the caller's at return: 8-11 ms of a 130 ms call)
+struct HitSpan { const Hit * p; size_t n; const Hit * begin() const { return p; } const Hit * end() const { return p + n; } size_t size() const { return n; } };
+template <typename FRange>
+static int marshal_hits_from(uint64_t nq, FRange range_of, vsx_hits * out, int thread_budget /* the searcher's: S->threads */)
 {
-  const uint64_t nq = kept.size();
   out->n_queries = nq;
   out->first = (uint64_t *) std::malloc((nq + 1) * sizeof(uint64_t));
   if (!out->first) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "host allocation failed"); }
@@ -565,8 +568,9 @@ static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out, in
     {
       out->first[q] = total;
       blob_at[q] = bytes;
-      total += kept[q].size();
-      for (const Hit & h : kept[q]) bytes += h.cigar.size() + 1;
+      const HitSpan sp = range_of(q);
+      total += sp.size();
+      for (const Hit & h : sp) bytes += h.cigar.size() + 1;
     }
   out->first[nq] = total;
   blob_at[nq] = bytes;
@@ -579,7 +583,7 @@ static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out, in
     for (uint64_t q = q0; q < q1; ++q)
       {
         uint64_t pos = out->first[q], at = blob_at[q];
-        for (const Hit & h : kept[q])
+        for (const Hit & h : range_of(q))
           {
             vsx_hit & o = out->hit[pos++];
             std::memset(&o, 0, sizeof o);
@@ -609,6 +613,11 @@ static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out, in
       for (std::thread & t : pool) t.join();
     }
   return VSX_OK;
+}
+
+static int marshal_hits(std::vector<std::vector<Hit>> & kept, vsx_hits * out, int thread_budget)
+{
+  return marshal_hits_from(kept.size(), [&](uint64_t q) { return HitSpan {kept[q].data(), kept[q].size()}; }, out, thread_budget);
 }
 
 struct Acct { double t_align = 0, t_advance = 0, t_replay = 0; uint64_t pairs = 0, cells = 0, stages = 0, sentinels = 0; };
@@ -1059,6 +1068,7 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
   S->ma = (opts->maxaccepts == 0 || opts->maxaccepts > sc) ? sc : opts->maxaccepts;
   S->tophits = std::min<int64_t>(S->mr + S->ma + 8, sc);
   S->threads = opts->threads > 0 ? opts->threads : usable_cpus();
+  if (opts->threads <= 0 && std::getenv("VSX_SEARCH_THREADS")) S->threads = std::max(1, std::atoi(std::getenv("VSX_SEARCH_THREADS")));      // A/B only
 
   // soft masking: the set keeps a case bitmap for its device k-mer index (the alignment itself is case-blind)
   // (2 = DUST: the device masks the set, vsx_mask.hip, and the host copy takes the result over -- from here on a dust-masked
@@ -1201,8 +1211,22 @@ int vsx_search_batch(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t
   return vsx_search_batch_meta(S, nq, qblob, qbytes, qoff, qlen, nullptr, out);
 }
 
+static int search_batch_impl(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t qbytes, const uint64_t * qoff,
+                             const uint32_t * qlen, const vsx_seq_meta * qmeta, vsx_hits * out);
 int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t qbytes, const uint64_t * qoff,
                           const uint32_t * qlen, const vsx_seq_meta * qmeta, vsx_hits * out)
+{
+  const double t0 = now_s();
+  const int rc = search_batch_impl(S, nq, qblob, qbytes, qoff, qlen, qmeta, out);
+  // (seconds_total is what the caller waits for: it includes the release of the call's host state -- r06: that was 8-11 ms of a 130 ms
+  //  call and invisible in the call's own accounting, profiles/r06/r06b_search_timeline.txt)
+  if (rc == VSX_OK && out) out->seconds_total = now_s() - t0;
+  static const bool timing = std::getenv("VSX_DEBUG_TIMING") != nullptr;
+  if (timing) std::fprintf(stderr, "vsx_search_batch: returned after %.3f s\n", now_s() - t0);
+  return rc;
+}
+static int search_batch_impl(vsx_searcher * S, uint64_t nq, const char * qblob, uint64_t qbytes, const uint64_t * qoff,
+                             const uint32_t * qlen, const vsx_seq_meta * qmeta, vsx_hits * out)
 {
   if (!S || !out || (nq && (!qblob || !qoff || !qlen))) return sfail(VSX_EINVAL, "vsx_search_batch: null argument");
   std::memset(out, 0, sizeof *out);
@@ -1252,7 +1276,8 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
     }
   const size_t n_windows = cut.size() - 1;
   auto window_of = [&](uint64_t w0) -> size_t { return (size_t) (std::upper_bound(cut.begin(), cut.end(), w0) - cut.begin()) - 1; };
-  std::vector<std::vector<Hit>> kept(nq);
+  struct WinKept { uint64_t w0 = 0; std::vector<Hit> flat; std::vector<uint32_t> first; };      // a window's reported hits, query after query
+  std::vector<WinKept> wkept(n_windows);
   double t_kmer = 0, t_align = 0, t_adv = 0, t_rep = 0, t_qset = 0, t_join = 0;
   uint64_t pairs = 0, cells = 0, stages = 0, sentinels = 0;
 
@@ -1438,15 +1463,22 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
       vsx_seqset_destroy(qset);
       // search_joinhits (:1028-1052): accepted | weak of the plus strand, then of the minus strand, ordered by hit_compare_byid
       const double tj = now_s();
+      WinKept & K = wkept[window_of(w0)];
+      K.w0 = w0;
+      K.first.assign(wn + 1, 0);
+      K.flat.reserve(wn + wn / 8);
       for (uint64_t k = 0; k < wn; ++k)
         {
-          std::vector<Hit> & dst = kept[w0 + k];
+          std::vector<Hit> & dst = K.flat;
+          const size_t from = dst.size();
           for (Hit & h : st[k].hits) if (h.accepted || h.weak) dst.push_back(std::move(h));
           if (both)
             for (Hit & h : st[wn + k].hits) if (h.accepted || h.weak) { h.minus = true; dst.push_back(std::move(h)); }
           // STABLE: the comparator ties when both strands hit the same target with the same identity; the reference's qsort is
           // glibc's merge sort, which keeps the plus-strand hit first (found by oracle/soak_search.py)
-          std::stable_sort(dst.begin(), dst.end(), [](const Hit & a, const Hit & b) { return hit_compare_byid(a, b) < 0; });
+          if (dst.size() - from > 1)
+            std::stable_sort(dst.begin() + (long) from, dst.end(), [](const Hit & a, const Hit & b) { return hit_compare_byid(a, b) < 0; });
+          K.first[k + 1] = (uint32_t) dst.size();
         }
       { std::lock_guard<std::mutex> lk(acc_mu); t_join += now_s() - tj; }
       if (timeline) std::fprintf(stderr, "  [%7.1f ms] window %llu: align done (%.1f ms)\n", (now_s() - t_begin) * 1e3, (unsigned long long) window_of(w0), (now_s() - tc0) * 1e3);
@@ -1589,10 +1621,16 @@ int vsx_search_batch_meta(vsx_searcher * S, uint64_t nq, const char * qblob, uin
   // ---- marshal ----
   const double tm = now_s();
   {
-    const int mrc = marshal_hits(kept, out, S->threads);
+    const int mrc = marshal_hits_from(nq, [&](uint64_t q) {
+        const WinKept & K = wkept[window_of(q)];
+        const uint64_t k = q - K.w0;
+        return HitSpan {K.flat.data() + K.first[k], (size_t) (K.first[k + 1] - K.first[k])};
+      }, out, S->threads);
     if (mrc != VSX_OK) return mrc;
   }
   if (timeline) std::fprintf(stderr, "  [%7.1f ms] hits marshalled\n", (now_s() - t_begin) * 1e3);
+  std::vector<WinKept>().swap(wkept);
+  if (timeline) std::fprintf(stderr, "  [%7.1f ms] window hits released\n", (now_s() - t_begin) * 1e3);
   out->pairs_aligned = pairs; out->cells_aligned = cells; out->stages = stages; out->sentinel_pairs = sentinels;
   out->seconds_kmer = t_kmer; out->seconds_align = t_align; out->seconds_total = now_s() - t_begin;
   if (std::getenv("VSX_DEBUG_TIMING"))
