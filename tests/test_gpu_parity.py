@@ -59,7 +59,9 @@ def test_reference_batch_shape(gpu_required):
         dbs.close()
 
 
-@pytest.mark.parametrize("seed,qlen,dlen", [(1, 250, 1000), (2, 150, 300), (3, 400, 400), (4, 64, 64), (5, 300, 80)])
+# (r06: (150, 1000) and (300, 300) are the pair shapes of BASELINE configs[4] and [2]: R = 10 against long targets, R = 20 with the
+#  half-height traceback tiles -- until now pinned only by bench.py's digests)
+@pytest.mark.parametrize("seed,qlen,dlen", [(1, 250, 1000), (2, 150, 300), (3, 400, 400), (4, 64, 64), (5, 300, 80), (6, 150, 1000), (7, 300, 300)])
 def test_family_pairs_vs_oracle(gpu_required, oracle, seed, qlen, dlen):
     """BASELINE-shaped synthetic pairs (family-structured DB) vs the oracle"""
     from vsearch_amd import Aligner

@@ -718,7 +718,10 @@ qs = [common.mutate(rng, rng.choice(db), rng.choice([0.0, 0.03, 0.08, 0.15]))[:r
 out = {}
 with Aligner() as al:
     for name, kw in (("default", dict(id=0.9)), ("three", dict(id=0.93, maxaccepts=3, maxrejects=5)), ("strict", dict(id=0.97, maxaccepts=1, maxrejects=12)),
-                     ("all", dict(id=0.8, maxaccepts=0, maxrejects=0)), ("both", dict(id=0.9, strand_both=1, maxaccepts=2))):
+                     ("all", dict(id=0.8, maxaccepts=0, maxrejects=0)), ("both", dict(id=0.9, strand_both=1, maxaccepts=2)),
+                     # r06 (VERDICT r05 "next" 5): few rejects allowed, weak hits reported, both at once on both strands, unlimited accepts with a reject limit
+                     ("two_four", dict(id=0.95, maxaccepts=2, maxrejects=4)), ("weak", dict(id=0.96, weak_id=0.85, maxaccepts=1, maxrejects=4)),
+                     ("both_weak", dict(id=0.95, weak_id=0.8, strand_both=1, maxaccepts=2, maxrejects=4)), ("all_four", dict(id=0.9, maxaccepts=0, maxrejects=4))):
         ss = SearchSession(al, db, **kw)
         res = ss.search_batch(qs)
         h = hashlib.sha256(json.dumps(res, sort_keys=True).encode()).hexdigest()
@@ -731,8 +734,9 @@ print("OUT", json.dumps(out))
 @pytest.mark.gpu
 def test_lazy_first_batches_align_a_subset_with_the_same_hits(gpu_required):
     """r05: vsx_search_batch aligns a query's first batch lazily -- as many candidates as it still needs accepts, then the rest of the
-    reference's first eight, then eights.  Five option sets (default, maxaccepts 3, a strict identity with many first-candidate failures,
-    unlimited accepts / rejects, both strands): every hit field identical to the run with the reference's batches (VSX_SEARCH_LAZY=0), and
+    reference's first eight, then eights.  Nine option sets (default, maxaccepts 3, a strict identity with many first-candidate failures,
+    unlimited accepts / rejects, both strands; r06: maxaccepts 2 / maxrejects 4, --weak_id, both strands + weak hits, unlimited accepts
+    with maxrejects 4): every hit field identical to the run with the reference's batches (VSX_SEARCH_LAZY=0), and
     never more pairs aligned -- fewer wherever maxaccepts is below eight."""
     import json
     import sys
@@ -746,7 +750,7 @@ def test_lazy_first_batches_align_a_subset_with_the_same_hits(gpu_required):
         eager, lazy = outs["0"][name], outs["1"][name]
         assert eager[0] == lazy[0] and eager[2] == lazy[2], name             # same hits, every field
         assert lazy[1] <= eager[1], (name, lazy, eager)                      # a subset of the reference's pairs
-        if name in ("default", "three", "strict", "both"):
+        if name in ("default", "three", "strict", "both", "two_four", "weak", "both_weak"):
             assert lazy[1] < eager[1], (name, lazy, eager)
         else:
             assert lazy[1] == eager[1], (name, lazy, eager)                  # unlimited accepts: the first batch is the reference's

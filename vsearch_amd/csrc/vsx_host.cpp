@@ -303,6 +303,11 @@ struct vsx_ctx {
   bool ev_tb_used[3] = {false, false, false};
   int last_tb_slot = -1;            // the slot whose traceback was queued last (VSX_ALIGN_SERIAL: the next plan's DP waits for it)
   std::atomic<unsigned> plan_seq {0};
+  // r06: which block a new plan takes (vsx_plan_create).  slot_refs[s] = live plans on block s (a plan is destroyed after its traceback
+  // has finished), slot_stamp[s] = plan_seq at the last acquisition.
+  std::mutex slot_mu;
+  int slot_refs[3] = {0, 0, 0};
+  unsigned slot_stamp[3] = {0, 0, 0};
   // pinned host memory: results cross PCIe into it (vsx_plan_fetch), one fetch at a time; grow-only
   std::mutex stage_mu;
   uint8_t * stage = nullptr;
@@ -486,7 +491,8 @@ struct vsx_plan {
   PoolBuf<VsxTask> d_tasks;
   PoolBuf<uint32_t> d_pair_slot, d_pair_ids;
   SharedBuf<uint32_t> d_dir[1], d_slab;         // stream-ordered scratch shared by the context's plans
-  int dir_slot = 0;                             // which of the context's two checkpoint blocks
+  int dir_slot = 0;                             // which of the context's checkpoint blocks
+  bool slot_held = false;                       // counted in ctx->slot_refs[dir_slot]
   bool alt_fwd = false;                         // DP kernels on the context's second DP stream (pipelined slices, see vsx_align_pairs)
   PoolBuf<uint32_t> d_runs;
   PoolBuf<uint64_t> d_slab_off;
@@ -517,6 +523,7 @@ struct vsx_plan {
     if (ev_begin) (void) hipEventDestroy(ev_begin);
     if (ev_end) (void) hipEventDestroy(ev_end);
     if (h_cursor) { std::lock_guard<std::mutex> lk(ctx->stage_mu); ctx->cursor_slots.push_back(h_cursor); }
+    if (slot_held) { std::lock_guard<std::mutex> lk(ctx->slot_mu); --ctx->slot_refs[dir_slot]; }
   }
 };
 
@@ -612,6 +619,19 @@ int vsx_internal_scratch_reserve(vsx_ctx * ctx, const uint64_t want[4])
         if (e != hipSuccess) { (void) hipGetLastError(); return e == hipErrorOutOfMemory ? VSX_ENOMEM : VSX_EHIP; }
       }
   return VSX_OK;
+}
+static int pick_rows(int Q);
+// r06: what the checkpoint block of ONE plan of `ntasks` whole-wave tasks (a query of qlen rows against up to eight targets of tlen columns)
+// will ask for -- a caller that knows the largest plan it is going to submit (vsx_cluster_fast: a round of queries, eight candidates each)
+// reserves the block once instead of letting it grow over its first rounds; 0 when the context keeps direction bits instead of checkpoints
+uint64_t vsx_internal_ckpt_bytes_estimate(const vsx_ctx * ctx, uint64_t ntasks, uint32_t qlen, uint32_t tlen)
+{
+  if (!ctx->ckpt || qlen == 0 || tlen == 0) return 0;
+  const int rows = pick_rows((int) qlen);
+  const uint64_t total_lanes = ((uint64_t) qlen + (uint64_t) rows - 1) / (uint64_t) rows, nstrips = (total_lanes + 15) / 16;
+  const uint64_t steps = (((uint64_t) tlen + 3) & ~3ull) + 16;
+  const int tilt = (ctx->Pt.tilt != 0 && rows >= 4) ? 1 : 0;
+  return (ntasks * vsx_ckpt_dwords(nstrips, steps, (uint64_t) rows, tilt) + 2 * VSX_CK_SLACK_DW) * 4;
 }
 hipStream_t vsx_internal_stream(const vsx_ctx * ctx) { return ctx->stream; }
 // host copies of the set's lengths (the k-mer index build of long words lays its key slots out by their running sum)
@@ -1099,7 +1119,30 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   std::unique_ptr<vsx_plan> pl(new vsx_plan);
   pl->ctx = ctx; pl->Q = queries; pl->T = targets; pl->n_pairs = n_pairs;
   static const unsigned ck_blocks = (std::getenv("VSX_CK_BLOCKS") && std::atoi(std::getenv("VSX_CK_BLOCKS")) == 2) ? 2u : 3u;
-  pl->dir_slot = (int) (ctx->plan_seq.fetch_add(1) % ck_blocks);
+  // r06: a block nobody uses, the LARGEST such -- plans that follow one another (the stages of a clustering round, of a search window:
+  // each is destroyed, i.e. its traceback has finished, before the next is made) then keep ONE block warm instead of growing three in
+  // turn: 2 M x 300 bp --cluster_fast spent 1.1 s of its 6-7 s in eight multi-GB hipMallocs (profiles/r06/r06e_cluster_blocks.txt).
+  // A pipeline of slices (vsx_align_pairs) finds the earlier plans' blocks taken and so still alternates; when all are taken, the one
+  // acquired longest ago (its traceback finishes first).  VSX_CK_ROTATE=1: the blind rotation of r04 / r05 (A/B).
+  {
+    static const bool rotate_env = std::getenv("VSX_CK_ROTATE") && std::strcmp(std::getenv("VSX_CK_ROTATE"), "1") == 0;
+    std::lock_guard<std::mutex> lk(ctx->slot_mu);
+    const unsigned seq = ctx->plan_seq.fetch_add(1);
+    int pick = -1;
+    if (rotate_env) pick = (int) (seq % ck_blocks);
+    else
+      {
+        for (int k = 0; k < (int) ck_blocks; ++k)
+          if (ctx->slot_refs[k] == 0 && (pick < 0 || ctx->shared_dir[k].bytes() > ctx->shared_dir[pick].bytes())) pick = k;
+        if (pick < 0)
+          for (int k = 0; k < (int) ck_blocks; ++k)
+            if (pick < 0 || (int) (seq - ctx->slot_stamp[k]) > (int) (seq - ctx->slot_stamp[pick])) pick = k;
+      }
+    ++ctx->slot_refs[pick];
+    ctx->slot_stamp[pick] = seq;
+    pl->dir_slot = pick;
+    pl->slot_held = true;
+  }
 
   // ---- the reference's closed-form / sentinel cases (no DP) ----
   // host threads classify contiguous slices: the common case (a pair for the GPU) is handled in place, the rare closed-form

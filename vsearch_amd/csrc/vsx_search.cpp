@@ -37,6 +37,7 @@ extern "C" int vsx_internal_device(const vsx_ctx * ctx);
 extern "C" void vsx_internal_scratch_sizes(vsx_ctx * ctx, uint64_t out[4]);
 extern "C" void vsx_internal_scratch_requests(vsx_ctx * ctx, uint64_t out[2], int reset);
 extern "C" int vsx_internal_scratch_reserve(vsx_ctx * ctx, const uint64_t want[4]);
+extern "C" uint64_t vsx_internal_ckpt_bytes_estimate(const vsx_ctx * ctx, uint64_t ntasks, uint32_t qlen, uint32_t tlen);
 extern "C" int vsx_internal_seqset_create_cased(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const char * blob, uint64_t blob_bytes,
                                                 const uint64_t * offsets, const uint32_t * lengths, int mode);
 extern "C" int vsx_internal_seqset_lower_download(const vsx_seqset * s, uint8_t * dst, uint64_t nbytes);
@@ -1611,7 +1612,10 @@ static int search_batch_impl(vsx_searcher * S, uint64_t nq, const char * qblob, 
               want[0] = std::max(want[0], asked[0]);                       // (the bare requests: a block that served them is big enough;
               want[3] = std::max(want[3], asked[1]);                       //  a block that has to grow gets the usual headroom on top)
             }
-        want[1] = want[2] = want[0];                                     // the checkpoint blocks rotate
+        // (r06: a consumer's plans follow one another, and vsx_plan_create gives such plans the context's largest idle block: only
+        //  block 0 is ever used here, the other two are no longer levelled -- they would be reserved for nothing)
+        static const bool rotate_env = std::getenv("VSX_CK_ROTATE") && std::strcmp(std::getenv("VSX_CK_ROTATE"), "1") == 0;
+        if (rotate_env) want[1] = want[2] = want[0];
         if (timeline) std::fprintf(stderr, "  [%7.1f ms] stages joined\n", (now_s() - t_begin) * 1e3);
         for (vsx_ctx * c : all) if (c) (void) vsx_internal_scratch_reserve(c, want);
         if (timeline) std::fprintf(stderr, "  [%7.1f ms] scratch levelled\n", (now_s() - t_begin) * 1e3);
@@ -2088,6 +2092,22 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
   const uint64_t n = S->len.size();
   if (round == 0) round = 16384;          // (r03: 4096 before; with the next round's main ranking prefetched, fewer and larger rounds win: 10.4 -> 8.5 s at 2 M sequences)
   const uint64_t nk = 1ull << (2 * S->w);
+  // r06: the largest plan of the run is a full round with eight candidates per member: its checkpoint block is reserved now, in one
+  // piece -- left to grow with the early rounds' plans (few centroids: few candidates) the context re-allocated multi-GB blocks eight times,
+  // 1.1 s of a 6-7 s run (profiles/r06/r06e_cluster_blocks.txt).  Sized for the mean length + 10 % (amplicons), never more than a
+  // quarter of the device; a run that outgrows it grows the block as before.
+  if (n > 0)
+    {
+      uint64_t tot = 0;
+      for (uint64_t i = 0; i < n; ++i) tot += S->len[i];
+      const uint32_t typical = (uint32_t) std::min<uint64_t>(65535, tot / n + tot / n / 10 + 1);
+      uint64_t want[4] = {vsx_internal_ckpt_bytes_estimate(S->ctx, std::min<uint64_t>(round, n), typical, typical), 0, 0, 0};
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); free_b = 0; }
+      want[0] = std::min<uint64_t>(want[0], (uint64_t) free_b / 4);
+      static const bool no_reserve = std::getenv("VSX_CLUSTER_RESERVE") && std::strcmp(std::getenv("VSX_CLUSTER_RESERVE"), "0") == 0;      // A/B
+      if (want[0] >= (16ull << 20) && !no_reserve) (void) vsx_internal_scratch_reserve(S->ctx, want);
+    }
   IncIndex inc;
   inc.post.assign(nk, {});
   S->is_centroid.assign(n, 0);
