@@ -529,6 +529,8 @@ struct vsx_plan {
 
 extern "C" {
 
+// the host worker pool for vsx_search.cpp (fn(0) runs on the caller, which also helps with queued jobs while it waits)
+void vsx_internal_run_threads(int nth, void (*fn)(int, void *), void * arg) { run_threads(nth, [&](int t) { fn(t, arg); }); }
 // shared with vsx_search.cpp: one thread-local error slot for the whole library
 void vsx_internal_set_error(const char * msg) { g_err = msg ? msg : ""; }
 const vsx_scoring * vsx_internal_scoring(const vsx_ctx * ctx) { return &ctx->sc; }

@@ -38,6 +38,7 @@ extern "C" void vsx_internal_scratch_sizes(vsx_ctx * ctx, uint64_t out[4]);
 extern "C" void vsx_internal_scratch_requests(vsx_ctx * ctx, uint64_t out[2], int reset);
 extern "C" int vsx_internal_scratch_reserve(vsx_ctx * ctx, const uint64_t want[4]);
 extern "C" uint64_t vsx_internal_ckpt_bytes_estimate(const vsx_ctx * ctx, uint64_t ntasks, uint32_t qlen, uint32_t tlen);
+extern "C" void vsx_internal_run_threads(int nth, void (*fn)(int, void *), void * arg);        // the library's host worker pool (vsx_host.cpp)
 extern "C" int vsx_internal_seqset_create_cased(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const char * blob, uint64_t blob_bytes,
                                                 const uint64_t * offsets, const uint32_t * lengths, int mode);
 extern "C" int vsx_internal_seqset_lower_download(const vsx_seqset * s, uint8_t * dst, uint64_t nbytes);
@@ -50,6 +51,16 @@ int sfail(int code, const std::string & msg) { vsx_internal_set_error(msg.c_str(
 double now_s()
 {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// f(0) on the caller, f(1) ... f(nth - 1) on the library's persistent worker pool (r06: every parallel pass of a search window or a
+// clustering round used to create and join its own std::threads -- a dozen passes of 16 threads per round, ~3 ms of a 45 ms round)
+template <typename F>
+void run_pool(int nth, F && f)
+{
+  if (nth <= 1) { f(0); return; }
+  using Fn = typename std::remove_reference<F>::type;
+  vsx_internal_run_threads(nth, [](int t, void * a) { (*static_cast<Fn *>(a))(t); }, (void *) &f);
 }
 
 int usable_cpus()
@@ -554,6 +565,20 @@ static int fill_hit(const vsx_searcher & S, FQ qtext, int64_t ql, Hit & h, const
 
 // (range_of(q) -> the hits of query q as a span; r06: the search keeps a window's hits in ONE vector -- a vector per query was 10^5 small
 //  blocks allocated on the consumer threads and released on the caller's at return: 8-11 ms of a 130 ms call)
+static void hit_record(const Hit & h, uint32_t q, uint64_t cigar_off, vsx_hit & o)
+{
+  std::memset(&o, 0, sizeof o);
+  o.query = q; o.target = h.target; o.count = h.count;
+  o.accepted = h.accepted; o.weak = h.weak; o.used_fallback = h.fallback; o.strand = h.minus ? 1 : 0;
+  o.nwscore = h.nwscore; o.nwdiff = h.nwdiff; o.nwgaps = h.nwgaps; o.nwindels = h.nwindels;
+  o.nwalignmentlength = h.nwalignmentlength; o.matches = h.matches; o.mismatches = h.mismatches;
+  o.internal_alignmentlength = h.internal_alignmentlength; o.internal_gaps = h.internal_gaps;
+  o.internal_indels = h.internal_indels;
+  o.trim_q_left = h.trim_q_left; o.trim_q_right = h.trim_q_right; o.trim_t_left = h.trim_t_left; o.trim_t_right = h.trim_t_right;
+  o.shortest = h.shortest; o.longest = h.longest;
+  o.nwid = h.nwid; o.id = h.id; o.id0 = h.id0; o.id1 = h.id1; o.id2 = h.id2; o.id3 = h.id3; o.id4 = h.id4;
+  o.cigar_off = cigar_off;
+}
 struct HitSpan { const Hit * p; size_t n; const Hit * begin() const { return p; } const Hit * end() const { return p + n; } size_t size() const { return n; } };
 template <typename FRange>
 static int marshal_hits_from(uint64_t nq, FRange range_of, vsx_hits * out, int thread_budget /* the searcher's: S->threads */)
@@ -587,17 +612,7 @@ static int marshal_hits_from(uint64_t nq, FRange range_of, vsx_hits * out, int t
         for (const Hit & h : range_of(q))
           {
             vsx_hit & o = out->hit[pos++];
-            std::memset(&o, 0, sizeof o);
-            o.query = (uint32_t) q; o.target = h.target; o.count = h.count;
-            o.accepted = h.accepted; o.weak = h.weak; o.used_fallback = h.fallback; o.strand = h.minus ? 1 : 0;
-            o.nwscore = h.nwscore; o.nwdiff = h.nwdiff; o.nwgaps = h.nwgaps; o.nwindels = h.nwindels;
-            o.nwalignmentlength = h.nwalignmentlength; o.matches = h.matches; o.mismatches = h.mismatches;
-            o.internal_alignmentlength = h.internal_alignmentlength; o.internal_gaps = h.internal_gaps;
-            o.internal_indels = h.internal_indels;
-            o.trim_q_left = h.trim_q_left; o.trim_q_right = h.trim_q_right; o.trim_t_left = h.trim_t_left; o.trim_t_right = h.trim_t_right;
-            o.shortest = h.shortest; o.longest = h.longest;
-            o.nwid = h.nwid; o.id = h.id; o.id0 = h.id0; o.id1 = h.id1; o.id2 = h.id2; o.id3 = h.id3; o.id4 = h.id4;
-            o.cigar_off = at;
+            hit_record(h, (uint32_t) q, at, o);
             std::memcpy(out->cigar_blob + at, h.cigar.data(), h.cigar.size());
             at += h.cigar.size();
             out->cigar_blob[at++] = '\0';
@@ -657,10 +672,7 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
               if (advance(S, st[k], qseq(k), qlen(k), qidx(k), qmeta(k), p.pq, p.pt, lazy)) p.waiting.push_back(k);     // req_first: slice-relative
             }
         };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto & th : pool) th.join();
+        run_pool(nth, work);
         for (int t = 0; t < nth; ++t)
           {
             Part & p = part[(size_t) t];
@@ -732,10 +744,7 @@ static int run_stages(const vsx_searcher & S, std::vector<QState> & st, FSeq qse
                 }
             }
         };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto & th : pool) th.join();
+        run_pool(nth, work);
         for (int t = 0; t < nth; ++t)
           {
             acct.cells += part[(size_t) t].cells; acct.sentinels += part[(size_t) t].sentinels;
@@ -826,10 +835,7 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
         }
     };
     const int nfill = (int) std::min<uint64_t>((uint64_t) nth, std::max<uint64_t>(1, nq / 1024));
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nfill; ++t) pool.emplace_back(fill);
-    fill();
-    for (auto & th : pool) th.join();
+    run_pool(nfill, [&](int) { fill(); });
   }
   // count on the device; the records come back grouped by query
   VsxKmerResult res;
@@ -868,10 +874,7 @@ static int device_rank(const vsx_searcher * S, VsxKmerIndex * ix, const std::vec
         else std::sort(out.begin(), out.end(), [](const Cand & a, const Cand & b) { return a.target < b.target; });
       }
   };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nth; ++t) pool.emplace_back(work);
-  work();
-  for (auto & th : pool) th.join();
+  run_pool(nth, [&](int) { work(); });
   return VSX_OK;
 }
 
@@ -916,10 +919,7 @@ static void dust_states(const vsx_searcher * S, char * text, uint64_t n, FOff of
         for (uint64_t k = k0; k < std::min(n, k0 + 32); ++k) vsx_internal_dust_one(text + off(k), (int64_t) len(k), scratch);
       }
   };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nth; ++t) pool.emplace_back(work);
-  work();
-  for (auto & th : pool) th.join();
+  run_pool(nth, [&](int) { work(); });
 }
 
 // device path of search_topscores, stage 1: unique words per query (host threads; unique_count, core/unique.cpp:155-352)
@@ -939,10 +939,7 @@ static void kmer_words(const vsx_searcher * S, uint64_t nq, FSeq qseq, FLen qlen
         unique_kmers(qseq(k), qlen(k), S->w, S->qmode != 0, words[k], seen[(size_t) tid]);
       }
   };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
-  work(0);
-  for (auto & th : pool) th.join();
+  run_pool(nth, work);
 }
 
 // stage 2: count on the device index (built on first use), threshold, rank; queries the 16-bit counters cannot serve go
@@ -995,10 +992,7 @@ static int batch_candidates(vsx_searcher * S, bool device, uint64_t nq, FSeq qse
   auto parallel = [&](auto && fn) {
     std::atomic<uint64_t> next {0};
     auto work = [&](int tid) { for (;;) { const uint64_t k = next.fetch_add(1); if (k >= nq) break; fn(tid, k); } };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto & th : pool) th.join();
+    run_pool(nth, work);
   };
 
   if (!device)
@@ -1101,10 +1095,7 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
             text[i] = (char) c;
           }
       };
-      std::vector<std::thread> pool;
-      for (int t = 1; t < nth; ++t) pool.emplace_back(fold, t);
-      fold(0);
-      for (auto & th : pool) th.join();
+      run_pool(nth, fold);
     }
   *out = S.release();
   return VSX_OK;
@@ -1713,10 +1704,7 @@ static int ap_enumerate(const vsx_searcher * S, int32_t acceptall, const uint32_
             if (acceptable_unaligned(*S, S->blob.data() + S->off[qi], S->len[qi], (uint32_t) t, S->meta_of(qi))) v.push_back((uint32_t) t);
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nth; ++t) pool.emplace_back(work);
-    work();
-    for (auto & th : pool) th.join();
+    run_pool(nth, [&](int) { work(); });
     uint64_t total = 0;
     for (uint64_t k = 0; k < count; ++k) { qfirst[k] = total; total += tl[k].size(); }
     qfirst[count] = total;
@@ -1851,10 +1839,7 @@ static int ap_complete(vsx_searcher * S, int32_t acceptall, const ApList & L, Ap
           }
       };
       {
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto & th : pool) th.join();
+        run_pool(nth, work);
       }
       for (int t = 0; t < nth; ++t)
         if (err[(size_t) t] != VSX_OK)
@@ -1927,10 +1912,7 @@ static int ap_complete(vsx_searcher * S, int32_t acceptall, const ApList & L, Ap
           });
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto & th : pool) th.join();
+    run_pool(nth, work);
     for (int t = 0; t < nth; ++t)
       {
         sentinels += psent[(size_t) t];
@@ -2112,11 +2094,14 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
   inc.post.assign(nk, {});
   S->is_centroid.assign(n, 0);
   std::vector<uint32_t> clusterno(n, 0);
-  std::vector<std::vector<Hit>> kept(n);
+  // r06: a member's one reported hit goes straight into the result's record form, in sequence order (a vector of Hit per sequence was
+  // 1.2 M small blocks made one by one and released one by one at return)
+  std::vector<vsx_hit> kept_rec;
+  std::string kept_cigar;
   uint32_t nclusters = 0;
   Acct acct;
   double t_kmer = 0;
-  double tm_words = 0, tm_rebuild = 0, tm_rank = 0, tm_stages = 0, tm_near = 0, tm_spec = 0, tm_recon = 0;      // VSX_DEBUG_TIMING
+  double tm_words = 0, tm_rebuild = 0, tm_rank = 0, tm_stages = 0, tm_near = 0, tm_spec = 0, tm_recon = 0, tm_free = 0;      // VSX_DEBUG_TIMING
   const int64_t hit_capacity = std::min<int64_t>(S->ma + S->mr - 1, S->tophits);
 
   const int nth = std::max(1, S->threads);
@@ -2177,13 +2162,12 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
           for (uint64_t x = k; x < std::min(cnt, k + 16); ++x) unique_kmers(seq_of(a0 + x), S->len[a0 + x], S->w, S->o.soft_mask != 0, dst[x], seen[(size_t) tid]);
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto & th : pool) th.join();
+    run_pool(threads, work);
   };
   struct Joiner { std::thread & t; ~Joiner() { if (t.joinable()) t.join(); } } joiner {pre_thread};
   std::vector<std::vector<uint64_t>> main_seen;
+  std::thread reaper;                                    // releases the previous round's host state (see the end of the round loop)
+  Joiner reaper_joiner {reaper};
 
   for (uint64_t s0 = 0; s0 < n; s0 += round)
     {
@@ -2286,10 +2270,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
                       }
                   }
               };
-              std::vector<std::thread> pool;
-              for (int t = 1; t < std::min(nth, 8); ++t) pool.emplace_back(merge);
-              merge();
-              for (auto & th : pool) th.join();
+              run_pool(std::min(nth, 8), [&](int) { merge(); });
             }
           tm_rank += now_s() - tr0;
           for (uint64_t k = 0; k < wn; ++k) st[k].cands = std::move(cands[k]);
@@ -2326,10 +2307,7 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
               kmers[k] = sc.km;
             }
         };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (auto & th : pool) th.join();
+        run_pool(nth, work);
       }
       t_kmer += now_s() - t0;
 
@@ -2568,7 +2546,9 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
           if (best)
             {
               clusterno[seqno] = clusterno[best->target];
-              kept[seqno].push_back(*best);
+              kept_rec.emplace_back();
+              hit_record(*best, (uint32_t) seqno, kept_cigar.size(), kept_rec.back());
+              kept_cigar.append(best->cigar.c_str(), best->cigar.size() + 1);
             }
           else
             {
@@ -2586,14 +2566,56 @@ int vsx_cluster_fast(vsx_searcher * S, uint64_t round, vsx_cluster_out * out)
         }
       vsx_results_free(&spec);
       tm_recon += now_s() - t20;
+      // (the round's host state -- 16 384 candidate lists, hit lists, word lists, near lists -- released here so that it shows in the accounting)
+      // r06: the round's host state -- 16 384 candidate lists, hit lists, word lists, near lists: ~80 000 heap blocks -- is released on a
+      // helper thread beside the next round; on the main thread it was 7.6 ms per round, 0.93 s of a 5.9 s run at 2 M sequences, and in
+      // nobody's accounting (profiles/r06/r06g_cluster_phases.txt).  VSX_CLUSTER_REAPER=0: on this thread (A/B).
+      const double tf0 = now_s();
+      if (near_thread.joinable()) near_thread.join();
+      static const bool reaper_on = !(std::getenv("VSX_CLUSTER_REAPER") && std::strcmp(std::getenv("VSX_CLUSTER_REAPER"), "0") == 0);
+      if (reaper.joinable()) reaper.join();
+      if (reaper_on)
+        {
+          auto * dead_st = new std::vector<QState>(std::move(st));
+          auto * dead_km = new std::vector<std::vector<uint32_t>>(std::move(kmers));
+          auto * dead_near = new std::vector<std::vector<Near>>(std::move(near));
+          reaper = std::thread([dead_st, dead_km, dead_near]() { delete dead_st; delete dead_km; delete dead_near; });
+        }
+      else
+        {
+          std::vector<QState>().swap(st);
+          std::vector<std::vector<uint32_t>>().swap(kmers);
+          std::vector<std::vector<Near>>().swap(near);
+        }
+      tm_free += now_s() - tf0;
     }
+  if (reaper.joinable()) reaper.join();
   if (std::getenv("VSX_DEBUG_TIMING"))
     std::fprintf(stderr, "vsx_cluster_fast: words %.2f  centroid-index rebuild %.2f  rank vs centroids %.2f  staged search %.2f (align calls %.2f)  "
-                         "intra-round counts %.2f  speculative align %.2f  reconcile %.2f  total %.2f s\n",
-                 tm_words, tm_rebuild, tm_rank, tm_stages, acct.t_align - tm_spec, tm_near, tm_spec, tm_recon, now_s() - t_begin);
+                         "intra-round counts %.2f  speculative align %.2f  reconcile %.2f  round state released %.2f  total %.2f s\n",
+                 tm_words, tm_rebuild, tm_rank, tm_stages, acct.t_align - tm_spec, tm_near, tm_spec, tm_recon, tm_free, now_s() - t_begin);
 
-  int rc = marshal_hits(kept, &out->hits, S->threads);
-  if (rc != VSX_OK) return rc;
+  {
+    vsx_hits * H = &out->hits;
+    H->n_queries = n;
+    H->n_hits = kept_rec.size();
+    H->cigar_bytes = kept_cigar.size();
+    H->first = (uint64_t *) std::malloc((n + 1) * sizeof(uint64_t));
+    H->hit = (vsx_hit *) std::malloc(std::max<size_t>(kept_rec.size(), 1) * sizeof(vsx_hit));
+    H->cigar_blob = (char *) std::malloc(std::max<size_t>(kept_cigar.size(), 1));
+    if (!H->first || !H->hit || !H->cigar_blob) { vsx_hits_free(H); return sfail(VSX_ENOMEM, "host allocation failed"); }
+    if (!kept_rec.empty()) std::memcpy(H->hit, kept_rec.data(), kept_rec.size() * sizeof(vsx_hit));
+    if (!kept_cigar.empty()) std::memcpy(H->cigar_blob, kept_cigar.data(), kept_cigar.size());
+    // the records are in sequence order, at most one per sequence
+    uint64_t at = 0;
+    for (uint64_t q = 0; q < n; ++q)
+      {
+        H->first[q] = at;
+        if (at < kept_rec.size() && kept_rec[at].query == q) ++at;
+      }
+    H->first[n] = at;
+    if (at != kept_rec.size()) { vsx_hits_free(H); return sfail(VSX_EHIP, "vsx_cluster_fast: hit records out of order"); }
+  }
   out->n = n;
   out->n_clusters = nclusters;
   out->clusterno = (uint32_t *) std::malloc(std::max<uint64_t>(n, 1) * sizeof(uint32_t));
