@@ -1062,6 +1062,22 @@ DEV int wave_max_i32(int v)
 // forms v_add_u16 / v_sub_u16 / v_max_u16 (2 cycles per wave, measured: profiles/r01_ubench_valu.txt) give the same
 // numbers as the clamped packed ops (4 cycles), the comparison a > b is the sign of an exact 32-bit v_sub_u32, and one
 // v_alignbit_b32 shifts that sign into the direction word.
+// r06: the compaction of a ranked plan (VsxFilterDev::rank_counts): a kept pair (accepted or weak) or a refused one (score sentinel, no
+// verdict: the overflow rule fired at run time) takes the next slot of its list.  Kept pairs are a fraction of a per cent of an
+// --allpairs_global plan, so the atomic is rare; the lists come out in arrival order and the host orders the few entries.
+DEV void rank_note(const VsxFilterDev & FL, u32 pid, u32 verdict, int score, double idv)
+{
+  if (FL.rank_counts == nullptr) return;
+  if (verdict == 1u || verdict == 2u)
+    {
+      const u32 pos = atomicAdd(FL.rank_counts, 1u);
+      FL.kept_pair[pos] = pid;
+      FL.kept_id[pos] = idv;
+    }
+  else if (verdict == 0u && score == 32767)
+    FL.refused_pair[atomicAdd(FL.rank_counts + 1, 1u)] = pid;
+}
+
 template <bool FAST> struct TbOps;
 template <> struct TbOps<false>
 {
@@ -1620,6 +1636,7 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
     {
       o.score = 32767; o.aligned = 0; o.matches = 0; o.mismatches = 0; o.gaps = 0;
       out[pair_ids[k]] = o;
+      rank_note(FL, pair_ids[k], 0u, 32767, 0.0);
       return;
     }
   if (i >= 0) { al += (u32) (i + 1); if (op != 2) ++ga; push_n(2, (u32) (i + 1)); }     // left-terminal runs
@@ -1666,8 +1683,10 @@ vsx_traceback_ck_kernel(const VsxDevParams P, const VsxFilterDev FL, const VsxTa
   }
 
   u32 verdict = 0;
-  if (FL.enabled && nruns > 0) verdict = accept_verdict(FL, Q, D, (int) al, (int) ma, (int) mi, (int) ga, my[nruns - 1], my[0]);
+  double idv = 0.0;
+  if (FL.enabled && nruns > 0) verdict = accept_verdict(FL, Q, D, (int) al, (int) ma, (int) mi, (int) ga, my[nruns - 1], my[0], &idv);
   if (verdict == 3u) nruns = 0;                          // rejected: the runs never leave the device
+  rank_note(FL, pair_ids[k], verdict, (int) so.score, idv);
 
   const unsigned long long base = atomicAdd(cursor, (unsigned long long) nruns);
   if (base + nruns <= runs_capacity)
@@ -2232,6 +2251,7 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
     {
       o.score = 32767; o.aligned = 0; o.matches = 0; o.mismatches = 0; o.gaps = 0;
       out[pair_ids[k]] = o;
+      rank_note(FL, pair_ids[k], 0u, 32767, 0.0);
       return;
     }
   if (i >= 0) { al += (u32) (i + 1); if (op != 2) ++ga; push_n(2, (u32) (i + 1)); }     // left-terminal runs
@@ -2276,8 +2296,10 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
   }
 
   u32 verdict = 0;
-  if (FL.enabled && nruns > 0) verdict = accept_verdict(FL, Q, D, (int) al, (int) ma, (int) mi, (int) ga, my[nruns - 1], my[0]);
+  double idv = 0.0;
+  if (FL.enabled && nruns > 0) verdict = accept_verdict(FL, Q, D, (int) al, (int) ma, (int) mi, (int) ga, my[nruns - 1], my[0], &idv);
   if (verdict == 3u) nruns = 0;
+  rank_note(FL, pair_ids[k], verdict, (int) so.score, idv);
 
   const unsigned long long base = atomicAdd(cursor, (unsigned long long) nruns);
   if (base + nruns <= runs_capacity)

@@ -501,6 +501,9 @@ struct vsx_plan {
   PoolBuf<VsxPairOut> d_out;
   PoolBuf<unsigned long long> d_cursor;  // [0] run words used, [1] text bytes used
   PoolBuf<uint8_t> d_text, d_soa;        // CIGAR text and the output arrays, written by vsx_cigar_text_kernel (vsx_tbtext.hip)
+  // r06, ranked plans: the lists the traceback's epilogue fills (VsxFilterDev::rank_counts ...), see plan_set_ranked()
+  PoolBuf<uint32_t> d_rank_counts, d_kept_pair, d_refused_pair;
+  PoolBuf<double> d_kept_id;
   VsxSoaOut soa {};
   uint64_t soa_bytes = 0, soa_off[7] {};
   uint64_t text_capacity = 0;
@@ -1636,7 +1639,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
 int vsx_plan_set_filter(vsx_plan * pl, const vsx_filter * f)
 {
   if (!pl) return fail(VSX_EINVAL, "vsx_plan_set_filter: null plan");
-  pl->filter = VsxFilterDev {};
+  pl->filter = VsxFilterDev {};            // (also drops the lists of a ranked plan: plan_set_ranked() follows the filter)
   if (!f) return VSX_OK;
   if (!pl->ctx->ckpt) return fail(VSX_EINVAL, "vsx_plan_set_filter: needs the checkpoint traceback (VSX_TRACEBACK=dirs is set)");
   if (f->iddef < 0 || f->iddef > 4) return fail(VSX_EINVAL, "vsx_plan_set_filter: iddef must be 0..4");
@@ -1648,6 +1651,30 @@ int vsx_plan_set_filter(vsx_plan * pl, const vsx_filter * f)
   return VSX_OK;
 }
 
+// r06: make `pl` a RANKED plan -- its traceback lists the kept and the refused pairs (vsx_device.hip rank_note) for fetch_ranked_core.
+// VSX_RANK_PRIM=1 keeps the r02-r05 path (flag kernel + rocPRIM scan / segmented sort over all pairs) for A/B.
+static bool rank_lists_on()
+{
+  static const bool prim = std::getenv("VSX_RANK_PRIM") && std::strcmp(std::getenv("VSX_RANK_PRIM"), "1") == 0;
+  return !prim;
+}
+static int plan_set_ranked(vsx_plan * pl)
+{
+  if (!rank_lists_on() || !pl->filter.enabled) return VSX_OK;
+  vsx_ctx * ctx = pl->ctx;
+  const size_t n = (size_t) pl->n_pairs;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(pl->d_rank_counts.alloc(&ctx->pool, 2));
+  HIPCHK(pl->d_kept_pair.alloc(&ctx->pool, n + 1));
+  HIPCHK(pl->d_kept_id.alloc(&ctx->pool, n + 1));
+  HIPCHK(pl->d_refused_pair.alloc(&ctx->pool, n + 1));
+  pl->filter.rank_counts = pl->d_rank_counts.p;
+  pl->filter.kept_pair = pl->d_kept_pair.p;
+  pl->filter.kept_id = pl->d_kept_id.p;
+  pl->filter.refused_pair = pl->d_refused_pair.p;
+  return VSX_OK;
+}
+
 int vsx_plan_run(vsx_plan * pl)
 {
   if (!pl) return fail(VSX_EINVAL, "vsx_plan_run: null plan");
@@ -1656,6 +1683,7 @@ int vsx_plan_run(vsx_plan * pl)
   hipStream_t st = pl->alt_fwd ? ctx->stream_b : ctx->stream, st2 = ctx->stream2;
   const int slot = pl->dir_slot;
   HIPCHK(hipMemsetAsync(pl->d_cursor.p, 0, 2 * sizeof(unsigned long long), st));
+  if (pl->filter.rank_counts) HIPCHK(hipMemsetAsync(pl->d_rank_counts.p, 0, 2 * sizeof(uint32_t), st));      // (every run: settle() may run a plan twice)
   HIPCHK(hipEventRecord(pl->ev_begin, st));
   // DP kernels on `st`, tracebacks + text on `st2`.  A plan's DP waits only for the last traceback that read ITS checkpoint
   // block (the context alternates two), so it overlaps the previous plan's traceback; inside a plan the chunks share the block.
@@ -1924,6 +1952,97 @@ struct RankedSink {
   ~RankedSink() { std::free(blob); }
 };
 
+// r06: the ranked fetch from the lists the traceback's epilogue wrote.  Kept pairs arrive in arbitrary order: their fields are gathered
+// as they lie, cross PCIe, and the HOST puts the few of them in report order -- per query (queries ascending = pair index ascending
+// across groups), identity descending, pair index ascending among equals: what the stable segmented sort produced.
+static int fetch_ranked_lists(vsx_plan * pl, uint64_t first, const uint32_t * qkey, RankedSink & S, unsigned long long text_used)
+{
+  vsx_ctx * ctx = pl->ctx;
+  hipStream_t st = ctx->stream_dn;
+  const uint64_t n = pl->n_pairs;
+  uint32_t counts[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(counts, pl->d_rank_counts.p, sizeof counts, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const uint32_t kept = counts[0], n_refused = counts[1];
+  if (kept > n || n_refused > n) return fail(VSX_EHIP, "vsx_align_pairs_ranked: the kept / refused lists are corrupt");
+  if (n_refused)
+    {
+      // (include/vsx.h: a pair the 16-bit aligner refused is `undecided`, never silently dropped)
+      std::vector<uint32_t> rf(n_refused);
+      HIPCHK(hipMemcpy(rf.data(), pl->d_refused_pair.p, (size_t) n_refused * 4, hipMemcpyDeviceToHost));
+      std::sort(rf.begin(), rf.end());
+      for (uint32_t k : rf) S.undecided.push_back((uint32_t) (first + k));
+    }
+  if (!kept) return VSX_OK;
+  const uint64_t width[9] = {4, 8, 8, 2, 2, 2, 2, 2, 1};
+  uint64_t off[9], at = 0;
+  for (int x = 0; x < 9; ++x) { off[x] = at; at += ((uint64_t) kept * width[x] + 15) & ~15ull; }
+  const uint64_t rank_bytes = at;
+  PoolBuf<uint8_t> d_rank;
+  HIPCHK(d_rank.alloc(&ctx->pool, rank_bytes));
+  VsxRankedOut R;
+  R.pair = reinterpret_cast<uint32_t *>(d_rank.p + off[0]);
+  R.id = reinterpret_cast<double *>(d_rank.p + off[1]);
+  R.text_off = reinterpret_cast<uint64_t *>(d_rank.p + off[2]);
+  R.score = reinterpret_cast<int16_t *>(d_rank.p + off[3]);
+  R.aligned = reinterpret_cast<uint16_t *>(d_rank.p + off[4]);
+  R.matches = reinterpret_cast<uint16_t *>(d_rank.p + off[5]);
+  R.mismatches = reinterpret_cast<uint16_t *>(d_rank.p + off[6]);
+  R.gaps = reinterpret_cast<uint16_t *>(d_rank.p + off[7]);
+  R.verdict = d_rank.p + off[8];
+  HIPCHK(vsx_rank_gather_list(pl->d_kept_pair.p, pl->d_kept_id.p, kept, pl->d_out.p, pl->soa.text_off, R, st));
+  std::lock_guard<std::mutex> lk(ctx->stage_mu);
+  int rc = stage_reserve(ctx, rank_bytes + ((text_used + 15) & ~15ull));
+  if (rc != VSX_OK) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->stage, d_rank.p, rank_bytes, hipMemcpyDeviceToHost, st));
+  if (text_used) HIPCHK(hipMemcpyAsync(ctx->stage + rank_bytes, pl->d_text.p, text_used, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const uint8_t * sg = ctx->stage;
+  const char * text = reinterpret_cast<const char *>(sg + rank_bytes);
+  const uint32_t * h_pair = reinterpret_cast<const uint32_t *>(sg + off[0]);
+  const double * h_id = reinterpret_cast<const double *>(sg + off[1]);
+  const uint64_t * h_toff = reinterpret_cast<const uint64_t *>(sg + off[2]);
+  const int16_t * h_score = reinterpret_cast<const int16_t *>(sg + off[3]);
+  const uint16_t * h_al = reinterpret_cast<const uint16_t *>(sg + off[4]), * h_ma = reinterpret_cast<const uint16_t *>(sg + off[5]);
+  const uint16_t * h_mi = reinterpret_cast<const uint16_t *>(sg + off[6]), * h_ga = reinterpret_cast<const uint16_t *>(sg + off[7]);
+  const uint8_t * h_vd = sg + off[8];
+  std::vector<uint32_t> order;
+  order.reserve(kept);
+  for (uint32_t j = 0; j < kept; ++j)
+    {
+      if (h_pair[j] >= n) return fail(VSX_EHIP, "vsx_align_pairs_ranked: a kept pair is out of range");
+      if (h_vd[j] == 1u || (S.keep_weak && h_vd[j] == 2u)) order.push_back(j);
+    }
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    const uint32_t pa = h_pair[a], pb = h_pair[b];
+    if (qkey[pa] != qkey[pb]) return pa < pb;                 // (the pairs of a query are contiguous: another query = another segment)
+    if (h_id[a] != h_id[b]) return h_id[a] > h_id[b];
+    return pa < pb;
+  });
+  const size_t m = order.size(), base = S.pair.size();
+  S.pair.resize(base + m); S.id.resize(base + m); S.cigar_off.resize(base + m);
+  S.score.resize(base + m); S.aligned.resize(base + m); S.matches.resize(base + m);
+  S.mismatches.resize(base + m); S.gaps.resize(base + m); S.verdict.resize(base + m);
+  uint64_t need = 0;
+  std::vector<uint32_t> slen(m);
+  for (size_t x = 0; x < m; ++x) { slen[x] = (uint32_t) std::strlen(text + h_toff[order[x]]) + 1; need += slen[x]; }
+  char * nb = (char *) std::realloc(S.blob, std::max<uint64_t>(S.blob_used + need, 1));
+  if (!nb) return fail(VSX_ENOMEM, "vsx_align_pairs_ranked: host allocation failed");
+  S.blob = nb;
+  for (size_t x = 0; x < m; ++x)
+    {
+      const uint32_t j = order[x];
+      S.pair[base + x] = (uint32_t) (first + h_pair[j]);
+      S.id[base + x] = h_id[j];
+      S.score[base + x] = h_score[j]; S.aligned[base + x] = h_al[j]; S.matches[base + x] = h_ma[j];
+      S.mismatches[base + x] = h_mi[j]; S.gaps[base + x] = h_ga[j]; S.verdict[base + x] = h_vd[j];
+      S.cigar_off[base + x] = S.blob_used;
+      std::memcpy(S.blob + S.blob_used, text + h_toff[j], slen[x]);
+      S.blob_used += slen[x];
+    }
+  return VSX_OK;
+}
+
 // `first` = index of the plan's pair 0 in the caller's list; `qkey` = the caller's query index per pair (plan-local view)
 static int fetch_ranked_core(vsx_plan * pl, uint64_t first, const uint32_t * qkey, RankedSink & S)
 {
@@ -1935,6 +2054,7 @@ static int fetch_ranked_core(vsx_plan * pl, uint64_t first, const uint32_t * qke
   for (uint32_t k : pl->host_pairs) S.undecided.push_back((uint32_t) (first + k));
   if (n == 0) return VSX_OK;
   hipStream_t st = ctx->stream_dn;             // the plan's kernels are done; the next slice may own `stream`
+  if (pl->filter.rank_counts) return fetch_ranked_lists(pl, first, qkey, S, text_used);
 
   // query groups of the pair list (pairs of one query are contiguous)
   std::vector<uint32_t> qstart;
@@ -2165,6 +2285,7 @@ static int align_pairs_single(vsx_ctx * ctx, const vsx_seqset * queries, const v
   int rc = vsx_plan_create(ctx, &pl, queries, targets, n_pairs, qidx, tidx, 0);
   if (rc != VSX_OK) return rc;
   if (filter && ctx->ckpt) { rc = vsx_plan_set_filter(pl, filter); if (rc != VSX_OK) { vsx_plan_destroy(pl); return rc; } }
+  if (sink) { rc = plan_set_ranked(pl); if (rc != VSX_OK) { vsx_plan_destroy(pl); return rc; } }
   const double t1 = now();
   rc = vsx_plan_run(pl);
   double t2 = t1, t3 = t1;
@@ -2259,6 +2380,7 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
         vsx_plan * pl = nullptr;
         int rc = vsx_plan_create(ctx, &pl, queries, targets, cut[i + 1] - cut[i], qidx + cut[i], tidx + cut[i], slice_budget);
         if (rc == VSX_OK && filter && ctx->ckpt) rc = vsx_plan_set_filter(pl, filter);
+        if (rc == VSX_OK && sink) rc = plan_set_ranked(pl);
         if (rc != VSX_OK) { plan_msg[i] = vsx_last_error(); if (pl) vsx_plan_destroy(pl); pl = nullptr; }
         if (timing) std::fprintf(stderr, "  slice %zu (%llu pairs): planned at %.1f ms\n", i, (unsigned long long) (cut[i + 1] - cut[i]), (now() - t_begin) * 1e3);
         std::lock_guard<std::mutex> lk(mu);

@@ -86,6 +86,13 @@ struct VsxFilterDev {
   int32_t enabled, iddef, leftjust, rightjust;
   double  id, weak_id, maxid, mid, query_cov, target_cov;
   int64_t maxsubs, maxgaps, mincols, maxdiffs;
+  // r06, ranked plans (vsx_align_pairs_ranked): the traceback's epilogue appends every accepted / weak pair (plan-local pair index + the
+  // identity the filter compared) and every pair the 16-bit DP refused at run time to two lists -- the hand-written compaction that
+  // replaces the flag kernel + rocPRIM scan / scatter / segmented sort over ALL pairs of a plan (vsx_rank.hip).  rank_counts == nullptr: off.
+  uint32_t * rank_counts;      // [0] kept, [1] refused
+  uint32_t * kept_pair;
+  double   * kept_id;
+  uint32_t * refused_pair;
 };
 
 // Per (task, slot) output of the DP kernel.
@@ -130,6 +137,8 @@ extern "C" {
 #endif
 
 // vsx_rank.hip: keep flags + identities + exclusive scan (d_temp == NULL: only *temp_bytes is set) ...
+hipError_t vsx_rank_gather_list(const uint32_t * d_kept_pair, const double * d_kept_id, uint32_t kept, const VsxPairOut * d_out,
+                                const uint64_t * d_text_off, VsxRankedOut r, hipStream_t st);
 hipError_t vsx_rank_flag_scan(VsxFilterDev F, int keep_weak, const VsxPairOut * d_out, const uint32_t * d_pair_ids,
                               const uint32_t * d_pair_slot, const VsxTask * d_tasks, uint32_t ngpu_pairs, uint32_t n_pairs,
                               const uint32_t * d_runs, uint64_t runs_capacity, uint32_t * d_flag, uint32_t * d_pos, double * d_id,

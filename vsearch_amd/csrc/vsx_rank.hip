@@ -85,6 +85,16 @@ vsx_rank_gather_kernel(const u32 * __restrict__ ranked, const double * __restric
   r.text_off[j] = text_off[pid];
 }
 
+// r06: the kept pairs of a ranked plan as the traceback's epilogue listed them (arrival order; VsxFilterDev::kept_pair / kept_id) ->
+// the compact arrays; the host orders the few entries (fetch_ranked_core, vsx_host.cpp)
+extern "C" hipError_t vsx_rank_gather_list(const uint32_t * d_kept_pair, const double * d_kept_id, uint32_t kept, const VsxPairOut * d_out,
+                                           const uint64_t * d_text_off, VsxRankedOut r, hipStream_t st)
+{
+  if (kept)
+    hipLaunchKernelGGL(vsx_rank_gather_kernel, dim3((kept + 255) / 256), dim3(256), 0, st, d_kept_pair, d_kept_id, kept, d_out, d_text_off, r);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t vsx_rank_flag_scan(VsxFilterDev F, int keep_weak, const VsxPairOut * d_out, const uint32_t * d_pair_ids,
                                          const uint32_t * d_pair_slot, const VsxTask * d_tasks, uint32_t ngpu_pairs, uint32_t n_pairs,
                                          const uint32_t * d_runs, uint64_t runs_capacity, uint32_t * d_flag /* n + 1 */,
