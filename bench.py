@@ -348,7 +348,7 @@ def main():
             "cells_per_step_per_gpu": cells,
         },
         "roofline": {
-            "kernel": (f"vsx_forward_kernel<{info['rows_dominant']},true,false,true,true,{'true' if max3 else 'false'},{sparse_nq(info)}>" if tilted
+            "kernel": (f"vsx_forward_kernel<{info['rows_dominant']},true,false,true,true,{'true' if max3 else 'false'},{sparse_nq(info)},false,{'true' if info['rows_dominant'] * 16 >= a.qlen and sparse_nq(info) == 1 else 'false'}>" if tilted
                        else f"vsx_forward_kernel<{info['rows_dominant']},true,...>"),
             "bound": "valu-issue",
             "achieved": round(achieved, 3),

@@ -337,6 +337,9 @@ def test_chunked_plan_equals_single_chunk(gpu_required, oracle):
     {"VSX_TRACEBACK": "dirs"}, {"VSX_TB_ARITH": "packed"}, {"VSX_SCORE": "arith"}, {"VSX_NO_SHARE_SUB": "1"}, {"VSX_ROWS": "4"},
     {"VSX_TILT": "0"}, {"VSX_TILT": "0", "VSX_ROWS": "4"}, {"VSX_MAX3": "0"}, {"VSX_MAX3": "0", "VSX_ROWS": "4"},
     {"VSX_SPARSE": "0"}, {"VSX_SPARSE": "0", "VSX_MAX3": "0"},
+    # r06: single-strip launches run the ONE variants of the TILT kernels by default; VSX_ONESTRIP=0 keeps the general (multi-strip capable)
+    # kernels for every launch -- with whole-wave tasks only, and in the 16-bit TILT class
+    {"VSX_ONESTRIP": "0"}, {"VSX_ONESTRIP": "0", "VSX_SPARSE": "0"}, {"VSX_ONESTRIP": "0", "VSX_SPARSE": "0", "VSX_MAX3": "0"},
 ], ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_kernel_modes(gpu_required, env):
     """the A/B switches of DESIGN.md section 8 select other kernel variants (stored direction bits, saturating packed traceback,

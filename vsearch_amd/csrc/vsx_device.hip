@@ -170,7 +170,15 @@ DEV u32 pk_max3_bits(u32 a, u32 b, u32 c)            // IEEE maximum of three: t
 // four waves sharing it can, when a query has >= 32 targets (--allpairs_global).  No look-ahead register set: the R dwords of a step are
 // read at its top, row r's compute waits for its own quarter only.  Everything a task owns -- VsxTask, checkpoint block, VsxSlotOut -- is
 // as in the whole-wave class, so the traceback is unchanged.  The planner forms the groups of four (vsx_host.cpp).
-template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false, bool MAX3 = false, int NQ = 1, bool PAIR = false>
+// ONE (r06): every task of the launch is a SINGLE-STRIP query (Q <= 16 R -- which pick_rows() gives every query of at most 512 symbols;
+// the planner knows per launch, Launch::multi).  The strip loop, its hand-over buffer and the per-strip address set then fold away at
+// compile time.  What that is worth was measured before it was built (a forced build, profiles/r06/r06l_onestrip_ab.txt): the whole-wave
+// MAX3 kernels lose their scratch -- R = 16: 128 VGPRs + 188 B of scratch (46 VGPR + 63 SGPR spills) -> 128 VGPRs, none; R = 10: 72 B -> 0
+// at 111 VGPRs; R = 20: 196 -> 76 B; R = 26: 250 -> 197 VGPRs -- and run 3.4-4.9 % faster: 250 x 1000 DP 22.19 -> 21.10 ms, 150 x 1000
+// 16.22 -> 15.6, 300 x 300 10.10 -> 9.76, 400 x 400 16.83 -> 16.07, 150 x 300 5.43 -> 5.22 (same box, two runs each).  The sparse-task
+// classes (NQ > 1) always were single-strip, which is why they compiled without spills (VERDICT r05 "next" 3b asked what they do not
+// keep live: the strip state).
+template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false, bool MAX3 = false, int NQ = 1, bool PAIR = false, bool ONE = false>
 __global__ void __launch_bounds__(PAIR ? 256 : 64) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? VSX_FWD_WAVES(R, TILT) : VSX_FWD_WAVES_NQ(R, NQ), 8)))
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
@@ -254,7 +262,8 @@ vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
   const int total_lanes = (Q + R - 1) / R;         // pipeline positions holding query rows
   const int rcnt0 = Q - (total_lanes - 1) * R;     // rows in position 0 (1..R); all others hold R
   const int rc0 = __builtin_amdgcn_readfirstlane(rcnt0);   // provably scalar: keeps the per-row capture test on the SALU
-  const int nstrips = (NQ == 1) ? (total_lanes + 15) >> 4 : 1;
+  static_assert(!PAIR || ONE, "the pair-profile classes are planned for single-strip queries only");
+  const int nstrips = (NQ == 1 && !ONE) ? (total_lanes + 15) >> 4 : 1;
   const int steps = (NQ == 1) ? (int) T.steps : __builtin_amdgcn_readfirstlane((int) T.steps);   // (NQ > 1: the planner gives the tasks of a wave ONE step range)
 
   const int DA = sub_on ? (int) T.tlen[2 * g] : 0;
@@ -2448,7 +2457,7 @@ extern "C" hipError_t vsx_launch_purity(const uint8_t * d_codes, const uint64_t 
 #define VSX_FWD_GO(GRID_, ...) hipLaunchKernelGGL((vsx_forward_kernel<__VA_ARGS__>), dim3(GRID_), dim3(64), 0, st, P, d_tasks, q, t, dir, strip, slot, ntasks)
 #define VSX_FWD_GO4(GRID_, ...) hipLaunchKernelGGL((vsx_forward_kernel<__VA_ARGS__>), dim3(GRID_), dim3(256), 0, st, P, d_tasks, q, t, dir, strip, slot, ntasks)
 template <int R, bool CK>
-static hipError_t launch_fwd2(int generic, int track, int nq, const VsxDevParams & P, const VsxTask * d_tasks, uint32_t ntasks,
+static hipError_t launch_fwd2(int generic, int track, int nq, int one, const VsxDevParams & P, const VsxTask * d_tasks, uint32_t ntasks,
                               const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
                               VsxSlotOut * slot, hipStream_t st)
 {
@@ -2458,7 +2467,8 @@ static hipError_t launch_fwd2(int generic, int track, int nq, const VsxDevParams
       if (!(P.tilt != 0 && CK && generic && !track) || (ntasks & 3u)) return hipErrorInvalidValue;
       if constexpr (CK && R >= 4 && VSX_QPL != 0 && VSX_FEED2 != 0 && !VSX_CKT)
         {
-          if (P.max3) VSX_FWD_GO4(ntasks / 4, R, true, false, true, true, true, 1, true); else VSX_FWD_GO4(ntasks / 4, R, true, false, true, true, false, 1, true);
+          if (!one) return hipErrorInvalidValue;
+          if (P.max3) VSX_FWD_GO4(ntasks / 4, R, true, false, true, true, true, 1, true, true); else VSX_FWD_GO4(ntasks / 4, R, true, false, true, true, false, 1, true, true);
           return hipGetLastError();
         }
       else return hipErrorInvalidValue;
@@ -2481,6 +2491,15 @@ static hipError_t launch_fwd2(int generic, int track, int nq, const VsxDevParams
       if (!(CK && generic && !track)) return hipErrorInvalidValue;
       if constexpr (CK)
         {
+          if constexpr (R >= 4 && VSX_QPL != 0 && !VSX_CKT)
+            {
+              if (one)
+                {
+                  if (P.max3) VSX_FWD_GO(ntasks, R, true, false, true, true, true, 1, false, true);
+                  else VSX_FWD_GO(ntasks, R, true, false, true, true, false, 1, false, true);
+                  return hipGetLastError();
+                }
+            }
           if (P.max3 && !VSX_CKT) VSX_FWD_GO(ntasks, R, true, false, true, true, (VSX_CKT == 0));
           else VSX_FWD_GO(ntasks, R, true, false, true, true);
         }
@@ -2496,13 +2515,14 @@ static hipError_t launch_fwd2(int generic, int track, int nq, const VsxDevParams
 
 // nq = tasks per wave: 1, or 2 / 4 for the sparse-task classes (tasks of <= 4 / <= 2 targets, TILT family, single-strip queries);
 // 8 = the pair-profile class: workgroups of four whole-wave tasks of one pure-ACGT query (ntasks a multiple of 4)
-extern "C" hipError_t vsx_launch_forward(int rows, int generic, int track, int ckpt, int nq, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
+// one != 0: every task of the launch is a single-strip query (ONE)
+extern "C" hipError_t vsx_launch_forward(int rows, int generic, int track, int ckpt, int nq, int one, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
                                          const uint8_t * q, const uint8_t * t, uint32_t * dir, uint2 * strip,
                                          VsxSlotOut * slot, hipStream_t st)
 {
   if (ntasks == 0) return hipSuccess;
-#define FWDR(RR) case RR: return ckpt ? launch_fwd2<RR, true>(generic, track, nq, P, d_tasks, ntasks, q, t, dir, strip, slot, st) \
-                                       : launch_fwd2<RR, false>(generic, track, nq, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
+#define FWDR(RR) case RR: return ckpt ? launch_fwd2<RR, true>(generic, track, nq, one, P, d_tasks, ntasks, q, t, dir, strip, slot, st) \
+                                       : launch_fwd2<RR, false>(generic, track, nq, one, P, d_tasks, ntasks, q, t, dir, strip, slot, st)
   switch (rows)
     {
     FWDR(1); FWDR(4); FWDR(8); FWDR(10); FWDR(12); FWDR(14); FWDR(16); FWDR(18); FWDR(20); FWDR(22); FWDR(24); FWDR(26); FWDR(28); FWDR(32);

@@ -349,7 +349,8 @@ struct vsx_seqset {
 
 namespace {
 
-struct Launch { int rows; int generic; int track; int tilt; int nq /* tasks per wave: 1, or 2 / 4 = a sparse-task class */; uint32_t first, count; uint32_t pair_first, pair_count; };
+struct Launch { int rows; int generic; int track; int tilt; int nq /* tasks per wave: 1, or 2 / 4 = a sparse-task class */; uint32_t first, count; uint32_t pair_first, pair_count;
+                bool multi = false /* r06: some task of the launch spans several strips (Q > 16 rows): the general kernel; otherwise the ONE variants */; };
 
 struct Chunk {
   uint32_t task_first = 0, task_count = 0;
@@ -1267,7 +1268,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
               pt.nq = pt.n <= 2 ? 4 : 2;
             outp.push_back(pt);
           }
-        if (pair_try && rows >= 4 && outp.size() - first_of_query >= 4)
+        if (pair_try && rows >= 4 && outp.size() - first_of_query >= 4 && (int64_t) queries->len[q] <= 16ll * rows)     // (one strip: the PAIR kernels are ONE variants)
           {
             size_t eligible = 0;
             for (size_t k = first_of_query; k < outp.size(); ++k) eligible += (outp[k].nq == 1 && outp[k].tilt) ? 1 : 0;
@@ -1527,6 +1528,7 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
           cur.launches.back().track != pt.track || cur.launches.back().tilt != pt.tilt || cur.launches.back().nq != pt.nq)
         cur.launches.push_back(Launch {pt.rows, pt.generic, pt.track, pt.tilt, pt.nq, (uint32_t) x, 0, cur.pair_first + cur.pair_count, 0});
       cur.launches.back().count++;
+      if (strip != 0) cur.launches.back().multi = true;           // (a task owns hand-over rows only when it has a second strip)
       cur.launches.back().pair_count += pt.n;
       t_pair0[x] = np_out;
       np_out += pt.n;
@@ -1702,7 +1704,8 @@ int vsx_plan_run(vsx_plan * pl)
         {
           VsxDevParams Pf = L.tilt ? ctx->Pt : ctx->P;
           Pf.max3 = (L.tilt == 2) ? 1 : 0;
-          HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, L.nq, Pf, pl->d_tasks.p + L.first, L.count,
+          static const bool one_off = std::getenv("VSX_ONESTRIP") && std::strcmp(std::getenv("VSX_ONESTRIP"), "0") == 0;      // A/B, tests: the general kernels
+          HIPCHK(vsx_launch_forward(L.rows, L.generic, L.track, ctx->ckpt ? 1 : 0, L.nq, (L.multi || (one_off && L.nq != 8)) ? 0 : 1, Pf, pl->d_tasks.p + L.first, L.count,
                                     pl->Q->codes(), pl->T->codes(), dir, pl->d_strip.p,
                                     pl->d_slot.p + (size_t) L.first * VSX_TASK_SLOTS, st));
         }

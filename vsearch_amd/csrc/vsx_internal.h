@@ -167,7 +167,7 @@ hipError_t vsx_launch_purity(const uint8_t * d_codes, const uint64_t * d_off, co
 // rows must be one of vsx_supported_rows(); generic != 0 selects the LDS score-table variant;
 // track == 0 selects the variant without overflow (H min/max) tracking
 // nq = tasks per wave (1; 2 / 4 = the sparse-task classes of the TILT family: tasks of <= 4 / <= 2 targets in their first slots)
-hipError_t vsx_launch_forward(int rows, int generic, int track, int ckpt, int nq, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
+hipError_t vsx_launch_forward(int rows, int generic, int track, int ckpt, int nq, int one /* every task single-strip */, VsxDevParams P, const VsxTask * d_tasks, uint32_t ntasks,
                               const uint8_t * d_qcodes, const uint8_t * d_tcodes,
                               uint32_t * d_dir, uint2 * d_strip, VsxSlotOut * d_slot, hipStream_t st);
 hipError_t vsx_launch_traceback(VsxDevParams P, const VsxTask * d_tasks, const uint32_t * d_pair_slot,
