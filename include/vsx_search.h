@@ -51,7 +51,7 @@ typedef struct vsx_search_opts {
                                           searcher is created (vsx_mask.hip), every query -- each strand on its own -- on the
                                           host threads (core/mask.cpp:79-199, core/search.cpp:294-303), then as 1.
                                All three stay on the device k-mer path (a per-symbol case bitmap beside the 4-bit codes);
-                               the alignment itself never reads the case.  --hardmask is not provided. */
+                               the alignment itself never reads the case.  See `hardmask` below. */
   int64_t maxsubs, maxgaps, mincols, maxdiffs;
   double  query_cov, target_cov, maxid, mid;
   int32_t leftjust, rightjust;
@@ -79,6 +79,13 @@ typedef struct vsx_search_opts {
   int32_t qmask;            /* --qmask when it differs from --dbmask: 0 = the queries are masked as soft_mask says (default),
                                otherwise 1 + mode (1 none, 2 soft, 3 dust).  Searching only; clustering uses soft_mask */
   double  unoise_alpha;     /* --unoise_alpha, default 2.0                                                              */
+  int32_t hardmask;         /* --hardmask (core/mask.cpp:137-191,248-271; core/search.cpp:294-303; commands/usearch_global.cpp,
+                               core/cluster.cpp:1192-1197): masked symbols become 'N' IN THE SEQUENCE -- the k-mer stage and the
+                               alignment both see them.  Bit 0: the database text handed to vsx_searcher_create (mode dust: the DUST
+                               intervals become 'N' and the text keeps its case; mode soft: every lower-case symbol becomes 'N'; none:
+                               nothing); bit 1: the queries, each strand on its own, by the query mask mode.  3 = the reference's command
+                               line; 2 = a caller whose database is already hard-masked (the library API, shim/vsx_api_adapter.cpp).
+                               Default 0.  Hits, %id and CIGARs then refer to the masked sequences, as in the reference. */
 } vsx_search_opts;
 
 void vsx_search_opts_default(vsx_search_opts * o);
@@ -119,6 +126,10 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
                         uint64_t n, const char * blob, uint64_t blob_bytes,
                         const uint64_t * offsets, const uint32_t * lengths);
 void vsx_searcher_destroy(vsx_searcher * s);
+/* The database text AS INDEXED AND ALIGNED: the caller's blob with the searcher's masking applied (DUST: upper case with the masked
+   A C G T U in lower case -- a masked ambiguity code stays upper case, no step reads its case; --hardmask: the masked symbols as 'N', core/mask.cpp:137-191,248-271).  What the reference prints as the target
+   rows of --alnout after dust_all / hardmask_all rewrote the Database (db.hpp:179).  Copies min(cap, blob_bytes) bytes; returns blob_bytes. */
+uint64_t vsx_searcher_db_text(const vsx_searcher * s, char * dst, uint64_t cap);
 
 /* Per-sequence annotations the filters above read: Database::getabundance / getheader (core/db.hpp).  Either member may
    be NULL (abundances all 1, no labels).  The arrays are copied. */

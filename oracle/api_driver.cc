@@ -83,6 +83,7 @@ static void apply_options(struct Parameters & p, int argc, char ** argv, int fir
       else if (key == "minsizeratio") p.opt_minsizeratio = v;
       else if (key == "maxsizeratio") p.opt_maxsizeratio = v;
       else if (key == "sizeorder") p.opt_sizeorder = v != 0;
+      else if (key == "hardmask") p.opt_hardmask = v != 0;
       else if (key == "sizes") g_sizes = v != 0;
       else if (key == "match") p.opt_match = (int64_t) v;
       else if (key == "mismatch") p.opt_mismatch = (int64_t) v;
@@ -109,6 +110,7 @@ static void load(Database & db, struct Parameters & parameters, char const * pat
   for (size_t i = 0; i < labels.size(); ++i)
     db.add(false, labels[i].c_str(), seqs[i].c_str(), nullptr, labels[i].size(), seqs[i].size(), size_of(labels[i]));
   if (mode == Masking::dust) dust_all(db, parameters);
+  else if (mode == Masking::soft && parameters.opt_hardmask) hardmask_all(db);       // (usearch_global.cpp / cluster.cpp:1192-1197)
 }
 
 static int run_search(int argc, char ** argv)

@@ -17,7 +17,7 @@
 //     the batch boundaries -- that is what the reference's intra-batch fix-up guarantees) and serves every later range from
 //     that result; the caller's Dbindex is not grown.  A session that started with cluster_assign_single stays on the
 //     reference's code for its whole life.
-//   * --hardmask and opt_strand with clustering take the reference's code.  maxaccepts / maxrejects == 0 are NOT "unlimited" in the
+//   * opt_strand with clustering takes the reference's code (--hardmask is covered since r06).  maxaccepts / maxrejects == 0 are NOT "unlimited" in the
 //     library (only the CLI rewrites them, search.cpp:521-529): search_onequery's loop condition accepts < maxaccepts /
 //     rejects < maxrejects (searchcore.cpp:915-918) is false at once, so search_batch reports no hit for any query -- answered
 //     here directly; clustering with such a configuration takes the reference's code.
@@ -137,6 +137,7 @@ vsx_search_opts opts_of(struct Parameters const & p, bool clustering)
   o.sizeorder = p.opt_sizeorder ? 1 : 0;
   o.cluster_unoise = p.opt_cluster_unoise != nullptr ? 1 : 0;
   o.unoise_alpha = p.opt_unoise_alpha;
+  o.hardmask = p.opt_hardmask ? 2 : 0;               // bit 1: the queries (search.cpp:294-303); the Database was masked by the caller
   bool const inf[12] = {p.opt_gap_open_query_left_infinite, p.opt_gap_open_target_left_infinite,
                         p.opt_gap_open_query_interior_infinite, p.opt_gap_open_target_interior_infinite,
                         p.opt_gap_open_query_right_infinite, p.opt_gap_open_target_right_infinite,
@@ -149,7 +150,7 @@ vsx_search_opts opts_of(struct Parameters const & p, bool clustering)
 
 bool covered(struct Parameters const & p, bool clustering)
 {
-  if (p.opt_hardmask) return false;
+  // (r06: --hardmask is covered -- the caller's Database arrives hard-masked already, the queries are hard-masked here: vsx_search_opts::hardmask = 2)
   if (clustering && (p.opt_maxaccepts == 0 || p.opt_maxrejects == 0)) return false;
   if (clustering && p.opt_strand) return false;
   return true;

@@ -128,6 +128,68 @@ def test_masked_search_matches_reference_cli(gpu_required, tmp_path, mode, mask_
     assert dev == host
 
 
+@pytest.mark.parametrize("mode,mask_args", [
+    (1, ["--qmask", "soft", "--dbmask", "soft"]),
+    (2, []),                                                    # dust on both sides (the default) + --hardmask
+])
+@pytest.mark.parametrize("strand_both", [0, 1])
+def test_hardmask_search_matches_reference_cli(gpu_required, tmp_path, mode, mask_args, strand_both):
+    """r06, --hardmask (core/mask.cpp:137-191,248-271; core/search.cpp:294-303): masked symbols become 'N' in the sequence, so the k-mer
+    stage AND the alignment see them -- scores, %id and CIGARs change against the soft-masked run.  vsx_search_opts::hardmask = 3 against the
+    reference CLI's own --hardmask run: soft masking (every lower-case symbol) and DUST (the intervals, input case kept), both strands."""
+    _need_ref()
+    from vsearch_amd import Aligner, SearchSession
+    rng = random.Random(700 + 10 * mode + strand_both)
+    db = _masked_families(rng, 40, 5, 420, 0.05, True)
+    qs = _queries(rng, db, 150, 200, 0.03, True)
+    if strand_both:
+        for k in range(0, len(qs), 2):
+            qs[k] = "".join(COMP[c] for c in reversed(qs[k]))
+    extra = ["--id", "0.7", "--maxaccepts", "2", "--maxrejects", "4"] + (["--strand", "both"] if strand_both else [])
+    tmp = str(tmp_path)
+    exp = _reference_userout(tmp, db, qs, mask_args + ["--hardmask"], extra)
+    soft = _reference_userout(tmp, db, qs, mask_args, extra)
+    with Aligner() as al:
+        ss = SearchSession(al, db, id=0.7, maxaccepts=2, maxrejects=4, strand_both=strand_both, soft_mask=mode, hardmask=3)
+        got = ss.userout(qs, fields=FIELDS)
+        sub = qs[:40]
+        dev, host = ss.candidates_batch(sub, device=True), ss.candidates_batch(sub, device=False)
+        # a caller whose database text is hard-masked already (the library API): hardmask = 2 on that text gives the same answer
+        ss2 = SearchSession(al, ss.masked_db_text(), id=0.7, maxaccepts=2, maxrejects=4, strand_both=strand_both, soft_mask=1, qmask=1 + mode, hardmask=2)
+        got2 = ss2.userout(qs, fields=FIELDS)
+    assert len(exp) > 80
+    assert got == exp, _first_diff(got, exp)
+    assert exp != soft, "the data set does not exercise --hardmask"
+    assert dev == host
+    assert got2 == exp, _first_diff(got2, exp)
+
+
+def test_hardmask_cluster_fast_matches_reference_cli(gpu_required, tmp_path):
+    """--cluster_fast --hardmask (cluster.cpp:1192-1197: dust with 'N', or hardmask_all under --qmask soft)"""
+    _need_ref()
+    from vsearch_amd import Aligner, SearchSession
+    for mode, mask in ((2, []), (1, ["--qmask", "soft"])):
+        rng = random.Random(4200 + mode)
+        seqs = _masked_families(rng, 30, 7, 300, 0.02, True)
+        rng.shuffle(seqs)
+        names = [f"s{i:04d}" for i in range(len(seqs))]
+        f_in, f_uc = str(tmp_path / "c.fa"), str(tmp_path / "c.uc")
+        _write(f_in, names, seqs)
+        outs = {}
+        for key, more in (("hard", ["--hardmask"]), ("plain", [])):
+            p = subprocess.run([REF_BIN, "--cluster_fast", f_in, "--id", "0.9", "--threads", "1", "--uc", f_uc, "--quiet", "--maxaccepts", "1",
+                                "--maxrejects", "2"] + mask + more, capture_output=True, text=True)
+            assert p.returncode == 0, p.stderr
+            outs[key] = open(f_uc).read().splitlines()
+        order = sorted(range(len(seqs)), key=lambda i: (-len(seqs[i]), names[i]))
+        sseqs, snames = [seqs[i] for i in order], [names[i] for i in order]
+        with Aligner() as al:
+            ss = SearchSession(al, sseqs, id=0.9, maxaccepts=1, maxrejects=2, soft_mask=mode, hardmask=3)
+            got = ss.uc_lines(snames, round=32)
+        assert got == outs["hard"], (mode, _first_diff(got, outs["hard"]))
+        assert outs["hard"] != outs["plain"], "the data set does not exercise --hardmask"
+
+
 def test_device_dust_bits_match_host_dust(gpu_required):
     """vsx_mask.hip (one wave per sequence) against vsx_mask.cpp, which tests/test_host_cpu.py pins to the reference CLI:
     the same intervals, bit for bit, on the golden inputs and on a larger random set with window-boundary lengths"""

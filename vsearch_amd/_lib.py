@@ -23,7 +23,7 @@ SYMBOLS = [
     "vsx_align_pairs", "vsx_align_pairs_filtered", "vsx_align_pairs_ranked", "vsx_ranked_free", "vsx_plan_set_filter", "vsx_results_free", "vsx_plan_describe",
 ]
 # include/vsx_search.h
-SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_search_batch",
+SEARCH_SYMBOLS = ["vsx_search_opts_default", "vsx_searcher_create", "vsx_searcher_destroy", "vsx_searcher_db_text", "vsx_search_batch",
                   "vsx_search_batch_meta", "vsx_searcher_set_meta",
                   "vsx_hits_free", "vsx_search_candidates", "vsx_search_candidates_batch", "vsx_candidates_free", "vsx_lma_align", "vsx_allpairs_block", "vsx_allpairs_rows", "vsx_allpairs_stream", "vsx_cluster_fast", "vsx_cluster_out_free", "vsx_msa", "vsx_msa_out_free",
                   "vsx_msa_device", "vsx_msa_device_batch", "vsx_dust_mask", "vsx_abundance_ratio_cmp",
@@ -51,7 +51,7 @@ class SearchOpts(C.Structure):
                 ("window", C.c_int64), ("gap_infinite", C.c_uint32), ("strand_both", C.c_uint32),
                 ("maxqsize", C.c_int64), ("mintsize", C.c_int64), ("minsizeratio", C.c_double), ("maxsizeratio", C.c_double),
                 ("self", C.c_int32), ("sizeorder", C.c_int32), ("cluster_unoise", C.c_int32), ("qmask", C.c_int32),
-                ("unoise_alpha", C.c_double)]
+                ("unoise_alpha", C.c_double), ("hardmask", C.c_int32)]
 
 
 class SeqMeta(C.Structure):

@@ -134,6 +134,12 @@ DEV u32 dpp_rol1(u32 src) { return (u32) __builtin_amdgcn_update_dpp((int) src, 
 #ifndef VSX_FWD_WAVES
 #define VSX_FWD_WAVES(R_, TILT_) ((R_) <= 16 ? 4 : ((R_) <= 24 ? 3 : 2))
 #endif
+// r06: the ONE variants need fewer registers, and R = 26 (400-bp queries: BASELINE configs[3]) now pays at three waves: 168 VGPRs + 124 B of
+// scratch, 400 x 400 DP 16.06 -> 15.68 ms, with 32 candidates per query (the PAIR class) 13.74 -> 13.37; R = 28 is level (18.39 / 18.44),
+// R = 32 loses (500 x 500: 21.9 -> 23.6 ms) -- profiles/r06/r06n_waves3_ab.txt
+#ifndef VSX_FWD_WAVES_ONE
+#define VSX_FWD_WAVES_ONE(R_, TILT_) ((R_) == 26 ? 3 : VSX_FWD_WAVES(R_, TILT_))
+#endif
 // MAX3 (r03, a sub-class of TILT for tasks whose tilted range fits 15 bits): the values are biased by 0x3E00 instead of 0x8000, i.e.
 // every H / E / F lies in [0, 0x7BFF] -- the bit patterns of the non-negative, finite fp16 numbers, whose IEEE order IS the
 // order of the patterns read as integers.  H = max(h0, F, E) is then ONE instruction for both halves, v_pk_maximum3_f16 (new on
@@ -179,7 +185,7 @@ DEV u32 pk_max3_bits(u32 a, u32 b, u32 c)            // IEEE maximum of three: t
 // classes (NQ > 1) always were single-strip, which is why they compiled without spills (VERDICT r05 "next" 3b asked what they do not
 // keep live: the strip state).
 template <int R, bool GENERIC, bool TRACK, bool CKPT, bool TILT = false, bool MAX3 = false, int NQ = 1, bool PAIR = false, bool ONE = false>
-__global__ void __launch_bounds__(PAIR ? 256 : 64) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? VSX_FWD_WAVES(R, TILT) : VSX_FWD_WAVES_NQ(R, NQ), 8)))
+__global__ void __launch_bounds__(PAIR ? 256 : 64) __attribute__((amdgpu_waves_per_eu(NQ == 1 ? (ONE ? VSX_FWD_WAVES_ONE(R, TILT) : VSX_FWD_WAVES(R, TILT)) : VSX_FWD_WAVES_NQ(R, NQ), 8)))
 vsx_forward_kernel(const VsxDevParams P, const VsxTask * __restrict__ tasks,
                    const uint8_t * __restrict__ qc, const uint8_t * __restrict__ tc,
                    u32 * __restrict__ dir, uint2 * strip, VsxSlotOut * __restrict__ slot_out, const u32 ntasks)

@@ -93,21 +93,24 @@ int window_best(const char * s, int n, int & first, int & last)
   return best;
 }
 
-void dust_one(char * seq, int64_t len, std::vector<char> & orig)
+// hard (--hardmask, core/mask.cpp:137-191 with use_hardmask): the text keeps its case and every symbol of a masked interval becomes 'N'
+void dust_one(char * seq, int64_t len, std::vector<char> & orig, bool hard = false)
 {
   orig.assign(seq, seq + len);
-  for (int64_t i = 0; i < len; ++i)
-    {
-      const unsigned char c = (unsigned char) seq[i];
-      if (c >= 'a' && c <= 'z') seq[i] = (char) (c - 32);
-    }
+  if (!hard)
+    for (int64_t i = 0; i < len; ++i)
+      {
+        const unsigned char c = (unsigned char) seq[i];
+        if (c >= 'a' && c <= 'z') seq[i] = (char) (c - 32);
+      }
   for (int64_t i = 0; i < len; i += kHalf)
     {
       const int n = (int) (len > i + kWindow ? kWindow : len - i);
       int a = 0, b = 0;
       if (window_best(orig.data() + i, n, a, b) > kLevel)
         {
-          for (int64_t j = i + a; j <= i + b; ++j) seq[j] = (char) ((unsigned char) orig[(size_t) j] | 0x20u);
+          if (hard) for (int64_t j = i + a; j <= i + b; ++j) seq[j] = 'N';
+          else for (int64_t j = i + a; j <= i + b; ++j) seq[j] = (char) ((unsigned char) orig[(size_t) j] | 0x20u);
           if (b < kHalf) i += kHalf - b;
         }
     }
@@ -142,4 +145,4 @@ int vsx_dust_mask(char * blob, uint64_t n, const uint64_t * offsets, const uint3
 }  // extern "C"
 
 // one sequence, for the dispatch layer's per-query masking (the caller owns the scratch copy)
-void vsx_internal_dust_one(char * seq, int64_t len, std::vector<char> & scratch) { dust_one(seq, len, scratch); }
+void vsx_internal_dust_one(char * seq, int64_t len, std::vector<char> & scratch, bool hard) { dust_one(seq, len, scratch, hard); }

@@ -42,7 +42,7 @@ extern "C" void vsx_internal_run_threads(int nth, void (*fn)(int, void *), void 
 extern "C" int vsx_internal_seqset_create_cased(vsx_ctx * ctx, vsx_seqset ** out, uint64_t n, const char * blob, uint64_t blob_bytes,
                                                 const uint64_t * offsets, const uint32_t * lengths, int mode);
 extern "C" int vsx_internal_seqset_lower_download(const vsx_seqset * s, uint8_t * dst, uint64_t nbytes);
-void vsx_internal_dust_one(char * seq, int64_t len, std::vector<char> & scratch);        // vsx_mask.cpp
+void vsx_internal_dust_one(char * seq, int64_t len, std::vector<char> & scratch, bool hard = false);        // vsx_mask.cpp (hard: --hardmask)
 
 namespace {
 
@@ -906,7 +906,7 @@ static bool sequences_disjoint(uint64_t n, FOff off, FLen len)
 // anything else reads it (core/search.cpp:294-303, commands/usearch_global.cpp:386-392); text[off(k) .. + len(k)) for k < n.
 // The sequences must not overlap in the blob (sequences_disjoint; the callers check).
 template <typename FOff, typename FLen>
-static void dust_states(const vsx_searcher * S, char * text, uint64_t n, FOff off, FLen len)
+static void dust_states(const vsx_searcher * S, char * text, uint64_t n, FOff off, FLen len, bool hard = false)
 {
   const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, S->threads), n / 32 + 1));
   std::atomic<uint64_t> next {0};
@@ -916,10 +916,30 @@ static void dust_states(const vsx_searcher * S, char * text, uint64_t n, FOff of
       {
         const uint64_t k0 = next.fetch_add(32);
         if (k0 >= n) break;
-        for (uint64_t k = k0; k < std::min(n, k0 + 32); ++k) vsx_internal_dust_one(text + off(k), (int64_t) len(k), scratch);
+        for (uint64_t k = k0; k < std::min(n, k0 + 32); ++k) vsx_internal_dust_one(text + off(k), (int64_t) len(k), scratch, hard);
       }
   };
   run_pool(nth, [&](int) { work(); });
+}
+// --hardmask with soft masking (core/mask.cpp:248-271): every lower-case symbol -- bit 0x20 set -- becomes 'N'
+template <typename FOff, typename FLen>
+static void hardmask_states(const vsx_searcher * S, char * text, uint64_t n, FOff off, FLen len)
+{
+  const int nth = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) std::max(1, S->threads), n / 256 + 1));
+  std::atomic<uint64_t> next {0};
+  run_pool(nth, [&](int) {
+    for (;;)
+      {
+        const uint64_t k0 = next.fetch_add(256);
+        if (k0 >= n) break;
+        for (uint64_t k = k0; k < std::min(n, k0 + 256); ++k)
+          {
+            char * p = text + off(k);
+            const uint64_t L = (uint64_t) len(k);
+            for (uint64_t i = 0; i < L; ++i) if (((unsigned char) p[i] & 0x20u) != 0u) p[i] = 'N';
+          }
+      }
+  });
 }
 
 // device path of search_topscores, stage 1: unique words per query (host threads; unique_count, core/unique.cpp:155-352)
@@ -1073,10 +1093,24 @@ int vsx_searcher_create(vsx_ctx * ctx, vsx_searcher ** out, const vsx_search_opt
   S->qmode = S->o.qmask ? S->o.qmask - 1 : S->o.soft_mask;
   if (S->o.soft_mask == 2 && !sequences_disjoint(n, [&](uint64_t k) { return offsets[k]; }, [&](uint64_t k) { return (uint64_t) lengths[k]; }))
     return sfail(VSX_EINVAL, "vsx_searcher_create: DUST masking (soft_mask 2) needs sequences that do not overlap in the blob");
-  int rc = S->o.soft_mask ? vsx_internal_seqset_create_cased(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths, S->o.soft_mask)
+  if (S->o.hardmask < 0 || S->o.hardmask > 3) return sfail(VSX_EINVAL, "vsx_searcher_create: hardmask must be 0..3 (bit 0: database, bit 1: queries)");
+  // r06, --hardmask on the database: the TEXT is rewritten first (host: the option is rare, the exact DUST intervals are needed -- the
+  // device bitmap also flags every ambiguity code -- and a symbol that becomes 'N' changes the alignment); what is indexed and aligned
+  // from here on is the masked text, with its remaining lower case masked for the k-mers as in every mode but "none"
+  const bool hard_db = (S->o.hardmask & 1) && S->o.soft_mask != 0 && blob_bytes;
+  if (hard_db)
+    {
+      if (!sequences_disjoint(n, [&](uint64_t k) { return offsets[k]; }, [&](uint64_t k) { return (uint64_t) lengths[k]; }))
+        return sfail(VSX_EINVAL, "vsx_searcher_create: --hardmask needs sequences that do not overlap in the blob");
+      char * const text = S->blob.data();
+      if (S->o.soft_mask == 2) dust_states(S.get(), text, n, [&](uint64_t k) { return offsets[k]; }, [&](uint64_t k) { return (int64_t) lengths[k]; }, true);
+      else hardmask_states(S.get(), text, n, [&](uint64_t k) { return offsets[k]; }, [&](uint64_t k) { return (int64_t) lengths[k]; });
+      blob = text;
+    }
+  int rc = S->o.soft_mask ? vsx_internal_seqset_create_cased(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths, hard_db ? 1 : S->o.soft_mask)
                           : vsx_seqset_create(ctx, &S->dbset, n, blob, blob_bytes, offsets, lengths);
   if (rc != VSX_OK) return rc;
-  if (S->o.soft_mask == 2 && blob_bytes)
+  if (S->o.soft_mask == 2 && blob_bytes && !hard_db)
     {
       std::vector<uint8_t> bits((blob_bytes + 7) / 8);
       rc = vsx_internal_seqset_lower_download(S->dbset, bits.data(), bits.size());
@@ -1117,6 +1151,14 @@ int vsx_searcher_set_meta(vsx_searcher * S, const vsx_seq_meta * meta)
   return VSX_OK;
 }
 
+uint64_t vsx_searcher_db_text(const vsx_searcher * s, char * dst, uint64_t cap)
+{
+  if (!s) return 0;
+  const uint64_t n = s->blob.empty() ? 0 : s->blob.size() - 1;          // (the copy carries a terminating NUL)
+  if (dst && cap) std::memcpy(dst, s->blob.data(), (size_t) std::min<uint64_t>(cap, n));
+  return n;
+}
+
 void vsx_searcher_destroy(vsx_searcher * s)
 {
   if (!s) return;
@@ -1136,7 +1178,14 @@ int64_t vsx_search_candidates(vsx_searcher * S, const char * q, uint32_t qlen, u
   std::vector<uint64_t> seen(S->w < 10 ? ((1ull << (2 * S->w)) + 63) / 64 : 1, 0);
   std::vector<Cand> c;
   std::vector<char> masked, scratch;
-  if (S->qmode == 2 && qlen) { masked.assign(q, q + qlen); vsx_internal_dust_one(masked.data(), qlen, scratch); q = masked.data(); }
+  const bool hard_q = (S->o.hardmask & 2) != 0;
+  if (S->qmode == 2 && qlen) { masked.assign(q, q + qlen); vsx_internal_dust_one(masked.data(), qlen, scratch, hard_q); q = masked.data(); }
+  else if (S->qmode == 1 && hard_q && qlen)
+    {
+      masked.assign(q, q + qlen);
+      for (char & ch : masked) if (((unsigned char) ch & 0x20u) != 0u) ch = 'N';
+      q = masked.data();
+    }
   candidates_for(*S, q, qlen, cnt, touched, km, seen, c);
   for (size_t i = 0; i < c.size() && i < cap; ++i) { targets[i] = c[i].target; counts[i] = c[i].count; }
   return (int64_t) c.size();
@@ -1156,12 +1205,14 @@ int vsx_search_candidates_batch(vsx_searcher * S, int32_t device, uint64_t nq, c
   KmerAcct acct;
   acct.want_streamed = true;                   // this entry reports postings_streamed (bench_kmer.py's roofline)
   std::string masked;
-  if (S->qmode == 2 && qbytes)
+  const bool hard_q = (S->o.hardmask & 2) != 0 && S->qmode != 0;
+  if ((S->qmode == 2 || hard_q) && qbytes)
     {
       if (!sequences_disjoint(nq, [&](uint64_t k) { return qoff[k]; }, [&](uint64_t k) { return (uint64_t) qlen[k]; }))
-        return sfail(VSX_EINVAL, "vsx_search_candidates_batch: DUST query masking needs queries that do not overlap in the blob");
+        return sfail(VSX_EINVAL, "vsx_search_candidates_batch: DUST / hard query masking needs queries that do not overlap in the blob");
       masked.assign(qblob, qbytes);
-      dust_states(S, &masked[0], nq, [&](uint64_t k) { return qoff[k]; }, [&](uint64_t k) { return qlen[k]; });
+      if (S->qmode == 2) dust_states(S, &masked[0], nq, [&](uint64_t k) { return qoff[k]; }, [&](uint64_t k) { return qlen[k]; }, hard_q);
+      else hardmask_states(S, &masked[0], nq, [&](uint64_t k) { return qoff[k]; }, [&](uint64_t k) { return qlen[k]; });
       qblob = masked.data();
     }
   const int rc = batch_candidates(S, device != 0, nq, [&](uint64_t k) { return qblob + qoff[k]; },
@@ -1280,7 +1331,11 @@ static int search_batch_impl(vsx_searcher * S, uint64_t nq, const char * qblob, 
   // the '*' penalties send every pair to the linear-memory aligner; VSX_RC_TEXT=1 forces it for tests)
   static const bool rc_text_env = std::getenv("VSX_RC_TEXT") != nullptr;
   const bool dust = S->qmode == 2;                // every strand of every query is DUST-masked on its own (search.cpp:294-303)
-  const bool need_rc_text = both && (!dev_kmer || S->o.idprefix > 0 || S->o.idsuffix > 0 || S->o.selfid != 0 || S->o.gap_infinite != 0 || rc_text_env || dust);
+  // r06, --hardmask on the queries (search.cpp:294-303): the masked symbols of each strand become 'N' in the text the k-mer stage AND the
+  // aligner read -- the window's strands then exist as (masked) text, which is what the device set is made from
+  const bool hardq = (S->o.hardmask & 2) != 0 && S->qmode != 0;
+  const bool per_strand = dust || hardq;          // every strand's words come from its own masked text
+  const bool need_rc_text = both && (!dev_kmer || S->o.idprefix > 0 || S->o.idsuffix > 0 || S->o.selfid != 0 || S->o.gap_infinite != 0 || rc_text_env || per_strand);
 
   struct Window {
     uint64_t w0 = 0, wn = 0, ns = 0, mn = 0, hi = 0;
@@ -1341,17 +1396,18 @@ static int search_batch_impl(vsx_searcher * S, uint64_t nq, const char * qblob, 
         }
       Window * w = W.get();
       const double t0 = now_s();
-      if (dust)
+      if (per_strand)
         {
           // masked copies of the window's strands; from here on the window is a soft-masked one
           if (W->joined.empty()) W->joined.assign(qblob + mn, hi - mn);
-          dust_states(S, &W->joined[0], ns, [w](uint64_t k) { return w->lo[k]; }, [w](uint64_t k) { return w->ln[k]; });
+          if (dust) dust_states(S, &W->joined[0], ns, [w](uint64_t k) { return w->lo[k]; }, [w](uint64_t k) { return w->ln[k]; }, hardq);
+          else hardmask_states(S, &W->joined[0], ns, [w](uint64_t k) { return w->lo[k]; }, [w](uint64_t k) { return w->ln[k]; });
           W->wblob = W->joined.data();
         }
       if (dev_kmer)
         {
-          kmer_words(S, dust ? ns : wn, [w](uint64_t k) { return w->wblob + w->lo[k]; }, [w](uint64_t k) { return (int64_t) w->ln[k]; }, w->words);
-          if (both && !dust)
+          kmer_words(S, per_strand ? ns : wn, [w](uint64_t k) { return w->wblob + w->lo[k]; }, [w](uint64_t k) { return (int64_t) w->ln[k]; }, w->words);
+          if (both && !per_strand)
             {
               // unique words of the reverse complement = reverse complements of the unique words (a word over unmasked
               // symbols stays one; unique_count's set semantics, core/unique.cpp:155-352): reverse the 2-bit symbols, complement
@@ -1417,7 +1473,9 @@ static int search_batch_impl(vsx_searcher * S, uint64_t nq, const char * qblob, 
       const double tq = now_s();
       {
         // both strands: the plus strands are uploaded, the minus strands are made on the device
-        int rc2 = both ? vsx_seqset_create_both_strands(ctx, &qset, wn, qblob + W.mn, W.hi - W.mn, W.lo.data(), W.ln.data())
+        // (hard-masked queries: the strands as the masked text -- an 'N' is a different symbol for the aligner)
+        int rc2 = hardq ? vsx_seqset_create(ctx, &qset, ns, W.wblob, W.joined.size(), W.lo.data(), W.ln.data())
+                : both ? vsx_seqset_create_both_strands(ctx, &qset, wn, qblob + W.mn, W.hi - W.mn, W.lo.data(), W.ln.data())
                        : vsx_seqset_create(ctx, &qset, ns, W.wblob, W.hi - W.mn, W.lo.data(), W.ln.data());
         if (rc2 != VSX_OK) return rc2;
       }

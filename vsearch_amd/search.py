@@ -94,6 +94,16 @@ class SearchSession:
         except Exception:
             pass
 
+    def masked_db_text(self):
+        """the database sequences as indexed and aligned (vsx_searcher_db_text): the searcher's masking applied to the text"""
+        lib = _lib.load()
+        lib.vsx_searcher_db_text.restype = C.c_uint64
+        blob, off, lens = self._keep
+        buf = C.create_string_buffer(max(1, len(blob)))
+        n = lib.vsx_searcher_db_text(self.h, buf, C.c_uint64(len(blob)))
+        raw = buf.raw[:int(n)]
+        return [raw[int(o):int(o) + int(l)].decode("latin-1") for o, l in zip(off, lens)]
+
     def candidates(self, query, cap=4096):
         """(target, shared-kmer count) in the order search_topscores + minheap_sort hand them out"""
         q = query.encode() if isinstance(query, str) else bytes(query)
