@@ -39,6 +39,32 @@ def usable_cpus():
     return n
 
 
+KMER_SOURCES = ("vsearch_amd/csrc/vsx_kmer.hip", "vsearch_amd/csrc/vsx_kmer.h", "vsearch_amd/csrc/vsx_kmer_pack.h")
+
+
+def kmer_source_sha():
+    import hashlib
+    h = hashlib.sha256()
+    for f in KMER_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def kmer_traffic(a):
+    """HBM bytes of the counting kernel per batch from profiles/pmc_kmer_current.json (separate rocprofv3 --pmc passes of THIS command,
+    profiles/pmc_kmer.py; refused when the k-mer kernel sources changed since or the workload differs) -> (bytes or None, note)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_kmer_current.json")))
+    except Exception as e:                        # noqa: BLE001
+        return None, f"no profiles/pmc_kmer_current.json ({e.__class__.__name__})"
+    if d.get("kernel_source_sha") != kmer_source_sha():
+        return None, "profiles/pmc_kmer_current.json was measured on other k-mer kernel sources"
+    if d.get("workload") != {"queries": a.queries, "qlen": a.qlen, "db": a.db, "dlen": a.dlen}:
+        return None, "profiles/pmc_kmer_current.json was measured on another workload"
+    return int(d["count_kernel"]["hbm_bytes_per_batch"]), d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--db", type=int, default=1_000_000)
@@ -129,6 +155,7 @@ def main():
                 lib.vsx_hits_free(C.byref(hits))
             bytes_streamed = best["bytes_streamed"]                 # what the index format makes the kernel read (packed: 16 B per unit of <= 15 postings)
             gbps = bytes_streamed / (best["kernel_ms"] * 1e-3) / 1e9
+            traffic, pmc = kmer_traffic(a)
             out = {
                 "metric": "k-mer candidate lists per second (search_topscores: count + threshold, device kernel)",
                 "value": round(a.queries / (best["kernel_ms"] * 1e-3), 1), "unit": "queries/s",
@@ -142,7 +169,14 @@ def main():
                 "increments_per_s": round(best["postings_streamed"] / (best["kernel_ms"] * 1e-3), 1),
                 "bytes_per_posting": round(bytes_streamed / max(1, best["postings_streamed"]), 3),
                 "roofline": {"kernel": "vsx_kmer_count_packed_kernel / vsx_kmer_count_kernel (VSX_KMER_PACKED=0)", "bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0,
-                             "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": None,
+                             "unit": "GB/s", "frac": round(gbps / 8000.0, 4), "traffic": traffic,
+                             "traffic_note": (pmc if traffic is None else
+                                              {"per": "batch of all queries (the count kernel's launches of one vsx_kmer_count_batch call summed)",
+                                               "FETCH_SIZE_KiB": pmc["count_kernel"]["fetch_size_kib"], "WRITE_SIZE_KiB": pmc["count_kernel"]["write_size_kib"],
+                                               "dispatches": pmc["count_kernel"]["dispatches"], "kernel_source_sha": pmc["kernel_source_sha"],
+                                               "SQ": pmc["count_kernel"].get("sq"),
+                                               "method": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate rocprofv3 --pmc passes (MI355X_MICROARCH.md: KiB units, gfx950 FETCH_SIZE halving)"}),
+                             "traffic_GBps": (round(traffic / (best["kernel_ms"] * 1e-3) / 1e9, 1) if traffic else None),
                              "algorithmic_bytes_per_launch": int(bytes_streamed)},
                 "lds_atomics": {"per_clock_and_cu": round(best["postings_streamed"] / (best["kernel_ms"] * 1e-3) / (256 * 2.4e9), 2),
                                 "measured_random_address_rate": 8.1,
