@@ -639,7 +639,7 @@ def test_memory_pressure_releases_idle_blocks(gpu_required, oracle):
 
 
 _PAIR_SNIPPET = r"""
-import random, sys
+import os, random, sys
 import numpy as np
 sys.path.insert(0, %r)
 from tests import common
@@ -669,7 +669,7 @@ for k, Q in enumerate((120, 150, 250, 256, 300, 333, 400, 640, 200, 260)):
 qi = np.array(qi, np.uint32); ti = np.array(ti, np.uint32)
 with Aligner(scoring=P, n_mismatch=nmm) as al:
     Qs, Ts = al.sequences(qs), al.sequences(ts)
-    p = al.plan(Qs, Ts, qi, ti)
+    p = al.plan(Qs, Ts, qi, ti, dir_budget_bytes=int(os.environ.get("VSX_TEST_DIR_BUDGET", "0")))
     info = p.describe()
     p.run()
     res = p.fetch()
@@ -678,7 +678,7 @@ bad = 0
 for k in range(len(qi)):
     if res.row(k) != tuple(orc.align(qs[qi[k]], ts[ti[k]], P, nmm)):
         bad += 1
-print("INFO", info["tasks"], info["tasks_pair"], info["tasks_tilted"], bad)
+print("INFO", info["tasks"], info["tasks_pair"], info["tasks_tilted"], bad, info["chunks"])
 """
 
 
@@ -699,9 +699,17 @@ def test_pair_profile_class(gpu_required, name):
         p = subprocess.run([sys.executable, "-c", _PAIR_SNIPPET % (root, tuple(sc["P"]), bool(sc["n_mismatch"]))], env=e, capture_output=True, text=True,
                            timeout=600, cwd=root)
         assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-        tasks, pair, tilted, bad = (int(x) for x in [ln for ln in p.stdout.splitlines() if ln.startswith("INFO")][-1].split()[1:])
+        tasks, pair, tilted, bad, chunks = (int(x) for x in [ln for ln in p.stdout.splitlines() if ln.startswith("INFO")][-1].split()[1:])
         assert bad == 0, (name, mode, bad)
         seen[mode] = (tasks, pair, tilted)
+    # r06: the same plan cut into several chunks -- a small checkpoint budget -- so that chunk and launch boundaries fall
+    # between PAIR groups of four (never inside one) and the traceback's LDS staging meets first / last tasks of many chunks
+    e = dict(os.environ, VSX_PAIRPROF="1", VSX_TEST_DIR_BUDGET=str(24 << 20))
+    p = subprocess.run([sys.executable, "-c", _PAIR_SNIPPET % (root, tuple(sc["P"]), bool(sc["n_mismatch"]))], env=e, capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    tasks, pair, tilted, bad, chunks = (int(x) for x in [ln for ln in p.stdout.splitlines() if ln.startswith("INFO")][-1].split()[1:])
+    assert bad == 0 and chunks >= 3 and (tasks, pair, tilted) == seen["1"], (name, bad, chunks, tasks, pair, tilted, seen)
     assert seen["0"][1] == 0
     if seen["1"][2] > 0:
         assert seen["1"][1] >= 16 and seen["1"][1] % 4 == 0, seen          # whole groups of four, in several row classes

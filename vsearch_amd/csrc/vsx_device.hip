@@ -1926,7 +1926,10 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
 #endif
 
       // ---- what a tile reads from HBM: nine two-step pairs of the row (or mid-row) checkpoints above it, the column checkpoint left of
-      // it, 20 target symbols.  Issued as one batch; tile 2's batch is issued between tile 1's recompute and its walk ----
+      // it, 20 target symbols.  Issued as one batch, at the top of the tile's trip of the two-trip loop below -- i.e. tile 2's batch is
+      // issued AFTER tile 1's walk.  LSTAGE depends on that order: its LDS-DMA lands on the direction-bit array and the first 512 B of the
+      // symbol array of the tile before, which are dead only once that tile has been walked (an earlier form of this comment
+      // still described the r04 order, batch 2 between tile 1's recompute and its walk -- restoring it would corrupt the walk silently) ----
       struct TileIn { Trio v3[LSTAGE ? 1 : 9]; int par; Quad fq[NBQ]; u32 sw[5]; };
       auto load_tile = [&](TileIn & in, const int cst, const int mleft) __attribute__((always_inline)) {
         in.par = 0;

@@ -1404,10 +1404,13 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
   if (!std::is_sorted(protos.begin(), protos.end(), by_class)) std::stable_sort(protos.begin(), protos.end(), by_class);
 
   // ---- direction-buffer budget ----
+  double t_budget = 0;
   if (dir_budget_bytes == 0)
     {
       size_t free_b = 0, total_b = 0;
+      const double tb0 = now();
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      t_budget = now() - tb0;
       free_b += ctx->pool.idle_bytes() + ctx->shared_dir[pl->dir_slot].bytes();   // blocks this context can hand straight back / already holds
       dir_budget_bytes = std::min<uint64_t>((uint64_t) (free_b * 0.4), 128ull << 30);
       // stay inside the context's current checkpoint block unless it is less than half of what could be had: a slightly
@@ -1632,8 +1635,8 @@ int vsx_plan_create(vsx_ctx * ctx, vsx_plan ** out, const vsx_seqset * queries, 
     }
   HIPCHK(hipStreamSynchronize(ctx->stream_up));
   if (timing)
-    std::fprintf(stderr, "vsx_plan_create: %llu pairs, %zu tasks: classify %.3f s, group %.3f s, tasks %.3f s, device buffers + upload %.3f s\n",
-                 (unsigned long long) n_pairs, pl->tasks.size(), tc1 - tc0, tc2 - tc1, tc3 - tc2, now() - tc3);
+    std::fprintf(stderr, "vsx_plan_create: %llu pairs, %zu tasks: classify %.2f ms, group %.2f ms (budget query %.2f), tasks %.2f ms, device buffers + upload %.2f ms\n",
+                 (unsigned long long) n_pairs, pl->tasks.size(), (tc1 - tc0) * 1e3, (tc2 - tc1) * 1e3, t_budget * 1e3, (tc3 - tc2) * 1e3, (now() - tc3) * 1e3);
   *out = pl.release();
   return VSX_OK;
 }
@@ -2368,12 +2371,22 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
     }
   std::mutex mu;
   std::condition_variable cv;
-  size_t ready = 0, consumed = 0;
+  size_t consumed = 0;
+  std::vector<char> is_ready(S, 0);
   bool stop = false;
+  int plan_failed = VSX_OK;
+  std::string plan_failed_msg;
   static const size_t depth = std::getenv("VSX_PIPELINE_DEPTH") ? (size_t) std::max(1, std::min(6, std::atoi(std::getenv("VSX_PIPELINE_DEPTH")))) : 2;
-  std::thread planner([&]() {
+  // r06, measured and NOT adopted: VSX_PLANNERS=2 / 3 planner threads (slices i = k, k + n, ...; plans of one context may be made
+  // concurrently: pool, block and slot choices are locked, uploads share stream_up).  A planner needs 2.1-2.8 ms per slice where the
+  // GPU needs 5.3, so a second one only adds contention: 29.9 / 31.2 ms per 800 k-pair call with one, 30.6 / 35.4 with two, 30.8 with
+  // three (profiles/r06/r06r_e2e_planners_ab.txt).  What the call loses against its 25.4 ms of kernels is on the device: the traceback of
+  // slice i runs starved beside the DP kernels of slices i + 1, i + 2 (a retiring DP wave frees 128 VGPRs, a traceback wave needs 168),
+  // and the slice that reuses its checkpoint block waits for it.
+  static const size_t n_planners = std::getenv("VSX_PLANNERS") ? (size_t) std::max(1, std::min(4, std::atoi(std::getenv("VSX_PLANNERS")))) : 1;
+  auto planner_body = [&](size_t first_slice) {
     (void) hipSetDevice(ctx->device);
-    for (size_t i = 0; i < S; ++i)
+    for (size_t i = first_slice; i < S; i += n_planners)
       {
         {
           std::unique_lock<std::mutex> lk(mu);
@@ -2387,11 +2400,18 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
         if (rc != VSX_OK) { plan_msg[i] = vsx_last_error(); if (pl) vsx_plan_destroy(pl); pl = nullptr; }
         if (timing) std::fprintf(stderr, "  slice %zu (%llu pairs): planned at %.1f ms\n", i, (unsigned long long) (cut[i + 1] - cut[i]), (now() - t_begin) * 1e3);
         std::lock_guard<std::mutex> lk(mu);
-        plans[i] = pl; plan_rc[i] = rc; ready = i + 1;
+        plans[i] = pl; plan_rc[i] = rc; is_ready[i] = 1;
         cv.notify_all();
-        if (rc != VSX_OK) return;
+        if (rc != VSX_OK)                                          // (the consumer stops at this slice or, if the other planner then
+          {                                                        //  leaves an earlier one unplanned, at that one: plan_failed)
+            if (plan_failed == VSX_OK) { plan_failed = rc; plan_failed_msg = plan_msg[i]; }
+            stop = true;
+            return;
+          }
       }
-  });
+  };
+  std::vector<std::thread> planners;
+  for (size_t k = 0; k < std::min(n_planners, S); ++k) planners.emplace_back(planner_body, k);
   int rc = VSX_OK;
   std::string msg;
   size_t launched = 0;
@@ -2415,7 +2435,8 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
     {
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return ready > i; });
+        cv.wait(lk, [&] { return is_ready[i] != 0 || plan_failed != VSX_OK; });
+        if (!is_ready[i]) { rc = plan_failed; msg = plan_failed_msg; break; }
       }
       if (plan_rc[i] != VSX_OK) { rc = plan_rc[i]; msg = plan_msg[i]; break; }
       // odd slices launch their DP kernels on the second DP stream: a slice is ~3-6 rounds of resident waves, its last round drains
@@ -2440,7 +2461,7 @@ static int align_pairs_impl(vsx_ctx * ctx, const vsx_seqset * queries, const vsx
     stop = true;
   }
   cv.notify_all();
-  planner.join();
+  for (std::thread & t : planners) t.join();
   for (size_t i = 0; i < S; ++i)
     if (plans[i]) { vsx_plan_destroy(plans[i]); plans[i] = nullptr; }
   if (rc != VSX_OK)
