@@ -1892,7 +1892,11 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
       const int total_lanes = ((int) Qb + R - 1) / R;
       const int rcnt0 = (int) Qb - (total_lanes - 1) * R;
       const int pad = R - rcnt0;                   // dummy slots above the rows of position 0 (TOPPAD layout)
+#ifdef VSX_TB_FORCE_ONE
+      const int nstrips = 1;                     // (A/B build only: every query single-strip; profiles/r06/r06t_tb_onestrip_ab.txt)
+#else
       const int nstrips = (total_lanes + 15) >> 4;
+#endif
       const size_t steps = stb;
       const size_t nblk = (steps + 15) >> 4;
       const size_t rowsteps = ((size_t) nstrips * steps + 1) & ~(size_t) 1;
@@ -1900,7 +1904,11 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
       const u32 * __restrict__ rowck = ck + dob;
       const u32 * __restrict__ colck = rowck + rowck_dw;
       const u32 * __restrict__ midck = colck + (size_t) nstrips * nblk * COL_DW;
+#ifdef VSX_TB_FORCE_ONE
+      const int s = 0, l = L;
+#else
       const int s = L >> 4, l = L & 15;
+#endif
       const int jj = busy ? j : 0;
       const int m = (jj + l) >> 4;
       const int c0 = (16 * m - l) > 0 ? 16 * m - l : 0;                     // tile 1 = columns c0 .. c0 + 15
@@ -1944,7 +1952,13 @@ vsx_traceback_tilt_kernel(const VsxDevParams P, const VsxFilterDev FL, const Vsx
               }
             else
               {
+                
+#ifdef VSX_TB_FORCE_ONE
+                const int Lp = L - 1, sp = 0, lp = Lp;
+#else
                 const int Lp = L - 1, sp = Lp >> 4, lp = Lp & 15;
+#endif
+
                 base = rowck + (size_t) VSX_CK_SLOT(true, g, lp) * 3;
                 gstart = (long) ((size_t) sp * steps) + (long) (cst - 1 + lp);
               }

@@ -1319,7 +1319,9 @@ static int search_batch_impl(vsx_searcher * S, uint64_t nq, const char * qblob, 
     }
   const size_t n_windows = cut.size() - 1;
   auto window_of = [&](uint64_t w0) -> size_t { return (size_t) (std::upper_bound(cut.begin(), cut.end(), w0) - cut.begin()) - 1; };
-  struct WinKept { uint64_t w0 = 0; std::vector<Hit> flat; std::vector<uint32_t> first; };      // a window's reported hits, query after query
+  // a window's reported hits, query after query, already in the result's record form (r06: converted by the window's consumer thread -- the
+  // final marshalling is one pass of block copies; the intermediate Hit objects die with the window, on the thread that made them)
+  struct WinKept { uint64_t w0 = 0; std::vector<vsx_hit> rec; std::string cigar; std::vector<uint32_t> first; };
   std::vector<WinKept> wkept(n_windows);
   double t_kmer = 0, t_align = 0, t_adv = 0, t_rep = 0, t_qset = 0, t_join = 0;
   uint64_t pairs = 0, cells = 0, stages = 0, sentinels = 0;
@@ -1516,11 +1518,12 @@ static int search_batch_impl(vsx_searcher * S, uint64_t nq, const char * qblob, 
       WinKept & K = wkept[window_of(w0)];
       K.w0 = w0;
       K.first.assign(wn + 1, 0);
-      K.flat.reserve(wn + wn / 8);
+      K.rec.reserve(wn + wn / 8);
+      std::vector<Hit> dst;
       for (uint64_t k = 0; k < wn; ++k)
         {
-          std::vector<Hit> & dst = K.flat;
-          const size_t from = dst.size();
+          dst.clear();
+          const size_t from = 0;
           for (Hit & h : st[k].hits) if (h.accepted || h.weak) dst.push_back(std::move(h));
           if (both)
             for (Hit & h : st[wn + k].hits) if (h.accepted || h.weak) { h.minus = true; dst.push_back(std::move(h)); }
@@ -1528,7 +1531,13 @@ static int search_batch_impl(vsx_searcher * S, uint64_t nq, const char * qblob, 
           // glibc's merge sort, which keeps the plus-strand hit first (found by oracle/soak_search.py)
           if (dst.size() - from > 1)
             std::stable_sort(dst.begin() + (long) from, dst.end(), [](const Hit & a, const Hit & b) { return hit_compare_byid(a, b) < 0; });
-          K.first[k + 1] = (uint32_t) dst.size();
+          for (const Hit & h : dst)
+            {
+              K.rec.emplace_back();
+              hit_record(h, (uint32_t) (w0 + k), K.cigar.size(), K.rec.back());          // (cigar_off: window-relative until the marshalling)
+              K.cigar.append(h.cigar.c_str(), h.cigar.size() + 1);
+            }
+          K.first[k + 1] = (uint32_t) K.rec.size();
         }
       { std::lock_guard<std::mutex> lk(acc_mu); t_join += now_s() - tj; }
       if (timeline) std::fprintf(stderr, "  [%7.1f ms] window %llu: align done (%.1f ms)\n", (now_s() - t_begin) * 1e3, (unsigned long long) window_of(w0), (now_s() - tc0) * 1e3);
@@ -1674,12 +1683,31 @@ static int search_batch_impl(vsx_searcher * S, uint64_t nq, const char * qblob, 
   // ---- marshal ----
   const double tm = now_s();
   {
-    const int mrc = marshal_hits_from(nq, [&](uint64_t q) {
-        const WinKept & K = wkept[window_of(q)];
-        const uint64_t k = q - K.w0;
-        return HitSpan {K.flat.data() + K.first[k], (size_t) (K.first[k + 1] - K.first[k])};
-      }, out, S->threads);
-    if (mrc != VSX_OK) return mrc;
+    // windows in query order: their records and CIGAR text back to back, the offsets rebased
+    std::vector<uint64_t> hbase(n_windows + 1, 0), cbase(n_windows + 1, 0);
+    for (size_t wi = 0; wi < n_windows; ++wi) { hbase[wi + 1] = hbase[wi] + wkept[wi].rec.size(); cbase[wi + 1] = cbase[wi] + wkept[wi].cigar.size(); }
+    out->n_queries = nq;
+    out->n_hits = hbase[n_windows];
+    out->cigar_bytes = cbase[n_windows];
+    out->first = (uint64_t *) std::malloc((nq + 1) * sizeof(uint64_t));
+    out->hit = (vsx_hit *) std::malloc(std::max<uint64_t>(out->n_hits, 1) * sizeof(vsx_hit));
+    out->cigar_blob = (char *) std::malloc(std::max<uint64_t>(out->cigar_bytes, 1));
+    if (!out->first || !out->hit || !out->cigar_blob) { vsx_hits_free(out); return sfail(VSX_ENOMEM, "host allocation failed"); }
+    std::atomic<size_t> next_w {0};
+    run_pool((int) std::max<size_t>(1, std::min<size_t>((size_t) std::min(std::max(1, S->threads), 8), n_windows)), [&](int) {
+      for (;;)
+        {
+          const size_t wi = next_w.fetch_add(1);
+          if (wi >= n_windows) break;
+          const WinKept & K = wkept[wi];
+          const uint64_t wn = cut[wi + 1] - cut[wi];
+          for (uint64_t k = 0; k < wn; ++k) out->first[cut[wi] + k] = hbase[wi] + K.first[k];
+          vsx_hit * dst = out->hit + hbase[wi];
+          for (size_t x = 0; x < K.rec.size(); ++x) { dst[x] = K.rec[x]; dst[x].cigar_off += cbase[wi]; }
+          if (!K.cigar.empty()) std::memcpy(out->cigar_blob + cbase[wi], K.cigar.data(), K.cigar.size());
+        }
+    });
+    out->first[nq] = out->n_hits;
   }
   if (timeline) std::fprintf(stderr, "  [%7.1f ms] hits marshalled\n", (now_s() - t_begin) * 1e3);
   std::vector<WinKept>().swap(wkept);
