@@ -139,6 +139,10 @@ def parse():
                     help="N > 1: the final gather of hit records + CIGAR run words per step -- async: one fixed-capacity non-blocking "
                          "collective that overlaps the next step's kernels (sharding.FixedGather); sync: counts first, then padded payload")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL; gloo: the one-GPU tests)")
+    ap.add_argument("--single-rank-dist", action="store_true",
+                    help="N = 1 only: initialise torch.distributed with ONE rank and run the N > 1 code path on it -- export, the (asynchronous) gather, "
+                         "gather_check, --dry-collectives.  With --backend nccl that is RCCL executing every collective of the path on a box that has "
+                         "one GPU (RCCL refuses two ranks on one device); the collectives are degenerate, the API usage is the real one")
     ap.add_argument("--dry-collectives", action="store_true",
                     help="N > 1: run ONLY the gather path (sharding.gather_results and FixedGather, incl. a forced overflow step) on tiny "
                          "tensors -- no database, no kernels -- and print one JSON line: tells a collective failure from a kernel failure")
@@ -161,7 +165,11 @@ def main():
         torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index) if have_gpu else torch.device("cpu")
     dist = None
-    if world > 1:
+    multi = world > 1 or (a.single_rank_dist and world == 1)      # the sharded code path (world == 1 only with --single-rank-dist)
+    if multi:
+        if world == 1:
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29651"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         import torch.distributed as dist
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)     # RCCL
@@ -172,7 +180,7 @@ def main():
 
     # what the collectives run on (VERDICT r03 "next" 8: the line of an N > 1 run describes its own transport)
     rccl = None
-    if world > 1:
+    if multi:
         try:
             nccl_version = ".".join(str(x) for x in torch.cuda.nccl.version()) if a.backend == "nccl" else None
         except Exception as e:                              # (never lose the run over a version string)
@@ -186,8 +194,8 @@ def main():
                 "gpu": torch.cuda.get_device_name(dev_index) if have_gpu else None,
                 "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG", "MASTER_ADDR", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}}
     if a.dry_collectives:
-        if world == 1:
-            raise SystemExit("--dry-collectives needs N > 1 ranks")
+        if not multi:
+            raise SystemExit("--dry-collectives needs N > 1 ranks (or --single-rank-dist)")
         res = dry_collectives(dist, sharding, dev if a.backend == "nccl" else torch.device("cpu"), rank, world)
         if rank == 0:
             print(json.dumps({"dry_collectives": res, "rccl": rccl, "n_gpus": world}), flush=True)
@@ -226,14 +234,14 @@ def main():
     cells = int((q_len[qidx].astype(np.int64) * db_len[tidx].astype(np.int64)).sum())
     scratch = {}
     gathered = None
-    fixed = sharding.FixedGather(dist, dst=0) if (world > 1 and a.gather == "async") else None
-    gloo = world > 1 and a.backend == "gloo"
+    fixed = sharding.FixedGather(dist, dst=0) if (multi and a.gather == "async") else None
+    gloo = multi and a.backend == "gloo"
 
     def step():
         nonlocal gathered
         plan.run()
         tm = plan.sync()
-        if world > 1:
+        if multi:
             # the only collective on the path: final gather of the hit records and the CIGAR run words over RCCL/xGMI, to rank 0 (which
             # would write the output) -- the functions the world-2 tests drive (vsearch_amd/sharding.py).  async: the collective of this
             # step is posted and the PREVIOUS step's is collected, so it travels while the next step's kernels run
@@ -256,7 +264,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -279,7 +287,7 @@ def main():
     elapsed = time.perf_counter() - t0
     job_cells, job_pairs = cells, n_pairs
     per_rank_ms = None
-    if world > 1:
+    if multi:
         cdev = torch.device("cpu") if gloo else dev
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         tall = [torch.zeros_like(tmax) for _ in range(world)]
@@ -292,13 +300,20 @@ def main():
         job_cells, job_pairs = int(tot[0]), int(tot[1])
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.barrier()
             dist.destroy_process_group()
         return
 
     gather_check = None
-    if world > 1:
+    if multi and world == 1:
+        # --single-rank-dist: the one rank's block must come back unchanged through the collective
+        rec_all, runs_all, counts = gathered
+        mine = sharding.decode_records(rec_all[:n_pairs])
+        own = sharding.decode_records(scratch["rec"])
+        gather_check = bool(list(counts) == [n_pairs] and np.array_equal(mine["score"], own["score"]) and np.array_equal(mine["run_off"], own["run_off"])
+                            and np.array_equal(mine["nruns"], own["nruns"]) and int(runs_all.numel()) >= int(own["nruns"].sum()))
+    elif world > 1:
         # rank 0 holds every rank's pairs: its own block must come back unchanged, offsets of the others rebased past it
         rec_all, runs_all, counts = gathered
         mine = sharding.decode_records(rec_all[:n_pairs])
@@ -344,7 +359,7 @@ def main():
                           "search_end_to_end runs the real device k-mer stage (vsx_kmer.hip) in front of the aligner",
             "parallelism": (f"query-sharded x{world} (sharding.shard_queries, {'strong: one job of ' + str(a.queries) + ' queries cut into blocks' if strong else 'weak: ' + str(a.queries) + ' queries per rank'}), "
                             f"DB replicated, one {a.gather} gather of records + CIGAR runs per step over {a.backend}")
-                           if world > 1 else "single GPU",
+                           if multi else "single GPU",
             "cells_per_step_per_gpu": cells,
         },
         "roofline": {
@@ -451,7 +466,7 @@ def main():
         except Exception as e:
             out["shapes"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

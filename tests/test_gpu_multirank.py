@@ -162,3 +162,43 @@ def test_bench_two_ranks_on_one_gpu(gpu_required, mode, gather):
     pairs_per_step = d["pairs_per_s"] * d["ms_per_step"] * 1e-3
     expect = nq * 8 * (1 if mode == "strong" else 2)
     assert abs(pairs_per_step - expect) < 0.01 * expect, (pairs_per_step, expect)
+
+
+@pytest.mark.parametrize("gather", ["async", "sync"])
+def test_bench_single_rank_over_rccl(gpu_required, gather):
+    """r06: the N > 1 code path of bench.py with ONE rank and the `nccl` backend -- RCCL itself executes every collective of the path on the
+    one GPU of this box (it refuses two ranks on one device: profiles/r06/r06z_rccl_two_ranks_one_gpu.txt): process-group init with a
+    device id, the rank-identity all-gather, vsx_plan_export_hits / _runs into device tensors, the asynchronous fixed-capacity gather
+    (non-blocking gather + flag all-reduce, Work.is_completed / wait) or the synchronous all-gathers, the timing all-reduces, gather_check.
+    The collectives are degenerate; the tensors, dtypes, devices and call sequence are the ones an 8-GPU run issues."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29581", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    nq = 6000
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--single-rank-dist", "--backend", "nccl", "--gather", gather, "--kernels-only",
+           "--steps", "4", "--warmup", "1", "--queries", str(nq), "--db", "20000", "--dlen", "600", "--qlen", "200"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["gather_check"] is True, d.get("gather_check")
+    r = d["rccl"]
+    assert r["backend"] == "nccl" and r["world"] == 1 and r["nccl_version"] and r["device_of_rank"] == [0]
+    if gather == "async":
+        st = r["fixed_gather_overlap"]
+        assert st["collects"] + (1 if st["degraded_to_sync"] else 0) >= 4 and r["fixed_gather_sync_steps"] == 0, r
+    pairs_per_step = d["pairs_per_s"] * d["ms_per_step"] * 1e-3
+    assert abs(pairs_per_step - nq * 8) < 0.01 * nq * 8
+
+
+def test_dry_collectives_single_rank_over_rccl(gpu_required):
+    """bench.py --dry-collectives on one rank with the nccl backend: the gather path alone on DEVICE tensors through RCCL -- synchronous gather,
+    the asynchronous fixed-capacity form incl. overflow steps (the synchronous redo inside collect), the collective degrade vote"""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29582", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--single-rank-dist", "--backend", "nccl", "--dry-collectives"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["dry_collectives"] == {"gather_results_to_rank0": True, "fixed_gather_async_incl_one_rank_overflow": True, "fixed_gather_sync_steps": 1,
+                                     "fixed_gather_overlap_samples": True, "fixed_gather_mixed_votes_one_rank_overflows": True,
+                                     "fixed_gather_degraded_at_step": 5}, d
+    assert d["rccl"]["backend"] == "nccl" and d["rccl"]["nccl_version"]
