@@ -188,6 +188,10 @@ def main():
         ident = torch.tensor([rank, dev_index, torch.cuda.device_count() if have_gpu else 0], dtype=torch.int64, device=(dev if a.backend == "nccl" else torch.device("cpu")))
         idents = [torch.zeros_like(ident) for _ in range(world)]
         dist.all_gather(idents, ident)                      # the first collective of the job: a transport problem shows HERE
+        if a.backend == "nccl":
+            torch.cuda.synchronize()
+        _flush_c_stdio()                                    # (RCCL's version banner -- NCCL_DEBUG=VERSION on these boxes -- sits in the C stdout buffer:
+                                                            #  out NOW, so that rank 0's JSON line is the last line of its stdout)
         rccl = {"world": world, "backend": a.backend, "nccl_version": nccl_version, "torch": torch.__version__,
                 "hip": getattr(torch.version, "hip", None),
                 "device_of_rank": [int(t[1]) for t in idents], "visible_devices_of_rank": [int(t[2]) for t in idents],
@@ -198,6 +202,7 @@ def main():
             raise SystemExit("--dry-collectives needs N > 1 ranks (or --single-rank-dist)")
         res = dry_collectives(dist, sharding, dev if a.backend == "nccl" else torch.device("cpu"), rank, world)
         if rank == 0:
+            _flush_c_stdio()
             print(json.dumps({"dry_collectives": res, "rccl": rccl, "n_gpus": world}), flush=True)
         dist.barrier()
         dist.destroy_process_group()
@@ -465,6 +470,7 @@ def main():
             out["shapes"] = shapes_leg(a, al, dev)
         except Exception as e:
             out["shapes"] = {"error": repr(e)}
+    _flush_c_stdio()
     print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()
@@ -777,6 +783,15 @@ def reference_search(ref_bin, db_blob, db_off, db_len, q_blob, q_off, q_len, nre
                 "hits": len(theirs), "same_hits_as_vsx": bool(theirs == ours),
                 "same_pairs_as_vsx": bool({x[:2] for x in theirs} == {x[:2] for x in ours}),
                 "compared_fields": "query+target+id+caln (every --userout line of the sample as a tuple; set equality)"}
+
+
+def _flush_c_stdio():
+    """flush every C stdio stream of the process (fflush(NULL)): text written by native libraries with printf"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                              # noqa: BLE001
+        pass
 
 
 def baseline_label(a):
